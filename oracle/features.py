@@ -1,0 +1,87 @@
+"""Feature extractors (oracle, CPU): TorchMFCC, Log1pMaxNormAbsSTFT, concat.
+
+Follows tssep/train/feature_extractor_torchaudio.py:22-106 (TorchMFCC),
+tssep/train/feature_extractor.py:233-248 (Log1pMaxNormAbsSTFT) and :352-360
+(ConcaternatedSTFTFeatures).  The mel filterbank / AmplitudeToDB / DCT live in
+torchaudio==2.0.2 (absent): restated from its published algorithm, parity
+unpinned (no reference test asserts an MFCC value).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk')."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0)  # [n_freqs, n_mels]
+
+
+def create_dct(n_mfcc, n_mels, norm="ortho"):
+    """torchaudio.functional.create_dct -> [n_mels, n_mfcc]."""
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    if norm is None:
+        dct *= 2.0
+    else:
+        dct[0] *= 1.0 / math.sqrt(2.0)
+        dct *= math.sqrt(2.0 / float(n_mels))
+    return dct.t()
+
+
+def mfcc_tables(size=1024, sample_rate=16000, n_mfcc=40, f_min=40.0,
+                f_max=-400.0, n_mels=40, dct_norm="ortho"):
+    """fb[F, n_mels], dct[n_mels, n_mfcc] as built at
+    feature_extractor_torchaudio.py:57-85 (negative f_max wraps to sr+f_max)."""
+    if f_max and f_max < 0:
+        f_max = sample_rate + f_max
+    fb = melscale_fbanks(size // 2 + 1, f_min, f_max, n_mels, sample_rate)
+    return fb, create_dct(n_mfcc, n_mels, dct_norm)
+
+
+def amplitude_to_db_power(x, top_db=80.0):
+    """torchaudio AmplitudeToDB('power', top_db) incl. its batching quirk:
+    3-D input is treated as the channels of ONE item (max over everything),
+    4-D as [batch, channel, freq, time] (max per batch item)."""
+    x_db = 10.0 * torch.log10(torch.clamp(x, min=1e-10))
+    shape = x_db.size()
+    packed_channels = shape[-3] if x_db.dim() > 2 else 1
+    v = x_db.reshape(-1, packed_channels, shape[-2], shape[-1])
+    v = torch.max(v, (v.amax(dim=(-3, -2, -1)) - top_db).view(-1, 1, 1, 1))
+    return v.reshape(shape)
+
+
+def torch_mfcc(X, fb, dct, top_db=80.0):
+    """feature_extractor_torchaudio.py:93-106.  X[..., T, F] complex."""
+    power = abs(X.transpose(-1, -2)).to(torch.float32) ** 2   # [..., F, T]
+    mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
+    mel = amplitude_to_db_power(mel, top_db)                  # [..., n_mels, T]
+    return torch.matmul(mel.transpose(-1, -2), dct)           # [..., T, n_mfcc]
+
+
+def log1p_max_norm_abs(X, statistics_axis="tf"):
+    """feature_extractor.py:233-248 (torch branch) / :249-263 (numpy)."""
+    if isinstance(X, np.ndarray):
+        s = np.abs(X)
+        axis = {"tf": (-2, -1), "t": -2, "f": -1}[statistics_axis]
+        return np.log1p(s * ((np.e - 1) / np.amax(s, keepdims=True, axis=axis)))
+    s = abs(X)
+    dim = {"tf": (-2, -1), "t": -2, "f": -1}[statistics_axis]
+    s = s * ((np.e - 1) / torch.amax(s, keepdim=True, dim=dim))
+    return torch.log1p(s)
+
+
+def concat_features(X, fb, dct):
+    """ConcaternatedSTFTFeatures(TorchMFCC, Log1pMaxNormAbsSTFT)
+    (feature_extractor.py:352-360, init_cfg_common.yaml:13-50) -> [..., T, 553]."""
+    return torch.concat([torch_mfcc(X, fb, dct), log1p_max_norm_abs(X)], dim=-1)

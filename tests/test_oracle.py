@@ -1,0 +1,195 @@
+"""Pin the CPU oracle: against fixtures generated from the reference classes
+(tests/golden/make_golden.py) and against the reference's doctest numbers."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data as odata, features, loss as oloss, model as omodel, net as onet
+from oracle import rnnp as ornnp, stft as ostft
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.as_tensor
+
+
+def _params(g, pre="p."):
+    return {k[len(pre):]: T(v) for k, v in g.items() if k.startswith(pre)}
+
+
+def test_stft_doctest_numbers():
+    # tssep/train/feature_extractor.py:197-202
+    rng = np.random.RandomState(0)
+    f = features.log1p_max_norm_abs(ostft.stft(rng.uniform(0, 1, size=10_000), window="blackman"))
+    assert f.shape == (43, 513)
+    assert np.mean(f) == pytest.approx(0.03461471931132962, rel=1e-12)
+    assert np.min(f) == pytest.approx(1.0003006801514706e-06, rel=1e-9)
+    assert np.max(f) == 1.0
+    assert np.std(f) == pytest.approx(0.051645387514742555, rel=1e-12)
+    assert ostft.num_frames(80000) == 316          # tssep/train/model.py:480
+    # feature_extractor.py:194-196
+    k = features.log1p_max_norm_abs(np.array([[1, 5], [3 + 4j, -5]]))
+    np.testing.assert_allclose(k, [[0.29539453, 1.0], [1.0, 1.0]], atol=1e-8)
+
+
+def test_istft_inverts_stft_and_matches_autograd_adjoint():
+    x = torch.randn(2, 3, 3000, dtype=torch.float64)
+    X = ostft.stft(x)
+    assert (ostft.istft(X, num_samples=3000) - x).abs().max() < 1e-12
+    # <istft(X), y> == <X, istft^T y> is what the HIP backward implements
+    X = torch.randn(1, 9, 513, dtype=torch.complex128, requires_grad=True)
+    y = torch.randn(1, 1500, dtype=torch.float64)
+    (ostft.istft(X, num_samples=1500) * y).sum().backward()
+    assert X.grad.shape == X.shape
+
+
+def test_rnnp_against_reference_fixture(golden):
+    g = golden("rnnp")
+    p = _params(g)
+    for tag in ("x3", "x4", "x2"):
+        x = T(g[tag]).requires_grad_()
+        pp = {k: v.clone().requires_grad_() for k, v in p.items()}
+        y = ornnp.rnnp(x, pp, "")
+        np.testing.assert_allclose(y.detach().numpy(), g[tag + "_y"], rtol=1e-5, atol=1e-6)
+        yf = ornnp.rnnp(x, pp, "", fast=True)
+        np.testing.assert_allclose(yf.detach().numpy(), g[tag + "_y"], rtol=1e-5, atol=1e-6)
+        (y * T(g[tag + "_g"])).sum().backward()
+        np.testing.assert_allclose(x.grad.numpy(), g[tag + "_dx"], rtol=1e-4, atol=1e-6)
+        for k, v in pp.items():
+            np.testing.assert_allclose(v.grad.numpy(), g[f"{tag}_dp.{k}"], rtol=1e-4, atol=1e-6)
+
+
+ME_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "me_*.npz")))
+
+
+@pytest.mark.parametrize("name", ME_CASES)
+def test_mask_estimator_against_reference_fixture(golden, name):
+    g = golden(name)
+    comb, ts_vad, res, nap = [str(s) for s in g["cfg"]]
+    ts_vad = False if ts_vad == "False" else int(ts_vad)
+    p = {"mask_estimator." + k: v.requires_grad_() for k, v in _params(g).items()}
+    out = onet.mask_estimator_forward(
+        p, T(g["xs"]), T(g["aux"]), odim=9, combination=comb, ts_vad=ts_vad,
+        output_resolution=res, num_averaged_permutations=int(nap), perm=g["perm"])
+    np.testing.assert_allclose(out["logit"].detach().numpy(), g["logit"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(out["mask"].detach().numpy(), g["mask"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["embedding"].numpy(), g["embedding"])
+    (out["mask"] * T(g["g"])).sum().backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["dp." + k[len("mask_estimator."):]],
+                                   rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_mask_estimator_consumes_np_random_like_reference(golden):
+    # net.py:824-826: one np.random.permutation(K) per batch entry, batch order
+    g = golden("me_mul_4_tf_1")
+    p = {"mask_estimator." + k: v for k, v in _params(g).items()}
+    np.random.seed(100 + ME_CASES_ORDER.index("me_mul_4_tf_1"))
+    torch.manual_seed(0)
+    # the generator seeds np.random and then builds the module (no np draws) -> same stream
+    out = onet.mask_estimator_forward(p, T(g["xs"]), T(g["aux"]), odim=9, combination="mul",
+                                      ts_vad=4, output_resolution="tf")
+    np.testing.assert_array_equal(out["perm"], g["perm"])
+    np.testing.assert_allclose(out["logit"].numpy(), g["logit"], rtol=1e-5, atol=2e-6)
+
+
+# generation order of make_golden.py (seed = 100 + case index)
+ME_CASES_ORDER = [f"me_{c}_{v}_{r}_{n}" for c in ("mul", "cat") for v in (False, 3, 4)
+                  for r in ("t", "tf") for n in (1, 2) if not (v is False and n != 1)]
+
+
+def test_enhancer_and_losses_against_reference_fixture(golden):
+    g = golden("enh_loss")
+    np.testing.assert_allclose(oloss.masking(T(g["mask"]), T(g["Obs"])).numpy(), g["est"], rtol=1e-6)
+    np.testing.assert_allclose(oloss.log_mae(T(g["e"]), T(g["t"])).numpy(), g["logmae"], rtol=1e-6)
+    np.testing.assert_allclose(oloss.mae(T(g["e"]), T(g["t"])).numpy(), g["mae"], rtol=1e-6)
+    np.testing.assert_allclose(oloss.vad_sigmoid_bce(T(g["logit"]), T(g["vad"])).numpy(), g["bce"],
+                               rtol=1e-6)
+
+
+def test_loss_doctest_known_answers(golden):
+    # tssep/train/loss.py:198-204, 223-234, 286-299
+    torch.manual_seed(0)
+    target = torch.rand((2, 10000))
+    estimate = target + 0.5 * torch.rand((2, 10000))
+    assert float(oloss.mae(estimate, target)) == pytest.approx(0.5018, abs(5e-5))
+    assert float(oloss.log_mae(estimate, target)) == pytest.approx(-0.2995, abs=5e-5)
+    assert float(oloss.log_mae(target, target)) == -np.inf
+    estimate[1, :] = 0
+    target[1, :] = 0
+    assert float(oloss.log_mae(estimate, target)) == pytest.approx(-0.5980, abs=5e-5)
+    k = golden("kat_loss")
+    assert float(k["logmae"]) == pytest.approx(-0.2995, abs=5e-5)
+    # BCE with the target already in VAD form (prepare_target is off the hot path)
+    torch.manual_seed(0)
+    tgt = torch.rand((2, 100, 257))
+    vad = (abs(tgt).sum(-1) / abs(tgt).sum(-1).amax(-1, keepdim=True) > 0.05).float()
+    est = ((abs(tgt) > 0.05).float() - 0.5) * 10
+    assert float(oloss.vad_sigmoid_bce(est, vad)) == pytest.approx(float(k["bce10"]), rel=1e-5)
+
+
+def test_vad2sep_broadcast(golden):
+    g = golden("vad2sep")
+    vad = _params(g, "vad.")
+    sep = _params(g, "sep.")
+    b = oloss.vad2sep_broadcast(vad, {k: v.shape for k, v in sep.items()})
+    for k in sep:
+        np.testing.assert_array_equal(b[k].numpy(), sep[k].numpy())
+    kw = dict(odim=9, combination="mul", ts_vad=4, random_speaker_order=False)
+    lv = onet.mask_estimator_forward(vad, T(g["xs"]), T(g["aux"]), output_resolution="t", **kw)
+    ls = onet.mask_estimator_forward(b, T(g["xs"]), T(g["aux"]), output_resolution="tf", **kw)
+    np.testing.assert_allclose(lv["logit"].numpy(), g["logit_vad"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ls["logit"].numpy(), g["logit_sep"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ls["logit"].numpy(), lv["logit"].numpy(), atol=1e-6)
+
+
+def test_dummy_reader(golden):
+    g = golden("dummy_reader")
+    ex = odata.dummy_example(1, sample_rate=64, aux_size=20)
+    np.testing.assert_array_equal(ex["observation"], g["obs"])
+    np.testing.assert_array_equal(ex["speaker_reverberation_early_ch0"], g["early"])
+    np.testing.assert_array_equal(ex["vad"], g["vad"])
+    np.testing.assert_array_equal(ex["auxInput"], g["aux"])
+    np.testing.assert_array_equal(odata.get_vad(71, 8), g["vad71"])
+    for i in range(2):
+        e = odata.dummy_example(i)
+        s = [e["observation"].astype(np.float64).sum(),
+             np.abs(e["speaker_reverberation_early_ch0"]).astype(np.float64).sum(),
+             e["auxInput"].sum()]
+        np.testing.assert_allclose(s, g[f"sum16_{i}"], rtol=1e-12)
+
+
+def test_end_to_end_known_answer():
+    # tssep/train/model.py:552-575: 114038 parameters, validate_LogMAE
+    # 0.74156505 / 0.744494, ||Input|| 58.8257, std 0.0960, max 1.
+    np.random.seed(0)
+    torch.manual_seed(0)
+    p = omodel.init_mask_estimator_params(idim=513, odim=513, units=10, projs=12,
+                                          combination="cat", aux_size=100)
+    assert sum(v.numel() for v in p.values()) == 114038
+    exs = [odata.dummy_example(s) for s in (0, 1)]
+    obs = T(np.stack([e["observation"] for e in exs]))
+    aux = T(np.stack([e["auxInput"] for e in exs]))
+    tgt = T(np.stack([e["speaker_reverberation_early_ch0"] for e in exs]))
+    cfg = dict(odim=513, combination="cat", ts_vad=False, output_resolution="tf")
+    o = omodel.forward_loss(p, obs, aux, tgt, cfg=cfg, mfcc=False, fast=True)
+    np.testing.assert_allclose(o["loss"].numpy(), [0.74156505, 0.744494], rtol=2e-5)
+    assert float(torch.norm(o["Input"])) == pytest.approx(58.8257, abs=2e-3)
+    assert float(torch.std(o["Input"])) == pytest.approx(0.0960, abs=5e-5)
+    assert float(o["Input"].abs().amax()) == 1.0
+
+
+def test_mfcc_restatement_properties():
+    # torchaudio is absent: parity unpinned.  Structural facts SURVEY App. A.2 records.
+    fb, dct = features.mfcc_tables(1024)
+    assert fb.shape == (513, 40) and dct.shape == (40, 40)
+    assert int((fb.sum(0) == 0).sum()) == 7          # f_max wraps to 15600 Hz > Nyquist
+    np.testing.assert_allclose((dct.t() @ dct).numpy(), np.eye(40), atol=1e-5)  # ortho
+    X = torch.randn(2, 6, 513, dtype=torch.complex64)
+    m3 = features.torch_mfcc(X, fb, dct)
+    assert m3.shape == (2, 6, 40)
+    # 3-D input: the top_db floor is taken over the whole batch (torchaudio quirk)
+    db = 10 * torch.log10(torch.clamp((abs(X) ** 2) @ fb, min=1e-10))
+    ref = torch.clamp(db, min=float(db.max()) - 80.0) @ dct
+    np.testing.assert_allclose(m3.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
