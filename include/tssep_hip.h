@@ -1,0 +1,246 @@
+/*
+ * tssep_hip.h -- C ABI of libtssep_hip.so: the MI355X (gfx950) kernels behind the
+ * TS-VAD / TS-SEP forward/backward hot path.
+ *
+ * The reference (merlresearch/tssep) has no FFI: every operation below replaces a
+ * PyTorch ATen call made from the reference's Python hot path.  Each entry point
+ * cites the reference call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - plain device pointers + explicit sizes/leading dimensions; no torch types
+ *   - the CALLER owns every buffer (inputs, outputs, workspace); nothing is
+ *     allocated, nothing global is mutated, no host synchronisation inside
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
+ *   - return value: 0 = ok, <0 = TSSEP_E_* (invalid shape / alignment / unsupported);
+ *     never throws across the boundary
+ *   - all floating point is IEEE fp32 (complex = interleaved re,im fp32)
+ *   - re-entrant across streams/devices; no internal locking
+ */
+#ifndef TSSEP_HIP_H
+#define TSSEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSSEP_OK 0
+#define TSSEP_E_SHAPE (-1)       /* a size is out of the supported range        */
+#define TSSEP_E_ALIGN (-2)       /* a pointer / leading dimension is misaligned */
+#define TSSEP_E_UNSUPPORTED (-3) /* valid request the kernels do not cover      */
+#define TSSEP_E_LAUNCH (-4)      /* hipLaunch reported an error                 */
+#define TSSEP_E_NULL (-5)        /* required pointer is NULL                    */
+
+/* Library identification: returns ABI version (bumped on any signature change). */
+int tssep_abi_version(void);
+/* Name of the code object target the library was built for ("gfx950"). */
+const char* tssep_arch(void);
+
+/* ------------------------------------------------------------------ probes ---
+ * Hardware self-checks used by tests: dump the lane<->element maps of the MFMA
+ * instructions the kernels rely on.  out: device float[...] (see probe.hip). */
+int tssep_probe_mfma(float* out_4x4, float* out_32x32, void* stream);
+
+/* ------------------------------------------------------------------- STFT ----
+ * paderbox-semantics STFT (fading + end padding + periodic window + rfft, no
+ * scaling).  Replaces fe.stft at tssep/train/model.py:503-504.
+ *   x      [rows, N]            real input (rows = B*C)
+ *   window [size]               analysis window
+ *   tw     [size/2 + size/4..]  twiddle table built by tssep_fft_twiddles
+ *   X      [rows, T, size/2+1]  complex64 out, T = tssep_stft_frames(N,...)
+ * size must be 1024 (the only FFT plan built so far) -> else TSSEP_E_UNSUPPORTED. */
+int64_t tssep_stft_frames(int64_t N, int size, int shift, int window_length,
+                          int pad, int fading);
+int tssep_fft_twiddles(int size, float* host_out /* HOST buffer, 2*(size/2 + size/2+1) floats */);
+int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size, int shift,
+                   int fading, const float* window, const float* tw,
+                   float* X, int64_t T, void* stream);
+
+/* Inverse STFT (irfft, biorthogonal synthesis window, overlap-add, un-fade,
+ * truncate).  Replaces fe.istft at tssep/train/model.py:661-664.
+ *   X [rows, T, F] complex64, wsyn [size], y [rows, N]
+ * Optional fused LogMAE partial sums (tssep/train/loss.py:244-247): with tgt [rows,N] and
+ * abs_partial [rows, tssep_istft_chunks(N)] non-NULL, abs_partial[row,c] = sum over the
+ * chunk's samples of |y - tgt| (summed in a fixed order -> deterministic). */
+int64_t tssep_istft_chunks(int64_t N);
+int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size, int shift,
+                    int fading, const float* wsyn, const float* tw,
+                    float* y, int64_t N, const float* tgt, float* abs_partial, void* stream);
+/* Adjoint of tssep_istft_fwd: dy [rows,N] -> dX [rows,T,F] complex64
+ * (torch convention: dRe + i dIm). */
+int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int size, int shift,
+                    int fading, const float* wsyn, const float* tw,
+                    float* dX, int64_t T, void* stream);
+
+/* --------------------------------------------------------------- features ----
+ * ConcaternatedSTFTFeatures(TorchMFCC, Log1pMaxNormAbsSTFT).stft_to_feature
+ * (tssep/train/feature_extractor.py:352-360, feature_extractor_torchaudio.py:93-106,
+ * feature_extractor.py:233-248).
+ *   X     [B, T, F] complex64 (reference channel already selected)
+ *   fb    [F, n_mels], dct [n_mels, n_mfcc]    (fp32, row major)
+ *   out   [B, T, ld_out] : cols [0,n_mfcc) = MFCC, [n_mfcc, n_mfcc+F) = log1p feature
+ *   ws    workspace, tssep_feat_workspace_bytes(B,T,n_mels) bytes
+ * n_mfcc == 0 skips the MFCC block (plain Log1pMaxNormAbsSTFT).
+ * The dB floor (top_db) is taken over the WHOLE batch, as torchaudio's
+ * AmplitudeToDB does for the 3-D input the reference passes. */
+int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels);
+int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F,
+                   const float* fb, const float* dct, int n_mels, int n_mfcc,
+                   float top_db, float* out, int64_t ld_out, void* ws, void* stream);
+
+/* ------------------------------------------------------------------- GEMM ----
+ * Exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32): C = epilogue(A x B).
+ * Replaces nn.Linear / the LSTM input GEMM (tssep/train/rnnp.py:88-96,146-161,
+ * tssep/train/net.py:663-666) and their autograd backward GEMMs.
+ *   op A: a_kmajor=0 -> A(m,k)=A[m*lda+k]   ; a_kmajor=1 -> A(m,k)=A[k*lda+m]
+ *   op B: b_kmajor=0 -> B(k,n)=B[n*ldb+k]   ; b_kmajor=1 -> B(k,n)=B[k*ldb+n]
+ *   (kmajor=0 is the "row x row" form y = x W^T; kmajor=1 reads the transposed
+ *    operand in place, used by dgrad / wgrad)
+ * see struct for the fused prologue / epilogue options. */
+typedef struct tssep_gemm_args {
+  const float* A; const float* B; float* C;
+  int64_t M, N, K;
+  int64_t lda, ldb, ldc;          /* lda, ldb multiples of 4; A, B 16-byte aligned */
+  int32_t a_kmajor, b_kmajor;     /* (1,0) is not built */
+  /* time shift on the reduction index of a k-major B (wgrad of W_hh pairs dgates_t with
+   * h_{t-1}): B row k is read at k+b_kshift and taken as 0 when (k % kperiod)+b_kshift
+   * falls outside [0,kperiod).  kperiod = 0 disables. */
+  int64_t b_kshift, kperiod;
+  /* epilogue */
+  const float* bias;              /* [N] added to every row; NULL = off */
+  int32_t act;                    /* 0 none, 1 tanh (Tanh between post-net layers, net.py:623-625) */
+  int32_t accumulate;             /* C += result */
+  /* output remap (c_remap != 0): row m = (b*c_K + k)*c_T + t and column n = q*c_cm + r are
+   * stored at C[b*c_sb + k*c_sk + t*c_st + q'*c_co + r], q' = c_perm ? c_perm[b*c_perm_ld+q] : q.
+   * Covers 'spk time feature -> 1 time (spk feature)' (net.py:608-611) and
+   * '1 time (spk mask freq) -> spk mask time freq' + the speaker un-permutation
+   * (net.py:637-641, 957-967) inside the producing GEMM's store. */
+  int32_t c_remap;
+  int64_t c_T, c_K, c_sb, c_sk, c_st, c_cm, c_co;
+  const int32_t* c_perm; int64_t c_perm_ld;
+  /* split-K: gridDim.z = splitk partial products are written to C + z*c_split_stride
+   * (no bias/act/remap); the caller reduces them.  <=1 = single pass. */
+  int32_t splitk; int64_t c_split_stride;
+} tssep_gemm_args;
+int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
+
+/* column sums: out[n] (+)= sum_m A[m*lda+n]  (bias gradients) */
+int tssep_colsum_f32(const float* A, int64_t M, int64_t N, int64_t lda, float* out,
+                     int accumulate, void* ws, void* stream);
+int64_t tssep_colsum_workspace_bytes(int64_t M, int64_t N);
+
+/* ------------------------------------------------------------------ BLSTM ----
+ * One bidirectional LSTM layer, zero initial state (torch.nn.LSTM as used at
+ * tssep/train/rnnp.py:88-95,146-153).  The input projection x W_ih^T + b is done by
+ * tssep_gemm_f32 into `gates`; these kernels run the T-sequential recurrence.
+ *
+ * Packed layouts (built by tssep_lstm_pack from torch-layout parameters):
+ *   gate columns are ordered [dir][unit][gate(i,f,g,o)]  (4H per direction)
+ *   wih_p  [2*4H, ld_i]   rows permuted to that order, K zero-padded to ld_i
+ *   bias_p [2*4H]         b_ih + b_hh, permuted
+ *   whh_f / whh_b         streaming layouts for the forward / backward recurrence
+ * sizes in floats: tssep_lstm_pack_sizes(). */
+typedef struct tssep_lstm_sizes {
+  int64_t wih_p, bias_p, whh_f, whh_b;   /* floats */
+} tssep_lstm_sizes;
+int tssep_lstm_pack_sizes(int H, int I, int64_t ld_i, tssep_lstm_sizes* out);
+/* torch-layout parameters of both directions (suffix _f = forward, _r = "_reverse"):
+ * w_ih [4H,I], w_hh [4H,H], b_ih [4H], b_hh [4H]  (gate-major rows i,f,g,o). */
+int tssep_lstm_pack(const float* w_ih_f, const float* w_hh_f, const float* b_ih_f,
+                    const float* b_hh_f, const float* w_ih_r, const float* w_hh_r,
+                    const float* b_ih_r, const float* b_hh_r, int H, int I, int64_t ld_i,
+                    float* wih_p, float* bias_p, float* whh_f, float* whh_b, void* stream);
+/* gates [N,T,2,H,4]: in = pre-activations from the input GEMM; out = activated gates
+ * (kept for backward).  cell [N,T,2,H]; hout [N,T,ldo] (cols d*dstride+u).  H <= 320. */
+int tssep_blstm_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+                    const float* whh_f, int64_t N, int64_t T, int H, void* stream);
+/* dhout [N,T,ldo] -> gates is overwritten with d(pre-activation) in the same layout. */
+int tssep_blstm_bwd(float* gates, const float* cell, const float* dhout, int64_t ldo,
+                    int64_t dstride, const float* whh_b, int64_t N, int64_t T, int H, void* stream);
+/* gradient unpack + split-K reduction: a matrix with packed (dir,unit,gate) rows back to
+ * torch's gate-major rows:
+ *   dst_d[(g*H + u)*ncols + k] = sum_{s<nsplit} src[s*split_stride + (d*4H + 4u + g)*ld + k] */
+int tssep_lstm_unpack(const float* src, int64_t ld, int nsplit, int64_t split_stride,
+                      int H, int ncols, float* dst_f, float* dst_r, void* stream);
+
+/* ---------------------------------------------------------- elementwise ------*/
+/* d(pre-tanh) = dy * (1 - y^2) for the Tanh between post-net layers (tssep/train/net.py:623-625).
+ * dz rows are (b,k,t) x P; combined_in != 0: dy and y live in the speaker-combined layout
+ * [B,T,K*P] of 'spk time feature -> 1 time (spk feature)' (net.py:608-611). */
+int tssep_tanh_bwd(const float* dy, const float* y, float* dz, int64_t rows, int64_t P,
+                   int64_t K, int64_t T, int combined_in, void* stream);
+/* Speaker conditioning (tssep/train/net.py:862-896) fused with the permutation-trial fold
+ * (net.py:913-924): xs rows are (b, trial, k, t); trial tr holds speaker (k+tr)%K at position k.
+ *   mul: xs[row, f] = pre[(b,t), f] * aux[(b,spk), f]
+ *   cat: xs[row, :] = [pre[(b,t), :F] | aux[(b,spk), :E]]
+ * bwd: dpre[(b,t), f] = sum over (trial,k) rows (aux has no gradient: aux_net is None). */
+int tssep_cond_mul_fwd(const float* pre, int64_t ld_pre, const float* aux, int64_t ld_aux,
+                       float* xs, int64_t ld_xs, int64_t B, int64_t K, int64_t T, int F,
+                       int trials, void* stream);
+int tssep_cond_mul_bwd(const float* dxs, int64_t ld_dxs, const float* aux, int64_t ld_aux,
+                       float* dpre, int64_t ld_dpre, int64_t B, int64_t K, int64_t T, int F,
+                       int trials, void* stream);
+int tssep_cond_cat_fwd(const float* pre, int64_t ld_pre, const float* aux, int64_t ld_aux,
+                       float* xs, int64_t ld_xs, int64_t B, int64_t K, int64_t T, int F, int E,
+                       int trials, void* stream);
+int tssep_cond_cat_bwd(const float* dxs, int64_t ld_dxs, float* dpre, int64_t ld_dpre,
+                       int64_t B, int64_t K, int64_t T, int F, int trials, void* stream);
+
+/* -------------------------------------------------------------- mask head ----
+ * mask = sigmoid(logit); est = Obs * mask   (tssep/train/net.py:981-986 +
+ * tssep/train/enhancer.py:98-100).   logit/mask [B,K,T,F] fp32, obs [B,T,F] c64,
+ * est [B,K,T,F] c64.  Algorithmic HBM bytes per (b,t): 16*K*F + 8*F. */
+int tssep_maskhead_fwd(const float* logit, const float* obs, float* mask, float* est,
+                       int64_t B, int64_t K, int64_t T, int F, void* stream);
+/* dlogit = (Re(conj(obs) * dest) + dmask) * m * (1 - m); dmask may be NULL. */
+int tssep_maskhead_bwd(const float* dest, const float* dmask, const float* mask,
+                       const float* obs, float* dlogit,
+                       int64_t B, int64_t K, int64_t T, int F, void* stream);
+
+/* ------------------------------------------------------------------ losses ---
+ * LogMAE (tssep/train/loss.py:244-247): loss[b] = log10(sum_k mean_n |est-tgt|).
+ * Deterministic two-stage reduction; `sums[b]` (the argument of the log) is kept for bwd.
+ * tssep_logmae_finalize consumes the partial sums tssep_istft_fwd can emit
+ * (partial [B*K, nchunks]).  bwd: dest = gout[b] * sign(est-tgt) / (N ln10 sums[b]). */
+int64_t tssep_logmae_chunks(int64_t N);
+int64_t tssep_logmae_workspace_bytes(int64_t B, int64_t K, int64_t N);
+int tssep_logmae_fwd(const float* est, const float* tgt, int64_t B, int64_t K, int64_t N,
+                     float* loss, float* sums, void* ws, void* stream);
+int tssep_logmae_finalize(const float* partial, int64_t B, int64_t K, int64_t nchunks, int64_t N,
+                          float* loss, float* sums, void* stream);
+int tssep_logmae_bwd(const float* est, const float* tgt, const float* sums, const float* gout,
+                     int64_t B, int64_t K, int64_t N, float* dest, void* stream);
+/* VADSigmoidBCE with target 'Vad' (tssep/train/loss.py:329-345,302-310):
+ * x = mean_f logit[b,k,t,:]; loss[b] = mean_{k,t} BCEWithLogits(x, vad).
+ * xmean [B,K,T] is kept for bwd; ws: tssep_vadbce_workspace_bytes.
+ * bwd writes dlogit[b,k,t,f] = gout[b]*(sigmoid(x)-y)/(K*T*F). */
+int64_t tssep_vadbce_workspace_bytes(int64_t B, int64_t K, int64_t T);
+int tssep_vadbce_fwd(const float* logit, const float* vad, int64_t B, int64_t K, int64_t T, int F,
+                     float* loss, float* xmean, void* ws, void* stream);
+int tssep_vadbce_bwd(const float* xmean, const float* vad, const float* gout,
+                     int64_t B, int64_t K, int64_t T, int F, float* dlogit, void* stream);
+
+/* -------------------------------------------------------- logit layout map ---
+ * Tail of MaskEstimator_v2.forward: final einops rearrange / reduce-repeat
+ * (tssep/train/net.py:631-659), mean over permutation trials (net.py:928-951) and the speaker
+ * un-permutation (net.py:957-967):  raw GEMM output -> out [B,K,T,F].
+ *   spk_rows = 0: raw[((b*trials+tr)*T + t) * (K*Fr) + k*Fr + fr]   (ts_vad combination layer)
+ *   spk_rows = 1: raw[((b*K + k)*T + t) * Fr + fr]                   (ts_vad off, trials == 1)
+ *   Fr = F ('tf') or 1 ('t': the value is repeated over frequency).
+ * perm[b,s] = output index of speaker s, iperm its inverse (both NULL = identity). */
+int tssep_logit_map_fwd(const float* raw, const int32_t* perm, const int32_t* iperm, int64_t B,
+                        int trials, int64_t K, int64_t T, int F, int Fr, int spk_rows,
+                        float* out, void* stream);
+int tssep_logit_map_bwd(const float* dout, const int32_t* perm, const int32_t* iperm, int64_t B,
+                        int trials, int64_t K, int64_t T, int F, int Fr, int spk_rows,
+                        float* draw, void* stream);
+
+/* split-K / slab reduction: dst[i] (+)= sum_{s<nsplit} src[s*stride + i] */
+int tssep_reduce_splits(const float* src, int nsplit, int64_t stride, int64_t count, float* dst,
+                        int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSSEP_HIP_H */

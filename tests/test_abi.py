@@ -1,0 +1,50 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports exactly the symbols
+include/tssep_hip.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+import subprocess
+
+from tssep_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_build_and_symbols():
+    import __graft_entry__ as g
+    g.build()
+    protos = _lib.parse_header()
+    assert len(protos) >= 30
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True,
+                         text=True, check=True).stdout
+    exported = set(re.findall(r" T (tssep_\w+)", out))
+    assert exported == set(protos), (exported ^ set(protos))
+    L = _lib.lib()
+    assert L.tssep_abi_version() == 1
+    assert L.tssep_arch() == b"gfx950"
+
+
+def test_host_side_helpers_match_oracle():
+    from oracle import stft as ostft
+    L = _lib.lib()
+    for n in (160, 1000, 10_000, 64_000, 80_000, 480_000):
+        assert L.tssep_stft_frames(n, 1024, 256, 1024, 1, 1) == ostft.num_frames(n)
+    assert L.tssep_stft_frames(80_000, 1024, 256, 1024, 1, 1) == 316   # tssep/train/model.py:480
+
+
+def test_header_is_plain_c():
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "tssep_hip.h")],
+                   check=True)
+
+
+def test_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "o.c"
+    fields = [f for f, _ in _lib.GemmArgs._fields_]
+    body = "".join(f'printf("%zu\\n", offsetof(tssep_gemm_args, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tssep_hip.h"\n'
+                   f'int main(){{{body}printf("%zu\\n", sizeof(tssep_gemm_args));return 0;}}')
+    exe = tmp_path / "o"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    import ctypes
+    assert vals[:-1] == [getattr(_lib.GemmArgs, f).offset for f in fields]
+    assert vals[-1] == ctypes.sizeof(_lib.GemmArgs)

@@ -1,0 +1,382 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against the CPU oracle
+(oracle/*, pinned to the reference by tests/test_oracle.py) on the same seeded inputs.
+Tolerances: fp32 path, 1e-3 relative is the north-star bar; kernels are held to ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import features as ofeat, loss as oloss, rnnp as ornnp, stft as ostft  # noqa: E402
+
+
+def H():
+    from tssep_amd import hip_ops
+    return hip_ops
+
+
+def close(got, want, rtol=1e-5, atol=1e-6, name=""):
+    got = got.detach().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(got)
+    want = want.detach().cpu() if isinstance(want, torch.Tensor) else torch.as_tensor(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if got.is_complex():
+        got, want = torch.view_as_real(got), torch.view_as_real(want)
+    err = (got.double() - want.double()).abs()
+    tol = atol + rtol * want.double().abs()
+    bad = err > tol
+    assert not bool(bad.any()), (
+        f"{name}: {int(bad.sum())}/{bad.numel()} off; max abs err {float(err.max()):.3e} "
+        f"at {np.unravel_index(int(err.argmax()), err.shape)}; ref scale {float(want.abs().max()):.3e}")
+
+
+def test_library_loaded_and_arch():
+    from tssep_amd import _lib
+    L = _lib.lib()
+    assert L.tssep_arch() == b"gfx950"
+    assert torch.cuda.is_available()
+
+
+def test_mfma_lane_maps():
+    """The kernels assume: 4x4x1_16b: A lane = 4*blk+i, B lane = 4*blk+j, D[reg=i][lane=4*blk+j];
+    32x32x2: A lane = i+32k, B lane = j+32k, D lane = j+32*((i/4)%2), reg = (i%4)+4*(i/8)."""
+    o4, o32 = H().probe_mfma()
+    for lane in range(64):
+        blk, j = lane // 4, lane % 4
+        for i in range(4):
+            assert float(o4[lane, i]) == float((1 + 4 * blk + i) * (101 + 4 * blk + j)), (lane, i)
+    for half in range(2):
+        for lane in range(64):
+            j = lane % 32
+            for e in range(16):
+                i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+                want = (i + 1) * ((100 if half == 0 else 200) + j)
+                assert float(o32[half, lane, e]) == float(want), (half, lane, e)
+
+
+@pytest.mark.parametrize("B,K,T,F", [(2, 4, 7, 513), (1, 3, 5, 9), (3, 8, 11, 513)])
+def test_maskhead(B, K, T, F):
+    torch.manual_seed(0)
+    logit = torch.randn(B, K, T, F) * 3
+    obs = torch.randn(B, T, F, dtype=torch.complex64)
+    dest = torch.randn(B, K, T, F, dtype=torch.complex64)
+    dmask = torch.randn(B, K, T, F)
+    lg = logit.clone().requires_grad_()
+    m_ref = torch.sigmoid(lg)
+    e_ref = obs[:, None] * m_ref
+    (torch.view_as_real(e_ref) * torch.view_as_real(dest)).sum().backward(retain_graph=True)
+    g1 = lg.grad.clone()
+    lg.grad = None
+    ((torch.view_as_real(e_ref) * torch.view_as_real(dest)).sum() + (m_ref * dmask).sum()).backward()
+    g2 = lg.grad.clone()
+    h = H()
+    mask, est = h.maskhead_fwd(logit.cuda(), obs.cuda())
+    close(mask, m_ref, name="mask")
+    close(est, e_ref, name="est")
+    close(h.maskhead_bwd(dest.cuda(), None, mask, obs.cuda()), g1, rtol=1e-4, name="dlogit")
+    close(h.maskhead_bwd(dest.cuda(), dmask.cuda(), mask, obs.cuda()), g2, rtol=1e-4, name="dlogit+dmask")
+
+
+GEMM_SHAPES = [(130, 70, 37), (257, 300, 553), (64, 129, 16), (1000, 2400, 513), (5, 3, 2)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_bias_tanh(M, N, K):
+    torch.manual_seed(1)
+    h = H()
+    ru = h.round_up
+    A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+    W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+    bias = torch.randn(N)
+    Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+    C = torch.full((M, N), float("nan"), device="cuda")
+    h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd)
+    ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+    close(C, ref, rtol=2e-5, atol=2e-5, name="nt+bias")
+    h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
+    close(C, torch.tanh(ref), rtol=2e-5, atol=2e-5, name="nt+bias+tanh")
+    C0 = torch.randn(M, N)
+    C = C0.cuda()
+    h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, accumulate=True)
+    close(C, C0 + ref - bias, rtol=2e-5, atol=3e-5, name="nt accumulate")
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nn_and_tn(M, N, K):
+    torch.manual_seed(2)
+    h = H()
+    ru = h.round_up
+    # NN: dX[M,N] = dY[M,K] @ W[K,N]   (W row-major [K, N], read k-major)
+    dY = torch.zeros(M, ru(K, 4)); dY[:, :K] = torch.randn(M, K)
+    W = torch.zeros(K, ru(N, 4)); W[:, :N] = torch.randn(K, N) / K ** 0.5
+    C = torch.full((M, N), float("nan"), device="cuda")
+    h.gemm(dY.cuda(), dY.shape[1], W.cuda(), W.shape[1], C, N, M, N, K, b_kmajor=True)
+    close(C, (dY[:, :K].double() @ W[:, :N].double()).float(), rtol=2e-5, atol=2e-5, name="nn")
+    # TN: dW[M,N] = P[K,M]^T @ Q[K,N], split-K partials then reduce
+    P = torch.zeros(K, ru(M, 4)); P[:, :M] = torch.randn(K, M) / K ** 0.5
+    Q = torch.zeros(K, ru(N, 4)); Q[:, :N] = torch.randn(K, N)
+    part, S = h.wgrad(P.cuda(), P.shape[1], Q.cuda(), Q.shape[1], M, N, K)
+    out = torch.empty(M * N, device="cuda")
+    h.reduce_splits(part, S, M * N, out)
+    close(out.view(M, N), (P[:, :M].double().t() @ Q[:, :N].double()).float(), rtol=2e-5,
+          atol=2e-5, name=f"tn splitk={S}")
+
+
+def test_gemm_tn_time_shift():
+    """dW_hh pairs dgates_t with h_{t-1} (shift -1) / h_{t+1} (shift +1) inside sequences of T."""
+    torch.manual_seed(3)
+    h = H()
+    n, T, Mg, Hh = 5, 7, 24, 12
+    dg = torch.randn(n * T, Mg)
+    hh = torch.randn(n * T, Hh)
+    for shift in (-1, 1):
+        hs = torch.zeros(n, T, Hh)
+        if shift == -1:
+            hs[:, 1:] = hh.view(n, T, Hh)[:, :-1]
+        else:
+            hs[:, :-1] = hh.view(n, T, Hh)[:, 1:]
+        ref = dg.double().t() @ hs.view(n * T, Hh).double()
+        part, S = h.wgrad(dg.cuda(), Mg, hh.cuda(), Hh, Mg, Hh, n * T, b_kshift=shift, kperiod=T)
+        out = torch.empty(Mg * Hh, device="cuda")
+        h.reduce_splits(part, S, Mg * Hh, out)
+        close(out.view(Mg, Hh), ref.float(), rtol=2e-5, atol=2e-5, name=f"shift {shift}")
+
+
+def test_gemm_store_remaps():
+    torch.manual_seed(4)
+    h = H()
+    B, K, T, P, F = 2, 3, 5, 8, 9
+    # (1) rows (b,k,t) x P -> combined [B,T,K*P]   (net.py:608-611)
+    A = torch.randn(B * K * T, 12); W = torch.randn(P, 12); bias = torch.randn(P)
+    C = torch.full((B, T, K * P), float("nan"), device="cuda")
+    h.gemm(A.cuda(), 12, W.cuda(), 12, C, 0, B * K * T, P, 12, bias=bias.cuda(), act=1,
+           remap=dict(T=T, K=K, sb=T * K * P, sk=P, st=K * P))
+    ref = torch.tanh(A @ W.t() + bias).view(B, K, T, P).permute(0, 2, 1, 3).reshape(B, T, K * P)
+    close(C, ref, rtol=2e-5, atol=2e-5, name="combine")
+    # (2) rows (b,t) x (k,f) -> [B, perm[k], T, F]   (net.py:637-641, 957-967)
+    A = torch.randn(B * T, 12); W = torch.randn(K * F, 12); bias = torch.randn(K * F)
+    perm = torch.stack([torch.randperm(K) for _ in range(B)]).int()
+    C = torch.full((B, K, T, F), float("nan"), device="cuda")
+    h.gemm(A.cuda(), 12, W.cuda(), 12, C, 0, B * T, K * F, 12, bias=bias.cuda(),
+           remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm.cuda(), perm_ld=K))
+    raw = (A @ W.t() + bias).view(B, T, K, F).permute(0, 2, 1, 3)       # [B,K,T,F] by position
+    ref = torch.empty(B, K, T, F)
+    for b in range(B):
+        for k in range(K):
+            ref[b, perm[b, k]] = raw[b, k]
+    close(C, ref, rtol=2e-5, atol=2e-5, name="logit remap")
+
+
+@pytest.mark.parametrize("rows,N", [(3, 4000), (2, 64000), (1, 1023)])
+def test_stft_istft(rows, N):
+    torch.manual_seed(5)
+    h = H()
+    x = torch.randn(rows, N)
+    win = torch.as_tensor(ostft.analysis_window("hann", 1024), dtype=torch.float32)
+    wsyn = torch.as_tensor(ostft.synthesis_window("hann", 1024, 256), dtype=torch.float32)
+    Xref = ostft.stft(x)
+    X = h.stft_fwd(x.cuda(), win.cuda())
+    assert X.shape == Xref.shape
+    close(X, Xref, rtol=1e-4, atol=2e-4 * float(Xref.abs().max()) / 50, name="stft")
+    Y = torch.randn(rows, Xref.shape[1], 513, dtype=torch.complex64)
+    tgt = torch.randn(rows, N)
+    yref = ostft.istft(Y, num_samples=N)
+    y, part = h.istft_fwd(Y.cuda(), wsyn.cuda(), N, tgt=tgt.cuda())
+    close(y, yref, rtol=1e-4, atol=2e-5, name="istft")
+    close(part.sum(-1), (yref - tgt).abs().sum(-1), rtol=1e-4, name="abs partials")
+    # adjoint == autograd of the oracle
+    Yg = Y.clone().requires_grad_()
+    dy = torch.randn(rows, N)
+    (ostft.istft(Yg, num_samples=N) * dy).sum().backward()
+    dX = h.istft_bwd(dy.cuda(), wsyn.cuda(), Xref.shape[1])
+    close(dX, Yg.grad, rtol=1e-4, atol=2e-6, name="istft_bwd")
+    # round trip at full size through the HIP path only
+    xr, _ = h.istft_fwd(X, wsyn.cuda(), N)
+    close(xr, x, rtol=1e-4, atol=2e-5, name="round trip")
+
+
+@pytest.mark.parametrize("B,T,mfcc", [(2, 9, True), (3, 30, True), (2, 9, False)])
+def test_features(B, T, mfcc):
+    torch.manual_seed(6)
+    h = H()
+    X = torch.randn(B, T, 513, dtype=torch.complex64) * torch.rand(B, 1, 1) * 10
+    X[0, 0, :5] = 0                                   # exercises the 1e-10 clamp / dB floor
+    fb, dct = ofeat.mfcc_tables(1024)
+    out, ld = h.feat_fwd(X.cuda(), fb.cuda(), dct.cuda(), 40 if mfcc else 0)
+    ref = ofeat.concat_features(X, fb, dct) if mfcc else ofeat.log1p_max_norm_abs(X)
+    if mfcc:
+        close(out[..., :40], ref[..., :40], rtol=1e-4, atol=2e-3, name="mfcc")  # dB scale ~1e2
+        close(out[..., 40:], ref[..., 40:], rtol=1e-5, atol=1e-6, name="log1p")
+    else:
+        close(out, ref, rtol=1e-5, atol=1e-6, name="log1p only")
+
+
+def _lstm_case(N, T, I, Hh, seed):
+    torch.manual_seed(seed)
+    lstm = torch.nn.LSTM(I, Hh, bidirectional=True, batch_first=True)
+    p = {k: v.detach().clone() for k, v in lstm.named_parameters()}
+    x = torch.randn(N, T, I)
+    return p, x
+
+
+@pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 5), (8, 9, 20, 40), (11, 5, 33, 300), (16, 12, 64, 64),
+                                      (2, 4, 9, 130)])
+def test_blstm_forward_backward(N, T, I, Hh):
+    h = H()
+    p, x = _lstm_case(N, T, I, Hh, 7)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    Hp = h.round_up(Hh, 4)
+    cell = torch.empty(N, T, 2, Hh, device="cuda")
+    hout = torch.zeros(N, T, 2 * Hp, device="cuda")
+    h.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+    # oracle
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    xr = x.clone().requires_grad_()
+    ref = ornnp.blstm(xr, pr, "")
+    got = torch.cat([hout[..., :Hh], hout[..., Hp:Hp + Hh]], -1)
+    close(got, ref, rtol=1e-4, atol=2e-6, name="blstm fwd")
+    # backward
+    dh = torch.randn(N, T, 2 * Hh)
+    (ref * dh).sum().backward()
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = dh[..., :Hh].cuda(); dhd[..., Hp:Hp + Hh] = dh[..., Hh:].cuda()
+    h.blstm_bwd(gates, cell, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)       # gates -> dGx
+    R = N * T
+    # dx
+    dx = torch.empty(R, I, device="cuda")
+    h.gemm(gates, 8 * Hh, pk["wih_p"], pk["ld_i"], dx, I, R, I, 8 * Hh, b_kmajor=True)
+    close(dx.view(N, T, I), xr.grad, rtol=2e-4, atol=2e-6, name="dx")
+    # dW_ih
+    part, S = h.wgrad(gates, 8 * Hh, xd, ld_x, 8 * Hh, I, R)
+    dwf = torch.empty(4 * Hh, I, device="cuda"); dwr = torch.empty(4 * Hh, I, device="cuda")
+    h.lstm_unpack(part, I, S, 8 * Hh * I, Hh, I, dwf, dwr)
+    close(dwf, pr["weight_ih_l0"].grad, rtol=2e-4, atol=5e-6, name="dW_ih")
+    close(dwr, pr["weight_ih_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="dW_ih_reverse")
+    # dW_hh (time shifted)
+    dwhh = torch.empty(2, 4 * Hh * Hh, device="cuda")
+    parts = []
+    for d in range(2):
+        part, S = h.wgrad((gates, d * 4 * Hh), 8 * Hh, (hout, d * Hp), 2 * Hp, 4 * Hh, Hh, R,
+                          b_kshift=(-1 if d == 0 else 1), kperiod=T)
+        h.reduce_splits(part, S, 4 * Hh * Hh, dwhh[d])
+    df = torch.empty(4 * Hh, Hh, device="cuda"); dr = torch.empty(4 * Hh, Hh, device="cuda")
+    h.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, df, dr)
+    close(df, pr["weight_hh_l0"].grad, rtol=2e-4, atol=5e-6, name="dW_hh")
+    close(dr, pr["weight_hh_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="dW_hh_reverse")
+    # bias
+    cs = h.colsum(gates, 8 * Hh, R, 8 * Hh)
+    bf = torch.empty(4 * Hh, device="cuda"); br = torch.empty(4 * Hh, device="cuda")
+    h.lstm_unpack(cs, 1, 1, 0, Hh, 1, bf, br)
+    close(bf, pr["bias_ih_l0"].grad, rtol=2e-4, atol=5e-6, name="db")
+    close(br, pr["bias_hh_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="db_reverse")
+
+
+def test_conditioning_tanh_colsum():
+    torch.manual_seed(8)
+    h = H()
+    B, K, T, F, E, trials = 2, 4, 5, 9, 6, 2
+    pre = torch.randn(B * T, 12)[:, :F].contiguous()
+    pre_p = torch.zeros(B * T, 12); pre_p[:, :F] = pre
+    aux = torch.rand(B, K, F)
+    idx = ((np.arange(K)[:, None] + np.arange(K)[None, :]) % K)[:trials].ravel()
+    for comb, a in (("mul", aux), ("cat", torch.rand(B, K, E))):
+        xs, ld, info = h.cond_fwd(pre_p.cuda(), 12, a.cuda(), B, K, T, F, trials, comb)
+        p4 = pre.view(B, 1, T, F)
+        full = p4 * a[:, :, None] if comb == "mul" else torch.cat(
+            [p4.expand(B, K, T, F), a[:, :, None].expand(B, K, T, a.shape[-1])], -1)
+        ref = full[:, idx]                                  # [B, trials*K, T, W]
+        W = ref.shape[-1]
+        close(xs[:, :W].view(B, trials * K, T, W), ref, name=f"cond {comb}")
+        dxs = torch.randn(B * trials * K * T, ld)
+        dpre, ldp = h.cond_bwd(dxs.cuda(), ld, info, B, K, T, F, trials, comb)
+        d4 = dxs[:, :F].view(B, trials * K, T, F)
+        if comb == "mul":
+            dref = (d4 * a[:, idx][:, :, None]).sum(1)
+        else:
+            dref = d4.sum(1)
+        close(dpre[:, :F].view(B, T, F), dref, rtol=1e-5, atol=1e-5, name=f"cond bwd {comb}")
+    P = 8
+    y = torch.tanh(torch.randn(B * K * T, P)); dy = torch.randn(B * K * T, P)
+    close(h.tanh_bwd(dy.cuda(), y.cuda(), B * K * T, P, K, T, False), dy * (1 - y * y), name="tanh_bwd")
+    yc = y.view(B, K, T, P).permute(0, 2, 1, 3).contiguous(); dyc = dy.view(B, K, T, P).permute(0, 2, 1, 3).contiguous()
+    close(h.tanh_bwd(dyc.cuda(), yc.cuda(), B * K * T, P, K, T, True), dy * (1 - y * y), name="tanh_bwd combined")
+    A = torch.randn(1000, 52)
+    close(h.colsum(A.cuda(), 52, 1000, 50), A[:, :50].double().sum(0).float(), rtol=1e-5, atol=1e-4, name="colsum")
+
+
+@pytest.mark.parametrize("spk_rows,trials,Fr", [(0, 1, 9), (0, 2, 9), (0, 2, 1), (1, 1, 9), (1, 1, 1), (0, 1, 1)])
+def test_logit_map(spk_rows, trials, Fr):
+    torch.manual_seed(9)
+    h = H()
+    B, K, T, F = 2, 4, 5, 9
+    perm = np.stack([np.random.RandomState(i).permutation(K) for i in range(B)])
+    iperm = np.argsort(perm, -1)
+    if spk_rows:
+        raw = torch.randn(B, K, T, Fr)
+        pos = raw.expand(B, K, T, F) if Fr == 1 else raw                  # [B, K(pos), T, F]
+        pos = pos[:, None]
+    else:
+        raw = torch.randn(B, trials, T, K, Fr)
+        pos = raw.permute(0, 1, 3, 2, 4)                                  # [B, tr, K(pos), T, Fr]
+        pos = pos.expand(B, trials, K, T, F) if Fr == 1 else pos
+    # speaker s in trial tr sits at position (s - tr) % K; mean over trials; then out[perm[s]] = spk[s]
+    spk = torch.stack([torch.stack([pos[:, tr, (s - tr) % K] for tr in range(trials)], 0).mean(0)
+                       for s in range(K)], 1)                              # [B, K(s), T, F]
+    ref = torch.empty(B, K, T, F)
+    for b in range(B):
+        for s in range(K):
+            ref[b, perm[b, s]] = spk[b, s]
+    pd, ipd = torch.as_tensor(perm).int().cuda(), torch.as_tensor(iperm).int().cuda()
+    out = h.logit_map_fwd(raw.contiguous().cuda(), pd, ipd, B, trials, K, T, F, Fr, spk_rows)
+    close(out, ref, rtol=1e-6, atol=1e-6, name="map fwd")
+    # adjoint by <fwd(raw), g> == <raw, bwd(g)>
+    g = torch.randn(B, K, T, F)
+    draw = h.logit_map_bwd(g.cuda(), pd, ipd, B, trials, K, T, F, Fr, spk_rows).cpu()
+    rawg = raw.clone().requires_grad_()
+    # autograd through a torch restatement
+    if spk_rows:
+        pos = (rawg.expand(B, K, T, F) if Fr == 1 else rawg)[:, None]
+    else:
+        pos = rawg.permute(0, 1, 3, 2, 4)
+        pos = pos.expand(B, trials, K, T, F) if Fr == 1 else pos
+    spk = torch.stack([torch.stack([pos[:, tr, (s - tr) % K] for tr in range(trials)], 0).mean(0)
+                       for s in range(K)], 1)
+    tot = 0
+    for b in range(B):
+        for s in range(K):
+            tot = tot + (spk[b, s] * g[b, perm[b, s]]).sum()
+    tot.backward()
+    close(draw.view(rawg.shape), rawg.grad, rtol=1e-5, atol=1e-5, name="map bwd")
+
+
+def test_losses():
+    torch.manual_seed(10)
+    h = H()
+    B, K, N = 3, 4, 10000
+    tgt = torch.randn(B, K, N)
+    est = (tgt + 0.5 * torch.randn(B, K, N)).requires_grad_()
+    ref = oloss.log_mae(est, tgt)
+    gout = torch.randn(B)
+    (ref * gout).sum().backward()
+    loss, sums = h.logmae_fwd(est.detach().cuda(), tgt.cuda())
+    close(loss, ref, rtol=1e-5, atol=1e-6, name="logmae")
+    close(h.logmae_bwd(est.detach().cuda(), tgt.cuda(), sums, gout.cuda()), est.grad, rtol=1e-4,
+          atol=1e-9, name="logmae bwd")
+    # doctest known answers (tssep/train/loss.py:223-234)
+    torch.manual_seed(0)
+    t = torch.rand((2, 10000)); e = t + 0.5 * torch.rand((2, 10000))
+    l, _ = h.logmae_fwd(e[None].cuda(), t[None].cuda())
+    assert float(l) == pytest.approx(-0.2995, abs=5e-5)
+    T, F = 7, 513
+    logit = torch.randn(B, K, T, F).requires_grad_()
+    vad = (torch.rand(B, K, T) > 0.5).float()
+    ref = oloss.vad_sigmoid_bce(logit, vad)
+    (ref * gout).sum().backward()
+    loss, xmean = h.vadbce_fwd(logit.detach().cuda(), vad.cuda())
+    close(loss, ref, rtol=1e-5, atol=1e-6, name="bce")
+    close(h.vadbce_bwd(xmean, vad.cuda(), gout.cuda(), F), logit.grad, rtol=1e-4, atol=1e-9, name="bce bwd")

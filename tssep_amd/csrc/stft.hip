@@ -1,0 +1,309 @@
+// STFT / inverse STFT / adjoint of the inverse STFT with paderbox semantics, size 1024.
+//
+// Replaces fe.stft (tssep/train/model.py:503-504) and fe.istft (tssep/train/model.py:661-664;
+// third-party padertorch/paderbox code, restated in oracle/stft.py) and the autograd backward
+// of the latter.
+//
+// FFT plan: a 1024-point real FFT is a 512-point complex FFT of z[n] = x[2n] + i x[2n+1]
+// plus a butterfly pass.  The 512-point transform is a Stockham autosort radix-8 x 3
+// (Govindaraju et al. formulation): ONE WAVE per frame, 8 complex points per lane in
+// registers, three in-register 8-point DFTs, the two transposes in between through a
+// per-wave LDS line.  The line index is padded (i + i/8) so the stride-8 scatter of the
+// first stage is bank-conflict free for ds_write_b64.
+//
+// All three kernels are HBM/L2 streaming kernels in the roofline sense
+// (5 128 B per frame for the STFT, K x 5 128 B per frame for the inverse).
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int NH = 512;          // complex FFT length
+constexpr int LINE = NH + NH / 8;  // padded LDS line (float2)
+#define PADI(i) ((i) + ((i) >> 3))
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// in-register 8-point DFT (forward, exp(-2 pi i nk/8)), natural order in and out
+__device__ __forceinline__ void fft8(float2 (&v)[8]) {
+  const float h = 0.70710678118654752440f;
+  float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+  float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+  float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+  float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  a5 = make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x));   // * exp(-i pi/4)
+  a6 = mul_mi(a6);                                          // * (-i)
+  a7 = make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y));  // * exp(-3 i pi/4)
+  float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = mul_mi(csub(a1, a3));
+  float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = mul_mi(csub(a5, a7));
+  v[0] = cadd(b0, b1); v[4] = csub(b0, b1);
+  v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
+  v[1] = cadd(b4, b5); v[5] = csub(b4, b5);
+  v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
+}
+
+// 512-point forward FFT by one wave.  In: v[r] = z[lane + 64 r].  Out: buf[PADI(k)] = Z[k].
+// twl[k] = exp(-2 pi i k / 512) (LDS copy).  Every wave of the block must call it
+// (block-wide barriers keep the compiler from reordering the LDS hand-offs).
+__device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* buf, const float2* twl, int lane) {
+  fft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[PADI(8 * lane + r)] = v[r];
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[PADI(lane + 64 * r)];
+  __syncthreads();
+  {
+    const int k = lane & 7;
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twl[k * r * 8]);
+    fft8(v);
+    const int d = (lane >> 3) * 64 + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[PADI(d + 8 * r)] = v[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[PADI(lane + 64 * r)];
+  __syncthreads();
+#pragma unroll
+  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twl[lane * r]);
+  fft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[PADI(lane + 64 * r)] = v[r];
+  __syncthreads();
+}
+
+// frames -> rfft.  Used as the STFT (window = analysis window, scales 1) and as the adjoint of
+// the inverse STFT (window = synthesis window, interior bins x 2/1024, DC/Nyquist x 1/1024).
+// tw: [512] exp(-2 pi i k/512) followed by [513] exp(-2 pi i k/1024).
+__global__ __launch_bounds__(256) void rfft_frames_kernel(
+    const float* __restrict__ x, int64_t rows, int64_t N, int64_t T, int shift, int pad_left,
+    const float* __restrict__ window, const float2* __restrict__ tw, float2* __restrict__ X,
+    float s_in, float s_edge, int iters) {
+  __shared__ float2 twl[NH];
+  __shared__ float2 line[4][LINE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
+  __syncthreads();
+  const float2* tw2 = tw + NH;
+  const int64_t total = rows * T;
+  for (int it = 0; it < iters; ++it) {
+    const int64_t fidx = ((int64_t)blockIdx.x * iters + it) * 4 + wave;
+    const bool valid = fidx < total;
+    const int64_t row = valid ? fidx / T : 0;
+    const int64_t t = valid ? fidx - row * T : 0;
+    const int64_t base = t * shift - pad_left;
+    const float* xr = x + row * N;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n2 = 2 * (lane + 64 * r);
+      const int64_t i0 = base + n2;
+      const float a = (valid && i0 >= 0 && i0 < N) ? xr[i0] * window[n2] : 0.f;
+      const float b = (valid && i0 + 1 >= 0 && i0 + 1 < N) ? xr[i0 + 1] * window[n2 + 1] : 0.f;
+      v[r] = make_float2(a, b);
+    }
+    float2* buf = line[wave];
+    fft512_wave(v, buf, twl, lane);
+    if (valid) {
+      float2* Xo = X + fidx * (NH + 1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        const float2 zk = buf[PADI(k)];
+        const int km = (NH - k) & (NH - 1);
+        float2 zm = buf[PADI(km)];
+        zm.y = -zm.y;
+        const float2 u = cmul(tw2[k], csub(zk, zm));
+        float2 o = make_float2(0.5f * (zk.x + zm.x + u.y), 0.5f * (zk.y + zm.y - u.x));
+        if (k == 0) {
+          o.x *= s_edge; o.y = 0.f;
+        } else {
+          o.x *= s_in; o.y *= s_in;
+        }
+        Xo[k] = o;
+      }
+      if (lane == 0) {
+        const float2 z0 = buf[0];
+        Xo[NH] = make_float2((z0.x - z0.y) * s_edge, 0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// inverse STFT: per workgroup HC output hops of one row; (HC + 3) frames are inverse
+// transformed (4 waves, strided), windowed and parked in LDS, then every output sample
+// sums its <= 4 frame contributions in a fixed order (deterministic overlap-add).
+constexpr int HC = 9;
+constexpr int NFR = HC + 3;
+
+__global__ __launch_bounds__(256) void istft_kernel(
+    const float2* __restrict__ X, int64_t T, int shift_, int64_t N,
+    const float* __restrict__ wsyn, const float2* __restrict__ tw, float* __restrict__ y,
+    const float* __restrict__ tgt, float* __restrict__ abs_partial, int nchunks) {
+  __shared__ float2 twl[NH];
+  __shared__ float2 line[4][LINE];
+  __shared__ __attribute__((aligned(16))) float fr[NFR][1024];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t row = blockIdx.y;
+  const int c = blockIdx.x;
+  for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
+  __syncthreads();
+  const float2* tw2 = tw + NH;
+  const int64_t t_lo = (int64_t)c * HC;  // = h0 - 3 with h0 = 3 + c*HC
+  const float inv = 1.0f / 512.0f;
+  for (int it = 0; it < NFR / 4; ++it) {
+    const int lf = it * 4 + wave;
+    const int64_t t = t_lo + lf;
+    const bool valid = t < T;
+    float2 v[8];
+    if (valid) {
+      const float2* Xr = X + (row * T + t) * (NH + 1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        float2 xk = Xr[k];
+        float2 xm = Xr[NH - k];
+        xm.y = -xm.y;
+        if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
+        const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
+        float2 w = tw2[k];
+        w.y = -w.y;
+        const float2 o = cmul(make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y)), w);
+        // Zi = E + i O ; feed conj(Zi) to the forward FFT
+        v[r] = make_float2(e.x - o.y, -(e.y + o.x));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    }
+    float2* buf = line[wave];
+    fft512_wave(v, buf, twl, lane);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int n = lane + 64 * r;
+      const float2 z = buf[PADI(n)];
+      const float2 w = *reinterpret_cast<const float2*>(wsyn + 2 * n);
+      *reinterpret_cast<float2*>(&fr[lf][2 * n]) = make_float2(z.x * inv * w.x, -z.y * inv * w.y);
+    }
+    __syncthreads();
+  }
+  // overlap-add + un-fade + truncate
+  const int64_t n0 = (int64_t)c * HC * 256;
+  float* yr = y + row * N;
+  const float* tr = tgt ? tgt + row * N : nullptr;
+  float asum = 0.f;
+  for (int i = tid; i < HC * 256; i += 256) {
+    const int64_t n = n0 + i;
+    if (n < N) {
+      const int hop = i >> 8, off = i & 255;
+      float s = fr[hop][off + 768];
+      s += fr[hop + 1][off + 512];
+      s += fr[hop + 2][off + 256];
+      s += fr[hop + 3][off];
+      yr[n] = s;
+      if (tr) asum += fabsf(s - tr[n]);
+    }
+  }
+  if (abs_partial) {
+    asum = wave_sum(asum);
+    if (lane == 0) red[wave] = asum;
+    __syncthreads();
+    if (tid == 0) abs_partial[row * nchunks + c] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t tssep_stft_frames(int64_t N, int size, int shift, int window_length, int pad,
+                                     int fading) {
+  if (window_length <= 0) window_length = size;
+  int64_t n = N;
+  if (fading) n += 2 * (int64_t)(window_length - shift);
+  if (pad) {
+    int64_t num = n - window_length;
+    int64_t q = num <= 0 ? 0 : (num + shift - 1) / shift;
+    return q + 1;
+  }
+  return (n - window_length) / shift + 1;
+}
+
+extern "C" int tssep_fft_twiddles(int size, float* host_out) {
+  if (!host_out) return TSSEP_E_NULL;
+  if (size != 1024) return TSSEP_E_UNSUPPORTED;
+  const int nh = size / 2;
+  for (int k = 0; k < nh; ++k) {
+    const double a = -2.0 * M_PI * (double)k / (double)nh;
+    host_out[2 * k] = (float)cos(a);
+    host_out[2 * k + 1] = (float)sin(a);
+  }
+  for (int k = 0; k <= nh; ++k) {
+    const double a = -2.0 * M_PI * (double)k / (double)size;
+    host_out[2 * (nh + k)] = (float)cos(a);
+    host_out[2 * (nh + k) + 1] = (float)sin(a);
+  }
+  return TSSEP_OK;
+}
+
+static int check_plan(int size, int shift) {
+  if (size != 1024 || shift != 256) return TSSEP_E_UNSUPPORTED;
+  return TSSEP_OK;
+}
+
+extern "C" int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size, int shift,
+                              int fading, const float* window, const float* tw, float* X,
+                              int64_t T, void* stream) {
+  if (!x || !window || !tw || !X) return TSSEP_E_NULL;
+  if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  const int iters = 4;
+  const int64_t total = rows * T;
+  const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
+  hipLaunchKernelGGL(rfft_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     x, rows, N, T, shift, fading ? size - shift : 0, window, (const float2*)tw,
+                     (float2*)X, 1.0f, 1.0f, iters);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int size, int shift,
+                               int fading, const float* wsyn, const float* tw, float* dX,
+                               int64_t T, void* stream) {
+  if (!dy || !wsyn || !tw || !dX) return TSSEP_E_NULL;
+  if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if ((((uintptr_t)dX) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  const int iters = 4;
+  const int64_t total = rows * T;
+  const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
+  hipLaunchKernelGGL(rfft_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     dy, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
+                     (float2*)dX, 2.0f / (float)size, 1.0f / (float)size, iters);
+  return tssep_launch_status();
+}
+
+extern "C" int64_t tssep_istft_chunks(int64_t N) { return (N + HC * 256 - 1) / (HC * 256); }
+
+extern "C" int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size, int shift,
+                               int fading, const float* wsyn, const float* tw, float* y, int64_t N,
+                               const float* tgt, float* abs_partial, void* stream) {
+  if (!X || !wsyn || !tw || !y) return TSSEP_E_NULL;
+  if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if (!fading) return TSSEP_E_UNSUPPORTED;
+  if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
+  if (rows > 65535) return TSSEP_E_SHAPE;
+  const int nchunks = (int)tssep_istft_chunks(N);
+  hipLaunchKernelGGL(istft_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)X, T, shift, N, wsyn, (const float2*)tw, y,
+                     tgt, abs_partial, nchunks);
+  return tssep_launch_status();
+}

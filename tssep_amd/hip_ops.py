@@ -1,0 +1,377 @@
+"""Tensor-level wrappers over the C ABI (include/tssep_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every computation below
+is a call into libtssep_hip.so.  Nothing here falls back to ATen math.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, LstmSizes, check
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t):
+    assert t.is_cuda and t.dtype == torch.float32, (t.device, t.dtype)
+    return t
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def rows_view(t):
+    """Return (tensor, ld) of a 2-D-like fp32 tensor whose rows are 16-byte aligned.
+    Accepts [..., C] with unit inner stride and uniform row stride; copies into a padded
+    buffer otherwise (layout glue only)."""
+    _f32(t)
+    c = t.shape[-1]
+    t2 = t.reshape(-1, c) if t.is_contiguous() else t
+    if t2.dim() == 2 and t2.stride(1) == 1 and t2.stride(0) % 4 == 0 and t2.data_ptr() % 16 == 0 \
+            and (t2.shape[0] == 1 or t2.stride(0) >= c):
+        return t2, t2.stride(0)
+    ld = round_up(c, 4)
+    buf = torch.zeros(t.numel() // c, ld, device=t.device, dtype=torch.float32)
+    buf[:, :c] = t.reshape(-1, c)
+    return buf, ld
+
+
+def padded(rows, cols, device, zero=False):
+    """[rows, cols] view of a buffer with leading dimension round_up(cols, 4)."""
+    ld = round_up(cols, 4)
+    buf = (torch.zeros if zero or ld != cols else torch.empty)(rows, ld, device=device,
+                                                              dtype=torch.float32)
+    return buf, ld
+
+
+# ----------------------------------------------------------------------------- probes
+def probe_mfma():
+    L = _lib.lib()
+    o4 = torch.zeros(64, 4, device="cuda")
+    o32 = torch.zeros(2, 64, 16, device="cuda")
+    check(L.tssep_probe_mfma(_p(o4), _p(o32), _stream()), "probe_mfma")
+    return o4.cpu(), o32.cpu()
+
+
+# ------------------------------------------------------------------------------- STFT
+_TABLES = {}
+
+
+def fft_tables(size, device):
+    key = (size, str(device))
+    if key not in _TABLES:
+        L = _lib.lib()
+        n = 2 * (size // 2 + size // 2 + 1)
+        host = np.zeros(n, dtype=np.float32)
+        check(L.tssep_fft_twiddles(size, host.ctypes.data_as(ctypes.c_void_p)), "fft_twiddles")
+        _TABLES[key] = torch.from_numpy(host).to(device)
+    return _TABLES[key]
+
+
+def stft_frames(N, size=1024, shift=256, window_length=None, pad=True, fading=True):
+    return int(_lib.lib().tssep_stft_frames(N, size, shift, window_length or size, int(pad),
+                                            int(fading)))
+
+
+def stft_fwd(x, window, size=1024, shift=256, fading=True):
+    """x [rows, N] -> complex64 [rows, T, size//2+1]"""
+    L = _lib.lib()
+    x = _f32(x).contiguous()
+    rows, N = x.shape
+    T = stft_frames(N, size, shift, None, True, fading)
+    X = torch.empty(rows, T, size // 2 + 1, 2, device=x.device, dtype=torch.float32)
+    check(L.tssep_stft_fwd(_p(x), rows, N, size, shift, int(fading), _p(window),
+                           _p(fft_tables(size, x.device)), _p(X), T, _stream()), "stft_fwd")
+    return torch.view_as_complex(X)
+
+
+def istft_fwd(X, wsyn, N, size=1024, shift=256, fading=True, tgt=None):
+    """X complex64 [rows, T, F] -> y [rows, N] (+ per-chunk sums of |y - tgt| when tgt given)"""
+    L = _lib.lib()
+    Xr = torch.view_as_real(X.contiguous())
+    rows, T = X.shape[0], X.shape[1]
+    y = torch.empty(rows, N, device=X.device, dtype=torch.float32)
+    part = None
+    if tgt is not None:
+        nch = int(L.tssep_istft_chunks(N))
+        part = torch.empty(rows, nch, device=X.device, dtype=torch.float32)
+        tgt = _f32(tgt).contiguous()
+    check(L.tssep_istft_fwd(_p(Xr), rows, T, size, shift, int(fading), _p(wsyn),
+                            _p(fft_tables(size, X.device)), _p(y), N, _p(tgt), _p(part),
+                            _stream()), "istft_fwd")
+    return y, part
+
+
+def istft_bwd(dy, wsyn, T, size=1024, shift=256, fading=True):
+    L = _lib.lib()
+    dy = _f32(dy).contiguous()
+    rows, N = dy.shape
+    dX = torch.empty(rows, T, size // 2 + 1, 2, device=dy.device, dtype=torch.float32)
+    check(L.tssep_istft_bwd(_p(dy), rows, N, size, shift, int(fading), _p(wsyn),
+                            _p(fft_tables(size, dy.device)), _p(dX), T, _stream()), "istft_bwd")
+    return torch.view_as_complex(dX)
+
+
+# --------------------------------------------------------------------------- features
+def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
+    """X complex64 [B,T,F] -> (view [B,T,n_mfcc+F], ld)."""
+    L = _lib.lib()
+    Xr = torch.view_as_real(X.contiguous())
+    B, T, F = X.shape
+    n_mels = fb.shape[1] if n_mfcc else 0
+    D = n_mfcc + F
+    ld = round_up(D, 4)
+    out = torch.zeros(B, T, ld, device=X.device, dtype=torch.float32)
+    ws = torch.empty(int(L.tssep_feat_workspace_bytes(B, T, max(n_mels, 1))) // 4 + 4,
+                     device=X.device, dtype=torch.float32)
+    check(L.tssep_feat_fwd(_p(Xr), B, T, F, _p(fb) if n_mfcc else None,
+                           _p(dct) if n_mfcc else None, n_mels, n_mfcc, float(top_db), _p(out),
+                           ld, _p(ws), _stream()), "feat_fwd")
+    return out[..., :D], ld
+
+
+# ------------------------------------------------------------------------------- GEMM
+def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
+         accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0):
+    """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
+    float_offset) tuples) whose data pointers are used as given."""
+    L = _lib.lib()
+
+    def ptr(x):
+        if isinstance(x, tuple):
+            return x[0].data_ptr() + 4 * x[1]
+        return x.data_ptr()
+    g = GemmArgs()
+    g.A, g.B, g.C = ptr(A), ptr(B), ptr(C)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = lda, ldb, ldc
+    g.a_kmajor, g.b_kmajor = int(a_kmajor), int(b_kmajor)
+    g.b_kshift, g.kperiod = b_kshift, kperiod
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.act, g.accumulate = act, int(accumulate)
+    if remap is not None:
+        g.c_remap = 1
+        g.c_T, g.c_K = remap["T"], remap.get("K", 1)
+        g.c_sb, g.c_sk, g.c_st = remap["sb"], remap.get("sk", 0), remap["st"]
+        g.c_cm, g.c_co = remap.get("cm", 0), remap.get("co", 0)
+        perm = remap.get("perm")
+        g.c_perm = perm.data_ptr() if perm is not None else None
+        g.c_perm_ld = remap.get("perm_ld", 0)
+    g.splitk, g.c_split_stride = splitk, split_stride
+    check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
+
+
+def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
+    tiles = math.ceil(M / 128) * math.ceil(N / 128)
+    ktiles = math.ceil(K / 16)
+    s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
+    return min(s, 64)
+
+
+def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0):
+    """dW[M,N] = dY[R,M]^T X[R,N] by split-K partials -> (partials [S, M*N], S)."""
+    S = pick_splitk(M, N, R)
+    dev = dY[0].device if isinstance(dY, tuple) else dY.device
+    part = torch.empty(S, M * N, device=dev, dtype=torch.float32)
+    gemm(dY, ld_dy, X, ld_x, part, N, M, N, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
+         kperiod=kperiod, splitk=S, split_stride=M * N)
+    return part, S
+
+
+def reduce_splits(part, S, count, dst, accumulate=False):
+    check(_lib.lib().tssep_reduce_splits(_p(part), S, count, count, _p(dst), int(accumulate),
+                                         _stream()), "reduce_splits")
+
+
+def colsum(A, lda, M, N, out=None, accumulate=False):
+    L = _lib.lib()
+    dev = A[0].device if isinstance(A, tuple) else A.device
+    if out is None:
+        out = torch.empty(N, device=dev, dtype=torch.float32)
+    ws = torch.empty(int(L.tssep_colsum_workspace_bytes(M, N)) // 4, device=dev,
+                     dtype=torch.float32)
+    a = A[0].data_ptr() + 4 * A[1] if isinstance(A, tuple) else A.data_ptr()
+    check(L.tssep_colsum_f32(ctypes.c_void_p(a), M, N, lda, _p(out), int(accumulate), _p(ws),
+                             _stream()), "colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------ BLSTM
+def lstm_sizes(H, I, ld_i):
+    sz = LstmSizes()
+    check(_lib.lib().tssep_lstm_pack_sizes(H, I, ld_i, ctypes.byref(sz)), "lstm_pack_sizes")
+    return sz
+
+
+def lstm_pack(params, H, I):
+    """params: 8 tensors (w_ih, w_hh, b_ih, b_hh forward, then reverse), torch layout."""
+    L = _lib.lib()
+    ld_i = round_up(I, 4)
+    sz = lstm_sizes(H, I, ld_i)
+    dev = params[0].device
+    buf = torch.empty(sz.wih_p + round_up(sz.bias_p, 4) + sz.whh_f + sz.whh_b, device=dev,
+                      dtype=torch.float32)
+    o1 = sz.wih_p
+    o2 = o1 + round_up(sz.bias_p, 4)
+    o3 = o2 + sz.whh_f
+    wih_p, bias_p, whh_f, whh_b = buf[:o1], buf[o1:o1 + sz.bias_p], buf[o2:o3], buf[o3:]
+    ps = [_f32(p.detach()).contiguous() for p in params]
+    check(L.tssep_lstm_pack(*[_p(p) for p in ps], H, I, ld_i, _p(wih_p), _p(bias_p), _p(whh_f),
+                            _p(whh_b), _stream()), "lstm_pack")
+    return dict(wih_p=wih_p, bias_p=bias_p, whh_f=whh_f, whh_b=whh_b, ld_i=ld_i, _keep=(buf, ps))
+
+
+def blstm_fwd(gates, cell, hout, ldo, dstride, whh_f, N, T, H):
+    check(_lib.lib().tssep_blstm_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_f), N, T,
+                                     H, _stream()), "blstm_fwd")
+
+
+def blstm_bwd(gates, cell, dhout, ldo, dstride, whh_b, N, T, H):
+    check(_lib.lib().tssep_blstm_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_b), N, T,
+                                     H, _stream()), "blstm_bwd")
+
+
+def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r):
+    check(_lib.lib().tssep_lstm_unpack(_p(src), ld, nsplit, split_stride, H, ncols, _p(dst_f),
+                                       _p(dst_r), _stream()), "lstm_unpack")
+
+
+# ------------------------------------------------------------------------ elementwise
+def tanh_bwd(dy, y, rows, P, K, T, combined):
+    dz = torch.empty(rows, P, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().tssep_tanh_bwd(_p(dy), _p(y), _p(dz), rows, P, K, T, int(combined),
+                                    _stream()), "tanh_bwd")
+    return dz
+
+
+def cond_fwd(pre, ld_pre, aux, B, K, T, F, trials, combination):
+    """-> (xs view [B*trials*K*T, W], ld)"""
+    L = _lib.lib()
+    aux2, ld_aux = rows_view(aux)
+    E = aux.shape[-1]
+    W = F if combination == "mul" else F + E
+    xs, ld = padded(B * trials * K * T, W, pre.device, zero=True)
+    if combination == "mul":
+        assert E == F, (E, F)
+        check(L.tssep_cond_mul_fwd(_p(pre), ld_pre, _p(aux2), ld_aux, _p(xs), ld, B, K, T, F,
+                                   trials, _stream()), "cond_mul_fwd")
+    else:
+        check(L.tssep_cond_cat_fwd(_p(pre), ld_pre, _p(aux2), ld_aux, _p(xs), ld, B, K, T, F, E,
+                                   trials, _stream()), "cond_cat_fwd")
+    return xs, ld, (aux2, ld_aux)
+
+
+def cond_bwd(dxs, ld_dxs, auxinfo, B, K, T, F, trials, combination):
+    L = _lib.lib()
+    dpre, ld = padded(B * T, F, dxs.device, zero=True)
+    aux2, ld_aux = auxinfo
+    if combination == "mul":
+        check(L.tssep_cond_mul_bwd(_p(dxs), ld_dxs, _p(aux2), ld_aux, _p(dpre), ld, B, K, T, F,
+                                   trials, _stream()), "cond_mul_bwd")
+    else:
+        check(L.tssep_cond_cat_bwd(_p(dxs), ld_dxs, _p(dpre), ld, B, K, T, F, trials, _stream()),
+              "cond_cat_bwd")
+    return dpre, ld
+
+
+# -------------------------------------------------------------------------- mask head
+def maskhead_fwd(logit, obs):
+    """logit [B,K,T,F] fp32, obs complex64 [B,T,F] -> mask [B,K,T,F], est complex64 [B,K,T,F]"""
+    B, K, T, F = logit.shape
+    logit = _f32(logit).contiguous()
+    obs_r = torch.view_as_real(obs.contiguous())
+    mask = torch.empty_like(logit)
+    est = torch.empty(B, K, T, F, 2, device=logit.device, dtype=torch.float32)
+    check(_lib.lib().tssep_maskhead_fwd(_p(logit), _p(obs_r), _p(mask), _p(est), B, K, T, F,
+                                        _stream()), "maskhead_fwd")
+    return mask, torch.view_as_complex(est)
+
+
+def maskhead_bwd(dest, dmask, mask, obs):
+    B, K, T, F = mask.shape
+    dest_r = torch.view_as_real(dest.contiguous())
+    obs_r = torch.view_as_real(obs.contiguous())
+    dlogit = torch.empty_like(mask)
+    if dmask is not None:
+        dmask = _f32(dmask).contiguous()
+    check(_lib.lib().tssep_maskhead_bwd(_p(dest_r), _p(dmask), _p(mask), _p(obs_r), _p(dlogit), B,
+                                        K, T, F, _stream()), "maskhead_bwd")
+    return dlogit
+
+
+# ----------------------------------------------------------------------------- losses
+def logmae_fwd(est, tgt):
+    L = _lib.lib()
+    B, K, N = est.shape
+    est, tgt = _f32(est).contiguous(), _f32(tgt).contiguous()
+    loss = torch.empty(B, device=est.device, dtype=torch.float32)
+    sums = torch.empty(B, device=est.device, dtype=torch.float32)
+    ws = torch.empty(int(L.tssep_logmae_workspace_bytes(B, K, N)) // 4, device=est.device,
+                     dtype=torch.float32)
+    check(L.tssep_logmae_fwd(_p(est), _p(tgt), B, K, N, _p(loss), _p(sums), _p(ws), _stream()),
+          "logmae_fwd")
+    return loss, sums
+
+
+def logmae_finalize(part, B, K, N):
+    L = _lib.lib()
+    loss = torch.empty(B, device=part.device, dtype=torch.float32)
+    sums = torch.empty(B, device=part.device, dtype=torch.float32)
+    check(L.tssep_logmae_finalize(_p(part), B, K, part.shape[-1], N, _p(loss), _p(sums),
+                                  _stream()), "logmae_finalize")
+    return loss, sums
+
+
+def logmae_bwd(est, tgt, sums, gout):
+    B, K, N = est.shape
+    dest = torch.empty_like(est)
+    check(_lib.lib().tssep_logmae_bwd(_p(est), _p(tgt), _p(sums), _p(_f32(gout).contiguous()), B,
+                                      K, N, _p(dest), _stream()), "logmae_bwd")
+    return dest
+
+
+def vadbce_fwd(logit, vad):
+    L = _lib.lib()
+    B, K, T, F = logit.shape
+    logit, vad = _f32(logit).contiguous(), _f32(vad).contiguous()
+    loss = torch.empty(B, device=logit.device, dtype=torch.float32)
+    xmean = torch.empty(B, K, T, device=logit.device, dtype=torch.float32)
+    ws = torch.empty(B * K * T, device=logit.device, dtype=torch.float32)
+    check(L.tssep_vadbce_fwd(_p(logit), _p(vad), B, K, T, F, _p(loss), _p(xmean), _p(ws),
+                             _stream()), "vadbce_fwd")
+    return loss, xmean
+
+
+def vadbce_bwd(xmean, vad, gout, F):
+    B, K, T = xmean.shape
+    dlogit = torch.empty(B, K, T, F, device=xmean.device, dtype=torch.float32)
+    check(_lib.lib().tssep_vadbce_bwd(_p(xmean), _p(_f32(vad).contiguous()),
+                                      _p(_f32(gout).contiguous()), B, K, T, F, _p(dlogit),
+                                      _stream()), "vadbce_bwd")
+    return dlogit
+
+
+def logit_map_fwd(raw, perm, iperm, B, trials, K, T, F, Fr, spk_rows):
+    out = torch.empty(B, K, T, F, device=raw.device, dtype=torch.float32)
+    check(_lib.lib().tssep_logit_map_fwd(_p(raw), _p(perm), _p(iperm), B, trials, K, T, F, Fr,
+                                         int(spk_rows), _p(out), _stream()), "logit_map_fwd")
+    return out
+
+
+def logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows):
+    n = B * trials * K * T * Fr
+    draw = torch.empty(n, device=dout.device, dtype=torch.float32)
+    check(_lib.lib().tssep_logit_map_bwd(_p(_f32(dout).contiguous()), _p(perm), _p(iperm), B,
+                                         trials, K, T, F, Fr, int(spk_rows), _p(draw), _stream()),
+          "logit_map_bwd")
+    return draw
