@@ -198,6 +198,13 @@ int tssep_maskhead_bwd(const float* dest, const float* dmask, const float* mask,
                        const float* obs, float* dlogit,
                        int64_t B, int64_t K, int64_t T, int F, void* stream);
 
+/* Masking on a given mask (standalone enhancer call, tssep/train/enhancer.py:98-100):
+ * est = Obs * mask, and its backward dmask = Re(conj(Obs) * dest). */
+int tssep_mask_mul_fwd(const float* mask, const float* obs, float* est,
+                       int64_t B, int64_t K, int64_t T, int F, void* stream);
+int tssep_mask_mul_bwd(const float* dest, const float* obs, float* dmask,
+                       int64_t B, int64_t K, int64_t T, int F, void* stream);
+
 /* ------------------------------------------------------------------ losses ---
  * LogMAE (tssep/train/loss.py:244-247): loss[b] = log10(sum_k mean_n |est-tgt|).
  * Deterministic two-stage reduction; `sums[b]` (the argument of the log) is kept for bwd.

@@ -36,7 +36,7 @@ def create_dct(n_mfcc, n_mels, norm="ortho"):
     else:
         dct[0] *= 1.0 / math.sqrt(2.0)
         dct *= math.sqrt(2.0 / float(n_mels))
-    return dct.t()
+    return dct.t().contiguous()
 
 
 def mfcc_tables(size=1024, sample_rate=16000, n_mfcc=40, f_min=40.0,

@@ -1,0 +1,217 @@
+"""Module-level parity on a real MI355X: the drop-in classes (tssep_amd.train.*) against
+(a) fixtures generated from the REFERENCE classes (tests/golden) and (b) the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import data as odata, model as omodel, net as onet  # noqa: E402
+from test_gpu_kernels import close  # noqa: E402
+from test_oracle import ME_CASES_ORDER  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+T_ = torch.as_tensor
+
+
+def _load(module, g, pre="p."):
+    sd = {k[len(pre):]: T_(v) for k, v in g.items() if k.startswith(pre)}
+    missing = module.load_state_dict(sd, strict=True)
+    return module.cuda()
+
+
+def test_rnnp_packed_against_reference_fixture(golden):
+    from tssep_amd.train.rnnp import RNNP_packed
+    g = golden("rnnp")
+    m = _load(RNNP_packed(7, 1, 5, 6, 0), g)
+    for tag in ("x3", "x4", "x2"):
+        x = T_(g[tag]).cuda().requires_grad_()
+        y = m(x)
+        close(y, g[tag + "_y"], rtol=1e-4, atol=2e-6, name=tag)
+        m.zero_grad()
+        (y * T_(g[tag + "_g"]).cuda()).sum().backward()
+        close(x.grad, g[tag + "_dx"], rtol=1e-3, atol=2e-6, name=tag + " dx")
+        for k, p in m.named_parameters():
+            close(p.grad, g[f"{tag}_dp.{k}"], rtol=1e-3, atol=5e-6, name=f"{tag} d{k}")
+
+
+ME_CASES = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "me_*.npz")))
+
+
+@pytest.mark.parametrize("name", ME_CASES)
+def test_mask_estimator_against_reference_fixture(golden, name):
+    from tssep_amd.train.net import MaskEstimator_v2
+    g = golden(name)
+    comb, ts_vad, res, nap = [str(s) for s in g["cfg"]]
+    ts_vad = False if ts_vad == "False" else int(ts_vad)
+    E = g["aux"].shape[-1]
+    me = _load(MaskEstimator_v2(idim=12, odim=9, layers=3, units=5, projs=6, combination=comb,
+                                aux_net_output_size=E, ts_vad=ts_vad, output_resolution=res,
+                                num_averaged_permutations=int(nap)), g)
+    assert list(me.state_dict().keys()) == [k[2:] for k in g if k.startswith("p.")]
+    np.random.seed(100 + ME_CASES_ORDER.index(name))     # same stream the reference forward consumed
+    aux = T_(g["aux"]).cuda()
+    out = me(T_(g["xs"]).cuda(), [[a for a in ab] for ab in aux])
+    close(out.logit, g["logit"], rtol=1e-3, atol=5e-6, name="logit")
+    close(out.mask, g["mask"], rtol=1e-3, atol=2e-6, name="mask")
+    close(out.embedding, g["embedding"], name="embedding")
+    (out.mask * T_(g["g"]).cuda()).sum().backward()
+    for k, p in me.named_parameters():
+        close(p.grad, g["dp." + k], rtol=2e-3, atol=5e-6, name="d" + k)
+
+
+def _example_batch(B, K, N, seed=0, E=513):
+    rng = np.random.RandomState(seed)
+    tgt = (rng.randn(B, K, N) * 0.1).astype(np.float32)
+    vad = np.zeros((B, K, N), dtype=np.float32)
+    for k in range(K):
+        vad[:, k, k * N // (K + 1):(k + 2) * N // (K + 1)] = 1
+    tgt *= vad
+    obs = tgt.sum(1, keepdims=True) + 0.05 * rng.rand(B, 1, N).astype(np.float32)
+    aux = rng.rand(B, K, E).astype(np.float32)
+    return T_(obs), T_(aux), T_(tgt), T_(vad)
+
+
+@pytest.mark.parametrize("res,loss_name", [("tf", "LogMAE"), ("t", "VADSigmoidBCE")])
+def test_model_end_to_end_against_oracle(res, loss_name):
+    """STFT -> MFCC+log1p features -> mask estimator -> mask head -> iSTFT -> loss, forward and
+    backward, HIP path vs CPU oracle on the same seeded inputs (1e-3 relative bar, fp32)."""
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    B, K, N, units, projs = 2, 4, 6000, 12, 16
+    obs, aux, tgt, vad = _example_batch(B, K, N)
+    torch.manual_seed(0)
+    fe1 = fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40)
+    fe2 = fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann")
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(fe1, fe2, size=1024, shift=256, window="hann"),
+        reader=None,
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=units, projs=projs,
+                                            combination="mul", aux_net_output_size=513, ts_vad=K,
+                                            output_resolution=res),
+        enhancer=enhancer.Masking(),
+        loss=loss.LogMAE() if loss_name == "LogMAE" else loss.VADSigmoidBCE()).cuda()
+    from tssep_amd.data import DummyReader
+    m.reader = DummyReader()
+    p = {"mask_estimator." + k: v.detach().cpu().clone().requires_grad_()
+         for k, v in m.mask_estimator.state_dict().items()}
+    from oracle import stft as ostft
+    T = ostft.num_frames(N)
+    Vad = vad.view(B, K, N)[..., ::256][..., :T]
+    Vad = torch.nn.functional.pad(Vad, (0, T - Vad.shape[-1]))
+    cfg = dict(odim=513, combination="mul", ts_vad=K, output_resolution=res)
+    np.random.seed(3)
+    o = omodel.forward_loss(p, obs, aux, tgt if loss_name == "LogMAE" else Vad, cfg=cfg,
+                            loss=loss_name, fast=True)
+    o["loss"].sum().backward()
+    ex = dict(observation=obs.cuda(), auxInput=aux.cuda(), reference_channel=0,
+              speaker_reverberation_early_ch0=tgt.cuda(), Vad=Vad.cuda(), dataset=["v"] * B)
+    np.random.seed(3)
+    out = m(ex)
+    summary = m.review(ex, out)
+    close(ex["Observation"], o["Observation"], rtol=1e-4, atol=1e-3, name="Observation")
+    close(ex["Input"][..., 40:], o["Input"][..., 40:], rtol=1e-4, atol=2e-6, name="Input log1p")
+    close(ex["Input"][..., :40], o["Input"][..., :40], rtol=1e-4, atol=5e-3, name="Input mfcc")
+    close(out.logit, o["logit"], rtol=1e-3, atol=2e-5, name="logit")
+    close(out.mask, o["mask"], rtol=1e-3, atol=1e-5, name="mask")
+    close(out.stft_estimate, o["stft_estimate"], rtol=1e-3, atol=1e-3, name="stft_estimate")
+    close(out.time_estimate, o["time_estimate"], rtol=1e-3, atol=1e-5, name="time_estimate")
+    close(summary["loss"], o["loss"].sum(), rtol=1e-4, atol=1e-6, name="loss")
+    summary["loss"].backward()
+    for k, v in m.mask_estimator.named_parameters():
+        ref = p["mask_estimator." + k].grad
+        scale = float(ref.abs().max())
+        close(v.grad, ref, rtol=1e-3, atol=1e-3 * scale + 1e-9, name="d" + k)
+
+
+def test_end_to_end_known_answer_of_the_reference():
+    """tssep/train/model.py:552-575: validate_LogMAE = 0.74156505 / 0.744494 for the default
+    Model config (Log1pMaxNormAbsSTFT, cat, 8 speakers, units 10 / projs 12), 114038 params."""
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    from tssep_amd.data import DummyReader
+    np.random.seed(0)
+    torch.manual_seed(0)
+    me = net.MaskEstimator_v2(idim=513, odim=513, units=10, projs=12, combination="cat",
+                              aux_net_output_size=100)
+    m = model.Model(fe=fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+                    reader=DummyReader(), mask_estimator=me, enhancer=enhancer.Masking(),
+                    loss=loss.LogMAE())
+    assert sum(p.numel() for p in m.parameters()) == 114038
+    m = m.cuda()
+    ex = m.prepare_validate_dataset(device="cuda", batch_size=2)[0]
+    summary = m.review(ex, m(ex))
+    got = [float(v) for v in summary["scalars"]["validate_LogMAE"]]
+    np.testing.assert_allclose(got, [0.74156505, 0.744494], rtol=2e-4)
+    assert float(torch.norm(ex["Input"])) == pytest.approx(58.8257, abs=5e-3)
+    assert float(ex["Input"].abs().amax()) == pytest.approx(1.0, abs=1e-6)
+    summary["loss"].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_vad_to_sep_checkpoint_broadcast(golden, tmp_path):
+    """tssep/train/init_ckpt.py:54-89: SEP logits equal VAD logits in every frequency bin."""
+    from tssep_amd.train import init_ckpt, net
+    g = golden("vad2sep")
+    kw = dict(idim=12, odim=9, units=5, projs=6, combination="mul", aux_net_output_size=9, ts_vad=4,
+              random_speaker_order=False)
+    vad = net.MaskEstimator_v2(output_resolution="t", **kw)
+    sep = net.MaskEstimator_v2(output_resolution="tf", **kw)
+    vad.load_state_dict({k[len("vad.mask_estimator."):]: T_(v) for k, v in g.items()
+                         if k.startswith("vad.")})
+    hv = torch.nn.Module(); hv.mask_estimator = vad
+    hs = torch.nn.Module(); hs.mask_estimator = sep
+    ck = tmp_path / "ckpt.pth"
+    torch.save({"model": hv.state_dict()}, ck)
+
+    class EG:
+        class trainer:
+            model = hs
+    init_ckpt.InitCheckPointVAD2Sep(init_ckpt=str(ck))(EG)
+    for k, v in hs.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), g["sep." + k])
+    xs, aux = T_(g["xs"]).cuda(), T_(g["aux"]).cuda()
+    lv = vad.cuda()(xs, aux).logit
+    ls = sep.cuda()(xs, aux).logit
+    close(lv, g["logit_vad"], rtol=1e-3, atol=5e-6, name="vad logit")
+    close(ls, g["logit_sep"], rtol=1e-3, atol=5e-6, name="sep logit")
+    close(ls, lv, rtol=0, atol=1e-6, name="sep == vad")
+
+
+def test_full_size_properties():
+    """BASELINE cfg3 sizes (K=4, 4 s @ 16 kHz, H=300, P=320): parity with the oracle on the
+    masks plus size-independent properties of the HIP path."""
+    from tssep_amd.train import net
+    from tssep_amd import hip_ops as H, functional as Fn
+    B, K, N = 2, 4, 64000
+    obs, aux, tgt, _ = _example_batch(B, K, N, seed=1)
+    torch.manual_seed(1)
+    me = net.MaskEstimator_v2(idim=553, odim=513, units=300, projs=320, combination="mul",
+                              aux_net_output_size=513, ts_vad=K, output_resolution="tf").cuda()
+    w, wsyn = Fn.windows("hann", 1024, 256, "cuda")
+    X = H.stft_fwd(obs[:, 0].cuda(), w)
+    assert X.shape == (B, 253, 513)
+    # STFT -> iSTFT round trip
+    xr, _ = H.istft_fwd(X, wsyn, N)
+    close(xr, obs[:, 0], rtol=1e-4, atol=2e-5, name="round trip")
+    from oracle import features as ofeat
+    fb, dct = ofeat.mfcc_tables(1024)
+    feat, _ = H.feat_fwd(X, fb.cuda(), dct.cuda(), 40)
+    np.random.seed(5)
+    out = me(feat, aux.cuda())
+    p = {"mask_estimator." + k: v.detach().cpu() for k, v in me.state_dict().items()}
+    np.random.seed(5)
+    ref = onet.mask_estimator_forward(p, feat.cpu().contiguous(), aux, odim=513, combination="mul",
+                                      ts_vad=K, output_resolution="tf", fast=True)
+    close(out.mask, ref["mask"], rtol=1e-3, atol=1e-5, name="mask @ cfg3")
+    # mask in (0,1); estimate magnitude never exceeds the observation
+    assert float(out.mask.min()) > 0 and float(out.mask.max()) < 1
+    mask, est = Fn.mask_head(out.logit[:, :, 0], X)
+    assert bool((est.abs() <= X.abs()[:, None] * (1 + 1e-6)).all())
+    # linearity of the iSTFT adjoint pair: <istft(E), y> == <E, istft^T(y)>
+    y = torch.randn(B * K, N, device="cuda")
+    t1 = (H.istft_fwd(est.reshape(B * K, 253, 513), wsyn, N)[0] * y).sum()
+    dX = H.istft_bwd(y, wsyn, 253)
+    t2 = (torch.view_as_real(est.reshape(B * K, 253, 513)) * torch.view_as_real(dX)).sum()
+    assert float(t1) == pytest.approx(float(t2), rel=1e-3)

@@ -114,6 +114,28 @@ __global__ __launch_bounds__(256) void maskhead_bwd_kernel(
   }
 }
 
+// Standalone Masking (mask given, not logits): est = Obs * mask and dmask = Re(conj(Obs) dest).
+__global__ __launch_bounds__(256) void mask_mul_kernel(
+    const float* __restrict__ mask, const float2* __restrict__ dest, const float2* __restrict__ obs,
+    float2* __restrict__ est, float* __restrict__ dmask, int64_t total, int64_t KTF, int64_t TF) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t stride_tf = stride % TF;
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  Pos p;
+  p.init(e, KTF, TF);
+  for (; e < total; e += stride, p.advance(stride, stride_tf, KTF, TF)) {
+    const float2 x = obs[p.ob + p.tf];
+    if (est) {
+      const float m = mask[e];
+      est[e] = make_float2(x.x * m, x.y * m);
+    } else {
+      const float2 d = dest[e];
+      dmask[e] = x.x * d.x + x.y * d.y;
+    }
+  }
+}
+
 inline unsigned stream_grid(int64_t total_vec4) {
   int64_t blocks = (total_vec4 + 255) / 256;
   const int64_t cap = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
@@ -147,5 +169,26 @@ extern "C" int tssep_maskhead_bwd(const float* dest, const float* dmask, const f
   hipLaunchKernelGGL(maskhead_bwd_kernel, dim3(stream_grid((total + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)dest, dmask, mask, (const float2*)obs,
                      dlogit, total, KTF, TF);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_mask_mul_fwd(const float* mask, const float* obs, float* est, int64_t B,
+                                  int64_t K, int64_t T, int F, void* stream) {
+  if (!mask || !obs || !est) return TSSEP_E_NULL;
+  if (B <= 0 || K <= 0 || T <= 0 || F <= 0) return TSSEP_E_SHAPE;
+  const int64_t TF = T * F, KTF = K * TF, total = B * KTF;
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     mask, (const float2*)nullptr, (const float2*)obs, (float2*)est,
+                     (float*)nullptr, total, KTF, TF);
+  return tssep_launch_status();
+}
+extern "C" int tssep_mask_mul_bwd(const float* dest, const float* obs, float* dmask, int64_t B,
+                                  int64_t K, int64_t T, int F, void* stream) {
+  if (!dest || !obs || !dmask) return TSSEP_E_NULL;
+  if (B <= 0 || K <= 0 || T <= 0 || F <= 0) return TSSEP_E_SHAPE;
+  const int64_t TF = T * F, KTF = K * TF, total = B * KTF;
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)nullptr, (const float2*)dest, (const float2*)obs,
+                     (float2*)nullptr, dmask, total, KTF, TF);
   return tssep_launch_status();
 }

@@ -1,0 +1,348 @@
+"""torch.autograd.Function wrappers around the HIP kernels (hip_ops).
+
+Each Function mirrors one ATen-level operator group of the reference hot path (SURVEY.md
+section 2.2) with an explicit backward; autograd is only the glue that chains them.
+"""
+import numpy as np
+import torch
+
+from . import hip_ops as H
+
+
+def _pad4(n):
+    return H.round_up(n, 4)
+
+
+# ------------------------------------------------------------------------------ RNNP
+class _RNNP(torch.autograd.Function):
+    """One RNNP_packed layer (tssep/train/rnnp.py:88-96,146-168): BLSTM + Linear (+ tanh).
+
+    x: [R, ld_x] buffer view, rows (n, t) for N sequences of T frames, I valid columns.
+    Output: [R, hdim] rows (padded leading dimension), or the speaker-combined layout
+    [B, T, K*hdim] when ``combine=K`` (net.py:608-611 fused into the projection's store)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj,
+                N, T, act, combine):
+        dev = x.device
+        Hh = w_hh.shape[1]
+        I = w_ih.shape[1]
+        hdim = w_proj.shape[0]
+        xv, ld_x = H.rows_view(x)
+        R = N * T
+        assert xv.shape[0] == R and xv.shape[1] >= I, (xv.shape, R, I)
+        pk = H.lstm_pack([w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r], Hh, I)
+        gates = torch.empty(R, 8 * Hh, device=dev, dtype=torch.float32)
+        H.gemm(xv, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, R, 8 * Hh, I, bias=pk["bias_p"])
+        Hp = _pad4(Hh)
+        cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
+        hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
+        H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+        # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
+        wp = _proj_layout(w_proj, Hh, Hp)
+        if combine:
+            K = combine
+            B = N // K
+            y = torch.empty(B * T, K * hdim, device=dev, dtype=torch.float32)
+            H.gemm(hout, 2 * Hp, wp, 2 * Hp, y, 0, R, hdim, 2 * Hp, bias=b_proj.detach(), act=act,
+                   remap=dict(T=T, K=K, sb=T * K * hdim, sk=hdim, st=K * hdim))
+            ld_y = K * hdim
+        else:
+            y, ld_y = H.padded(R, hdim, dev, zero=True)
+            H.gemm(hout, 2 * Hp, wp, 2 * Hp, y, ld_y, R, hdim, 2 * Hp, bias=b_proj.detach(), act=act)
+        ctx.save_for_backward(xv, gates, cell, hout, y, wp)
+        ctx.pk = pk
+        ctx.meta = (N, T, I, Hh, Hp, hdim, ld_x, ld_y, act, combine)
+        ctx.x_shape = x.shape
+        return y if combine else y[:, :hdim]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xv, gates, cell, hout, y, wp = ctx.saved_tensors
+        N, T, I, Hh, Hp, hdim, ld_x, ld_y, act, combine = ctx.meta
+        pk = ctx.pk
+        dev = dy.device
+        R = N * T
+        K = combine if combine else 1
+        # d(pre-activation) of the projection, rows (n,t) x hdim, contiguous
+        if act:
+            dyc = dy.contiguous() if combine else _dense_rows(dy, hdim)
+            yc = y if combine else _dense_rows(y[:, :hdim], hdim)
+            dz = H.tanh_bwd(dyc, yc, R, hdim, K, T, bool(combine))
+        else:
+            if combine:   # layout change only: reuse tanh_bwd's gather with y = 0
+                dz = H.tanh_bwd(dy.contiguous(), torch.zeros_like(dy), R, hdim, K, T, True)
+            else:
+                dz = _dense_rows(dy, hdim)
+        dz, ld_dz = H.rows_view(dz)
+        # projection: dW [hdim, 2Hp], db, dhout
+        part, S = H.wgrad(dz, ld_dz, hout, 2 * Hp, hdim, 2 * Hp, R)
+        dwp = torch.empty(hdim, 2 * Hp, device=dev, dtype=torch.float32)
+        H.reduce_splits(part, S, hdim * 2 * Hp, dwp)
+        d_w_proj = _proj_unlayout(dwp, Hh, Hp)
+        d_b_proj = H.colsum(dz, ld_dz, R, hdim)
+        dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
+        H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
+        # BPTT: gates <- d(pre-activations)
+        H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+        G = 8 * Hh
+        # dW_hh per direction (dgates_t paired with h_{t-1} / h_{t+1})
+        dwhh = torch.empty(2, 4 * Hh * Hh, device=dev, dtype=torch.float32)
+        for d in range(2):
+            part, S = H.wgrad((gates, d * 4 * Hh), G, (hout, d * Hp), 2 * Hp, 4 * Hh, Hh, R,
+                              b_kshift=(-1 if d == 0 else 1), kperiod=T)
+            H.reduce_splits(part, S, 4 * Hh * Hh, dwhh[d])
+        d_whh = torch.empty(4 * Hh, Hh, device=dev, dtype=torch.float32)
+        d_whh_r = torch.empty(4 * Hh, Hh, device=dev, dtype=torch.float32)
+        H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, d_whh, d_whh_r)
+        # dW_ih
+        part, S = H.wgrad(gates, G, xv, ld_x, G, I, R)
+        d_wih = torch.empty(4 * Hh, I, device=dev, dtype=torch.float32)
+        d_wih_r = torch.empty(4 * Hh, I, device=dev, dtype=torch.float32)
+        H.lstm_unpack(part, I, S, G * I, Hh, I, d_wih, d_wih_r)
+        # biases (b_ih and b_hh receive the same gradient)
+        cs = H.colsum(gates, G, R, G)
+        d_b = torch.empty(4 * Hh, device=dev, dtype=torch.float32)
+        d_b_r = torch.empty(4 * Hh, device=dev, dtype=torch.float32)
+        H.lstm_unpack(cs, 1, 1, 0, Hh, 1, d_b, d_b_r)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxb, ld_dx = H.padded(R, I, dev, zero=True)
+            H.gemm(gates, G, pk["wih_p"], pk["ld_i"], dxb, ld_dx, R, I, G, b_kmajor=True)
+            dx = dxb[:, :I]
+            if tuple(ctx.x_shape) != tuple(dx.shape):
+                dx = dx.reshape(ctx.x_shape)
+        return (dx, d_wih, d_whh, d_b, d_b.clone(), d_wih_r, d_whh_r, d_b_r, d_b_r.clone(),
+                d_w_proj, d_b_proj, None, None, None, None)
+
+
+def _dense_rows(t, cols):
+    t = t if t.dim() == 2 else t.reshape(-1, cols)
+    return t.contiguous()
+
+
+def _proj_layout(w_proj, Hh, Hp):
+    w = w_proj.detach()
+    if Hp == Hh and w.is_contiguous() and w.data_ptr() % 16 == 0:
+        return w
+    out = torch.zeros(w.shape[0], 2 * Hp, device=w.device, dtype=torch.float32)
+    out[:, :Hh] = w[:, :Hh]
+    out[:, Hp:Hp + Hh] = w[:, Hh:]
+    return out
+
+
+def _proj_unlayout(dwp, Hh, Hp):
+    if Hp == Hh:
+        return dwp
+    return torch.cat([dwp[:, :Hh], dwp[:, Hp:Hp + Hh]], dim=1).contiguous()
+
+
+def rnnp_layer(x, lstm, linear, N, T, act=0, combine=0):
+    """x rows (n,t); lstm = torch.nn.LSTM parameter container, linear = nn.Linear container."""
+    return _RNNP.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                       lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,
+                       lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse,
+                       linear.weight, linear.bias, N, T, act, combine)
+
+
+# ---------------------------------------------------------------------- conditioning
+class _Cond(torch.autograd.Function):
+    """tssep/train/net.py:862-896 (+ trial fold :913-924).  pre rows (b,t) -> rows (b,tr,k,t)."""
+
+    @staticmethod
+    def forward(ctx, pre, aux, B, K, T, trials, combination):
+        F = pre.shape[-1]
+        pv, ld_pre = H.rows_view(pre)
+        xs, ld, info = H.cond_fwd(pv, ld_pre, aux.detach(), B, K, T, F, trials, combination)
+        W = F if combination == "mul" else F + aux.shape[-1]
+        ctx.info = info
+        ctx.meta = (B, K, T, F, trials, combination, ld)
+        return xs[:, :W]
+
+    @staticmethod
+    def backward(ctx, dxs):
+        B, K, T, F, trials, combination, ld = ctx.meta
+        dv, ld_d = H.rows_view(dxs)
+        dpre, ldp = H.cond_bwd(dv, ld_d, ctx.info, B, K, T, F, trials, combination)
+        return dpre[:, :F], None, None, None, None, None, None
+
+
+def condition(pre, aux, B, K, T, trials, combination):
+    return _Cond.apply(pre, aux, B, K, T, trials, combination)
+
+
+# ------------------------------------------------------------------------ final linear
+class _Head(torch.autograd.Function):
+    """post_net.linear + final einops + trial mean + speaker un-permutation
+    (tssep/train/net.py:629-666, 928-967): x rows -> logit [B,K,T,F]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, perm, iperm, B, K, T, F, trials, Fr, spk_rows):
+        dev = x.device
+        xv, ld_x = H.rows_view(x)
+        P = weight.shape[1]
+        wv, ld_w = H.rows_view(weight.detach())
+        R = xv.shape[0]
+        Nout = weight.shape[0]
+        fast = (not spk_rows) and trials == 1 and Fr == F
+        if fast:      # store straight into [B, perm[k], T, F] from the GEMM epilogue
+            out = torch.empty(B, K, T, F, device=dev, dtype=torch.float32)
+            H.gemm(xv, ld_x, wv, ld_w, out, 0, R, Nout, P, bias=bias.detach(),
+                   remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm,
+                              perm_ld=K))
+        else:
+            raw = torch.empty(R, Nout, device=dev, dtype=torch.float32)
+            H.gemm(xv, ld_x, wv, ld_w, raw, Nout, R, Nout, P, bias=bias.detach())
+            out = H.logit_map_fwd(raw, perm, iperm, B, trials, K, T, F, Fr, spk_rows)
+        ctx.save_for_backward(xv, wv)
+        ctx.aux = (perm, iperm)
+        ctx.meta = (B, K, T, F, trials, Fr, spk_rows, ld_x, ld_w, P, R, Nout)
+        ctx.x_shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xv, wv = ctx.saved_tensors
+        perm, iperm = ctx.aux
+        B, K, T, F, trials, Fr, spk_rows, ld_x, ld_w, P, R, Nout = ctx.meta
+        dev = dout.device
+        draw = H.logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows).view(R, Nout)
+        dv, ld_d = H.rows_view(draw)
+        part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
+        dw = torch.empty(Nout, P, device=dev, dtype=torch.float32)
+        H.reduce_splits(part, S, Nout * P, dw)
+        db = H.colsum(dv, ld_d, R, Nout)
+        dxb, ld_dx = H.padded(R, P, dev, zero=True)
+        H.gemm(dv, ld_d, wv, ld_w, dxb, ld_dx, R, P, Nout, b_kmajor=True)
+        dx = dxb[:, :P]
+        if tuple(ctx.x_shape) != tuple(dx.shape):
+            dx = dx.reshape(ctx.x_shape)
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
+
+
+def head(x, linear, perm, iperm, B, K, T, F, trials, Fr, spk_rows):
+    return _Head.apply(x, linear.weight, linear.bias, perm, iperm, B, K, T, F, trials, Fr,
+                       spk_rows)
+
+
+# --------------------------------------------------------------------------- mask head
+class _MaskHead(torch.autograd.Function):
+    """sigmoid + Masking (tssep/train/net.py:981-986, tssep/train/enhancer.py:98-100)."""
+
+    @staticmethod
+    def forward(ctx, logit, obs):
+        mask, est = H.maskhead_fwd(logit, obs)
+        ctx.save_for_backward(mask, obs)
+        return mask, est
+
+    @staticmethod
+    def backward(ctx, dmask, dest):
+        mask, obs = ctx.saved_tensors
+        if dest is None:
+            dest = torch.zeros(mask.shape, device=mask.device, dtype=torch.complex64)
+        return H.maskhead_bwd(dest, dmask, mask, obs), None
+
+
+def mask_head(logit, obs):
+    """logit [B,K,T,F], obs complex [B,T,F] -> (mask, stft_estimate)."""
+    return _MaskHead.apply(logit, obs)
+
+
+class _Sigmoid(torch.autograd.Function):
+    """mask only (no observation available): reuses the mask-head kernel with obs = 0."""
+
+    @staticmethod
+    def forward(ctx, logit):
+        B, K, T, F = logit.shape
+        obs = torch.zeros(B, T, F, device=logit.device, dtype=torch.complex64)
+        mask, _ = H.maskhead_fwd(logit, obs)
+        ctx.save_for_backward(mask, obs)
+        return mask
+
+    @staticmethod
+    def backward(ctx, dmask):
+        mask, obs = ctx.saved_tensors
+        dest = torch.zeros(mask.shape, device=mask.device, dtype=torch.complex64)
+        return H.maskhead_bwd(dest, dmask, mask, obs)
+
+
+def sigmoid(logit):
+    return _Sigmoid.apply(logit)
+
+
+# ------------------------------------------------------------------------- STFT family
+_WINDOWS = {}
+
+
+def windows(window, size, shift, device):
+    from scipy.signal import get_window
+    key = (window, size, shift, str(device))
+    if key not in _WINDOWS:
+        w = get_window(window, size, fftbins=True).astype(np.float64)
+        denom = np.zeros(size)
+        for i in range(-(size // shift) - 1, size // shift + 2):
+            off = i * shift
+            lo, hi = max(0, off), min(size, size + off)
+            if lo < hi:
+                denom[lo:hi] += (w ** 2)[lo - off:hi - off]
+        _WINDOWS[key] = (torch.as_tensor(w, dtype=torch.float32).to(device),
+                         torch.as_tensor(w / denom, dtype=torch.float32).to(device))
+    return _WINDOWS[key]
+
+
+class _ISTFT(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, wsyn, N, size, shift, fading):
+        lead = X.shape[:-2]
+        T = X.shape[-2]
+        y, _ = H.istft_fwd(X.reshape(-1, T, X.shape[-1]), wsyn, N, size, shift, fading)
+        ctx.save_for_backward(wsyn)
+        ctx.meta = (lead, T, N, size, shift, fading)
+        return y.reshape(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (wsyn,) = ctx.saved_tensors
+        lead, T, N, size, shift, fading = ctx.meta
+        dX = H.istft_bwd(dy.reshape(-1, N), wsyn, T, size, shift, fading)
+        return dX.reshape(*lead, T, size // 2 + 1), None, None, None, None, None
+
+
+def istft(X, wsyn, N, size=1024, shift=256, fading=True):
+    return _ISTFT.apply(X, wsyn, N, size, shift, fading)
+
+
+# ------------------------------------------------------------------------------ losses
+class _LogMAE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est, tgt):
+        loss, sums = H.logmae_fwd(est, tgt)
+        ctx.save_for_backward(est, tgt, sums)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        est, tgt, sums = ctx.saved_tensors
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), sums, g), None
+
+
+def log_mae(est, tgt):
+    return _LogMAE.apply(est, tgt)
+
+
+class _VadBCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, vad):
+        loss, xmean = H.vadbce_fwd(logit, vad)
+        ctx.save_for_backward(xmean, vad)
+        ctx.F = logit.shape[-1]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        xmean, vad = ctx.saved_tensors
+        return H.vadbce_bwd(xmean, vad, g, ctx.F), None
+
+
+def vad_bce(logit, vad):
+    return _VadBCE.apply(logit, vad)

@@ -129,6 +129,8 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
     Xr = torch.view_as_real(X.contiguous())
     B, T, F = X.shape
     n_mels = fb.shape[1] if n_mfcc else 0
+    if n_mfcc:
+        fb, dct = _f32(fb).contiguous(), _f32(dct).contiguous()
     D = n_mfcc + F
     ld = round_up(D, 4)
     out = torch.zeros(B, T, ld, device=X.device, dtype=torch.float32)
@@ -307,6 +309,24 @@ def maskhead_bwd(dest, dmask, mask, obs):
     check(_lib.lib().tssep_maskhead_bwd(_p(dest_r), _p(dmask), _p(mask), _p(obs_r), _p(dlogit), B,
                                         K, T, F, _stream()), "maskhead_bwd")
     return dlogit
+
+
+def mask_mul_fwd(mask, obs):
+    B, K, T, F = mask.shape
+    est = torch.empty(B, K, T, F, 2, device=mask.device, dtype=torch.float32)
+    check(_lib.lib().tssep_mask_mul_fwd(_p(_f32(mask).contiguous()),
+                                        _p(torch.view_as_real(obs.contiguous())), _p(est), B, K, T,
+                                        F, _stream()), "mask_mul_fwd")
+    return torch.view_as_complex(est)
+
+
+def mask_mul_bwd(dest, obs):
+    B, K, T, F = dest.shape
+    dmask = torch.empty(B, K, T, F, device=dest.device, dtype=torch.float32)
+    check(_lib.lib().tssep_mask_mul_bwd(_p(torch.view_as_real(dest.contiguous())),
+                                        _p(torch.view_as_real(obs.contiguous())), _p(dmask), B, K,
+                                        T, F, _stream()), "mask_mul_bwd")
+    return dmask
 
 
 # ----------------------------------------------------------------------------- losses

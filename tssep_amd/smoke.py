@@ -1,0 +1,51 @@
+"""One tiny forward+backward of the TS-SEP hot path on cuda:0, checked against the CPU oracle
+(the oracle is imported here as the CHECKER only)."""
+import numpy as np
+import torch
+
+
+def run(verbose=True):
+    from oracle import model as omodel
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    B, K, N, units, projs = 2, 4, 4000, 16, 20
+    rng = np.random.RandomState(0)
+    tgt = (rng.randn(B, K, N) * 0.1).astype(np.float32)
+    obs = tgt.sum(1, keepdims=True) + 0.05 * rng.rand(B, 1, N).astype(np.float32)
+    aux = rng.rand(B, K, 513).astype(np.float32)
+    torch.manual_seed(0)
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=units, projs=projs,
+                                            combination="mul", aux_net_output_size=513, ts_vad=K,
+                                            output_resolution="tf"),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).to("cuda:0")
+    ex = dict(observation=torch.as_tensor(obs).cuda(), auxInput=torch.as_tensor(aux).cuda(),
+              reference_channel=0, speaker_reverberation_early_ch0=torch.as_tensor(tgt).cuda(),
+              dataset=["smoke"] * B)
+    np.random.seed(1)
+    out = m(ex)
+    summary = m.review(ex, out)
+    summary["loss"].backward()
+    torch.cuda.synchronize()
+    p = {"mask_estimator." + k: v.detach().cpu().clone().requires_grad_()
+         for k, v in m.mask_estimator.state_dict().items()}
+    np.random.seed(1)
+    o = omodel.forward_loss(p, torch.as_tensor(obs), torch.as_tensor(aux), torch.as_tensor(tgt),
+                            cfg=dict(odim=513, combination="mul", ts_vad=K, output_resolution="tf"),
+                            fast=True)
+    o["loss"].sum().backward()
+    merr = float((out.mask.cpu() - o["mask"]).abs().max())
+    lerr = abs(float(summary["loss"]) - float(o["loss"].sum()))
+    gerr = max(float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max()
+                     / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
+               for k, v in m.mask_estimator.named_parameters())
+    if verbose:
+        print(f"smoke: loss {float(summary['loss']):.6f} (oracle {float(o['loss'].sum()):.6f}), "
+              f"max |mask err| {merr:.2e}, max rel grad err {gerr:.2e}")
+    assert merr < 1e-3 and lerr < 1e-3 and gerr < 1e-2, (merr, lerr, gerr)
+    return dict(mask_err=merr, loss_err=lerr, grad_err=gerr)

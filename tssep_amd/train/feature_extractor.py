@@ -1,0 +1,183 @@
+"""STFT feature extractors -- drop-ins for tssep/train/feature_extractor.py (and the
+padertorch ``STFT`` base it star-imports, feature_extractor.py:8) on the HIP kernels.
+
+Implemented: ``STFT`` (base: stft / istft / __call__), ``Log1pMaxNormAbsSTFT`` (:183-263),
+``ConcaternatedSTFTFeatures`` (:290-367), ``TorchMFCC`` (feature_extractor_torchaudio.py).
+Inputs must be CUDA tensors: there is no CPU path in this package.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from .. import hip_ops as H
+from ..configurable import Configurable
+
+
+def _cuda_f32(x):
+    if isinstance(x, np.ndarray):
+        x = torch.as_tensor(x)
+    if not x.is_cuda:
+        raise RuntimeError("tssep_amd runs on the GPU only: move the input to cuda first "
+                           "(no CPU fallback)")
+    return x.to(torch.float32)
+
+
+class STFT(Configurable):
+    def __init__(self, size=1024, shift=256, window_length=None, pad=True, fading=True,
+                 output_size=None, window="blackman"):
+        if window_length is None:
+            window_length = size
+        if window_length != size:
+            raise NotImplementedError("window_length != size")
+        self.size, self.shift, self.window_length = size, shift, window_length
+        self.pad, self.fading, self.window = pad, fading, window
+        self.output_size = self._get_output_size(output_size)
+
+    @property
+    def frequencies(self):
+        return self.size // 2 + 1
+
+    def _get_output_size(self, output_size):
+        if output_size is None:
+            return self.frequencies
+        return output_size
+
+    def _windows(self, device):
+        return Fn.windows(self.window, self.size, self.shift, device)
+
+    def stft(self, signal):
+        """[..., N] -> complex64 [..., T, F]  (fe.stft, model.py:503-504)"""
+        x = _cuda_f32(signal)
+        if not self.pad:
+            raise NotImplementedError("pad=False")
+        w, _ = self._windows(x.device)
+        X = H.stft_fwd(x.reshape(-1, x.shape[-1]), w, self.size, self.shift, self.fading)
+        return X.reshape(*x.shape[:-1], X.shape[-2], X.shape[-1])
+
+    def istft(self, signal, num_samples=None):
+        """complex [..., T, F] -> [..., N]  (fe.istft, model.py:661-664); differentiable."""
+        T = signal.shape[-2]
+        full = (T - 1) * self.shift + self.size - (2 * (self.size - self.shift) if self.fading else 0)
+        N = full if num_samples is None else min(num_samples, full)
+        _, wsyn = self._windows(signal.device)
+        return Fn.istft(signal, wsyn, N, self.size, self.shift, self.fading)
+
+    def stft_to_feature(self, stft_signals):
+        raise NotImplementedError(type(self))
+
+    def __call__(self, signal):
+        return self.stft_to_feature(self.stft(signal))
+
+    def sample_index_to_frame_index(self, sample_index):
+        """paderbox STFT.sample_index_to_frame_index: frame whose centre covers the sample."""
+        pad = self.window_length - self.shift if self.fading else 0
+        return max(0, (int(sample_index) + pad - self.window_length // 2) // self.shift)
+
+
+class Log1pMaxNormAbsSTFT(STFT):
+    def __init__(self, size=1024, shift=256, window_length=None, pad=True, fading=True,
+                 output_size=None, window="blackman", statistics_axis="tf"):
+        super().__init__(size=size, shift=shift, window_length=window_length, pad=pad,
+                         fading=fading, output_size=output_size, window=window)
+        if statistics_axis != "tf":
+            raise NotImplementedError("statistics_axis != 'tf' (the shipped configs use 'tf')")
+        self.statistics_axis = statistics_axis
+
+    def stft_to_feature(self, stft_signals):
+        X = stft_signals
+        lead = X.shape[:-2]
+        out, _ = H.feat_fwd(X.reshape(-1, X.shape[-2], X.shape[-1]) if X.dim() != 3 else X,
+                            None, None, 0)
+        return out.reshape(*lead, X.shape[-2], X.shape[-1]) if X.dim() != 3 else out
+
+
+class TorchMFCC(STFT, torch.nn.Module):
+    """feature_extractor_torchaudio.py:11-106; filterbank / DCT tables restated from
+    torchaudio 2.0.2 (absent here; parity unpinned, see oracle/features.py)."""
+
+    def __init__(self, size=400, shift=200, window_length=None, pad=True, fading=True,
+                 output_size=None, window="hann", sample_rate: int = 16000, n_mfcc: int = 40,
+                 dct_norm: str = "ortho", log_mels: bool = False, f_min: float = 40,
+                 f_max: float = -400, n_mels: int = 40, mel_norm: str = None,
+                 mel_scale: str = "htk"):
+        torch.nn.Module.__init__(self)
+        self.n_mfcc = n_mfcc
+        STFT.__init__(self, size=size, shift=shift, window_length=window_length, pad=pad,
+                      fading=fading, output_size=output_size, window=window)
+        if log_mels or mel_norm is not None or mel_scale != "htk" or dct_norm != "ortho":
+            raise NotImplementedError("only the shipped TorchMFCC options are built")
+        self.sample_rate, self.f_min = sample_rate, f_min
+        if f_max and f_max < 0:
+            f_max = sample_rate + f_max                       # :57-58
+        self.f_max, self.n_mels = f_max, n_mels
+        self.dct_norm, self.mel_norm, self.top_db, self.log_mels = dct_norm, mel_norm, 80, log_mels
+        self.register_buffer("fb", _melscale_fbanks(size // 2 + 1, f_min, f_max, n_mels, sample_rate))
+        self.register_buffer("dct_mat", _create_dct(n_mfcc, n_mels))
+
+    def _get_output_size(self, output_size):
+        return self.n_mfcc if output_size is None else output_size
+
+    def stft_to_feature(self, stft_signals):
+        X = stft_signals
+        assert X.dim() == 3, X.shape
+        out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self.top_db)
+        return out[..., :self.n_mfcc]
+
+
+def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.min(down, up), min=0.0).contiguous()
+
+
+def _create_dct(n_mfcc, n_mels):
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
+    dct[0] *= 1.0 / math.sqrt(2.0)
+    dct *= math.sqrt(2.0 / float(n_mels))
+    return dct.t().contiguous()
+
+
+class ConcaternatedSTFTFeatures(STFT, torch.nn.Module):
+    @classmethod
+    def finalize_dogmatic_config(cls, config):               # feature_extractor.py:308-321
+        for fe in ["fe1", "fe2"]:
+            if isinstance(config.get(fe), dict):
+                for k in ("size", "shift", "pad", "fading", "window"):
+                    if k in config:
+                        config[fe][k] = config[k]
+                if config.get("window_length") is not None:
+                    config[fe]["window_length"] = config["window_length"]
+
+    def __init__(self, fe1, fe2, output_size=None, size=1024, shift=256, window="blackman",
+                 window_length=None, pad=True, fading=True):
+        torch.nn.Module.__init__(self)
+        self._tmp = [fe1, fe2]
+        STFT.__init__(self, size=size, shift=shift, window_length=window_length, pad=pad,
+                      fading=fading, output_size=output_size, window=window)
+        self.fe1, self.fe2 = fe1, fe2
+
+    def _get_output_size(self, output_size):
+        fe1, fe2 = self._tmp
+        if output_size is None:
+            return fe1._get_output_size(None) + fe2._get_output_size(None)
+        return output_size
+
+    def stft_to_feature(self, stft_signals):
+        X = stft_signals
+        if isinstance(self.fe1, TorchMFCC) and isinstance(self.fe2, Log1pMaxNormAbsSTFT) \
+                and X.dim() == 3:
+            # one fused pass pair writes [mfcc | log1p] side by side (feature_extractor.py:352-360)
+            out, _ = H.feat_fwd(X, self.fe1.fb, self.fe1.dct_mat, self.fe1.n_mfcc, self.fe1.top_db)
+            return out
+        return torch.concat([self.fe1.stft_to_feature(X), self.fe2.stft_to_feature(X)], dim=-1)

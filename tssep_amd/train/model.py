@@ -1,0 +1,172 @@
+"""Model -- drop-in for tssep/train/model.py: ``forward`` (:465-536) and the loss part of
+``review`` (:653-690) on the HIP kernels; dataset helpers follow :182-370 in a reduced form
+(no lazy_dataset: plain lists, the reader is synthetic)."""
+import dataclasses
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from ..configurable import Configurable
+from . import enhancer as _enh, feature_extractor as _fe, loss as _loss, net as _net
+from ..data import DummyReader
+
+
+class ReviewSummary(dict):
+    """The few members of padertorch's ReviewSummary the reference's review touches."""
+
+    def add_to_loss(self, value):
+        self["loss"] = self["loss"] + value if "loss" in self else value
+
+    def add_scalar(self, name, *value):
+        self.setdefault("scalars", {}).setdefault(name, []).extend(
+            float(v) if not isinstance(v, torch.Tensor) else v.detach() for v in value)
+
+    def add_histogram(self, name, values):
+        self.setdefault("histograms", {}).setdefault(name, []).append(
+            values.detach() if isinstance(values, torch.Tensor) else values)
+
+
+class Model(Configurable, torch.nn.Module):
+    @classmethod
+    def finalize_dogmatic_config(cls, config):              # model.py:71-149
+        config.setdefault("fe", None)
+        if config.get("fe") is None:
+            config["fe"] = dict(factory=_fe.Log1pMaxNormAbsSTFT, size=1024, shift=256, window="hann")
+        if config.get("reader") is None:
+            config["reader"] = dict(factory=DummyReader)
+        if config.get("enhancer") is None:
+            config["enhancer"] = dict(factory=_enh.Masking)
+        if config.get("loss") is None:
+            config["loss"] = dict(factory=_loss.LogMAE)
+        if config.get("mask_estimator") is None:
+            fe = Configurable.from_config(_fe.Log1pMaxNormAbsSTFT.get_config(
+                {k: v for k, v in config["fe"].items() if k != "factory"})) \
+                if not hasattr(config["fe"], "output_size") else config["fe"]
+            config["mask_estimator"] = dict(factory=_net.MaskEstimator_v2, idim=fe.output_size,
+                                            odim=fe.frequencies, nmask=1)
+
+    def __init__(self, fe=None, reader=None, mask_estimator=None, enhancer=None, loss=None):
+        super().__init__()
+        self.fe = fe
+        self.reader = reader
+        self.mask_estimator = mask_estimator
+        self.enhancer = enhancer
+        self.loss = loss
+        self.create_snapshot = False
+
+    # ------------------------------------------------------------------ data helpers
+    def example_to_device(self, ex, device):                # model.py:166-180
+        for k in {"Input", "observation", "auxInput", *self.loss.targets(lower=True),
+                  *self.loss.targets()}:
+            if k in ex:
+                v = ex[k]
+                if isinstance(v, np.ndarray):
+                    v = torch.as_tensor(v)
+                if isinstance(v, torch.Tensor):
+                    ex[k] = v.to(device)
+        return ex
+
+    def collate_fn(self, exs):                              # model.py:339-370
+        ex = {k: [e[k] for e in exs] for k in exs[0]}
+        ex["reference_channel"] = exs[0]["reference_channel"]
+        for k in ("observation", "auxInput", "vad", "Vad", *self.loss.targets(lower=True)):
+            if k in ex:
+                ex[k] = torch.as_tensor(np.stack([np.asarray(v) for v in ex[k]]))
+        return ex
+
+    def prepare_dataset(self, dataset_name, device, training=False, batch_size=None, **_):
+        load_keys = ["observation", *self.loss.targets(lower=True)]
+        out = []
+        for e in self.reader(dataset_name, pre_load_apply=None, load_keys=load_keys):
+            r = {"reference_channel": 0, "observation": e["audio_data"]["observation"]}
+            for t in self.loss.targets():
+                if t.lower() in e["audio_data"]:
+                    r[t.lower()] = e["audio_data"][t.lower()]
+            for k in ("example_id", "dataset", "auxInput", "vad"):
+                if k in e:
+                    r[k] = e[k]
+            out.append(r)
+        if batch_size is not None:
+            out = [self.collate_fn(out[i:i + batch_size]) for i in range(0, len(out), batch_size)]
+        if device is not None:
+            out = [self.example_to_device(e, device) for e in out]
+        return out
+
+    def prepare_train_dataset(self, device, batch_size=None, **kw):
+        return self.prepare_dataset(self.reader.train_dataset_name, device, True, batch_size)
+
+    def prepare_validate_dataset(self, device, batch_size=None, **kw):
+        return self.prepare_dataset(self.reader.validate_dataset_name, device, False, batch_size)
+
+    # ------------------------------------------------------------------------ forward
+    @dataclasses.dataclass
+    class ForwardOutput:                                    # model.py:454-463
+        mask: torch.Tensor
+        logit: torch.Tensor
+        embedding: torch.Tensor = None
+        stft_estimate: torch.Tensor = None
+        time_estimate: torch.Tensor = None
+        vad_mask: torch.Tensor = None
+        vad_logit: torch.Tensor = None
+
+    def forward(self, ex, feature_transform=None) -> "Model.ForwardOutput":
+        ex["AuxInput"] = [a for a in ex["auxInput"]]
+        if not isinstance(ex["reference_channel"], int):
+            raise NotImplementedError(type(ex["reference_channel"]), ex["reference_channel"])
+        ref = ex["reference_channel"]
+        if "Input" in ex:
+            pass
+        elif "Observation" in ex:
+            ex["Input"] = self.fe.stft_to_feature(ex["Observation"][..., ref, :, :]).to(torch.float32)
+        elif hasattr(self.fe, "stft"):
+            ex["Observation"] = self.fe.stft(ex["observation"])
+            ex["Input"] = self.fe.stft_to_feature(ex["Observation"][..., ref, :, :]).to(torch.float32)
+        else:
+            ex["Input"] = self.fe(ex["observation"][..., ref, :]).to(torch.float32)
+        if feature_transform is not None:
+            ex["Input"] = feature_transform(ex["Input"])
+        ex = self.reader.data_hooks.pre_net(ex)
+
+        aux = ex["auxInput"] if isinstance(ex["auxInput"], torch.Tensor) else ex["AuxInput"]
+        batched = ex["Input"].dim() == 3
+        logit, emb = self.mask_estimator.logits(ex["Input"], aux)
+        if "Observation" in ex:
+            obs = ex["Observation"][..., ref, :, :]
+            if isinstance(self.enhancer, _enh.Masking):
+                # sigmoid (net.py:983) + Masking (enhancer.py:98-100): one fused kernel
+                if batched:
+                    mask, est = Fn.mask_head(logit, obs.contiguous())
+                else:
+                    mask, est = Fn.mask_head(logit[None], obs[None].contiguous())
+                    mask, est = mask[0], est[0]
+            else:
+                mask = Fn.sigmoid(logit if batched else logit[None])
+                mask = mask if batched else mask[0]
+                est = self.enhancer(mask.unsqueeze(-3), ex, self)
+        else:
+            assert isinstance(self.loss, _loss.VADSigmoidBCE), type(self.loss)
+            mask = Fn.sigmoid(logit if batched else logit[None])
+            mask = mask if batched else mask[0]
+            est = None
+        return self.ForwardOutput(mask=mask.unsqueeze(-3), logit=logit.unsqueeze(-3),
+                                  embedding=emb, stft_estimate=est)
+
+    # ------------------------------------------------------------------------- review
+    def review(self, ex, out: "Model.ForwardOutput"):
+        summary = ReviewSummary()
+        if hasattr(self.fe, "istft") and "observation" in ex:          # model.py:661-664
+            out.time_estimate = self.fe.istft(out.stft_estimate,
+                                              num_samples=ex["observation"].shape[-1])
+        loss_value = self.loss.from_ex_out(ex, out, self, summary)
+        summary.add_to_loss(loss_value.sum())                            # model.py:669
+        with torch.no_grad():
+            name = self.loss.name
+            if loss_value.ndim == 0:
+                summary.add_scalar(f'{ex["dataset"]}_{name}', loss_value)
+            elif loss_value.ndim == 1:
+                for dataset_name, lv in zip(ex["dataset"], loss_value):
+                    summary.add_scalar(f"{dataset_name}_{name}", lv)
+            else:
+                raise NotImplementedError(loss_value.ndim, loss_value.shape)
+        return summary
