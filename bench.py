@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: STFT frames / second, forward + backward, 4-speaker TS-SEP on
+16 kHz 4 s chunks (BASELINE.json configs[2]), one process per MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--batch B]
+
+A step = STFT -> MFCC+log1p features -> RNNP pre-net -> 'mul' conditioning -> 3 RNNP post-net
+layers (TS-VAD speaker combination) -> mask head -> iSTFT -> LogMAE, then backward to every
+parameter and (N > 1) the all-reduce(SUM) of the flat gradient.  Inputs are synthetic and
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+K_SPK, N_SAMPLES, UNITS, PROJS, FBINS = 4, 64000, 300, 320, 513
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+
+
+def synth_batch(B, K, N, seed):
+    """LibriSpeech-style statistics without data: per-speaker low-passed noise
+    gated by a staircase VAD with 50 % neighbour overlap, plus a noise floor."""
+    rng = np.random.RandomState(seed)
+    src = rng.randn(B, K, N).astype(np.float32)
+    src = 0.1 * (src + np.roll(src, 1, -1) + np.roll(src, 2, -1)) / 3 ** 0.5
+    vad = np.zeros((K, N), dtype=np.float32)
+    start = 0
+    for i in range(K):
+        end = N * (i + 2) // (K + 1)
+        vad[i, start:end] = 1
+        start = end - (end - start) // 2
+    tgt = src * vad[None]
+    obs = tgt.sum(1, keepdims=True) + 0.05 * rng.rand(B, 1, N).astype(np.float32)
+    aux = rng.rand(B, K, FBINS).astype(np.float32)
+    return obs, aux, tgt
+
+
+def build_model():
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    torch.manual_seed(0)
+    return model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
+                                            combination="mul", aux_net_output_size=FBINS,
+                                            ts_vad=K_SPK, output_resolution="tf",
+                                            random_speaker_order=True, num_averaged_permutations=1),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE())
+
+
+def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS):
+    """Dense-GEMM FLOPs per STFT frame, forward; backward = 2x."""
+    pre = 16 * H * (D + H) + 2 * 2 * H * F
+    b0 = 16 * H * (F + H) + 2 * 2 * H * P
+    b1 = 16 * H * (P + H) + 2 * 2 * H * P
+    b2 = 16 * H * (P * K + H) + 2 * 2 * H * P
+    return pre + K * (b0 + b1) + b2 + 2 * P * F * K
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a port of the reference's torch code path, pinned to it by tests) timed on
+    this host: same model size and chunk length, a bounded sample."""
+    from oracle import model as omodel
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, 1234)
+    p = omodel.init_mask_estimator_params(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
+                                          combination="mul", aux_size=FBINS, ts_vad=K_SPK)
+    for v in p.values():
+        v.requires_grad_()
+    cfg = dict(odim=FBINS, combination="mul", ts_vad=K_SPK, output_resolution="tf")
+    T = None
+    times = []
+    t_all = time.time()
+    while True:
+        t0 = time.time()
+        o = omodel.forward_loss(p, torch.as_tensor(obs), torch.as_tensor(aux), torch.as_tensor(tgt),
+                                cfg=cfg, fast=True)
+        o["loss"].sum().backward()
+        times.append(time.time() - t0)
+        T = o["mask"].shape[-2]
+        for v in p.values():
+            v.grad = None
+        if len(times) >= 2 and time.time() - t_all > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return dict(value=round(B * T / best, 1), unit="frames/s", cores=cores, kind="port",
+                sample=f"oracle fwd+bwd, batch {B} x 4 s, {len(times)} steps, best step "
+                       f"{best:.3f} s, torch {torch.__version__} CPU, {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 64)),
+                    help="utterances per GPU (weak scaling: global batch = batch * gpus)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tssep_amd import hip_ops as H
+    from tssep_amd.distributed import GradBucket
+    model = build_model().to(dev)
+    bucket = GradBucket(model.parameters())
+    B = args.batch
+    obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, seed=rank)      # each rank its own shard
+    ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
+               speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
+               reference_channel=0, dataset=["bench"] * B)
+    np.random.seed(rank)
+
+    def step():
+        ex = dict(ex0)
+        bucket.zero()
+        out = model(ex)
+        summary = model.review(ex, out)
+        summary["loss"].backward()
+        bucket.all_reduce()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    T = int(out.mask.shape[-2])
+    H.KERNEL_TIMERS.clear()
+    H.KERNEL_TIMING = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    H.KERNEL_TIMING = False
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+
+    # dominant kernel, timed live with HIP events on the launch stream
+    ktimes = H.kernel_time_summary()
+    roofline = None
+    if ktimes:
+        name, (n_launch, total_ms) = max(ktimes.items(), key=lambda kv: kv[1][1])
+        avg_ms = total_ms / n_launch
+        flops = H.KERNEL_FLOPS.get(name, 0) / max(n_launch, 1)
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        launches=n_launch, avg_ms=round(avg_ms, 4),
+                        share_of_step=round(total_ms / (dt * 1e3), 3))
+    if rank == 0:
+        frames = B * world * T * args.steps
+        line = {
+            "metric": "frames/sec fwd+bwd, 4-spk TS-SEP, 16kHz 4s chunks",
+            "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])",
+                       "speakers": K_SPK, "samples": N_SAMPLES, "frames_per_chunk": T,
+                       "batch_per_gpu": B, "global_batch": B * world, "units": UNITS,
+                       "projs": PROJS, "parallelism": f"dp{world}",
+                       "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
+            "roofline": roofline,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

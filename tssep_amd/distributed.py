@@ -1,0 +1,43 @@
+"""Data-parallel gradient exchange: one process per GPU, one flat fp32 bucket, one
+all-reduce(SUM) over RCCL/xGMI per optimizer step.
+
+The reference has no distributed path (tssep/train/experiment.py:181-184 refuses >1 GPU).  Its
+loss is SUMMED over the batch (tssep/train/model.py:669), so gradients of the shards are summed,
+not averaged, to equal a single-process run over the concatenated batch.  Utterances are
+independent in forward and backward, so the data path needs no other collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    """Flat view over all parameter gradients: grads live inside ONE contiguous buffer, so the
+    all-reduce needs no pack/unpack copies."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.flat = torch.zeros(n, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self, group=None, async_op=False):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
+
+    def global_norm(self):
+        return torch.linalg.vector_norm(self.flat)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items units for `rank` (pure data parallel)."""
+    per, rem = divmod(n_items, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)

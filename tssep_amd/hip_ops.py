@@ -13,6 +13,35 @@ from . import _lib
 from ._lib import GemmArgs, LstmSizes, check
 
 
+# ---- optional live kernel timing (bench.py): HIP events on the launch stream -----------------
+KERNEL_TIMING = False
+KERNEL_TIMERS = {}      # name -> list of (start_event, end_event)
+KERNEL_FLOPS = {}       # name -> algorithmic FLOPs accumulated over the timed launches
+
+
+class _timed:
+    def __init__(self, name, flops=0):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if KERNEL_TIMING:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_TIMING:
+            self.e.record()
+            KERNEL_TIMERS.setdefault(self.name, []).append((self.s, self.e))
+            KERNEL_FLOPS[self.name] = KERNEL_FLOPS.get(self.name, 0) + self.flops
+
+
+def kernel_time_summary():
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in KERNEL_TIMERS.items()}
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -170,7 +199,8 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
         g.c_perm = perm.data_ptr() if perm is not None else None
         g.c_perm_ld = remap.get("perm_ld", 0)
     g.splitk, g.c_split_stride = splitk, split_stride
-    check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
+    with _timed("gemm_f32", 2 * M * N * K):
+        check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
 
 def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
@@ -234,13 +264,15 @@ def lstm_pack(params, H, I):
 
 
 def blstm_fwd(gates, cell, hout, ldo, dstride, whh_f, N, T, H):
-    check(_lib.lib().tssep_blstm_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_f), N, T,
-                                     H, _stream()), "blstm_fwd")
+    with _timed("blstm_fwd", 2 * 2 * N * T * 4 * H * H):
+        check(_lib.lib().tssep_blstm_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_f), N,
+                                         T, H, _stream()), "blstm_fwd")
 
 
 def blstm_bwd(gates, cell, dhout, ldo, dstride, whh_b, N, T, H):
-    check(_lib.lib().tssep_blstm_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_b), N, T,
-                                     H, _stream()), "blstm_bwd")
+    with _timed("blstm_bwd", 2 * 2 * N * T * 4 * H * H):
+        check(_lib.lib().tssep_blstm_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_b), N,
+                                         T, H, _stream()), "blstm_bwd")
 
 
 def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r):
