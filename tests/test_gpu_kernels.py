@@ -380,3 +380,45 @@ def test_losses():
     loss, xmean = h.vadbce_fwd(logit.detach().cuda(), vad.cuda())
     close(loss, ref, rtol=1e-5, atol=1e-6, name="bce")
     close(h.vadbce_bwd(xmean, vad.cuda(), gout.cuda(), F), logit.grad, rtol=1e-4, atol=1e-9, name="bce bwd")
+
+
+@pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 40), (8, 9, 20, 64), (11, 5, 33, 300), (40, 7, 16, 300),
+                                      (70, 4, 8, 130), (200, 3, 8, 300)])
+def test_blstm_cluster_kernels(N, T, I, Hh):
+    """W-stationary cluster recurrence (inter-workgroup granule exchange) == oracle, forward and
+    backward; also bit-identical gate/cell layout to the streaming kernels' contract."""
+    h = H()
+    p, x = _lstm_case(N, T, I, Hh, 11)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    cf, cb = h.lstm_pack_cluster(p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda(), Hh)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    Hp = h.round_up(Hh, 4)
+    cell = torch.empty(N, T, 2, Hh, device="cuda")
+    hout = torch.zeros(N, T, 2 * Hp, device="cuda")
+    h.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
+    h.check_cluster_errors()
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    xr = x.clone().requires_grad_()
+    ref = ornnp.blstm(xr, pr, "")
+    got = torch.cat([hout[..., :Hh], hout[..., Hp:Hp + Hh]], -1)
+    close(got, ref, rtol=1e-4, atol=2e-6, name="cluster fwd")
+    dh = torch.randn(N, T, 2 * Hh)
+    (ref * dh).sum().backward()
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = dh[..., :Hh].cuda(); dhd[..., Hp:Hp + Hh] = dh[..., Hh:].cuda()
+    h.blstm_cluster_bwd(gates, cell, dhd, 2 * Hp, Hp, cb, N, T, Hh)
+    h.check_cluster_errors()
+    R = N * T
+    dx = torch.empty(R, I, device="cuda")
+    h.gemm(gates, 8 * Hh, pk["wih_p"], pk["ld_i"], dx, I, R, I, 8 * Hh, b_kmajor=True)
+    close(dx.view(N, T, I), xr.grad, rtol=2e-4, atol=2e-6, name="cluster dx")
+    cs = h.colsum(gates, 8 * Hh, R, 8 * Hh)
+    bf = torch.empty(4 * Hh, device="cuda"); br = torch.empty(4 * Hh, device="cuda")
+    h.lstm_unpack(cs, 1, 1, 0, Hh, 1, bf, br)
+    close(bf, pr["bias_ih_l0"].grad, rtol=2e-4, atol=5e-6, name="cluster db")
+    close(br, pr["bias_hh_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="cluster db_reverse")

@@ -1,0 +1,40 @@
+"""Micro-benchmark (GPU box): streaming vs cluster BLSTM recurrence, per launch, H=300, T=253."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tssep_amd import hip_ops as h
+
+T, Hh, I = 253, 300, 320
+torch.manual_seed(0)
+lstm = torch.nn.LSTM(I, Hh, bidirectional=True, batch_first=True).cuda()
+names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+plist = [getattr(lstm, n) for n in names] + [getattr(lstm, n + "_reverse") for n in names]
+pk = h.lstm_pack(plist, Hh, I)
+cf, cb = h.lstm_pack_cluster(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
+
+
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
+    g0 = torch.randn(N * T, 8 * Hh, device="cuda") * 0.5
+    cell = torch.empty(N, T, 2, Hh, device="cuda")
+    hout = torch.zeros(N, T, 2 * Hh, device="cuda")
+    dh = torch.randn(N, T, 2 * Hh, device="cuda") * 0.1
+    res = dict(N=N)
+    for name, fwd, bwd in (("stream", lambda g: h.blstm_fwd(g, cell, hout, 2 * Hh, Hh, pk["whh_f"], N, T, Hh),
+                            lambda g: h.blstm_bwd(g, cell, dh, 2 * Hh, Hh, pk["whh_b"], N, T, Hh)),
+                           ("cluster", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh),
+                            lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh))):
+        g = g0.clone()
+        res[name + "_fwd_ms"] = round(timeit(lambda: fwd(g)), 3)
+        res[name + "_bwd_ms"] = round(timeit(lambda: bwd(g)), 3)
+        h.check_cluster_errors()
+    print(json.dumps(res), flush=True)

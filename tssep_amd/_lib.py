@@ -53,7 +53,7 @@ def _ctype(decl):
             return ctypes.POINTER(LstmSizes)
         if decl.replace(" ", "").startswith("constchar*"):
             return ctypes.c_char_p
-        return ctypes.c_void_p
+        return ctypes.c_void_p          # float*, int*, int32_t*, void* ... : raw device pointers
     base = decl.replace("const", "").split()
     # "int64_t N" -> type is the first token
     return _SCALARS[base[0]]

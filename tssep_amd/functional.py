@@ -37,7 +37,14 @@ class _RNNP(torch.autograd.Function):
         Hp = _pad4(Hh)
         cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
         hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
-        H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+        cf = cb = None
+        if H.use_cluster(N, Hh, False) or H.use_cluster(N, Hh, True):
+            cf, cb = H.lstm_pack_cluster(w_hh, w_hh_r, Hh)
+        if H.use_cluster(N, Hh, False):
+            H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
+        else:
+            H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+        pk["whh_cb"] = cb
         # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
         wp = _proj_layout(w_proj, Hh, Hp)
         if combine:
@@ -84,7 +91,10 @@ class _RNNP(torch.autograd.Function):
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
         H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
         # BPTT: gates <- d(pre-activations)
-        H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+        if pk.get("whh_cb") is not None and H.use_cluster(N, Hh, True):
+            H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
+        else:
+            H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
         G = 8 * Hh
         # dW_hh per direction (dgates_t paired with h_{t-1} / h_{t+1})
         dwhh = torch.empty(2, 4 * Hh * Hh, device=dev, dtype=torch.float32)

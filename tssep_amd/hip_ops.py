@@ -275,6 +275,72 @@ def blstm_bwd(gates, cell, dhout, ldo, dstride, whh_b, N, T, H):
                                          T, H, _stream()), "blstm_bwd")
 
 
+# cluster (W-stationary) recurrence ------------------------------------------------------------
+_ERR = {}
+RECURRENCE = "auto"          # "auto" | "stream" (lstm.hip) | "cluster" (lstm_cluster.hip)
+
+
+def _err_flag(device):
+    key = str(device)
+    if key not in _ERR:
+        _ERR[key] = torch.zeros(1, device=device, dtype=torch.int32)
+    return _ERR[key]
+
+
+def check_cluster_errors(device="cuda"):
+    """Synchronising check of the cluster kernels' timeout flag (tests / end of a bench run)."""
+    f = _err_flag(torch.device(device) if not isinstance(device, torch.device) else device)
+    v = int(f.item())
+    if v:
+        f.zero_()
+        raise RuntimeError(f"cluster recurrence kernel timed out waiting for a peer (code {v})")
+
+
+def n_cus(device):
+    return torch.cuda.get_device_properties(device).multi_processor_count
+
+
+def use_cluster(N, H, backward):
+    """Pick the recurrence kernel: per-step cost model fitted on MI355X."""
+    if RECURRENCE == "stream" or not _lib.lib().tssep_lstm_cluster_supported(H) or H < 128:
+        return False
+    if RECURRENCE == "cluster":
+        return True
+    return N <= (256 if not backward else 128)
+
+
+def lstm_pack_cluster(w_hh_f, w_hh_r, H):
+    L = _lib.lib()
+    nf, nb = int(L.tssep_lstm_cluster_pack_floats(H, 0)), int(L.tssep_lstm_cluster_pack_floats(H, 1))
+    buf = torch.empty(nf + nb, device=w_hh_f.device, dtype=torch.float32)
+    a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
+    check(L.tssep_lstm_pack_cluster(_p(a), _p(b), H, _p(buf[:nf]), _p(buf[nf:]), _stream()),
+          "lstm_pack_cluster")
+    return buf[:nf], buf[nf:]
+
+
+def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 0, cus)) // 8 + 1,
+                       device=gates.device, dtype=torch.int64)
+    with _timed("blstm_cluster_fwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_cluster_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_cf),
+                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus,
+                                        _stream()), "blstm_cluster_fwd")
+
+
+def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 1, cus)) // 8 + 1,
+                       device=gates.device, dtype=torch.int64)
+    with _timed("blstm_cluster_bwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_cluster_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_cb),
+                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus,
+                                        _stream()), "blstm_cluster_bwd")
+
+
 def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r):
     check(_lib.lib().tssep_lstm_unpack(_p(src), ld, nsplit, split_stride, H, ncols, _p(dst_f),
                                        _p(dst_r), _stream()), "lstm_unpack")
