@@ -168,20 +168,22 @@ int tssep_lstm_unpack(const float* src, int64_t ld, int nsplit, int64_t split_st
  * batches that do not fill the chip (same math, same tensor layouts; see lstm_cluster.hip).
  * A cluster of ceil(H/32) co-resident workgroups keeps W_hh in registers and exchanges h / dh
  * through 8-byte {tag,value} granules in `xbuf` (tssep_lstm_cluster_xbuf_bytes; zeroed inside
- * the call by a memset node on `stream`).  `max_wgs` = number of CUs: every workgroup of the
- * launch must be resident at once.  `err` (device int, caller zeroes it once) is set non-zero if
- * a bounded spin timed out.  H <= 304. */
+ * the call by a memset node on `stream`).  `max_wgs` = number of CUs (sizes the grid so that
+ * neighbouring clusters hide each other's exchange latency; cluster membership is taken by
+ * arrival ticket, so correctness does not depend on residency or dispatch order).
+ * `ms` = sequences per cluster / 4: 2, 4, or 0 = automatic.  `err` (device int, caller zeroes it
+ * once) is set non-zero if a bounded spin timed out.  H <= 304. */
 int tssep_lstm_cluster_supported(int H);
 int64_t tssep_lstm_cluster_pack_floats(int H, int which /* 0: whh_cf, 1: whh_cb */);
 int tssep_lstm_pack_cluster(const float* w_hh_f, const float* w_hh_r, int H,
                             float* whh_cf, float* whh_cb, void* stream);
-int64_t tssep_lstm_cluster_xbuf_bytes(int64_t N, int H, int backward, int max_wgs);
+int64_t tssep_lstm_cluster_xbuf_bytes(int64_t N, int H, int backward, int max_wgs, int ms);
 int tssep_blstm_cluster_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
                             const float* whh_cf, void* xbuf, int* err,
-                            int64_t N, int64_t T, int H, int max_wgs, void* stream);
+                            int64_t N, int64_t T, int H, int max_wgs, int ms, void* stream);
 int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout, int64_t ldo,
                             int64_t dstride, const float* whh_cb, void* xbuf, int* err,
-                            int64_t N, int64_t T, int H, int max_wgs, void* stream);
+                            int64_t N, int64_t T, int H, int max_wgs, int ms, void* stream);
 
 /* ---------------------------------------------------------- elementwise ------*/
 /* d(pre-tanh) = dy * (1 - y^2) for the Tanh between post-net layers (tssep/train/net.py:623-625).

@@ -382,9 +382,10 @@ def test_losses():
     close(h.vadbce_bwd(xmean, vad.cuda(), gout.cuda(), F), logit.grad, rtol=1e-4, atol=1e-9, name="bce bwd")
 
 
+@pytest.mark.parametrize("ms", [0, 2, 4])
 @pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 40), (8, 9, 20, 64), (11, 5, 33, 300), (40, 7, 16, 300),
-                                      (70, 4, 8, 130), (200, 3, 8, 300)])
-def test_blstm_cluster_kernels(N, T, I, Hh):
+                                      (70, 4, 8, 130), (500, 3, 8, 300)])
+def test_blstm_cluster_kernels(N, T, I, Hh, ms):
     """W-stationary cluster recurrence (inter-workgroup granule exchange) == oracle, forward and
     backward; also bit-identical gate/cell layout to the streaming kernels' contract."""
     h = H()
@@ -400,7 +401,7 @@ def test_blstm_cluster_kernels(N, T, I, Hh):
     Hp = h.round_up(Hh, 4)
     cell = torch.empty(N, T, 2, Hh, device="cuda")
     hout = torch.zeros(N, T, 2 * Hp, device="cuda")
-    h.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
+    h.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh, ms)
     h.check_cluster_errors()
     pr = {k: v.clone().requires_grad_() for k, v in p.items()}
     xr = x.clone().requires_grad_()
@@ -411,7 +412,7 @@ def test_blstm_cluster_kernels(N, T, I, Hh):
     (ref * dh).sum().backward()
     dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
     dhd[..., :Hh] = dh[..., :Hh].cuda(); dhd[..., Hp:Hp + Hh] = dh[..., Hh:].cuda()
-    h.blstm_cluster_bwd(gates, cell, dhd, 2 * Hp, Hp, cb, N, T, Hh)
+    h.blstm_cluster_bwd(gates, cell, dhd, 2 * Hp, Hp, cb, N, T, Hh, ms)
     h.check_cluster_errors()
     R = N * T
     dx = torch.empty(R, I, device="cuda")

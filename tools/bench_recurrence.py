@@ -31,8 +31,10 @@ for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
     res = dict(N=N)
     for name, fwd, bwd in (("stream", lambda g: h.blstm_fwd(g, cell, hout, 2 * Hh, Hh, pk["whh_f"], N, T, Hh),
                             lambda g: h.blstm_bwd(g, cell, dh, 2 * Hh, Hh, pk["whh_b"], N, T, Hh)),
-                           ("cluster", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh),
-                            lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh))):
+                           ("cluster2", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh, 2),
+                            lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh, 2)),
+                           ("cluster4", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh, 4),
+                            lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh, 4))):
         g = g0.clone()
         res[name + "_fwd_ms"] = round(timeit(lambda: fwd(g)), 3)
         res[name + "_bwd_ms"] = round(timeit(lambda: bwd(g)), 3)

@@ -75,12 +75,12 @@ __device__ __forceinline__ bool gather_granules(const u64* const (&p)[R], unsign
 // packed weights for the cluster kernels (built by tssep_lstm_pack_cluster):
 //   whh_cf [dir][g][wave 4][kk KH][lane 64]    = W_hh[gate*H + u][kh*KH + kk],
 //          u = 32g + 16*(wave>>1) + lane/4, gate = lane%4, kh = wave&1
-//   whh_cb [dir][g][wave 5][kk 128][lane 64]   = W_hh[gc][64*wave + lane],
-//          gc = gate*H + (32g + kk/4) with gate = kk%4       (own gate columns, (unit,gate) order)
+//   whh_cb [dir][g][wave 4][kk 32][b 5][lane 64] = W_hh[gc][64*b + lane],
+//          gc = gate*H + (32g + 8*wave + kk/4) with gate = kk%4   (own gate columns, (unit,gate) order)
 __global__ void lstm_pack_cluster_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G,
                                          float* cf, float* cb) {
   const int64_t n_f = (int64_t)2 * G * 4 * KH * 64;
-  const int64_t n_b = (int64_t)2 * G * 5 * 128 * 64;
+  const int64_t n_b = (int64_t)2 * G * 4 * 32 * 5 * 64;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_f + n_b;
        e += (int64_t)gridDim.x * blockDim.x) {
     if (e < n_f) {
@@ -97,12 +97,13 @@ __global__ void lstm_pack_cluster_kernel(const float* w_hh_f, const float* w_hh_
     } else {
       int64_t r = e - n_f;
       const int lane = (int)(r & 63); r >>= 6;
-      const int kk = (int)(r & 127); r >>= 7;
-      const int wave = (int)(r % 5); r /= 5;
+      const int b = (int)(r % 5); r /= 5;
+      const int kk = (int)(r & 31); r >>= 5;
+      const int wave = (int)(r & 3); r >>= 2;
       const int g = (int)(r % G);
       const int d = (int)(r / G);
-      const int uo = 64 * wave + lane;
-      const int ui = 32 * g + (kk >> 2), gate = kk & 3;
+      const int uo = 64 * b + lane;
+      const int ui = 32 * g + 8 * wave + (kk >> 2), gate = kk & 3;
       const float* w = d ? w_hh_r : w_hh_f;
       cb[e - n_f] = (uo < H && ui < H) ? w[(int64_t)(gate * H + ui) * H + uo] : 0.f;
     }
@@ -113,7 +114,7 @@ __global__ void lstm_pack_cluster_kernel(const float* w_hh_f, const float* w_hh_
 // grid = nclusters * G workgroups of 256 threads; cluster c = blockIdx.x / G walks the work items
 // (sequence group, direction) c, c + nclusters, ...   MS = sequences per group / 4 (even).
 template <int MS>
-__global__ __launch_bounds__(256, 1) void blstm_cluster_fwd_kernel(
+__global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const float* __restrict__ whh_cf, u64* __restrict__ xbuf,
     int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters) {
@@ -122,14 +123,23 @@ __global__ __launch_bounds__(256, 1) void blstm_cluster_fwd_kernel(
   const int Hp = G * UPW;
   __shared__ __attribute__((aligned(16))) float hs[M * KROW];
   __shared__ __attribute__((aligned(16))) float part[4 * HQ * 64 * 4];
-  __shared__ int s_fail;
+  __shared__ int s_fail, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ub = wave >> 1, kh = wave & 1;
-  const int g = blockIdx.x % G, cid = blockIdx.x / G;
+  // Cluster membership by arrival ticket: the first G workgroups that START form cluster 0, the
+  // next G cluster 1, ...  A cluster therefore only ever waits for workgroups that are already
+  // running or will be scheduled as soon as a complete (running) cluster retires -- no assumption
+  // about dispatch order or co-residency of the whole grid.
+  if (tid == 0) {
+    s_fail = 0;
+    s_ticket = (int)atomicAdd(reinterpret_cast<unsigned*>(xbuf), 1u);
+  }
+  __syncthreads();
+  const int g = s_ticket % G, cid = s_ticket / G;
+  xbuf += 8;                                   // skip the 64-byte header
   const int j = lane & 3;
   const int unit = UPW * g + 16 * ub + (lane >> 2);
   const bool uvalid = unit < H;
-  if (tid == 0) s_fail = 0;
 
   const int64_t ngroups = (N + M - 1) / M;
   for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
@@ -162,29 +172,26 @@ __global__ __launch_bounds__(256, 1) void blstm_cluster_fwd_kernel(
           v = *reinterpret_cast<const f32x4*>(gates + (((n * T + t) * 2 + dir) * (int64_t)H + unit) * 4);
         gx[q] = v;
       }
-      // ---- gather h_{t-1} (published with tag = step) into LDS, 10 granules per thread per round
+      // ---- gather h_{t-1} (published with tag = step) into LDS: every thread issues all of its
+      // granule loads at once (one memory round trip when the peers have already published)
       if (step > 0) {
         const u64* src = xb + (int64_t)((step - 1) & 1) * M * Hp;
-        bool fail = false;
-        constexpr int CH = 10;
-        for (int base = 0; base < M * Hp; base += 256 * CH) {
-          const u64* p[CH];
-          int off[CH];
+        constexpr int CH = 5 * MS;               // M * 320 / 256 granules per thread
+        const u64* p[CH];
+        int off[CH];
 #pragma unroll
-          for (int r = 0; r < CH; ++r) {
-            const int i = base + r * 256 + tid;
-            const int s = i / Hp, uu = i - s * Hp;
-            const bool ok = i < M * Hp && uu < H;
-            p[r] = ok ? src + i : nullptr;
-            off[r] = ok ? s * KROW + uu : -1;
-          }
-          float v[CH];
-          if (!gather_granules<CH>(p, (unsigned)step, v)) fail = true;
-#pragma unroll
-          for (int r = 0; r < CH; ++r)
-            if (off[r] >= 0) hs[off[r]] = v[r];
+        for (int r = 0; r < CH; ++r) {
+          const int i = r * 256 + tid;
+          const int s = i / Hp, uu = i - s * Hp;
+          const bool ok = i < M * Hp && uu < H;
+          p[r] = ok ? src + i : nullptr;
+          off[r] = ok ? s * KROW + uu : -1;
         }
-        if (fail) s_fail = 1;
+        float v[CH];
+        if (!gather_granules<CH>(p, (unsigned)step, v)) s_fail = 1;
+#pragma unroll
+        for (int r = 0; r < CH; ++r)
+          if (off[r] >= 0) hs[off[r]] = v[r];
       }
       __syncthreads();
       if (s_fail) {
@@ -241,52 +248,61 @@ __global__ __launch_bounds__(256, 1) void blstm_cluster_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------ backward
-// 320 threads: waves 0..3 run the lane-local cell backward for this WG's 32 units x M sequences,
-// all 5 waves multiply the WG's 128 d(gate) columns into partial dh for output units 64*wave+lane.
+// 256 threads.  Cell backward is lane-local for this WG's 32 units x M sequences (same lane map
+// as forward).  dh_prev = dgates x W_hh is a reduce-scatter: wave w multiplies ITS 32 gate columns
+// (units 8w..8w+7 of the WG, 4 gates each; 160 stationary registers = 32 k x 5 output blocks of
+// 64 units) into partial sums for ALL output units, the 4 waves are summed through LDS and the
+// WG publishes one partial per (unit, sequence); the owner of a unit adds the G partials in a
+// fixed order (deterministic).
 template <int MS>
-__global__ __launch_bounds__(320, 1) void blstm_cluster_bwd_kernel(
+__global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_bwd_kernel(
     float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dhout,
     int64_t ldo, int64_t dstride, const float* __restrict__ whh_cb, u64* __restrict__ xbuf,
     int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters) {
   constexpr int M = 4 * MS, HQ = MS / 2;
   constexpr int DROW = 128 + 4;              // d(gate) row per sequence: own 32 units x 4 gates
-  const int Hp = G * UPW;                    // multiple of 32; output blocks of 64 cover 5*64 >= Hp
+  constexpr int NBLK = 5;                    // output blocks of 64 units (H <= 320)
+  const int Hp = G * UPW;
   __shared__ __attribute__((aligned(16))) float dgs[M * DROW];
-  __shared__ int s_fail;
+  __shared__ __attribute__((aligned(16))) float part[4 * NBLK * MS * 64 * 4];
+  __shared__ int s_fail, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ub = (wave >> 1) & 1, kh = wave & 1;
-  const int g = blockIdx.x % G, cid = blockIdx.x / G;
+  const int ub = wave >> 1, kh = wave & 1;
+  if (tid == 0) {
+    s_fail = 0;
+    s_ticket = (int)atomicAdd(reinterpret_cast<unsigned*>(xbuf), 1u);
+  }
+  __syncthreads();
+  const int g = s_ticket % G, cid = s_ticket / G;
+  xbuf += 8;
   const int j = lane & 3;
   const int unit = UPW * g + 16 * ub + (lane >> 2);
   const int ulocal = 16 * ub + (lane >> 2);
-  const bool uvalid = unit < H && wave < 4;
-  if (tid == 0) s_fail = 0;
+  const bool uvalid = unit < H;
 
   const int64_t ngroups = (N + M - 1) / M;
   for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
     const int dir = (int)(work & 1);
     const int64_t sgid = work >> 1;
     const int64_t seq0 = sgid * M;
-    float w[128];
+    float w[32 * NBLK];
     {
-      const float* wp = whh_cb + (((int64_t)(dir * G + g) * 5 + wave) * 128) * 64 + lane;
+      const float* wp = whh_cb + (((int64_t)(dir * G + g) * 4 + wave) * 32 * NBLK) * 64 + lane;
 #pragma unroll
-      for (int kk = 0; kk < 128; ++kk) w[kk] = wp[(int64_t)kk * 64];
+      for (int kk = 0; kk < 32 * NBLK; ++kk) w[kk] = wp[(int64_t)kk * 64];
     }
-    for (int i = tid; i < M * DROW; i += 320) dgs[i] = 0.f;
+    for (int i = tid; i < M * DROW; i += 256) dgs[i] = 0.f;
     float dcc[HQ];
 #pragma unroll
     for (int q = 0; q < HQ; ++q) dcc[q] = 0.f;
-    // exchange buffer: [slot 2][src g' G][seq M][Hp]
-    u64* xb = xbuf + (int64_t)work * 2 * G * M * Hp;
+    u64* xb = xbuf + (int64_t)work * 2 * G * M * Hp;      // [slot 2][src G][seq M][Hp]
     __syncthreads();
 
     for (int64_t step = 0; step < T; ++step) {
       const int64_t t = dir ? step : T - 1 - step;
       const bool has_prev = step + 1 < T;
       const int64_t tp = dir ? t + 1 : t - 1;
-      bool fail = false;
-      if (wave < 4) {
+      {
         // (1) saved activations of this lane's cells: issued first, independent of the exchange
         f32x4 g4[HQ];
         float ct[HQ], cp[HQ], dh[HQ];
@@ -310,18 +326,21 @@ __global__ __launch_bounds__(320, 1) void blstm_cluster_bwd_kernel(
         // (2) reduce-scatter: the G partial dh of every cell, published with tag = step
         if (step > 0 && uvalid) {
           constexpr int GMAX = 10;
+          const u64* p[GMAX * HQ];
 #pragma unroll
           for (int q = 0; q < HQ; ++q) {
             const int s = 4 * (kh * HQ + q) + j;
             const u64* src = xb + (int64_t)((step - 1) & 1) * G * M * Hp + (int64_t)s * Hp + unit;
-            const u64* p[GMAX];
 #pragma unroll
-            for (int gs = 0; gs < GMAX; ++gs) p[gs] = gs < G ? src + (int64_t)gs * M * Hp : nullptr;
-            float v[GMAX];
-            if (!gather_granules<GMAX>(p, (unsigned)step, v)) fail = true;
-#pragma unroll
-            for (int gs = 0; gs < GMAX; ++gs) dh[q] += v[gs];     // fixed order: deterministic
+            for (int gs = 0; gs < GMAX; ++gs)
+              p[q * GMAX + gs] = gs < G ? src + (int64_t)gs * M * Hp : nullptr;
           }
+          float v[GMAX * HQ];
+          if (!gather_granules<GMAX * HQ>(p, (unsigned)step, v)) s_fail = 1;
+#pragma unroll
+          for (int q = 0; q < HQ; ++q)
+#pragma unroll
+            for (int gs = 0; gs < GMAX; ++gs) dh[q] += v[q * GMAX + gs];   // fixed order
         }
         // (3) cell backward
 #pragma unroll
@@ -342,38 +361,56 @@ __global__ __launch_bounds__(320, 1) void blstm_cluster_bwd_kernel(
           *reinterpret_cast<f32x4*>(dgs + s * DROW + 4 * ulocal) = dg4;
         }
       }
-      if (fail) s_fail = 1;
       __syncthreads();
       if (s_fail) {
         if (tid == 0) atomicExch(err, 2);
         return;
       }
-      // ---- partial dh_prev[uo, seq] = sum over own 128 gate columns; publish for every unit
       if (has_prev) {
-        f32x4 acc[MS];
+        // ---- partial dh_prev[uo, seq] over this wave's 32 gate columns
+        f32x4 acc[NBLK][MS];
 #pragma unroll
-        for (int q = 0; q < MS; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* db = dgs + j * DROW;
+        for (int b = 0; b < NBLK; ++b)
 #pragma unroll
-        for (int k4 = 0; k4 < 32; ++k4) {
+          for (int q = 0; q < MS; ++q) acc[b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* db = dgs + j * DROW + 32 * wave;
 #pragma unroll
-          for (int q = 0; q < MS; ++q) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(db + 4 * q * DROW + 4 * k4);
+        for (int k4 = 0; k4 < 8; ++k4) {
+          f32x4 dv[MS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q] = MFMA4(w[4 * k4 + e], dv[e], acc[q]);
-          }
+          for (int q = 0; q < MS; ++q)
+            dv[q] = *reinterpret_cast<const f32x4*>(db + 4 * q * DROW + 4 * k4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+              for (int q = 0; q < MS; ++q)
+                acc[b][q] = MFMA4(w[(4 * k4 + e) * NBLK + b], dv[q][e], acc[b][q]);
         }
-        // D: lane (blk = lane>>2, j) reg i -> output unit 64*wave + 4*blk + i, sequence 4q + j
-        u64* dst = xb + ((int64_t)(step & 1) * G + g) * M * Hp;
-        const int uo0 = 64 * wave + 4 * (lane >> 2);
 #pragma unroll
-        for (int q = 0; q < MS; ++q)
+        for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+          for (int q = 0; q < MS; ++q)
+            *reinterpret_cast<f32x4*>(part + (((wave * NBLK + b) * MS + q) * 64 + lane) * 4) = acc[b][q];
+        __syncthreads();
+        // ---- sum the 4 waves and publish: pair p = (b, q); D lane (blk = lane>>2, j), reg i ->
+        //      output unit 64 b + 4 blk + i, sequence 4 q + j
+        u64* dst = xb + ((int64_t)(step & 1) * G + g) * M * Hp;
+        for (int pr = wave; pr < NBLK * MS; pr += 4) {
+          const int b = pr / MS, q = pr - b * MS;
+          f32x4 sum = *reinterpret_cast<const f32x4*>(part + (((0 * NBLK + b) * MS + q) * 64 + lane) * 4);
+#pragma unroll
+          for (int ww = 1; ww < 4; ++ww)
+            sum += *reinterpret_cast<const f32x4*>(part + (((ww * NBLK + b) * MS + q) * 64 + lane) * 4);
+          const int uo0 = 64 * b + 4 * (lane >> 2);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (uo0 + i < H)
-              granule_store(dst + (int64_t)(4 * q + j) * Hp + uo0 + i, (unsigned)(step + 1), acc[q][i]);
+              granule_store(dst + (int64_t)(4 * q + j) * Hp + uo0 + i, (unsigned)(step + 1), sum[i]);
+        }
       }
-      __syncthreads();      // dgs may be rewritten by the next step's cell backward
+      __syncthreads();      // dgs / part are rewritten by the next step
     }
   }
 }
@@ -384,7 +421,7 @@ extern "C" int tssep_lstm_cluster_supported(int H) { return H > 0 && H <= 2 * KH
 
 extern "C" int64_t tssep_lstm_cluster_pack_floats(int H, int which) {
   const int G = (H + UPW - 1) / UPW;
-  return which == 0 ? (int64_t)2 * G * 4 * KH * 64 : (int64_t)2 * G * 5 * 128 * 64;
+  return which == 0 ? (int64_t)2 * G * 4 * KH * 64 : (int64_t)2 * G * 4 * 32 * 5 * 64;
 }
 
 extern "C" int tssep_lstm_pack_cluster(const float* w_hh_f, const float* w_hh_r, int H,
@@ -400,36 +437,36 @@ extern "C" int tssep_lstm_pack_cluster(const float* w_hh_f, const float* w_hh_r,
   return tssep_launch_status();
 }
 
-// Choice of the group size M (sequences per cluster) and the number of clusters for N sequences:
-// all workgroups must be co-resident (one per CU), so nclusters * G <= max_wgs.
-static void cluster_plan(int64_t N, int G, int max_wgs, int allowed_ms_max, int* ms, int* nclusters) {
-  const int cap = max_wgs / G > 0 ? max_wgs / G : 1;
-  static const int choices[] = {2, 4, 6, 8, 12};
-  int pick = 2;
-  for (int c : choices) {
-    if (c > allowed_ms_max) break;
-    pick = c;
-    const int64_t groups = (N + 4 * c - 1) / (4 * c);
-    if (2 * groups <= cap) break;
+// Plan: ms (= M/4 sequences per cluster / 4) is 2 (two workgroups per CU can be resident: 256
+// registers per lane) or 4; the number of clusters is capped by what can be resident at once so
+// that the exchange latency of one cluster is hidden behind its neighbours' MFMAs.
+static void cluster_plan(int64_t N, int G, int max_wgs, int ms_req, int* ms, int* nclusters) {
+  int pick = ms_req;
+  if (pick != 2 && pick != 4) {
+    const int64_t w2 = 2 * ((N + 7) / 8);
+    pick = (w2 <= (2 * max_wgs) / G) ? 2 : 4;
   }
-  const int64_t groups = (N + 4 * pick - 1) / (4 * pick);
+  const int cap = ((pick == 2 ? 2 : 1) * max_wgs) / G > 0 ? ((pick == 2 ? 2 : 1) * max_wgs) / G : 1;
+  const int64_t work = 2 * ((N + 4 * pick - 1) / (4 * pick));
   *ms = pick;
-  *nclusters = (int)(2 * groups < cap ? 2 * groups : cap);
+  *nclusters = (int)(work < cap ? work : cap);
 }
 
-extern "C" int64_t tssep_lstm_cluster_xbuf_bytes(int64_t N, int H, int backward, int max_wgs) {
+extern "C" int64_t tssep_lstm_cluster_xbuf_bytes(int64_t N, int H, int backward, int max_wgs,
+                                                 int ms_req) {
   const int G = (H + UPW - 1) / UPW;
   int ms, nc;
-  cluster_plan(N, G, max_wgs, backward ? 4 : 12, &ms, &nc);
+  cluster_plan(N, G, max_wgs, ms_req, &ms, &nc);
   const int M = 4 * ms;
   const int64_t groups = (N + M - 1) / M;
   const int64_t per_work = (int64_t)2 * M * G * UPW * (backward ? G : 1);
-  return 2 * groups * per_work * 8 + 64;
+  return 64 + 2 * groups * per_work * 8;
 }
 
 extern "C" int tssep_blstm_cluster_fwd(float* gates, float* cell, float* hout, int64_t ldo,
                                        int64_t dstride, const float* whh_cf, void* xbuf, int* err,
-                                       int64_t N, int64_t T, int H, int max_wgs, void* stream) {
+                                       int64_t N, int64_t T, int H, int max_wgs, int ms_req,
+                                       void* stream) {
   if (!gates || !cell || !hout || !whh_cf || !xbuf || !err) return TSSEP_E_NULL;
   if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!tssep_lstm_cluster_supported(H)) return TSSEP_E_UNSUPPORTED;
@@ -437,29 +474,25 @@ extern "C" int tssep_blstm_cluster_fwd(float* gates, float* cell, float* hout, i
   const int G = (H + UPW - 1) / UPW;
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int ms, nc;
-  cluster_plan(N, G, max_wgs, 12, &ms, &nc);
+  cluster_plan(N, G, max_wgs, ms_req, &ms, &nc);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 0, max_wgs) - 64, s) != hipSuccess)
+  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 0, max_wgs, ms_req), s) !=
+      hipSuccess)
     return TSSEP_E_LAUNCH;
   dim3 grid((unsigned)(nc * G));
-#define L(MS_)                                                                                  \
-  hipLaunchKernelGGL((blstm_cluster_fwd_kernel<MS_>), grid, dim3(256), 0, s, gates, cell, hout, \
-                     ldo, dstride, whh_cf, (u64*)xbuf, err, N, T, H, G, nc)
-  switch (ms) {
-    case 2: L(2); break;
-    case 4: L(4); break;
-    case 6: L(6); break;
-    case 8: L(8); break;
-    default: L(12); break;
-  }
-#undef L
+  if (ms == 2)
+    hipLaunchKernelGGL((blstm_cluster_fwd_kernel<2>), grid, dim3(256), 0, s, gates, cell, hout, ldo,
+                       dstride, whh_cf, (u64*)xbuf, err, N, T, H, G, nc);
+  else
+    hipLaunchKernelGGL((blstm_cluster_fwd_kernel<4>), grid, dim3(256), 0, s, gates, cell, hout, ldo,
+                       dstride, whh_cf, (u64*)xbuf, err, N, T, H, G, nc);
   return tssep_launch_status();
 }
 
 extern "C" int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
                                        int64_t ldo, int64_t dstride, const float* whh_cb,
                                        void* xbuf, int* err, int64_t N, int64_t T, int H,
-                                       int max_wgs, void* stream) {
+                                       int max_wgs, int ms_req, void* stream) {
   if (!gates || !cell || !dhout || !whh_cb || !xbuf || !err) return TSSEP_E_NULL;
   if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!tssep_lstm_cluster_supported(H)) return TSSEP_E_UNSUPPORTED;
@@ -467,18 +500,17 @@ extern "C" int tssep_blstm_cluster_bwd(float* gates, const float* cell, const fl
   const int G = (H + UPW - 1) / UPW;
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int ms, nc;
-  cluster_plan(N, G, max_wgs, 4, &ms, &nc);
+  cluster_plan(N, G, max_wgs, ms_req, &ms, &nc);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 1, max_wgs) - 64, s) != hipSuccess)
+  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 1, max_wgs, ms_req), s) !=
+      hipSuccess)
     return TSSEP_E_LAUNCH;
   dim3 grid((unsigned)(nc * G));
-#define L(MS_)                                                                                   \
-  hipLaunchKernelGGL((blstm_cluster_bwd_kernel<MS_>), grid, dim3(320), 0, s, gates, cell, dhout, \
-                     ldo, dstride, whh_cb, (u64*)xbuf, err, N, T, H, G, nc)
-  switch (ms) {
-    case 2: L(2); break;
-    default: L(4); break;
-  }
-#undef L
+  if (ms == 2)
+    hipLaunchKernelGGL((blstm_cluster_bwd_kernel<2>), grid, dim3(256), 0, s, gates, cell, dhout,
+                       ldo, dstride, whh_cb, (u64*)xbuf, err, N, T, H, G, nc);
+  else
+    hipLaunchKernelGGL((blstm_cluster_bwd_kernel<4>), grid, dim3(256), 0, s, gates, cell, dhout,
+                       ldo, dstride, whh_cb, (u64*)xbuf, err, N, T, H, G, nc);
   return tssep_launch_status();
 }

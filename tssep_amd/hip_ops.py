@@ -306,7 +306,10 @@ def use_cluster(N, H, backward):
         return False
     if RECURRENCE == "cluster":
         return True
-    return N <= (256 if not backward else 128)
+    # measured on MI355X, H=300, T=253 (profiles/r1_recurrence_microbench.jsonl): the cluster
+    # kernels take ~6 us/step for up to ~200 sequences (one resident round) while the streaming
+    # kernels take 18-24 us/step for anything up to 1024 sequences
+    return N <= (384 if not backward else 160)
 
 
 def lstm_pack_cluster(w_hh_f, w_hh_r, H):
@@ -319,25 +322,25 @@ def lstm_pack_cluster(w_hh_f, w_hh_r, H):
     return buf[:nf], buf[nf:]
 
 
-def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H):
+def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H, ms=2):
     L = _lib.lib()
     cus = n_cus(gates.device)
-    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 0, cus)) // 8 + 1,
+    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 0, cus, ms)) // 8 + 1,
                        device=gates.device, dtype=torch.int64)
     with _timed("blstm_cluster_fwd", 2 * 2 * N * T * 4 * H * H):
         check(L.tssep_blstm_cluster_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_cf),
-                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus,
+                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus, ms,
                                         _stream()), "blstm_cluster_fwd")
 
 
-def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H):
+def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H, ms=2):
     L = _lib.lib()
     cus = n_cus(gates.device)
-    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 1, cus)) // 8 + 1,
+    xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 1, cus, ms)) // 8 + 1,
                        device=gates.device, dtype=torch.int64)
     with _timed("blstm_cluster_bwd", 2 * 2 * N * T * 4 * H * H):
         check(L.tssep_blstm_cluster_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_cb),
-                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus,
+                                        _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus, ms,
                                         _stream()), "blstm_cluster_bwd")
 
 
