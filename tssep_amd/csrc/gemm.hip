@@ -40,71 +40,117 @@ __device__ __forceinline__ int64_t c_addr(const StoreMap& s, int64_t m, int64_t 
   return b * s.sb + k * s.sk + t * s.st + cq * s.co + cr;
 }
 
-// ---- global -> register tile loads -------------------------------------------------
-// "row" operand: element (r, k) at P[r*ld + k]; tile = 128 rows x 16 k; thread holds 2 float4.
-__device__ __forceinline__ void load_row_tile(const float* __restrict__ P, int64_t ld, int64_t R,
-                                              int64_t K, int64_t r0, int64_t k0, int tid,
-                                              f32x4 (&v)[2]) {
+// ---- per-thread load descriptors -----------------------------------------------------------
+// Every thread owns two 16-byte loads per operand per K tile.  Pointers are set up once (rows /
+// columns outside the matrix are CLAMPED to a valid address: their products only reach outputs
+// that are never stored), so the steady-state loop issues four unconditional global_load_dwordx4
+// and no address arithmetic beyond one add.  Only the last, partial K tile applies element masks.
+// ROWS = tile extent along the operand's non-K dimension (128, or 32 for the narrow edge tile:
+// then only the first 128 threads load).
+struct RowLoad {                 // "row" operand: element (r, k) at P[r*ld + k]
+  const float* p[2];             // row base + 4*(q&3)
+  int kq[2];
+};
+struct ColLoad {                 // "col" operand: element (k, c) at P[k*ld + c]
+  const float* p[2];             // column base + krow*ld
+  int krow[2];
+  int cmask[2];                  // bit e set: column c+e is inside the matrix
+};
+
+template <int ROWS>
+__device__ __forceinline__ RowLoad make_row_load(const float* P, int64_t ld, int64_t R, int64_t r0,
+                                                 int tid) {
+  RowLoad d;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int q = tid + NTHREADS * i;
+    if (q >= ROWS * 4) q = 0;                     // idle slot of a narrow tile: harmless duplicate
     int64_t r = r0 + (q >> 2);
-    int64_t k = k0 + ((q & 3) << 2);
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    if (r < R) {
-      const float* p = P + r * ld + k;
-      if (k + 4 <= K) {
-        x = *reinterpret_cast<const f32x4*>(p);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
-      }
-    }
-    v[i] = x;
+    if (r > R - 1) r = R - 1;
+    d.kq[i] = (q & 3) << 2;
+    d.p[i] = P + r * ld + d.kq[i];
   }
+  return d;
 }
-// "col" operand: element (k, c) at P[k*ld + c]; tile = 16 k x 128 cols; thread holds 2 float4.
-// kshift/kperiod: row k is read at k+kshift and is zero when (k % kperiod)+kshift leaves [0,kperiod).
-__device__ __forceinline__ void load_col_tile(const float* __restrict__ P, int64_t ld, int64_t Ccols,
-                                              int64_t K, int64_t c0, int64_t k0, int tid,
-                                              int64_t kshift, int64_t kperiod, f32x4 (&v)[2]) {
+template <int ROWS>
+__device__ __forceinline__ ColLoad make_col_load(const float* P, int64_t ld, int64_t C, int64_t c0,
+                                                 int tid) {
+  constexpr int CQ = ROWS / 4;                    // float4 per k row
+  ColLoad d;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int q = tid + NTHREADS * i;
-    int64_t k = k0 + (q >> 5);
-    int64_t c = c0 + ((q & 31) << 2);
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    bool ok = k < K;
-    int64_t kk = k;
-    if (kperiod > 0) {
-      int64_t ph = (k % kperiod) + kshift;
-      ok = ok && ph >= 0 && ph < kperiod;
-      kk = k + kshift;
-    }
-    if (ok) {
-      const float* p = P + kk * ld + c;
-      if (c + 4 <= Ccols) {
-        x = *reinterpret_cast<const f32x4*>(p);
-      } else {
+    if (q >= CQ * BK) q = 0;
+    const int64_t c = c0 + ((q % CQ) << 2);
+    int m = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (c + e < Ccols) x[e] = p[e];
-      }
+    for (int e = 0; e < 4; ++e) m |= (c + e < C) ? (1 << e) : 0;
+    d.cmask[i] = m;
+    d.krow[i] = q / CQ;
+    const int64_t cc = (c + 4 <= ld) ? c : 0;          // keep the 16-byte load inside the row
+    d.p[i] = P + cc + (int64_t)d.krow[i] * ld;
+  }
+  return d;
+}
+template <bool TAIL>
+__device__ __forceinline__ void row_load(const RowLoad& d, int64_t k0, int64_t K, f32x4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(d.p[i] + k0);
+    if (TAIL) {
+      const int64_t k = k0 + d.kq[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (k + e < K) ? x[e] : 0.f;
     }
     v[i] = x;
   }
 }
+// SHIFT: row k is read at k+kshift and is zero when (k % kperiod)+kshift leaves [0,kperiod)
+template <bool TAIL, bool SHIFT>
+__device__ __forceinline__ void col_load(const ColLoad& d, int64_t ld, int64_t k0, int64_t K,
+                                         int64_t kshift, int64_t kperiod, f32x4 (&v)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t k = k0 + d.krow[i];
+    bool ok = true;
+    int64_t kk = k0;
+    if (TAIL) {
+      ok = k < K;
+      if (!ok) kk = 0 - d.krow[i];            // row 0: valid address, value masked below
+    }
+    if (SHIFT) {
+      const int64_t ph = (k % kperiod) + kshift;
+      const bool in = ph >= 0 && ph < kperiod;
+      if (ok && in) kk = k0 + kshift;
+      ok = ok && in;
+    }
+    f32x4 x = *reinterpret_cast<const f32x4*>(d.p[i] + kk * ld);
+    if (TAIL || SHIFT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ok ? x[e] : 0.f;
+    }
+    if (d.cmask[i] != 15) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = ((d.cmask[i] >> e) & 1) ? x[e] : 0.f;
+    }
+    v[i] = x;
+  }
+}
+template <int ROWS>
 __device__ __forceinline__ void store_row_tile(float* S, int tid, const f32x4 (&v)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int q = tid + NTHREADS * i;
-    *reinterpret_cast<f32x4*>(S + (q >> 2) * ROW_PITCH + ((q & 3) << 2)) = v[i];
+    if (q < ROWS * 4) *reinterpret_cast<f32x4*>(S + (q >> 2) * ROW_PITCH + ((q & 3) << 2)) = v[i];
   }
 }
+template <int ROWS>
 __device__ __forceinline__ void store_col_tile(float* S, int tid, const f32x4 (&v)[2]) {
+  constexpr int CQ = ROWS / 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int q = tid + NTHREADS * i;
-    *reinterpret_cast<f32x4*>(S + (q >> 5) * COL_PITCH + ((q & 31) << 2)) = v[i];
+    if (q < CQ * BK) *reinterpret_cast<f32x4*>(S + (q / CQ) * COL_PITCH + ((q % CQ) << 2)) = v[i];
   }
 }
 // ---- LDS -> MFMA operand fragments: frag[s] = element (row = base + (lane&31), k = 8*(lane>>5) + s)
@@ -122,42 +168,59 @@ __device__ __forceinline__ void read_frag(const float* S, int base, int lane, fl
   }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+// NARROW = false: 128x128 tile (waves 2x2, 2x2 MFMA tiles each); true: 128x32 edge tile
+// (waves 4x1, one MFMA tile each) used for the last N % 128 columns so that e.g. N = 513 does not
+// pay a whole 128-wide tile for one column.
+template <bool A_KMAJOR, bool B_KMAJOR, bool SHIFT, bool NARROW>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
     int64_t b_kshift, int64_t kperiod, const float* __restrict__ bias, int act, int accumulate,
-    StoreMap sm, int splitk, int64_t c_split_stride) {
+    StoreMap sm, int splitk, int64_t c_split_stride, int64_t n_begin) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2, BNT = NARROW ? 32 : BN;
+  const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = n_begin + (int64_t)blockIdx.x * BNT;
 
   // split-K range (in K tiles)
   const int64_t ktiles = (K + BK - 1) / BK;
   const int64_t per = (ktiles + splitk - 1) / splitk;
   const int64_t kt_begin = (int64_t)blockIdx.z * per;
   const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;               // tiles [0, kt_full) need no K mask
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  RowLoad ra_d, rb_d;
+  ColLoad ca_d, cb_d;
+  if (!A_KMAJOR) ra_d = make_row_load<BM>(A, lda, M, m0, tid); else ca_d = make_col_load<BM>(A, lda, M, m0, tid);
+  if (!B_KMAJOR) rb_d = make_row_load<BNT>(B, ldb, N, n0, tid); else cb_d = make_col_load<BNT>(B, ldb, N, n0, tid);
 
   f32x4 ra[2], rb[2];
   auto gload = [&](int64_t kt) {
     const int64_t k0 = kt * BK;
-    if (!A_KMAJOR) load_row_tile(A, lda, M, K, m0, k0, tid, ra);
-    else load_col_tile(A, lda, M, K, m0, k0, tid, 0, 0, ra);
-    if (!B_KMAJOR) load_row_tile(B, ldb, N, K, n0, k0, tid, rb);
-    else load_col_tile(B, ldb, N, K, n0, k0, tid, b_kshift, kperiod, rb);
+    if (kt < kt_full) {
+      if (!A_KMAJOR) row_load<false>(ra_d, k0, K, ra);
+      else col_load<false, false>(ca_d, lda, k0, K, 0, 1, ra);
+      if (!B_KMAJOR) row_load<false>(rb_d, k0, K, rb);
+      else col_load<false, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, rb);
+    } else {
+      if (!A_KMAJOR) row_load<true>(ra_d, k0, K, ra);
+      else col_load<true, false>(ca_d, lda, k0, K, 0, 1, ra);
+      if (!B_KMAJOR) row_load<true>(rb_d, k0, K, rb);
+      else col_load<true, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, rb);
+    }
   };
   auto sstore = [&](int buf) {
-    if (!A_KMAJOR) store_row_tile(lds[buf][0], tid, ra); else store_col_tile(lds[buf][0], tid, ra);
-    if (!B_KMAJOR) store_row_tile(lds[buf][1], tid, rb); else store_col_tile(lds[buf][1], tid, rb);
+    if (!A_KMAJOR) store_row_tile<BM>(lds[buf][0], tid, ra); else store_col_tile<BM>(lds[buf][0], tid, ra);
+    if (!B_KMAJOR) store_row_tile<BNT>(lds[buf][1], tid, rb); else store_col_tile<BNT>(lds[buf][1], tid, rb);
   };
 
   if (kt_begin < kt_end) {
@@ -168,17 +231,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
       const bool more = kt + 1 < kt_end;
       if (more) gload(kt + 1);
-      float fa[2][8], fb[2][8];
+      float fa[TM][8], fb[TN][8];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) read_frag<A_KMAJOR>(lds[buf][0], wm * 64 + i * 32, lane, fa[i]);
+      for (int i = 0; i < TM; ++i) read_frag<A_KMAJOR>(lds[buf][0], (wm * TM + i) * 32, lane, fa[i]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) read_frag<B_KMAJOR>(lds[buf][1], wn * 64 + j * 32, lane, fb[j]);
+      for (int j = 0; j < TN; ++j) read_frag<B_KMAJOR>(lds[buf][1], (wn * TN + j) * 32, lane, fb[j]);
 #pragma unroll
       for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
       if (more) sstore(buf ^ 1);
       __syncthreads();
@@ -189,24 +252,58 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
   // epilogue: D[i][j] of a 32x32 tile: lane holds column j = lane&31, rows (e&3)+8*(e>>2)+4*(lane>>5)
   float* Cz = C + (int64_t)blockIdx.z * c_split_stride;
   const bool final_pass = splitk == 1;
+  int64_t ncol[TN], coff[TN], cq[TN];
+  float bv[TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int64_t n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    ncol[j] = n;
+    bv[j] = (final_pass && bias && n < N) ? bias[n] : 0.f;
+    if (sm.remap) {
+      cq[j] = n / sm.cm;
+      coff[j] = n - cq[j] * sm.cm;
+    } else {
+      cq[j] = 0;
+      coff[j] = n;
+    }
+  }
+#pragma unroll 1
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll 4
+    for (int e = 0; e < 16; ++e) {
+      const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
+      int64_t roff, b = 0;
+      if (sm.remap) {
+        const int64_t t = m % sm.T, q = m / sm.T;
+        const int64_t k = q % sm.K;
+        b = q / sm.K;
+        roff = b * sm.sb + k * sm.sk + t * sm.st;
+      } else {
+        roff = m * sm.ldc;
+      }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (n >= N) continue;
-      const float bv = (final_pass && bias) ? bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        if (ncol[j] >= N) continue;
+        int64_t a = roff + coff[j];
+        if (sm.remap) {
+          const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq[j]] : cq[j];
+          a += cqq * sm.co;
+        }
+        // static register index: select the accumulator element without dynamic indexing
+        float v = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (m >= M) continue;
-        float v = acc[i][j][e] + bv;
+        for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+          for (int ee = 0; ee < 16; ++ee)
+            if (ii == i && ee == e) v = acc[ii][j][ee];
+        v += bv[j];
         if (final_pass && act == 1) v = tanhf(v);
-        const int64_t a = c_addr(sm, m, n);
         if (accumulate) v += Cz[a];
         Cz[a] = v;
       }
     }
+  }
 }
 
 }  // namespace
@@ -225,16 +322,32 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   sm.sb = g->c_sb; sm.sk = g->c_sk; sm.st = g->c_st;
   sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
   sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
-  dim3 grid((unsigned)((g->N + BN - 1) / BN), (unsigned)((g->M + BM - 1) / BM), (unsigned)splitk);
-  if (grid.y > 65535u) return TSSEP_E_SHAPE;
+  const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
+  if (mtiles > 65535u) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(AK, BKM)                                                                          \
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM>), grid, dim3(NTHREADS), 0, s, g->A, g->B, g->C,   \
-                     g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod, g->bias, g->act, \
-                     g->accumulate, sm, splitk, g->c_split_stride)
-  if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false);
-  else if (!g->a_kmajor && g->b_kmajor) LAUNCH(false, true);
-  else LAUNCH(true, true);
+  // columns [0, n_main) by 128-wide tiles; a remainder of <= 96 columns by 32-wide edge tiles
+  int64_t n_main = (g->N / BN) * BN;
+  const int64_t rem = g->N - n_main;
+  // a full-width tile is cheaper than 4 narrow ones; split-K launches are short and
+  // under-filled already, a second serialized launch would only add a tail
+  if (rem > 96 || splitk > 1) n_main = g->N;
+  const bool shift = g->kperiod > 0;
+#define LAUNCH(AK, BKM, SH, NARROW, GRIDX, NBEGIN)                                                 \
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, SH, NARROW>), dim3((GRIDX), mtiles, (unsigned)splitk), \
+                     dim3(NTHREADS), 0, s, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb,      \
+                     g->b_kshift, g->kperiod, g->bias, g->act, g->accumulate, sm, splitk,           \
+                     g->c_split_stride, (int64_t)(NBEGIN))
+#define DISPATCH(NARROW, GRIDX, NBEGIN)                                                            \
+  do {                                                                                             \
+    if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false, NARROW, GRIDX, NBEGIN);          \
+    else if (!g->a_kmajor && shift) LAUNCH(false, true, true, NARROW, GRIDX, NBEGIN);              \
+    else if (!g->a_kmajor) LAUNCH(false, true, false, NARROW, GRIDX, NBEGIN);                      \
+    else if (shift) LAUNCH(true, true, true, NARROW, GRIDX, NBEGIN);                               \
+    else LAUNCH(true, true, false, NARROW, GRIDX, NBEGIN);                                         \
+  } while (0)
+  if (n_main > 0) DISPATCH(false, (unsigned)((n_main + BN - 1) / BN), 0);
+  if (n_main < g->N) DISPATCH(true, (unsigned)((g->N - n_main + 31) / 32), n_main);
+#undef DISPATCH
 #undef LAUNCH
   return tssep_launch_status();
 }
