@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 64)),
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "f32"),
+                    help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -127,6 +129,7 @@ def main():
 
     from tssep_amd import hip_ops as H
     from tssep_amd.distributed import GradBucket
+    H.GEMM_PRECISION = args.gemm
     model = build_model().to(dev)
     bucket = GradBucket(model.parameters())
     B = args.batch

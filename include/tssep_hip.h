@@ -122,6 +122,11 @@ typedef struct tssep_gemm_args {
   /* split-K: gridDim.z = splitk partial products are written to C + z*c_split_stride
    * (no bias/act/remap); the caller reduces them.  <=1 = single pass. */
   int32_t splitk; int64_t c_split_stride;
+  /* arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+   * 1 = split-bf16 "bf16x3": every fp32 operand is split on the fly into bf16 hi + bf16 lo and
+   *     the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+   *     (per-product relative error <= ~2^-16, i.e. fp32-class for the 1e-3 parity bar). */
+  int32_t precision;
 } tssep_gemm_args;
 int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 

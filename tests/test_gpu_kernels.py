@@ -79,8 +79,19 @@ def test_maskhead(B, K, T, F):
 GEMM_SHAPES = [(130, 70, 37), (257, 300, 553), (64, 129, 16), (1000, 2400, 513), (5, 3, 2)]
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def gemm_precision(request):
+    """Both GEMM arithmetics: exact fp32 MFMA and split-bf16 (fp32-class, looser tolerance)."""
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = request.param
+    yield (2e-5 if request.param == "f32" else 2e-4)
+    h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nt_bias_tanh(M, N, K):
+def test_gemm_nt_bias_tanh(M, N, K, gemm_precision):
+    tol = gemm_precision
     torch.manual_seed(1)
     h = H()
     ru = h.round_up
@@ -91,17 +102,18 @@ def test_gemm_nt_bias_tanh(M, N, K):
     C = torch.full((M, N), float("nan"), device="cuda")
     h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd)
     ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
-    close(C, ref, rtol=2e-5, atol=2e-5, name="nt+bias")
+    close(C, ref, rtol=tol, atol=tol, name="nt+bias")
     h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
-    close(C, torch.tanh(ref), rtol=2e-5, atol=2e-5, name="nt+bias+tanh")
+    close(C, torch.tanh(ref), rtol=tol, atol=tol, name="nt+bias+tanh")
     C0 = torch.randn(M, N)
     C = C0.cuda()
     h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, accumulate=True)
-    close(C, C0 + ref - bias, rtol=2e-5, atol=3e-5, name="nt accumulate")
+    close(C, C0 + ref - bias, rtol=tol, atol=1.5 * tol, name="nt accumulate")
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nn_and_tn(M, N, K):
+def test_gemm_nn_and_tn(M, N, K, gemm_precision):
+    tol = gemm_precision
     torch.manual_seed(2)
     h = H()
     ru = h.round_up
@@ -110,19 +122,20 @@ def test_gemm_nn_and_tn(M, N, K):
     W = torch.zeros(K, ru(N, 4)); W[:, :N] = torch.randn(K, N) / K ** 0.5
     C = torch.full((M, N), float("nan"), device="cuda")
     h.gemm(dY.cuda(), dY.shape[1], W.cuda(), W.shape[1], C, N, M, N, K, b_kmajor=True)
-    close(C, (dY[:, :K].double() @ W[:, :N].double()).float(), rtol=2e-5, atol=2e-5, name="nn")
+    close(C, (dY[:, :K].double() @ W[:, :N].double()).float(), rtol=tol, atol=tol, name="nn")
     # TN: dW[M,N] = P[K,M]^T @ Q[K,N], split-K partials then reduce
     P = torch.zeros(K, ru(M, 4)); P[:, :M] = torch.randn(K, M) / K ** 0.5
     Q = torch.zeros(K, ru(N, 4)); Q[:, :N] = torch.randn(K, N)
     part, S = h.wgrad(P.cuda(), P.shape[1], Q.cuda(), Q.shape[1], M, N, K)
     out = torch.empty(M * N, device="cuda")
     h.reduce_splits(part, S, M * N, out)
-    close(out.view(M, N), (P[:, :M].double().t() @ Q[:, :N].double()).float(), rtol=2e-5,
-          atol=2e-5, name=f"tn splitk={S}")
+    close(out.view(M, N), (P[:, :M].double().t() @ Q[:, :N].double()).float(), rtol=tol,
+          atol=tol, name=f"tn splitk={S}")
 
 
-def test_gemm_tn_time_shift():
+def test_gemm_tn_time_shift(gemm_precision):
     """dW_hh pairs dgates_t with h_{t-1} (shift -1) / h_{t+1} (shift +1) inside sequences of T."""
+    tol = gemm_precision
     torch.manual_seed(3)
     h = H()
     n, T, Mg, Hh = 5, 7, 24, 12
@@ -138,10 +151,11 @@ def test_gemm_tn_time_shift():
         part, S = h.wgrad(dg.cuda(), Mg, hh.cuda(), Hh, Mg, Hh, n * T, b_kshift=shift, kperiod=T)
         out = torch.empty(Mg * Hh, device="cuda")
         h.reduce_splits(part, S, Mg * Hh, out)
-        close(out.view(Mg, Hh), ref.float(), rtol=2e-5, atol=2e-5, name=f"shift {shift}")
+        close(out.view(Mg, Hh), ref.float(), rtol=tol, atol=tol, name=f"shift {shift}")
 
 
-def test_gemm_store_remaps():
+def test_gemm_store_remaps(gemm_precision):
+    tol = gemm_precision
     torch.manual_seed(4)
     h = H()
     B, K, T, P, F = 2, 3, 5, 8, 9
@@ -151,7 +165,7 @@ def test_gemm_store_remaps():
     h.gemm(A.cuda(), 12, W.cuda(), 12, C, 0, B * K * T, P, 12, bias=bias.cuda(), act=1,
            remap=dict(T=T, K=K, sb=T * K * P, sk=P, st=K * P))
     ref = torch.tanh(A @ W.t() + bias).view(B, K, T, P).permute(0, 2, 1, 3).reshape(B, T, K * P)
-    close(C, ref, rtol=2e-5, atol=2e-5, name="combine")
+    close(C, ref, rtol=tol, atol=tol, name="combine")
     # (2) rows (b,t) x (k,f) -> [B, perm[k], T, F]   (net.py:637-641, 957-967)
     A = torch.randn(B * T, 12); W = torch.randn(K * F, 12); bias = torch.randn(K * F)
     perm = torch.stack([torch.randperm(K) for _ in range(B)]).int()
@@ -163,7 +177,7 @@ def test_gemm_store_remaps():
     for b in range(B):
         for k in range(K):
             ref[b, perm[b, k]] = raw[b, k]
-    close(C, ref, rtol=2e-5, atol=2e-5, name="logit remap")
+    close(C, ref, rtol=tol, atol=tol, name="logit remap")
 
 
 @pytest.mark.parametrize("rows,N", [(3, 4000), (2, 64000), (1, 1023)])

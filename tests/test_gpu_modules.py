@@ -75,8 +75,17 @@ def _example_batch(B, K, N, seed=0, E=513):
     return T_(obs), T_(aux), T_(tgt), T_(vad)
 
 
+@pytest.fixture(params=["f32", "bf16x3"])
+def gemm_mode(request):
+    from tssep_amd import hip_ops
+    old = hip_ops.GEMM_PRECISION
+    hip_ops.GEMM_PRECISION = request.param
+    yield request.param
+    hip_ops.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("res,loss_name", [("tf", "LogMAE"), ("t", "VADSigmoidBCE")])
-def test_model_end_to_end_against_oracle(res, loss_name):
+def test_model_end_to_end_against_oracle(res, loss_name, gemm_mode):
     """STFT -> MFCC+log1p features -> mask estimator -> mask head -> iSTFT -> loss, forward and
     backward, HIP path vs CPU oracle on the same seeded inputs (1e-3 relative bar, fp32)."""
     from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
@@ -179,7 +188,7 @@ def test_vad_to_sep_checkpoint_broadcast(golden, tmp_path):
     close(ls, lv, rtol=0, atol=1e-6, name="sep == vad")
 
 
-def test_full_size_properties():
+def test_full_size_properties(gemm_mode):
     """BASELINE cfg3 sizes (K=4, 4 s @ 16 kHz, H=300, P=320): parity with the oracle on the
     masks plus size-independent properties of the HIP path."""
     from tssep_amd.train import net

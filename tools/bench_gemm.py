@@ -36,6 +36,9 @@ def run(name, M, N, K, kind):
                           tflops=round(2 * M * N * K / ms / 1e9, 1))), flush=True)
 
 
+import os as _o
+h.GEMM_PRECISION = _o.environ.get("TSSEP_GEMM_PRECISION", "f32")
+print("precision", h.GEMM_PRECISION)
 run("pre_net in", R1, 2400, 553, "nt")
 run("birnn0 in", R4, 2400, 513, "nt")
 run("birnn1 in", R4, 2400, 320, "nt")

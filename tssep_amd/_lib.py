@@ -29,6 +29,7 @@ class GemmArgs(ctypes.Structure):
         ("c_co", ctypes.c_int64),
         ("c_perm", ctypes.c_void_p), ("c_perm_ld", ctypes.c_int64),
         ("splitk", ctypes.c_int32), ("c_split_stride", ctypes.c_int64),
+        ("precision", ctypes.c_int32),
     ]
 
 

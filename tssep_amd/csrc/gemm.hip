@@ -15,30 +15,15 @@
 // ds_read_b128 per 32 rows and 8 MFMA steps.  The [BK+4]-float row pitch makes
 // those reads bank-conflict free (pitch 80 B: 16-B slot index 5*row mod 16 is a
 // bijection over the 16 rows of a ds_read_b128 lane group).
-#include "common.h"
+#include "gemm_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, NTHREADS = 256;
+using namespace gemm_detail;
+constexpr int BK = 16;
 constexpr int ROW_PITCH = BK + 4;     // floats, "row" operand  S[128][20]
 constexpr int COL_PITCH = BM + 4;     // floats, "col" operand  S[16][132]
 constexpr int OP_FLOATS = BM * ROW_PITCH;  // 2560 >= 16*132 = 2112
-
-struct StoreMap {
-  int64_t ldc;
-  int32_t remap;
-  int64_t T, K, sb, sk, st, cm, co;
-  const int32_t* perm; int64_t perm_ld;
-};
-
-__device__ __forceinline__ int64_t c_addr(const StoreMap& s, int64_t m, int64_t n) {
-  if (!s.remap) return m * s.ldc + n;
-  int64_t t = m % s.T, q = m / s.T;
-  int64_t k = q % s.K, b = q / s.K;
-  int64_t cq = n / s.cm, cr = n - cq * s.cm;
-  if (s.perm) cq = s.perm[b * s.perm_ld + cq];
-  return b * s.sb + k * s.sk + t * s.st + cq * s.co + cr;
-}
 
 // ---- per-thread load descriptors -----------------------------------------------------------
 // Every thread owns two 16-byte loads per operand per K tile.  Pointers are set up once (rows /
@@ -96,9 +81,11 @@ template <bool TAIL>
 __device__ __forceinline__ void row_load(const RowLoad& d, int64_t k0, int64_t K, f32x4 (&v)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    f32x4 x = *reinterpret_cast<const f32x4*>(d.p[i] + k0);
+    const int64_t k = k0 + d.kq[i];
+    // a 16-byte load that starts at or beyond K would leave the row: read the row start instead
+    const int64_t off = (!TAIL || k < K) ? k0 : -(int64_t)d.kq[i];
+    f32x4 x = *reinterpret_cast<const f32x4*>(d.p[i] + off);
     if (TAIL) {
-      const int64_t k = k0 + d.kq[i];
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = (k + e < K) ? x[e] : 0.f;
     }
@@ -249,61 +236,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     }
   }
 
-  // epilogue: D[i][j] of a 32x32 tile: lane holds column j = lane&31, rows (e&3)+8*(e>>2)+4*(lane>>5)
   float* Cz = C + (int64_t)blockIdx.z * c_split_stride;
-  const bool final_pass = splitk == 1;
-  int64_t ncol[TN], coff[TN], cq[TN];
-  float bv[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int64_t n = n0 + (wn * TN + j) * 32 + (lane & 31);
-    ncol[j] = n;
-    bv[j] = (final_pass && bias && n < N) ? bias[n] : 0.f;
-    if (sm.remap) {
-      cq[j] = n / sm.cm;
-      coff[j] = n - cq[j] * sm.cm;
-    } else {
-      cq[j] = 0;
-      coff[j] = n;
-    }
-  }
-#pragma unroll 1
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll 4
-    for (int e = 0; e < 16; ++e) {
-      const int64_t m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-      if (m >= M) continue;
-      int64_t roff, b = 0;
-      if (sm.remap) {
-        const int64_t t = m % sm.T, q = m / sm.T;
-        const int64_t k = q % sm.K;
-        b = q / sm.K;
-        roff = b * sm.sb + k * sm.sk + t * sm.st;
-      } else {
-        roff = m * sm.ldc;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (ncol[j] >= N) continue;
-        int64_t a = roff + coff[j];
-        if (sm.remap) {
-          const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq[j]] : cq[j];
-          a += cqq * sm.co;
-        }
-        // static register index: select the accumulator element without dynamic indexing
-        float v = 0.f;
-#pragma unroll
-        for (int ii = 0; ii < TM; ++ii)
-#pragma unroll
-          for (int ee = 0; ee < 16; ++ee)
-            if (ii == i && ee == e) v = acc[ii][j][ee];
-        v += bv[j];
-        if (final_pass && act == 1) v = tanhf(v);
-        if (accumulate) v += Cz[a];
-        Cz[a] = v;
-      }
-    }
-  }
+  gemm_epilogue<TM, TN>(acc, Cz, M, N, m0 + (int64_t)wm * TM * 32, n0 + (int64_t)wn * TN * 32, lane,
+                        bias, act, accumulate, sm, splitk == 1);
 }
 
 }  // namespace
@@ -322,6 +257,8 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   sm.sb = g->c_sb; sm.sk = g->c_sk; sm.st = g->c_st;
   sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
   sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
+  if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
+  if (g->precision != 0) return TSSEP_E_UNSUPPORTED;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
   if (mtiles > 65535u) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;

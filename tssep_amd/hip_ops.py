@@ -172,6 +172,14 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
 
 
 # ------------------------------------------------------------------------------- GEMM
+# Arithmetic of the non-recurrent GEMMs: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 on the
+# bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The LSTM
+# recurrences always run exact fp32.
+import os as _os
+GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
+_PREC = {"f32": 0, "bf16x3": 1}
+
+
 def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
          accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0):
     """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
@@ -199,6 +207,7 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
         g.c_perm = perm.data_ptr() if perm is not None else None
         g.c_perm_ld = remap.get("perm_ld", 0)
     g.splitk, g.c_split_stride = splitk, split_stride
+    g.precision = _PREC[GEMM_PRECISION]
     with _timed("gemm_f32", 2 * M * N * K):
         check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
