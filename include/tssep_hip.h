@@ -165,9 +165,9 @@ int tssep_blstm_bwd(float* gates, const float* cell, const float* dhout, int64_t
                     int64_t dstride, const float* whh_b, int64_t N, int64_t T, int H, void* stream);
 /* gradient unpack + split-K reduction: a matrix with packed (dir,unit,gate) rows back to
  * torch's gate-major rows:
- *   dst_d[(g*H + u)*ncols + k] = sum_{s<nsplit} src[s*split_stride + (d*4H + 4u + g)*ld + k] */
+ *   dst_d[(g*H + u)*ncols + k] (+)= sum_{s<nsplit} src[s*split_stride + (d*4H + 4u + g)*ld + k] */
 int tssep_lstm_unpack(const float* src, int64_t ld, int nsplit, int64_t split_stride,
-                      int H, int ncols, float* dst_f, float* dst_r, void* stream);
+                      int H, int ncols, float* dst_f, float* dst_r, int accumulate, void* stream);
 
 /* Cluster (W-stationary) recurrence -- latency-optimised alternative to tssep_blstm_fwd/bwd for
  * batches that do not fill the chip (same math, same tensor layouts; see lstm_cluster.hip).

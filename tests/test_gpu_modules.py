@@ -224,3 +224,35 @@ def test_full_size_properties(gemm_mode):
     dX = H.istft_bwd(y, wsyn, 253)
     t2 = (torch.view_as_real(est.reshape(B * K, 253, 513)) * torch.view_as_real(dX)).sum()
     assert float(t1) == pytest.approx(float(t2), rel=1e-3)
+
+
+def test_direct_grad_sink_matches_autograd():
+    """Weight gradients accumulated straight into the GradBucket on the side stream equal the
+    gradients returned through autograd (and accumulate over two backward passes)."""
+    from tssep_amd.distributed import GradBucket
+    from tssep_amd.train import net
+    from tssep_amd import hip_ops
+    B, K, T = 2, 4, 9
+    torch.manual_seed(0)
+    me = net.MaskEstimator_v2(idim=24, odim=17, units=12, projs=8, combination="mul",
+                              aux_net_output_size=17, ts_vad=K, output_resolution="tf").cuda()
+    xs = torch.randn(B, T, 24, device="cuda")
+    aux = torch.rand(B, K, 17, device="cuda")
+    g = torch.randn(B, K, 1, T, 17, device="cuda")
+
+    def run():
+        np.random.seed(1)
+        (me(xs, aux).mask * g).sum().backward()
+
+    run()
+    ref = [p.grad.clone() for p in me.parameters()]
+    me.zero_grad(set_to_none=True)
+    bucket = GradBucket(me.parameters())
+    assert hip_ops.OVERLAP_WGRAD
+    run()
+    run()
+    bucket.sync()
+    torch.cuda.synchronize()
+    for (name, p), r in zip(me.named_parameters(), ref):
+        assert p.grad.data_ptr() == p._tssep_grad_sink.data_ptr()
+        close(p.grad, 2 * r, rtol=1e-4, atol=1e-6 + 1e-5 * float(r.abs().max()), name=name)

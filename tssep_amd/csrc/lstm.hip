@@ -87,7 +87,7 @@ __global__ void lstm_pack_kernel(const float* w_ih_f, const float* w_hh_f, const
 // dst_d[(g*H + u)*ncols + k] = sum_s src[s*split_stride + (d*4H + 4u + g)*ld + k]
 __global__ void lstm_unpack_kernel(const float* __restrict__ src, int64_t ld, int nsplit,
                                    int64_t split_stride, int H, int ncols, float* dst_f,
-                                   float* dst_r) {
+                                   float* dst_r, int accumulate) {
   const int64_t per = (int64_t)4 * H * ncols, total = 2 * per;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -99,7 +99,8 @@ __global__ void lstm_unpack_kernel(const float* __restrict__ src, int64_t ld, in
     const float* p = src + ((int64_t)d * 4 * H + 4 * u + g) * ld + k;
     float s = 0.f;
     for (int i = 0; i < nsplit; ++i) s += p[i * split_stride];
-    (d ? dst_r : dst_f)[r] = s;
+    float* o = (d ? dst_r : dst_f) + r;
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -390,14 +391,15 @@ extern "C" int tssep_lstm_pack(const float* w_ih_f, const float* w_hh_f, const f
 }
 
 extern "C" int tssep_lstm_unpack(const float* src, int64_t ld, int nsplit, int64_t split_stride,
-                                 int H, int ncols, float* dst_f, float* dst_r, void* stream) {
+                                 int H, int ncols, float* dst_f, float* dst_r, int accumulate,
+                                 void* stream) {
   if (!src || !dst_f || !dst_r) return TSSEP_E_NULL;
   if (H <= 0 || ncols <= 0 || nsplit <= 0) return TSSEP_E_SHAPE;
   const int64_t total = (int64_t)8 * H * ncols;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(lstm_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r);
+                     src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulate);
   return tssep_launch_status();
 }
 

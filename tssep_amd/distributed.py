@@ -22,12 +22,22 @@ class GradBucket:
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            # the HIP backward may accumulate straight into this view (off the autograd engine,
+            # on a side stream): see tssep_amd.functional._grad_sink
+            p._tssep_grad_sink = p.grad
             off += p.numel()
 
     def zero(self):
         self.flat.zero_()
 
+    def sync(self):
+        """Wait for gradient work queued on the side stream (no-op on CPU / when unused)."""
+        if self.flat.is_cuda:
+            from . import hip_ops
+            hip_ops.join_side_stream(self.flat.device)
+
     def all_reduce(self, group=None, async_op=False):
+        self.sync()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None

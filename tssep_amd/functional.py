@@ -58,6 +58,7 @@ class _RNNP(torch.autograd.Function):
             y, ld_y = H.padded(R, hdim, dev, zero=True)
             H.gemm(hout, 2 * Hp, wp, 2 * Hp, y, ld_y, R, hdim, 2 * Hp, bias=b_proj.detach(), act=act)
         ctx.save_for_backward(xv, gates, cell, hout, y, wp)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj)
         ctx.pk = pk
         ctx.meta = (N, T, I, Hh, Hp, hdim, ld_x, ld_y, act, combine)
         ctx.x_shape = x.shape
@@ -82,39 +83,78 @@ class _RNNP(torch.autograd.Function):
             else:
                 dz = _dense_rows(dy, hdim)
         dz, ld_dz = H.rows_view(dz)
-        # projection: dW [hdim, 2Hp], db, dhout
-        part, S = H.wgrad(dz, ld_dz, hout, 2 * Hp, hdim, 2 * Hp, R)
-        dwp = torch.empty(hdim, 2 * Hp, device=dev, dtype=torch.float32)
-        H.reduce_splits(part, S, hdim * 2 * Hp, dwp)
-        d_w_proj = _proj_unlayout(dwp, Hh, Hp)
-        d_b_proj = H.colsum(dz, ld_dz, R, hdim)
+        G = 8 * Hh
+        params = ctx.params
+        sinks = [_grad_sink(p) for p in params]
+        direct = all(s_ is not None for s_ in sinks) and H.OVERLAP_WGRAD
+        main = torch.cuda.current_stream()
+        side = H.side_stream(dev) if direct else main
+
+        # ---- projection weight / bias gradients (side stream when direct)
+        def proj_wgrads():
+            part, S = H.wgrad(dz, ld_dz, hout, 2 * Hp, hdim, 2 * Hp, R)
+            if direct and Hp == Hh:
+                H.reduce_splits(part, S, hdim * 2 * Hp, sinks[8], accumulate=True)
+                H.colsum(dz, ld_dz, R, hdim, out=sinks[9], accumulate=True)
+                return None, None
+            dwp = torch.empty(hdim, 2 * Hp, device=dev, dtype=torch.float32)
+            H.reduce_splits(part, S, hdim * 2 * Hp, dwp)
+            d_w = _proj_unlayout(dwp, Hh, Hp)
+            d_b = H.colsum(dz, ld_dz, R, hdim)
+            if direct:
+                sinks[8].add_(d_w)
+                sinks[9].add_(d_b)
+                return None, None
+            return d_w, d_b
+
+        if direct:
+            side.wait_stream(main)
+            for t_ in (dz, hout):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                d_w_proj, d_b_proj = proj_wgrads()
+        else:
+            d_w_proj, d_b_proj = proj_wgrads()
+        # ---- critical path: dhout, BPTT (gates <- d pre-activations)
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
         H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
-        # BPTT: gates <- d(pre-activations)
         if pk.get("whh_cb") is not None and H.use_cluster(N, Hh, True):
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
         else:
             H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
-        G = 8 * Hh
-        # dW_hh per direction (dgates_t paired with h_{t-1} / h_{t+1})
-        dwhh = torch.empty(2, 4 * Hh * Hh, device=dev, dtype=torch.float32)
-        for d in range(2):
-            part, S = H.wgrad((gates, d * 4 * Hh), G, (hout, d * Hp), 2 * Hp, 4 * Hh, Hh, R,
-                              b_kshift=(-1 if d == 0 else 1), kperiod=T)
-            H.reduce_splits(part, S, 4 * Hh * Hh, dwhh[d])
-        d_whh = torch.empty(4 * Hh, Hh, device=dev, dtype=torch.float32)
-        d_whh_r = torch.empty(4 * Hh, Hh, device=dev, dtype=torch.float32)
-        H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, d_whh, d_whh_r)
-        # dW_ih
-        part, S = H.wgrad(gates, G, xv, ld_x, G, I, R)
-        d_wih = torch.empty(4 * Hh, I, device=dev, dtype=torch.float32)
-        d_wih_r = torch.empty(4 * Hh, I, device=dev, dtype=torch.float32)
-        H.lstm_unpack(part, I, S, G * I, Hh, I, d_wih, d_wih_r)
-        # biases (b_ih and b_hh receive the same gradient)
-        cs = H.colsum(gates, G, R, G)
-        d_b = torch.empty(4 * Hh, device=dev, dtype=torch.float32)
-        d_b_r = torch.empty(4 * Hh, device=dev, dtype=torch.float32)
-        H.lstm_unpack(cs, 1, 1, 0, Hh, 1, d_b, d_b_r)
+
+        # ---- LSTM weight / bias gradients from dgates (side stream when direct)
+        def lstm_wgrads():
+            dwhh = torch.empty(2, 4 * Hh * Hh, device=dev, dtype=torch.float32)
+            for d in range(2):   # dgates_t paired with h_{t-1} (forward dir) / h_{t+1} (reverse)
+                part, S = H.wgrad((gates, d * 4 * Hh), G, (hout, d * Hp), 2 * Hp, 4 * Hh, Hh, R,
+                                  b_kshift=(-1 if d == 0 else 1), kperiod=T)
+                H.reduce_splits(part, S, 4 * Hh * Hh, dwhh[d])
+            part, S = H.wgrad(gates, G, xv, ld_x, G, I, R)
+            cs = H.colsum(gates, G, R, G)
+            if direct:
+                H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, sinks[1], sinks[5], accumulate=True)
+                H.lstm_unpack(part, I, S, G * I, Hh, I, sinks[0], sinks[4], accumulate=True)
+                for a_, b_ in ((2, 6), (3, 7)):      # b_ih and b_hh receive the same gradient
+                    H.lstm_unpack(cs, 1, 1, 0, Hh, 1, sinks[a_], sinks[b_], accumulate=True)
+                return (None,) * 8
+            new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
+            d_whh, d_whh_r = new(4 * Hh, Hh), new(4 * Hh, Hh)
+            H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, d_whh, d_whh_r)
+            d_wih, d_wih_r = new(4 * Hh, I), new(4 * Hh, I)
+            H.lstm_unpack(part, I, S, G * I, Hh, I, d_wih, d_wih_r)
+            d_b, d_b_r = new(4 * Hh), new(4 * Hh)
+            H.lstm_unpack(cs, 1, 1, 0, Hh, 1, d_b, d_b_r)
+            return d_wih, d_whh, d_b, d_b.clone(), d_wih_r, d_whh_r, d_b_r, d_b_r.clone()
+
+        if direct:
+            side.wait_stream(main)
+            for t_ in (gates, hout, xv):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                lstm_grads = lstm_wgrads()
+        else:
+            lstm_grads = lstm_wgrads()
         dx = None
         if ctx.needs_input_grad[0]:
             dxb, ld_dx = H.padded(R, I, dev, zero=True)
@@ -122,8 +162,16 @@ class _RNNP(torch.autograd.Function):
             dx = dxb[:, :I]
             if tuple(ctx.x_shape) != tuple(dx.shape):
                 dx = dx.reshape(ctx.x_shape)
-        return (dx, d_wih, d_whh, d_b, d_b.clone(), d_wih_r, d_whh_r, d_b_r, d_b_r.clone(),
-                d_w_proj, d_b_proj, None, None, None, None)
+        return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None)
+
+
+def _grad_sink(p):
+    """Flat-bucket view a parameter's gradient may be accumulated into directly (set by
+    tssep_amd.distributed.GradBucket), or None -> return the gradient through autograd."""
+    s_ = getattr(p, "_tssep_grad_sink", None)
+    if s_ is None or p.grad is None or p.grad.data_ptr() != s_.data_ptr() or not s_.is_contiguous():
+        return None
+    return s_
 
 
 def _dense_rows(t, cols):
@@ -205,6 +253,7 @@ class _Head(torch.autograd.Function):
             H.gemm(xv, ld_x, wv, ld_w, raw, Nout, R, Nout, P, bias=bias.detach())
             out = H.logit_map_fwd(raw, perm, iperm, B, trials, K, T, F, Fr, spk_rows)
         ctx.save_for_backward(xv, wv)
+        ctx.params = (weight, bias)
         ctx.aux = (perm, iperm)
         ctx.meta = (B, K, T, F, trials, Fr, spk_rows, ld_x, ld_w, P, R, Nout)
         ctx.x_shape = x.shape
@@ -218,10 +267,23 @@ class _Head(torch.autograd.Function):
         dev = dout.device
         draw = H.logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows).view(R, Nout)
         dv, ld_d = H.rows_view(draw)
-        part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
-        dw = torch.empty(Nout, P, device=dev, dtype=torch.float32)
-        H.reduce_splits(part, S, Nout * P, dw)
-        db = H.colsum(dv, ld_d, R, Nout)
+        sw, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
+        direct = sw is not None and sb is not None and H.OVERLAP_WGRAD
+        if direct:
+            main, side = torch.cuda.current_stream(), H.side_stream(dev)
+            side.wait_stream(main)
+            for t_ in (dv, xv):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
+                H.reduce_splits(part, S, Nout * P, sw, accumulate=True)
+                H.colsum(dv, ld_d, R, Nout, out=sb, accumulate=True)
+            dw = db = None
+        else:
+            part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
+            dw = torch.empty(Nout, P, device=dev, dtype=torch.float32)
+            H.reduce_splits(part, S, Nout * P, dw)
+            db = H.colsum(dv, ld_d, R, Nout)
         dxb, ld_dx = H.padded(R, P, dev, zero=True)
         H.gemm(dv, ld_d, wv, ld_w, dxb, ld_dx, R, P, Nout, b_kmajor=True)
         dx = dxb[:, :P]

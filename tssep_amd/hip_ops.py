@@ -5,6 +5,7 @@ is a call into libtssep_hip.so.  Nothing here falls back to ATen math.
 """
 import ctypes
 import math
+import os as _os
 
 import numpy as np
 import torch
@@ -175,7 +176,6 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
 # Arithmetic of the non-recurrent GEMMs: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 on the
 # bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The LSTM
 # recurrences always run exact fp32.
-import os as _os
 GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
 _PREC = {"f32": 0, "bf16x3": 1}
 
@@ -353,9 +353,31 @@ def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H, ms=2):
                                         _stream()), "blstm_cluster_bwd")
 
 
-def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r):
+def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulate=False):
     check(_lib.lib().tssep_lstm_unpack(_p(src), ld, nsplit, split_stride, H, ncols, _p(dst_f),
-                                       _p(dst_r), _stream()), "lstm_unpack")
+                                       _p(dst_r), int(accumulate), _stream()), "lstm_unpack")
+
+
+# ---- side stream for weight gradients ---------------------------------------------------------
+# Weight-gradient GEMMs are off the critical path of backward (nothing downstream reads them):
+# with a GradBucket attached they are accumulated straight into the flat gradient buffer on a
+# second HIP stream, overlapping the T-sequential recurrences of the layers still to come.
+_SIDE = {}
+OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
+
+
+def side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for all gradient work queued on the side stream."""
+    for key, st in _SIDE.items():
+        if device is None or key == str(device):
+            torch.cuda.current_stream().wait_stream(st)
 
 
 # ------------------------------------------------------------------------ elementwise
