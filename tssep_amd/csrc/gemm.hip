@@ -163,17 +163,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
     int64_t b_kshift, int64_t kperiod, const float* __restrict__ bias, int act, int accumulate,
-    StoreMap sm, int splitk, int64_t c_split_stride, int64_t n_begin) {
+    StoreMap sm, int splitk, int64_t c_split_stride, int64_t n_begin, TileMap tmap) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2, BNT = NARROW ? 32 : BN;
   const int wm = NARROW ? wave : wave >> 1, wn = NARROW ? 0 : wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = n_begin + (int64_t)blockIdx.x * BNT;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * BM, n0 = n_begin + (int64_t)nt * BNT;
 
   // split-K range (in K tiles)
   const int64_t ktiles = (K + BK - 1) / BK;
   const int64_t per = (ktiles + splitk - 1) / splitk;
-  const int64_t kt_begin = (int64_t)blockIdx.z * per;
+  const int64_t kt_begin = (int64_t)zsplit * per;
   const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
   const int64_t kt_full = K / BK;               // tiles [0, kt_full) need no K mask
 
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     }
   }
 
-  float* Cz = C + (int64_t)blockIdx.z * c_split_stride;
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
   gemm_epilogue<TM, TN>(acc, Cz, M, N, m0 + (int64_t)wm * TM * 32, n0 + (int64_t)wn * TN * 32, lane,
                         bias, act, accumulate, sm, splitk == 1);
 }
@@ -260,7 +262,6 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
   if (g->precision != 0) return TSSEP_E_UNSUPPORTED;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
-  if (mtiles > 65535u) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   // columns [0, n_main) by 128-wide tiles; a remainder of <= 96 columns by 32-wide edge tiles
   int64_t n_main = (g->N / BN) * BN;
@@ -270,10 +271,14 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (rem > 96 || splitk > 1) n_main = g->N;
   const bool shift = g->kperiod > 0;
 #define LAUNCH(AK, BKM, SH, NARROW, GRIDX, NBEGIN)                                                 \
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, SH, NARROW>), dim3((GRIDX), mtiles, (unsigned)splitk), \
-                     dim3(NTHREADS), 0, s, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb,      \
-                     g->b_kshift, g->kperiod, g->bias, g->act, g->accumulate, sm, splitk,           \
-                     g->c_split_stride, (int64_t)(NBEGIN))
+  do {                                                                                             \
+    const TileMap tm_ = make_tile_map(mtiles, (GRIDX), splitk);                                    \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BKM, SH, NARROW>),                                     \
+                       dim3((unsigned)tile_map_blocks(tm_)), dim3(NTHREADS), 0, s, g->A, g->B,     \
+                       g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod, g->bias,   \
+                       g->act, g->accumulate, sm, splitk, g->c_split_stride, (int64_t)(NBEGIN),    \
+                       tm_);                                                                       \
+  } while (0)
 #define DISPATCH(NARROW, GRIDX, NBEGIN)                                                            \
   do {                                                                                             \
     if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false, NARROW, GRIDX, NBEGIN);          \

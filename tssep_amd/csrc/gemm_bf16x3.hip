@@ -22,9 +22,20 @@
 namespace {
 
 using namespace gemm_detail;
-constexpr int BK = 32;
-constexpr int PITCH = 80;                        // bytes per LDS row (32 bf16 + 16 B pad)
-constexpr int ARR = BM * PITCH;                  // one hi or lo array of one operand: 10240 B
+// BK = 32 (pitch 80 B) or 64 (pitch 144 B): bytes per LDS row = 2*BK + 16; both pitches put the
+// 16 rows of a ds_read_b128 lane group on 16 distinct 16-byte slots (5r resp. 9r mod 16).
+// Measured (ablation, 64768x2400x513): MFMA + fragment reads alone 0.46 ms, loads + split + LDS
+// stores alone 0.13 ms, together 0.91 ms -- the shared LDS pipe (512 cycles of fragment reads +
+// ~770 cycles of ds_write per tile pair vs 1536 MFMA cycles) is the co-limiter; BK = 64 and a
+// double-buffered LDS were both tried and gave nothing.  The next step is operands pre-split by
+// their producers and staged with global_load_lds (no VALU, no ds_write).
+template <int BK> struct Cfg {
+  static constexpr int PITCH = 2 * BK + 16;
+  static constexpr int ARR = BM * PITCH;
+  static constexpr int NL = BK / 8;              // float4 loads per thread, row operand
+  static constexpr int KQ = BK / 4;              // float4 per row
+  static constexpr int NC = BK / 2;              // scalar loads per thread, col operand
+};
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -43,33 +54,37 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 }
 
 // ---- "row" operand (k contiguous): tile 128 rows x 32 k = 1024 float4, 4 per thread -----------
+template <int BK>
 struct RowLoad {
-  const float* p;      // P + min(r0 + tid/8, R-1)*ld + 4*(tid&7)   (load 0)
-  int64_t step[3];     // element offsets of loads 1..3 relative to load 0 (rows +32, clamped)
+  const float* p;                       // load 0
+  int64_t step[Cfg<BK>::NL - 1];        // element offsets of the other loads (row + 256/KQ*i, clamped)
   int kq;
 };
-__device__ __forceinline__ RowLoad make_row_load(const float* P, int64_t ld, int64_t R, int64_t r0,
-                                                 int tid) {
-  RowLoad d;
-  d.kq = (tid & 7) << 2;
-  int64_t rr[4];
+template <int BK>
+__device__ __forceinline__ RowLoad<BK> make_row_load(const float* P, int64_t ld, int64_t R,
+                                                     int64_t r0, int tid) {
+  constexpr int NL = Cfg<BK>::NL, KQ = Cfg<BK>::KQ;
+  RowLoad<BK> d;
+  d.kq = (tid % KQ) << 2;
+  int64_t rr[NL];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t r = r0 + (tid >> 3) + 32 * i;
+  for (int i = 0; i < NL; ++i) {
+    int64_t r = r0 + tid / KQ + (NTHREADS / KQ) * i;
     rr[i] = r > R - 1 ? R - 1 : r;
   }
   d.p = P + rr[0] * ld + d.kq;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) d.step[i] = (rr[i + 1] - rr[0]) * ld;
+  for (int i = 0; i < NL - 1; ++i) d.step[i] = (rr[i + 1] - rr[0]) * ld;
   return d;
 }
-template <bool TAIL>
-__device__ __forceinline__ void row_load(const RowLoad& d, int64_t k0, int64_t K, f32x4 (&v)[4]) {
+template <int BK, bool TAIL>
+__device__ __forceinline__ void row_load(const RowLoad<BK>& d, int64_t k0, int64_t K,
+                                         f32x4 (&v)[Cfg<BK>::NL]) {
   const int64_t k = k0 + d.kq;
   // a 16-byte load that starts at or beyond K would leave the row: read the row start instead
   const float* p = d.p + ((!TAIL || k < K) ? k0 : -(int64_t)d.kq);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < Cfg<BK>::NL; ++i) {
     f32x4 x = *reinterpret_cast<const f32x4*>(i == 0 ? p : p + d.step[i - 1]);
     if (TAIL) {
 #pragma unroll
@@ -78,11 +93,13 @@ __device__ __forceinline__ void row_load(const RowLoad& d, int64_t k0, int64_t K
     v[i] = x;
   }
 }
-__device__ __forceinline__ void row_store(char* hi, char* lo, int tid, const f32x4 (&v)[4]) {
+template <int BK>
+__device__ __forceinline__ void row_store(char* hi, char* lo, int tid,
+                                          const f32x4 (&v)[Cfg<BK>::NL]) {
+  constexpr int KQ = Cfg<BK>::KQ;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = tid + NTHREADS * i;
-    const int off = (q >> 3) * PITCH + ((q & 7) << 3);          // 4 bf16 = 8 bytes
+  for (int i = 0; i < Cfg<BK>::NL; ++i) {
+    const int off = (tid / KQ + (NTHREADS / KQ) * i) * Cfg<BK>::PITCH + ((tid % KQ) << 3);
     unsigned h0, l0, h1, l1;
     split2(v[i][0], v[i][1], h0, l0);
     split2(v[i][2], v[i][3], h1, l1);
@@ -91,10 +108,10 @@ __device__ __forceinline__ void row_store(char* hi, char* lo, int tid, const f32
   }
 }
 
-// ---- "col" operand (k-major): lane = column, 16 consecutive k per thread ----------------------
+// ---- "col" operand (k-major): lane = column, BK/2 consecutive k per thread -------------------
 struct ColLoad {
   const float* p;      // P + c (clamped)
-  int khalf;           // 0 / 1: k in [16*khalf, 16*khalf + 16)
+  int khalf;           // 0 / 1: k in [BK/2*khalf, BK/2*khalf + BK/2)
   bool cvalid;
 };
 __device__ __forceinline__ ColLoad make_col_load(const float* P, int64_t C, int64_t c0, int tid) {
@@ -106,12 +123,13 @@ __device__ __forceinline__ ColLoad make_col_load(const float* P, int64_t C, int6
   d.khalf = tid >> 7;
   return d;
 }
-template <bool TAIL, bool SHIFT>
+template <int BK, bool TAIL, bool SHIFT>
 __device__ __forceinline__ void col_load(const ColLoad& d, int64_t ld, int64_t k0, int64_t K,
-                                         int64_t kshift, int64_t kperiod, float (&v)[16]) {
+                                         int64_t kshift, int64_t kperiod, float (&v)[Cfg<BK>::NC]) {
+  constexpr int NC = Cfg<BK>::NC;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int64_t k = k0 + d.khalf * 16 + i;
+  for (int i = 0; i < NC; ++i) {
+    const int64_t k = k0 + d.khalf * NC + i;
     bool ok = d.cvalid;
     int64_t kk = k;
     if (TAIL) {
@@ -127,23 +145,27 @@ __device__ __forceinline__ void col_load(const ColLoad& d, int64_t ld, int64_t k
     v[i] = ok ? x : 0.f;
   }
 }
-__device__ __forceinline__ void col_store(char* hi, char* lo, int tid, const float (&v)[16]) {
-  const int off = (tid & 127) * PITCH + (tid >> 7) * 32;        // 16 bf16 = 32 bytes
-  unsigned h[8], l[8];
+template <int BK>
+__device__ __forceinline__ void col_store(char* hi, char* lo, int tid, const float (&v)[Cfg<BK>::NC]) {
+  constexpr int NC = Cfg<BK>::NC;
+  const int off = (tid & 127) * Cfg<BK>::PITCH + (tid >> 7) * NC * 2;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
-  *reinterpret_cast<u32x4*>(hi + off) = u32x4{h[0], h[1], h[2], h[3]};
-  *reinterpret_cast<u32x4*>(hi + off + 16) = u32x4{h[4], h[5], h[6], h[7]};
-  *reinterpret_cast<u32x4*>(lo + off) = u32x4{l[0], l[1], l[2], l[3]};
-  *reinterpret_cast<u32x4*>(lo + off + 16) = u32x4{l[4], l[5], l[6], l[7]};
+  for (int c = 0; c < NC / 8; ++c) {             // 8 k = 16 bytes per store
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(v[8 * c + 2 * e], v[8 * c + 2 * e + 1], h[e], l[e]);
+    *reinterpret_cast<u32x4*>(hi + off + 16 * c) = u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(lo + off + 16 * c) = u32x4{l[0], l[1], l[2], l[3]};
+  }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR, bool SHIFT>
+template <int BK, bool A_KMAJOR, bool B_KMAJOR, bool SHIFT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t b_kshift, int64_t kperiod,
     const float* __restrict__ bias, int act, int accumulate, StoreMap sm, int splitk,
-    int64_t c_split_stride) {
+    int64_t c_split_stride, TileMap tmap) {
+  constexpr int PITCH = Cfg<BK>::PITCH, ARR = Cfg<BK>::ARR;
   __shared__ __attribute__((aligned(16))) char lds[4 * ARR];      // A hi, A lo, B hi, B lo
   char* const a_hi = lds;
   char* const a_lo = lds + ARR;
@@ -151,11 +173,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
   char* const b_lo = lds + 3 * ARR;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
 
   const int64_t ktiles = (K + BK - 1) / BK;
   const int64_t per = (ktiles + splitk - 1) / splitk;
-  const int64_t kt_begin = (int64_t)blockIdx.z * per;
+  const int64_t kt_begin = (int64_t)zsplit * per;
   const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
   const int64_t kt_full = K / BK;
 
@@ -167,26 +191,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  RowLoad ra_d, rb_d;
+  RowLoad<BK> ra_d, rb_d;
   ColLoad ca_d, cb_d;
-  if (!A_KMAJOR) ra_d = make_row_load(A, lda, M, m0, tid); else ca_d = make_col_load(A, M, m0, tid);
-  if (!B_KMAJOR) rb_d = make_row_load(B, ldb, N, n0, tid); else cb_d = make_col_load(B, N, n0, tid);
+  if (!A_KMAJOR) ra_d = make_row_load<BK>(A, lda, M, m0, tid); else ca_d = make_col_load(A, M, m0, tid);
+  if (!B_KMAJOR) rb_d = make_row_load<BK>(B, ldb, N, n0, tid); else cb_d = make_col_load(B, N, n0, tid);
 
-  f32x4 ra[4], rb[4];
-  float ca[16], cb[16];
+  f32x4 ra[Cfg<BK>::NL], rb[Cfg<BK>::NL];
+  float ca[Cfg<BK>::NC], cb[Cfg<BK>::NC];
   auto gload = [&](int64_t kt) {
     const int64_t k0 = kt * BK;
     if (kt < kt_full) {
-      if (!A_KMAJOR) row_load<false>(ra_d, k0, K, ra); else col_load<false, false>(ca_d, lda, k0, K, 0, 1, ca);
-      if (!B_KMAJOR) row_load<false>(rb_d, k0, K, rb); else col_load<false, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
+      if (!A_KMAJOR) row_load<BK, false>(ra_d, k0, K, ra); else col_load<BK, false, false>(ca_d, lda, k0, K, 0, 1, ca);
+      if (!B_KMAJOR) row_load<BK, false>(rb_d, k0, K, rb); else col_load<BK, false, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
     } else {
-      if (!A_KMAJOR) row_load<true>(ra_d, k0, K, ra); else col_load<true, false>(ca_d, lda, k0, K, 0, 1, ca);
-      if (!B_KMAJOR) row_load<true>(rb_d, k0, K, rb); else col_load<true, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
+      if (!A_KMAJOR) row_load<BK, true>(ra_d, k0, K, ra); else col_load<BK, true, false>(ca_d, lda, k0, K, 0, 1, ca);
+      if (!B_KMAJOR) row_load<BK, true>(rb_d, k0, K, rb); else col_load<BK, true, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
     }
   };
   auto sstore = [&]() {
-    if (!A_KMAJOR) row_store(a_hi, a_lo, tid, ra); else col_store(a_hi, a_lo, tid, ca);
-    if (!B_KMAJOR) row_store(b_hi, b_lo, tid, rb); else col_store(b_hi, b_lo, tid, cb);
+    if (!A_KMAJOR) row_store<BK>(a_hi, a_lo, tid, ra); else col_store<BK>(a_hi, a_lo, tid, ca);
+    if (!B_KMAJOR) row_store<BK>(b_hi, b_lo, tid, rb); else col_store<BK>(b_hi, b_lo, tid, cb);
   };
 
   if (kt_begin < kt_end) {
@@ -199,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
       const bool more = kt + 1 < kt_end;
       if (more) gload(kt + 1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
       }
     }
   }
-  float* Cz = C + (int64_t)blockIdx.z * c_split_stride;
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
   gemm_epilogue<2, 2>(acc, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias, act,
                       accumulate, sm, splitk == 1);
 }
@@ -238,20 +262,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
                              void* stream) {
-  const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
-  if (mtiles > 65535u) return TSSEP_E_SHAPE;
-  dim3 grid((unsigned)((g->N + BN - 1) / BN), mtiles, (unsigned)splitk);
+  const TileMap tmap = make_tile_map((g->M + BM - 1) / BM, (g->N + BN - 1) / BN, splitk);
+  dim3 grid((unsigned)tile_map_blocks(tmap));
   hipStream_t s = (hipStream_t)stream;
   const bool shift = g->kperiod > 0;
-#define LAUNCH(AK, BKM, SH)                                                                      \
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<AK, BKM, SH>), grid, dim3(NTHREADS), 0, s, g->A, g->B,  \
-                     g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod, g->bias,   \
-                     g->act, g->accumulate, sm, splitk, g->c_split_stride)
-  if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false);
-  else if (!g->a_kmajor && shift) LAUNCH(false, true, true);
-  else if (!g->a_kmajor) LAUNCH(false, true, false);
-  else if (shift) LAUNCH(true, true, true);
-  else LAUNCH(true, true, false);
+#define LAUNCH(BKV, AK, BKM, SH)                                                                 \
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<BKV, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s, g->A,   \
+                     g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod,      \
+                     g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride, tmap)
+#define DISPATCH(BKV)                                                                            \
+  do {                                                                                           \
+    if (!g->a_kmajor && !g->b_kmajor) LAUNCH(BKV, false, false, false);                          \
+    else if (!g->a_kmajor && shift) LAUNCH(BKV, false, true, true);                              \
+    else if (!g->a_kmajor) LAUNCH(BKV, false, true, false);                                      \
+    else if (shift) LAUNCH(BKV, true, true, true);                                               \
+    else LAUNCH(BKV, true, true, false);                                                         \
+  } while (0)
+  // BK = 64 was measured: no gain (the loop is bound by LDS traffic + MFMA, not by load latency)
+  DISPATCH(32);
+#undef DISPATCH
 #undef LAUNCH
   return tssep_launch_status();
 }

@@ -6,6 +6,51 @@ namespace gemm_detail {
 
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 
+// ---- XCD-aware workgroup -> tile map --------------------------------------------------------
+// MI355X: 8 XCDs with private 4 MB L2s; workgroup b is observed to run on XCD b % 8 (a speed
+// hint only -- any placement is correct).  With fp32 operands a 128x128 tile has an arithmetic
+// intensity of only 32 FLOP/byte, so the GEMMs are L2/HBM-bound unless operand panels are reused
+// out of the SAME L2:
+//  * splitk == 1 (M large): XCD x owns the m-tiles {x, x+8, ...}; inside an XCD the order is
+//    n-group (NG n-tiles whose weight slice stays in L2) > m-tile > n-tile, so an A panel is
+//    fetched from HBM once per n-group and the weight slice once per XCD.
+//  * splitk  > 1 (wgrad, K huge): the split index is the fastest-varying part of the id, so all
+//    tiles of one K slab run on one XCD at the same time and share the slab through its L2.
+constexpr int NXCD = 8, NGROUP_MAX = 8;
+struct TileMap {
+  int MT, NT, S, MTx, NGc, NG;      // NG = n-tiles per group (<= 8), chosen to leave few idle ids
+};
+__host__ __device__ inline TileMap make_tile_map(int64_t mtiles, int64_t ntiles, int splitk) {
+  TileMap t;
+  t.MT = (int)mtiles; t.NT = (int)ntiles; t.S = splitk;
+  t.MTx = (int)((mtiles + NXCD - 1) / NXCD);
+  t.NGc = (int)((ntiles + NGROUP_MAX - 1) / NGROUP_MAX);
+  t.NG = (int)((ntiles + t.NGc - 1) / t.NGc);
+  return t;
+}
+__host__ __device__ inline int64_t tile_map_blocks(const TileMap& t) {
+  if (t.S > 1) return (int64_t)t.S * t.MT * t.NT;
+  return (int64_t)NXCD * t.MTx * t.NGc * t.NG;
+}
+__device__ __forceinline__ bool tile_map_decode(const TileMap& t, int64_t bid, int& mt, int& nt, int& z) {
+  if (t.S > 1) {
+    z = (int)(bid % t.S);
+    const int64_t tile = bid / t.S;
+    mt = (int)(tile / t.NT);
+    nt = (int)(tile % t.NT);
+    return true;
+  }
+  z = 0;
+  const int xcd = (int)(bid % NXCD);
+  const int64_t l = bid / NXCD;
+  const int per_group = t.MTx * t.NG;
+  const int ng = (int)(l / per_group);
+  const int r = (int)(l % per_group);
+  mt = (r / t.NG) * NXCD + xcd;
+  nt = ng * t.NG + (r % t.NG);
+  return mt < t.MT && nt < t.NT;
+}
+
 struct StoreMap {
   int64_t ldc;
   int32_t remap;

@@ -216,6 +216,8 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
     s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
+    if s > 1:        # multiples of the XCD count: split z runs on XCD z % 8 (gemm_common.h)
+        s = min(round_up(s, 8), max(8, (ktiles // min_ktiles) // 8 * 8))
     return min(s, 64)
 
 
