@@ -22,7 +22,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 K_SPK, N_SAMPLES, UNITS, PROJS, FBINS = 4, 64000, 300, 320, 513
-PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+PEAK_F32_MFMA_TFLOPS = 157.3          # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1_16b)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; a bf16x3 GEMM issues 3 MFMA flops per algorithmic flop
+PEAK_HBM_GBPS = 8000.0
 
 
 def synth_batch(B, K, N, seed):
@@ -108,9 +111,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 64)),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 256)),
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
-    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "f32"),
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
                     help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -170,32 +173,47 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    # dominant kernel, timed live with HIP events on the launch stream
+    # dominant kernel (largest share of the step), timed live with HIP events on its launch stream
     ktimes = H.kernel_time_summary()
-    roofline = None
-    if ktimes:
-        name, (n_launch, total_ms) = max(ktimes.items(), key=lambda kv: kv[1][1])
+    roofline = mask_head = None
+    mfma = {k: v for k, v in ktimes.items() if H.KERNEL_FLOPS.get(k, 0) > 0}
+    if mfma:
+        name, (n_launch, total_ms) = max(mfma.items(), key=lambda kv: kv[1][1])
         avg_ms = total_ms / n_launch
-        flops = H.KERNEL_FLOPS.get(name, 0) / max(n_launch, 1)
-        ach = flops / (avg_ms * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                        launches=n_launch, avg_ms=round(avg_ms, 4),
-                        share_of_step=round(total_ms / (dt * 1e3), 3))
+        ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
+        peak = PEAK_BF16_MFMA_TFLOPS if name == "gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
+        roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=None, launches=n_launch,
+                        avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
+                        note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
+                              "the bf16 MFMA, so frac <= 1/3" if name == "gemm_bf16x3" else
+                              "exact fp32 MFMA"))
+    hb = [(k, ktimes[k]) for k in ("maskhead_fwd", "maskhead_bwd") if k in ktimes]
+    if hb:       # the mask head is the HBM-bound kernel the north star singles out
+        n_l = sum(v[0] for _, v in hb)
+        ms = sum(v[1] for _, v in hb)
+        by = sum(H.KERNEL_BYTES[k] for k, _ in hb)
+        gbps = by / (ms * 1e-3) / 1e9
+        mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
+                         peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
+                         traffic=None, launches=n_l, avg_ms=round(ms / n_l, 4))
     if rank == 0:
         frames = B * world * T * args.steps
         line = {
             "metric": "frames/sec fwd+bwd, 4-spk TS-SEP, 16kHz 4s chunks",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("bf16x3+f32" if args.gemm == "bf16x3" else "f32"),
             "data": "synthetic",
             "config": {"workload": "TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])",
                        "speakers": K_SPK, "samples": N_SAMPLES, "frames_per_chunk": T,
                        "batch_per_gpu": B, "global_batch": B * world, "units": UNITS,
                        "projs": PROJS, "parallelism": f"dp{world}",
+                       "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate; recurrences exact fp32"
+                                           if args.gemm == "bf16x3" else "exact fp32 MFMA"),
                        "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_mask_head": mask_head,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
         }
         print(json.dumps(line), flush=True)

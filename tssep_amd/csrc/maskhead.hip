@@ -31,40 +31,46 @@ struct Pos {
   }
 };
 
+// Work split: a wave walks 256 consecutive elements per iteration; lane l owns the element pairs
+// {2l, 2l+1} and {128+2l, 129+2l}.  Every store instruction of the dominant complex64 stream then
+// covers one contiguous 1 KB (16 B per lane, lanes adjacent) instead of 16-byte pieces at a
+// 32-byte stride; the fp32 streams move 8 B per lane.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void maskhead_fwd_kernel(
     const float* __restrict__ logit, const float2* __restrict__ obs, float* __restrict__ mask,
     float2* __restrict__ est, int64_t total, int64_t KTF, int64_t TF) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t stride = nwaves * 256;
   const int64_t stride_tf = stride % TF;
-  int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e0 >= total) return;
-  Pos p;
-  p.init(e0, KTF, TF);
-  for (; e0 < total; e0 += stride, p.advance(stride, stride_tf, KTF, TF)) {
-    const int n = total - e0 >= 4 ? 4 : (int)(total - e0);
-    float lg[4], m[4];
-    float2 o[4];
-    if (n == 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(logit + e0);
-      lg[0] = v[0]; lg[1] = v[1]; lg[2] = v[2]; lg[3] = v[3];
-    } else {
-      for (int i = 0; i < 4; ++i) lg[i] = i < n ? logit[e0 + i] : 0.f;
-    }
-    Pos q = p;
+  int64_t base = wave * 256;
+  if (base >= total) return;
+  Pos p0, p1;
+  p0.init(base + 2 * lane < total ? base + 2 * lane : 0, KTF, TF);
+  p1.init(base + 128 + 2 * lane < total ? base + 128 + 2 * lane : 0, KTF, TF);
+  for (; base < total; base += stride, p0.advance(stride, stride_tf, KTF, TF),
+                       p1.advance(stride, stride_tf, KTF, TF)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      m[i] = sigmoidf_acc(lg[i]);
-      const float2 x = i < n ? obs[q.ob + q.tf] : make_float2(0.f, 0.f);
-      o[i] = make_float2(x.x * m[i], x.y * m[i]);
-      q.advance(1, 1, KTF, TF);
-    }
-    if (n == 4) {
-      *reinterpret_cast<f32x4*>(mask + e0) = f32x4{m[0], m[1], m[2], m[3]};
-      f32x4* ep = reinterpret_cast<f32x4*>(est + e0);
-      ep[0] = f32x4{o[0].x, o[0].y, o[1].x, o[1].y};
-      ep[1] = f32x4{o[2].x, o[2].y, o[3].x, o[3].y};
-    } else {
-      for (int i = 0; i < n; ++i) { mask[e0 + i] = m[i]; est[e0 + i] = o[i]; }
+    for (int h = 0; h < 2; ++h) {
+      const int64_t e = base + 128 * h + 2 * lane;
+      Pos q = h ? p1 : p0;
+      if (e + 2 <= total) {
+        const f32x2 lg = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logit + e));
+        const float m0 = sigmoidf_acc(lg[0]), m1 = sigmoidf_acc(lg[1]);
+        const float2 x0 = obs[q.ob + q.tf];
+        q.advance(1, 1, KTF, TF);
+        const float2 x1 = obs[q.ob + q.tf];
+        __builtin_nontemporal_store(f32x2{m0, m1}, reinterpret_cast<f32x2*>(mask + e));
+        __builtin_nontemporal_store(f32x4{x0.x * m0, x0.y * m0, x1.x * m1, x1.y * m1},
+                                    reinterpret_cast<f32x4*>(est + e));
+      } else if (e < total) {
+        const float m0 = sigmoidf_acc(logit[e]);
+        const float2 x0 = obs[q.ob + q.tf];
+        mask[e] = m0;
+        est[e] = make_float2(x0.x * m0, x0.y * m0);
+      }
     }
   }
 }
@@ -73,44 +79,39 @@ __global__ __launch_bounds__(256) void maskhead_bwd_kernel(
     const float2* __restrict__ dest, const float* __restrict__ dmask,
     const float* __restrict__ mask, const float2* __restrict__ obs, float* __restrict__ dlogit,
     int64_t total, int64_t KTF, int64_t TF) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t stride = nwaves * 256;
   const int64_t stride_tf = stride % TF;
-  int64_t e0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e0 >= total) return;
-  Pos p;
-  p.init(e0, KTF, TF);
-  for (; e0 < total; e0 += stride, p.advance(stride, stride_tf, KTF, TF)) {
-    const int n = total - e0 >= 4 ? 4 : (int)(total - e0);
-    float m[4], dm[4] = {0.f, 0.f, 0.f, 0.f}, dre[4], dim[4], out[4];
-    if (n == 4) {
-      const f32x4 mv = *reinterpret_cast<const f32x4*>(mask + e0);
-      const f32x4* dp = reinterpret_cast<const f32x4*>(dest + e0);
-      const f32x4 d0 = dp[0], d1 = dp[1];
-      m[0] = mv[0]; m[1] = mv[1]; m[2] = mv[2]; m[3] = mv[3];
-      dre[0] = d0[0]; dim[0] = d0[1]; dre[1] = d0[2]; dim[1] = d0[3];
-      dre[2] = d1[0]; dim[2] = d1[1]; dre[3] = d1[2]; dim[3] = d1[3];
-      if (dmask) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dmask + e0);
-        dm[0] = g[0]; dm[1] = g[1]; dm[2] = g[2]; dm[3] = g[3];
-      }
-    } else {
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = i < n;
-        m[i] = ok ? mask[e0 + i] : 0.f;
-        const float2 d = ok ? dest[e0 + i] : make_float2(0.f, 0.f);
-        dre[i] = d.x; dim[i] = d.y;
-        dm[i] = (ok && dmask) ? dmask[e0 + i] : 0.f;
-      }
-    }
-    Pos q = p;
+  int64_t base = wave * 256;
+  if (base >= total) return;
+  Pos p0, p1;
+  p0.init(base + 2 * lane < total ? base + 2 * lane : 0, KTF, TF);
+  p1.init(base + 128 + 2 * lane < total ? base + 128 + 2 * lane : 0, KTF, TF);
+  for (; base < total; base += stride, p0.advance(stride, stride_tf, KTF, TF),
+                       p1.advance(stride, stride_tf, KTF, TF)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float2 x = i < n ? obs[q.ob + q.tf] : make_float2(0.f, 0.f);
-      out[i] = (x.x * dre[i] + x.y * dim[i] + dm[i]) * m[i] * (1.0f - m[i]);
-      q.advance(1, 1, KTF, TF);
+    for (int h = 0; h < 2; ++h) {
+      const int64_t e = base + 128 * h + 2 * lane;
+      Pos q = h ? p1 : p0;
+      if (e + 2 <= total) {
+        const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dest + e));
+        const f32x2 m = *reinterpret_cast<const f32x2*>(mask + e);
+        f32x2 g = {0.f, 0.f};
+        if (dmask) g = *reinterpret_cast<const f32x2*>(dmask + e);
+        const float2 x0 = obs[q.ob + q.tf];
+        q.advance(1, 1, KTF, TF);
+        const float2 x1 = obs[q.ob + q.tf];
+        const float o0 = (x0.x * d[0] + x0.y * d[1] + g[0]) * m[0] * (1.0f - m[0]);
+        const float o1 = (x1.x * d[2] + x1.y * d[3] + g[1]) * m[1] * (1.0f - m[1]);
+        *reinterpret_cast<f32x2*>(dlogit + e) = f32x2{o0, o1};
+      } else if (e < total) {
+        const float2 x0 = obs[q.ob + q.tf], d = dest[e];
+        const float m = mask[e];
+        dlogit[e] = (x0.x * d.x + x0.y * d.y + (dmask ? dmask[e] : 0.f)) * m * (1.0f - m);
+      }
     }
-    if (n == 4) *reinterpret_cast<f32x4*>(dlogit + e0) = f32x4{out[0], out[1], out[2], out[3]};
-    else for (int i = 0; i < n; ++i) dlogit[e0 + i] = out[i];
   }
 }
 

@@ -18,11 +18,12 @@ from ._lib import GemmArgs, LstmSizes, check
 KERNEL_TIMING = False
 KERNEL_TIMERS = {}      # name -> list of (start_event, end_event)
 KERNEL_FLOPS = {}       # name -> algorithmic FLOPs accumulated over the timed launches
+KERNEL_BYTES = {}       # name -> algorithmic HBM bytes accumulated over the timed launches
 
 
 class _timed:
-    def __init__(self, name, flops=0):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops=0, nbytes=0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
 
     def __enter__(self):
         if KERNEL_TIMING:
@@ -36,6 +37,7 @@ class _timed:
             self.e.record()
             KERNEL_TIMERS.setdefault(self.name, []).append((self.s, self.e))
             KERNEL_FLOPS[self.name] = KERNEL_FLOPS.get(self.name, 0) + self.flops
+            KERNEL_BYTES[self.name] = KERNEL_BYTES.get(self.name, 0) + self.nbytes
 
 
 def kernel_time_summary():
@@ -208,7 +210,7 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
         g.c_perm_ld = remap.get("perm_ld", 0)
     g.splitk, g.c_split_stride = splitk, split_stride
     g.precision = _PREC[GEMM_PRECISION]
-    with _timed("gemm_f32", 2 * M * N * K):
+    with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K):
         check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
 
@@ -428,8 +430,9 @@ def maskhead_fwd(logit, obs):
     obs_r = torch.view_as_real(obs.contiguous())
     mask = torch.empty_like(logit)
     est = torch.empty(B, K, T, F, 2, device=logit.device, dtype=torch.float32)
-    check(_lib.lib().tssep_maskhead_fwd(_p(logit), _p(obs_r), _p(mask), _p(est), B, K, T, F,
-                                        _stream()), "maskhead_fwd")
+    with _timed("maskhead_fwd", 0, B * T * (16 * K * F + 8 * F)):
+        check(_lib.lib().tssep_maskhead_fwd(_p(logit), _p(obs_r), _p(mask), _p(est), B, K, T, F,
+                                            _stream()), "maskhead_fwd")
     return mask, torch.view_as_complex(est)
 
 
@@ -440,8 +443,9 @@ def maskhead_bwd(dest, dmask, mask, obs):
     dlogit = torch.empty_like(mask)
     if dmask is not None:
         dmask = _f32(dmask).contiguous()
-    check(_lib.lib().tssep_maskhead_bwd(_p(dest_r), _p(dmask), _p(mask), _p(obs_r), _p(dlogit), B,
-                                        K, T, F, _stream()), "maskhead_bwd")
+    with _timed("maskhead_bwd", 0, B * T * (16 * K * F + 8 * F)):
+        check(_lib.lib().tssep_maskhead_bwd(_p(dest_r), _p(dmask), _p(mask), _p(obs_r), _p(dlogit),
+                                            B, K, T, F, _stream()), "maskhead_bwd")
     return dlogit
 
 
