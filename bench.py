@@ -72,38 +72,47 @@ def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS):
     return pre + K * (b0 + b1) + b2 + 2 * P * F * K
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (a port of the reference's torch code path, pinned to it by tests) timed on
-    this host: same model size and chunk length, a bounded sample."""
+    this host: same model size and chunk length, a bounded sample.  Thread count: torch's CPU LSTM
+    stops scaling (and collapses under oversubscription) well before the 256 hardware threads of
+    the GPU host, so the faster of 8 / 16 threads is reported together with the count used."""
     from oracle import model as omodel
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    B = 2
+    B = 4
     obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, 1234)
     p = omodel.init_mask_estimator_params(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
                                           combination="mul", aux_size=FBINS, ts_vad=K_SPK)
     for v in p.values():
         v.requires_grad_()
     cfg = dict(odim=FBINS, combination="mul", ts_vad=K_SPK, output_resolution="tf")
-    T = None
-    times = []
-    t_all = time.time()
-    while True:
+    x = [torch.as_tensor(a) for a in (obs, aux, tgt)]
+
+    def one_step():
         t0 = time.time()
-        o = omodel.forward_loss(p, torch.as_tensor(obs), torch.as_tensor(aux), torch.as_tensor(tgt),
-                                cfg=cfg, fast=True)
+        o = omodel.forward_loss(p, *x, cfg=cfg, fast=True)
         o["loss"].sum().backward()
-        times.append(time.time() - t0)
-        T = o["mask"].shape[-2]
         for v in p.values():
             v.grad = None
-        if len(times) >= 2 and time.time() - t_all > seconds_budget:
-            break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(B * T / best, 1), unit="frames/s", cores=cores, kind="port",
-                sample=f"oracle fwd+bwd, batch {B} x 4 s, {len(times)} steps, best step "
-                       f"{best:.3f} s, torch {torch.__version__} CPU, {cores} threads")
+        return time.time() - t0, o["mask"].shape[-2]
+
+    best = None
+    t_all = time.time()
+    for nt in sorted({min(8, os.cpu_count() or 1), min(16, os.cpu_count() or 1)}):
+        torch.set_num_threads(nt)
+        times = []
+        while len(times) < 3 or (time.time() - t_all < seconds_budget / 2 and len(times) < 20):
+            dt_, T = one_step()
+            times.append(dt_)
+            if time.time() - t_all > 4 * seconds_budget:        # hard stop on a slow host
+                break
+        cand = (min(times[1:]) if len(times) > 1 else times[0], nt, len(times), T)
+        best = cand if best is None or cand[0] < best[0] else best
+        t_all = time.time()
+    step_s, nt, n, T = best
+    return dict(value=round(B * T / step_s, 1), unit="frames/s", cores=nt, kind="port",
+                sample=f"CPU oracle fwd+bwd, batch {B} x 4 s, best of {n} steps = {step_s:.3f} s, "
+                       f"torch {torch.__version__}, {nt} threads of {os.cpu_count()} logical CPUs")
 
 
 def main():
