@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
                     help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-f32", action="store_true",
+                    help="skip the secondary exact-fp32 measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -165,22 +167,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    T = int(out.mask.shape[-2])
-    H.KERNEL_TIMERS.clear()
-    H.KERNEL_TIMING = True
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    H.KERNEL_TIMING = False
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    def timed_run(steps, warmup):
+        out = None
+        for _ in range(warmup):
+            out = step()
+        H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear()
+        H.KERNEL_TIMING = True
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        barrier()
+        dt_ = time.perf_counter() - t0
+        H.KERNEL_TIMING = False
+        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax), int(out.mask.shape[-2])
+
+    exact = None
+    if args.gemm != "f32" and world == 1 and not args.no_exact_f32:
+        # secondary line: the same step with every GEMM in exact fp32 (reference arithmetic)
+        H.GEMM_PRECISION = "f32"
+        dt_e, T_e = timed_run(max(2, args.steps // 3), 1)
+        n_e = max(2, args.steps // 3)
+        exact = dict(value=round(B * T_e * n_e / dt_e, 1), unit="frames/s",
+                     ms_per_step=round(dt_e / n_e * 1e3, 3), steps=n_e, dtype="f32")
+        H.GEMM_PRECISION = args.gemm
+    dt, T = timed_run(args.steps, args.warmup)
+    H.check_cluster_errors(dev)
 
     # dominant kernel (largest share of the step), timed live with HIP events on its launch stream
     ktimes = H.kernel_time_summary()
@@ -222,7 +237,7 @@ def main():
                        "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate; recurrences exact fp32"
                                            if args.gemm == "bf16x3" else "exact fp32 MFMA"),
                        "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
-            "roofline": roofline, "roofline_mask_head": mask_head,
+            "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
         }
         print(json.dumps(line), flush=True)
