@@ -124,6 +124,9 @@ def main():
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
                     help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
+    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("TSSEP_BENCH_MICROBATCHES", 1)),
+                    help="the batch is processed as this many micro-batches on separate HIP streams "
+                         "with gradient accumulation (the reference's virtual_minibatch_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the secondary exact-fp32 measurement")
@@ -145,22 +148,44 @@ def main():
     from tssep_amd.distributed import GradBucket
     H.GEMM_PRECISION = args.gemm
     model = build_model().to(dev)
-    bucket = GradBucket(model.parameters())
+    S = max(1, args.microbatches)
     B = args.batch
+    assert B % S == 0, (B, S)
+    bucket = GradBucket(model.parameters(), replicas=S)
     obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, seed=rank)      # each rank its own shard
-    ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
-               speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
-               reference_channel=0, dataset=["bench"] * B)
+    mb = B // S
+    exs = [dict(observation=torch.as_tensor(obs[i * mb:(i + 1) * mb]).to(dev),
+                auxInput=torch.as_tensor(aux[i * mb:(i + 1) * mb]).to(dev),
+                speaker_reverberation_early_ch0=torch.as_tensor(tgt[i * mb:(i + 1) * mb]).to(dev),
+                reference_channel=0, dataset=["bench"] * mb) for i in range(S)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     np.random.seed(rank)
 
     def step():
-        ex = dict(ex0)
+        """One optimizer-step worth of work: S micro-batches, forward + backward each on its own
+        stream (they overlap on the GPU: one micro-batch's T-sequential recurrences run beside the
+        other's GEMMs), gradients accumulated, then one all-reduce."""
+        main = streams[0]
         bucket.zero()
-        out = model(ex)
-        summary = model.review(ex, out)
-        summary["loss"].backward()
+        outs, losses = [], []
+        for i, st in enumerate(streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                ex = dict(exs[i])
+                out = model(ex)
+                losses.append(model.review(ex, out)["loss"])
+                outs.append(out)
+        for i, st in enumerate(streams):
+            H.ACTIVE_SINK = i
+            with torch.cuda.stream(st):
+                losses[i].backward()
+                H.join_side_stream(dev)
+        H.ACTIVE_SINK = 0
+        for st in streams[1:]:
+            main.wait_stream(st)
+        bucket.reduce_replicas()
         bucket.all_reduce()
-        return out
+        return outs[0]
 
     def barrier():
         if world > 1:
@@ -232,7 +257,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])",
                        "speakers": K_SPK, "samples": N_SAMPLES, "frames_per_chunk": T,
-                       "batch_per_gpu": B, "global_batch": B * world, "units": UNITS,
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "microbatches_per_gpu": S, "units": UNITS,
                        "projs": PROJS, "parallelism": f"dp{world}",
                        "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate; recurrences exact fp32"
                                            if args.gemm == "bf16x3" else "exact fp32 MFMA"),

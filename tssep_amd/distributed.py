@@ -12,23 +12,37 @@ import torch.distributed as dist
 
 class GradBucket:
     """Flat view over all parameter gradients: grads live inside ONE contiguous buffer, so the
-    all-reduce needs no pack/unpack copies."""
+    all-reduce needs no pack/unpack copies.
 
-    def __init__(self, params):
+    ``replicas`` > 1 keeps one extra flat buffer per concurrently running micro-batch (gradient
+    accumulation over micro-batches on separate HIP streams, the reference's
+    ``virtual_minibatch_size``, tssep/train/experiment.py:135-151): every micro-batch accumulates
+    into its own buffer (no read-modify-write races between streams) and ``reduce_replicas`` folds
+    them into buffer 0 = ``p.grad``."""
+
+    def __init__(self, params, replicas=1):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev, dt = self.params[0].device, self.params[0].dtype
-        self.flat = torch.zeros(n, device=dev, dtype=dt)
+        self.flats = [torch.zeros(n, device=dev, dtype=dt) for _ in range(replicas)]
+        self.flat = self.flats[0]
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            # the HIP backward may accumulate straight into this view (off the autograd engine,
+            views = [f[off:off + p.numel()].view_as(p) for f in self.flats]
+            p.grad = views[0]
+            # the HIP backward may accumulate straight into these views (off the autograd engine,
             # on a side stream): see tssep_amd.functional._grad_sink
-            p._tssep_grad_sink = p.grad
+            p._tssep_grad_sinks = views
+            p._tssep_grad_sink = views[0]
             off += p.numel()
 
+    def reduce_replicas(self):
+        for f in self.flats[1:]:
+            self.flat.add_(f)
+
     def zero(self):
-        self.flat.zero_()
+        for f in self.flats:
+            f.zero_()
 
     def sync(self):
         """Wait for gradient work queued on the side stream (no-op on CPU / when unused)."""

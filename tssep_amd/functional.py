@@ -168,10 +168,10 @@ class _RNNP(torch.autograd.Function):
 def _grad_sink(p):
     """Flat-bucket view a parameter's gradient may be accumulated into directly (set by
     tssep_amd.distributed.GradBucket), or None -> return the gradient through autograd."""
-    s_ = getattr(p, "_tssep_grad_sink", None)
-    if s_ is None or p.grad is None or p.grad.data_ptr() != s_.data_ptr() or not s_.is_contiguous():
+    sinks = getattr(p, "_tssep_grad_sinks", None)
+    if not sinks or p.grad is None or p.grad.data_ptr() != sinks[0].data_ptr():
         return None
-    return s_
+    return sinks[H.ACTIVE_SINK % len(sinks)]
 
 
 def _dense_rows(t, cols):

@@ -370,17 +370,22 @@ _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 
 
+ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
+
+
 def side_stream(device):
-    key = str(device)
+    """The weight-gradient stream paired with the CURRENT stream (one per compute stream)."""
+    cur = torch.cuda.current_stream(device)
+    key = (str(device), cur.cuda_stream)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for all gradient work queued on the side stream."""
-    for key, st in _SIDE.items():
-        if device is None or key == str(device):
+    """Make the current stream wait for all gradient work queued on the side streams."""
+    for (dev, _), st in _SIDE.items():
+        if device is None or dev == str(device):
             torch.cuda.current_stream().wait_stream(st)
 
 

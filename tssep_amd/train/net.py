@@ -159,10 +159,11 @@ class MaskEstimator_v2(Configurable, torch.nn.Module):
             # one np.random.permutation per batch entry, in batch order (net.py:824-826)
             perm = np.stack([np.random.permutation(K) for _ in range(B)])
             iperm = np.argsort(perm, axis=-1)
-            aux = torch.stack([a[torch.as_tensor(p, device=a.device)] for a, p in zip(aux, perm)], 0)
             # kernels want: output index of the speaker at shuffled position s == perm[b][s]
-            perm_d = torch.as_tensor(perm, dtype=torch.int32).to(dev)
-            iperm_d = torch.as_tensor(iperm, dtype=torch.int32).to(dev)
+            both = torch.as_tensor(np.stack([perm, iperm]), dtype=torch.int32).to(dev)   # one H2D copy
+            perm_d, iperm_d = both[0], both[1]
+            # shuffled aux[b, s] = aux[b, perm[b, s]]: one gather for the whole batch
+            aux = torch.gather(aux, 1, perm_d.long()[..., None].expand(-1, -1, aux.shape[-1]))
         aux = aux.to(torch.float32).contiguous()
         if self.ts_vad is not False:
             assert K == self.ts_vad, (K, self.ts_vad)
