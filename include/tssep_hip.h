@@ -269,6 +269,17 @@ int tssep_logit_map_bwd(const float* dout, const int32_t* perm, const int32_t* i
                         int trials, int64_t K, int64_t T, int F, int Fr, int spk_rows,
                         float* draw, void* stream);
 
+/* -------------------------------------------------------------- optimizer -----
+ * One optimizer step on flat fp32 buffers: global-norm gradient clipping
+ * (torch.nn.utils.clip_grad_norm_, max_norm <= 0 disables) + Adam (torch.optim.Adam update rule,
+ * amsgrad off) -- the reference's trainer settings (tssep/train/experiment.py:147-150).  No host
+ * synchronisation; norm_out[0] (optional) receives the pre-clip gradient norm.
+ * step = 1-based update count; ws: tssep_adam_workspace_bytes(). */
+int64_t tssep_adam_workspace_bytes(void);
+int tssep_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float* grad, int64_t n,
+                    int64_t step, float max_norm, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float* norm_out, void* ws, void* stream);
+
 /* split-K / slab reduction: dst[i] (+)= sum_{s<nsplit} src[s*stride + i] */
 int tssep_reduce_splits(const float* src, int nsplit, int64_t stride, int64_t count, float* dst,
                         int accumulate, void* stream);

@@ -256,3 +256,55 @@ def test_direct_grad_sink_matches_autograd():
     for (name, p), r in zip(me.named_parameters(), ref):
         assert p.grad.data_ptr() == p._tssep_grad_sink.data_ptr()
         close(p.grad, 2 * r, rtol=1e-4, atol=1e-6 + 1e-5 * float(r.abs().max()), name=name)
+
+
+def test_fused_adam_matches_torch_adam_with_clipping():
+    """tssep_adam_step == torch.nn.utils.clip_grad_norm_(10) + torch.optim.Adam (the reference's
+    optimizer settings, tssep/train/experiment.py:147-150) over three steps."""
+    from tssep_amd.train.optimizer import Adam
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+    ref = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5))
+    ref.load_state_dict(lin.state_dict())
+    lin.cuda()
+    opt = Adam(gradient_clipping=0.5, lr=1e-2)
+    opt.set_parameters(lin.parameters())
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    for it in range(3):
+        x = torch.randn(64, 33) * (5 if it == 0 else 0.01)      # first step clips, later ones do not
+        opt.zero_grad()
+        lin(x.cuda()).pow(2).sum().backward()
+        norm = float(opt.step())
+        ropt.zero_grad()
+        ref(x).pow(2).sum().backward()
+        rnorm = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5))
+        ropt.step()
+        assert norm == pytest.approx(rnorm, rel=1e-4)
+        for p, q in zip(lin.parameters(), ref.parameters()):
+            close(p, q, rtol=1e-4, atol=1e-6, name=f"param after step {it}")
+
+
+def test_toy_experiments_tsvad_then_tssep(tmp_path):
+    """BASELINE configs[0]/[1]: the toy TS-VAD run (8 speakers, 2 averaged permutations), then
+    TS-SEP initialised from its checkpoint (tssep/exp/run_tsvad.py, run_tssep.py; the reference's
+    tests/test_exp.py:135-162 asserts the same flow does not raise)."""
+    from tssep_amd.exp import run_tsvad, run_tssep
+    fast = ["eg.trainer.stop_trigger=[3,iteration]", "eg.trainer.checkpoint_trigger=[3,iteration]",
+            "eg.trainer.summary_trigger=[1,iteration]"]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    eg = run_tsvad.main(storage_dir=tmp_path / "tsvad", overrides=fast)
+    hist = eg.trainer.history
+    assert len(hist) == 3 and all(np.isfinite(l) for _, l in hist)
+    ck = tmp_path / "tsvad" / "checkpoints" / "ckpt_best_loss.pth"
+    assert ck.exists() and (tmp_path / "tsvad" / "config.yaml").exists()
+    sd = torch.load(ck, map_location="cpu")
+    assert sd["model"]["mask_estimator.post_net.linear2.weight"].shape == (8, 42)
+    eg2 = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck, overrides=fast)
+    w = eg2.trainer.model.mask_estimator.post_net.linear2.weight
+    assert w.shape == (8 * 513, 42)
+    assert len(eg2.trainer.history) == 3 and all(np.isfinite(l) for _, l in eg2.trainer.history)
+    # resume: a second call continues from ckpt_latest instead of re-initialising
+    eg3 = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck,
+                         overrides=["eg.trainer.stop_trigger=[4,iteration]"] + fast[1:])
+    assert eg3.trainer.iteration == 4

@@ -175,9 +175,10 @@ __global__ __launch_bounds__(256, 1) void blstm_fwd_kernel(
 #pragma unroll
       for (int sg = 0; sg < 2; ++sg) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        // streamed once: non-temporal so these lines do not push W_hh out of the XCD's L2
         if (nvalid[sg] && uvalid[i])
-          v = *reinterpret_cast<const f32x4*>(
-              gates + (((nrow[sg] * T + t) * 2 + dir) * (int64_t)H + u[i]) * 4);
+          v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(
+              gates + (((nrow[sg] * T + t) * 2 + dir) * (int64_t)H + u[i]) * 4));
         gx[i][sg] = v;
       }
     f32x4 acc[NB][2];
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(256, 1) void blstm_fwd_kernel(
           hnext[(sg * 4 + j) * KROW + u[i]] = h;
           if (nvalid[sg]) {
             const int64_t cellidx = ((nrow[sg] * T + t) * 2 + dir) * (int64_t)H + u[i];
-            *reinterpret_cast<f32x4*>(gates + cellidx * 4) = f32x4{ig, fg, gg, og};
-            cell[cellidx] = cn;
-            hout[(nrow[sg] * T + t) * ldo + dir * dstride + u[i]] = h;
+            __builtin_nontemporal_store(f32x4{ig, fg, gg, og},
+                                        reinterpret_cast<f32x4*>(gates + cellidx * 4));
+            __builtin_nontemporal_store(cn, cell + cellidx);
+            __builtin_nontemporal_store(h, hout + (nrow[sg] * T + t) * ldo + dir * dstride + u[i]);
           }
         }
       }
@@ -301,11 +303,13 @@ __global__ __launch_bounds__(256, 1) void blstm_bwd_kernel(
                      part[(2 * 8 + s) * PROW + u[i]] + part[(3 * 8 + s) * PROW + u[i]];
           if (nvalid[sg]) {
             const int64_t cellidx = ((nrow[sg] * T + t) * 2 + dir) * (int64_t)H + u[i];
-            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gates + cellidx * 4);
-            const float ct = cell[cellidx];
-            const float cp =
-                has_prev ? cell[((nrow[sg] * T + tp) * 2 + dir) * (int64_t)H + u[i]] : 0.f;
-            dh += dhout[(nrow[sg] * T + t) * ldo + dir * dstride + u[i]];
+            const f32x4 g4 =
+                __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gates + cellidx * 4));
+            const float ct = __builtin_nontemporal_load(cell + cellidx);
+            const float cp = has_prev ? __builtin_nontemporal_load(
+                                            cell + ((nrow[sg] * T + tp) * 2 + dir) * (int64_t)H + u[i])
+                                      : 0.f;
+            dh += __builtin_nontemporal_load(dhout + (nrow[sg] * T + t) * ldo + dir * dstride + u[i]);
             const float tc = tanhf_acc(ct);
             const float d_o = dh * tc;
             const float dc = dh * g4[3] * (1.f - tc * tc) + dcc[i][sg];
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void blstm_bwd_kernel(
             dg4[1] = dc * cp * g4[1] * (1.f - g4[1]);
             dg4[2] = dc * g4[0] * (1.f - g4[2] * g4[2]);
             dg4[3] = d_o * g4[3] * (1.f - g4[3]);
-            *reinterpret_cast<f32x4*>(gates + cellidx * 4) = dg4;
+            __builtin_nontemporal_store(dg4, reinterpret_cast<f32x4*>(gates + cellidx * 4));
           }
 #pragma unroll
           for (int g = 0; g < 4; ++g) dgs[(g * 8 + s) * KROW + u[i]] = dg4[g];

@@ -1,0 +1,68 @@
+"""Optimizer -- drop-in for ``padertorch.train.optimizer.Adam`` as configured by the reference
+(tssep/exp/init_cfg_common.yaml:85-94, tssep/train/experiment.py:147-150): global-norm gradient
+clipping + Adam, executed as ONE fused HIP launch pair over flat parameter / gradient buffers."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..configurable import Configurable
+from ..distributed import GradBucket
+
+
+class Adam(Configurable):
+    def __init__(self, gradient_clipping=1e10, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad (false in every shipped config)")
+        self.gradient_clipping = gradient_clipping
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self.amsgrad = amsgrad
+        self.bucket = None
+        self.step_count = 0
+
+    def set_parameters(self, parameters):
+        """Flatten parameters (each ``p.data`` becomes a view of one buffer: names, shapes and
+        state_dict are unchanged) and attach a flat gradient bucket."""
+        params = [p for p in parameters if p.requires_grad]
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:
+            self.flat_param[off:off + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.params = params
+        self.bucket = GradBucket(params)
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._ws = torch.empty(int(_lib.lib().tssep_adam_workspace_bytes()) // 4, device=dev,
+                               dtype=torch.float32)
+
+    def zero_grad(self):
+        self.bucket.zero()
+
+    def step(self):
+        """Clip to ``gradient_clipping`` (global L2 norm) and apply one Adam update.  Returns the
+        pre-clip gradient norm as a device tensor (no host sync)."""
+        self.bucket.all_reduce()            # joins the side stream; SUM over ranks when distributed
+        self.step_count += 1
+        p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        rc = _lib.lib().tssep_adam_step(
+            p(self.flat_param), p(self.exp_avg), p(self.exp_avg_sq), p(self.bucket.flat),
+            self.flat_param.numel(), self.step_count, float(self.gradient_clipping), float(self.lr),
+            float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+            p(self.grad_norm), p(self._ws),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "adam_step")
+        return self.grad_norm
+
+    def state_dict(self):
+        return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu())
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])

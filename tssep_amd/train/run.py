@@ -1,0 +1,90 @@
+"""Command line -- the sacred commands of tssep/train/run.py:154-201 without sacred:
+
+    python -m tssep_amd.train.run init with a.yaml b.yaml eg.trainer.storage_dir=/path key=value
+    python -m tssep_amd.train.run with config.yaml          (== train; run inside storage_dir)
+    python -m tssep_amd.train.run print_config with config.yaml
+
+YAML files are merged left to right, then ``key=value`` overrides (dotted paths, YAML values)."""
+import datetime
+import shlex
+import sys
+from pathlib import Path
+
+import yaml
+
+from .experiment import Experiment
+
+
+def _deep_update(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _deep_update(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+def build_config(args):
+    cfg = {}
+    for a in args:
+        if "=" in a and not Path(a).exists():
+            key, value = a.split("=", 1)
+            node = cfg
+            parts = key.split(".")
+            for part in parts[:-1]:
+                node = node.setdefault(part, {})
+            node[parts[-1]] = yaml.safe_load(value)
+        else:
+            with open(a) as f:
+                _deep_update(cfg, yaml.safe_load(f) or {})
+    cfg.setdefault("eg", {})
+    cfg["eg"] = Experiment.get_config(cfg["eg"])
+    return cfg
+
+
+def dump_config(storage_dir, cfg):                      # run.py:138-151 (+ backup :104-135)
+    storage_dir = Path(storage_dir)
+    path = storage_dir / "config.yaml"
+    text = yaml.safe_dump(cfg, sort_keys=False)
+    if path.exists() and path.read_text() != text:
+        stamp = datetime.datetime.today().strftime("%Y_%m_%d_%H_%M_%S")
+        (storage_dir / "backup").mkdir(exist_ok=True)
+        (storage_dir / "backup" / f"config_{stamp}.yaml").write_text(path.read_text())
+    path.write_text(text)
+
+
+def init(cfg):
+    storage_dir = Path(cfg["eg"]["trainer"]["storage_dir"])
+    storage_dir.mkdir(exist_ok=True, parents=True)
+    with open(storage_dir / "python_history.txt", "a") as fd:      # run.py:159-165
+        print(f"{shlex.join(sys.argv)}  # {datetime.datetime.today():%Y.%m.%d %H:%M:%S}  # {Path.cwd()}",
+              file=fd)
+    dump_config(storage_dir, cfg)
+    eg = Experiment.from_config(cfg["eg"])
+    eg.add_log_files()
+    print(f"Initialized {storage_dir}")
+    return eg
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    command = "train"
+    if argv and argv[0] in ("init", "train", "print_config"):
+        command = argv.pop(0)
+    if argv and argv[0] == "with":
+        argv.pop(0)
+    cfg = build_config(argv)
+    if cfg["eg"]["trainer"].get("storage_dir") is None:
+        cfg["eg"]["trainer"]["storage_dir"] = str(Path.cwd())
+    if command == "print_config":
+        print(yaml.safe_dump(cfg, sort_keys=False))
+        return cfg
+    eg = init(cfg)
+    if command == "train":
+        eg.train()
+    return eg
+
+
+if __name__ == "__main__":
+    print(shlex.join(sys.argv))
+    main()
