@@ -88,9 +88,8 @@ class Log1pMaxNormAbsSTFT(STFT):
     def stft_to_feature(self, stft_signals):
         X = stft_signals
         lead = X.shape[:-2]
-        out, _ = H.feat_fwd(X.reshape(-1, X.shape[-2], X.shape[-1]) if X.dim() != 3 else X,
-                            None, None, 0)
-        return out.reshape(*lead, X.shape[-2], X.shape[-1]) if X.dim() != 3 else out
+        out, _ = H.feat_fwd(X.reshape(-1, X.shape[-2], X.shape[-1]).contiguous(), None, None, 0)
+        return out.reshape(*lead, X.shape[-2], X.shape[-1])
 
 
 class TorchMFCC(STFT, torch.nn.Module):
@@ -121,6 +120,8 @@ class TorchMFCC(STFT, torch.nn.Module):
 
     def stft_to_feature(self, stft_signals):
         X = stft_signals
+        if X.dim() == 2:        # un-batched example: the dB floor is per utterance (torchaudio 2-D case)
+            return self.stft_to_feature(X[None])[0]
         assert X.dim() == 3, X.shape
         out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self.top_db)
         return out[..., :self.n_mfcc]
@@ -175,6 +176,8 @@ class ConcaternatedSTFTFeatures(STFT, torch.nn.Module):
 
     def stft_to_feature(self, stft_signals):
         X = stft_signals
+        if X.dim() == 2:
+            return self.stft_to_feature(X[None])[0]
         if isinstance(self.fe1, TorchMFCC) and isinstance(self.fe2, Log1pMaxNormAbsSTFT) \
                 and X.dim() == 3:
             # one fused pass pair writes [mfcc | log1p] side by side (feature_extractor.py:352-360)
