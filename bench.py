@@ -222,6 +222,17 @@ def main():
     dt, T = timed_run(args.steps, args.warmup)
     H.check_cluster_errors(dev)
 
+    # HBM traffic per launch from rocprofv3 PMC passes of this same command (separate --pmc runs,
+    # see profiles/r1_traffic_pmc.json); only used when it was collected for this configuration
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic_pmc.json")) as f:
+            tp = json.load(f)
+        c = tp["config"]
+        if (c["batch_per_gpu"], c["gemm"], c["microbatches"]) == (B, args.gemm, S) and world == 1:
+            traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
+    except (OSError, KeyError, ValueError):
+        pass
     # dominant kernel (largest share of the step), timed live with HIP events on its launch stream
     ktimes = H.kernel_time_summary()
     roofline = mask_head = None
@@ -232,7 +243,7 @@ def main():
         ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
         peak = PEAK_BF16_MFMA_TFLOPS if name == "gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
         roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=None, launches=n_launch,
+                        frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
                         avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
                         note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
                               "the bf16 MFMA, so frac <= 1/3" if name == "gemm_bf16x3" else
@@ -245,7 +256,8 @@ def main():
         gbps = by / (ms * 1e-3) / 1e9
         mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
                          peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
-                         traffic=None, launches=n_l, avg_ms=round(ms / n_l, 4))
+                         traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
+                         avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l)
     if rank == 0:
         frames = B * world * T * args.steps
         line = {
