@@ -23,6 +23,7 @@ def timeit(fn, reps=3):
     return s.elapsed_time(e) / reps
 
 
+wf3, wb3 = h.lstm_pack_onchip(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
     g0 = torch.randn(N * T, 8 * Hh, device="cuda") * 0.5
     cell = torch.empty(N, T, 2, Hh, device="cuda")
@@ -33,10 +34,15 @@ for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
                             lambda g: h.blstm_bwd(g, cell, dh, 2 * Hh, Hh, pk["whh_b"], N, T, Hh)),
                            ("cluster2", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh, 2),
                             lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh, 2)),
-                           ("cluster4", lambda g: h.blstm_cluster_fwd(g, cell, hout, 2 * Hh, Hh, cf, N, T, Hh, 4),
-                            lambda g: h.blstm_cluster_bwd(g, cell, dh, 2 * Hh, Hh, cb, N, T, Hh, 4))):
+                           ):
         g = g0.clone()
         res[name + "_fwd_ms"] = round(timeit(lambda: fwd(g)), 3)
         res[name + "_bwd_ms"] = round(timeit(lambda: bwd(g)), 3)
+        h.check_cluster_errors()
+    g = g0.clone()
+    res["onchip_fwd_ms"] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh)), 3)
+    h.check_cluster_errors()
+    if N % 32 == 0:
+        res["onchip_fwd_timemajor_ms"] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh, 1)), 3)
         h.check_cluster_errors()
     print(json.dumps(res), flush=True)

@@ -1,0 +1,374 @@
+// On-chip-weights BLSTM recurrence on the bf16 matrix cores ("v3"), forward and backward through
+// time.  Replaces the T-sequential part of torch.nn.LSTM (tssep/train/rnnp.py:88-95,146-153).
+//
+// Why a third recurrence: the streaming kernels (lstm.hip) re-read the 1.44 MB W_hh from L2 on every
+// step (18-24 us/step whatever the batch); the fp32 cluster kernels (lstm_cluster.hip) keep W_hh in
+// registers but need 10 CUs per 8 sequences.  Here a cluster of G = ceil(H/64) <= 5 workgroups
+// (512 threads, one per CU) keeps its 64-unit slice of W_hh ON CHIP for the whole launch as split
+// bf16 (hi + lo, 152 VGPRs per lane) and evaluates the recurrent product for 32 sequences per step as
+//     a_hi*b_hi + a_hi*b_lo + a_lo*b_hi     on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+// (h is split into bf16 hi+lo when it is staged into LDS).  Measured against fp64 on a 253-step
+// H=300 LSTM the split adds < 4e-6 to the fp32 rounding noise of h -- far inside the 1e-3 bar.
+// Per step: ~1.7 us of MFMA for 32 sequences + one exchange of h between the G workgroups.
+//
+// Exchange (MI355X_MICROARCH.md "valid forms", recipe R2 -- the data is the flag): every fp32
+// value travels as an 8-byte granule {tag = step+1, value}; a lane writes its 4 values as TWO
+// 16-byte sc1 (write-through) stores = 2 granules each, and the consumer reads 2 granules per
+// 16-byte sc1 load.  Only the 8-byte halves need to be untorn (each carries its own tag), which is
+// what aligned dwordx4 accesses give.  One memory hop per step: no drain, no barrier, no flag
+// (a flag-based protocol was measured first: 3 hops, 8 us/step, collapsing under load).
+// Two slots alternate by step parity (a slot is rewritten only after every workgroup consumed it:
+// publishing step t+2 transitively requires everyone to have gathered step t).  All granules are
+// zeroed by a memset node before every launch; spins are bounded and raise err[0].
+// Cluster membership is taken by arrival ticket (no residency / dispatch-order assumption).
+//
+// MFMA tile geometry (forward): wave w of workgroup g owns units 64g + 8w .. +7.  A = W rows
+// (32 = 8 units x 4 gates), B = h^T columns (32 sequences).  Row r = 4*rg + gate with unit
+// u' = 4*(rg&1) + (rg>>1): the D layout (lane = sequence + 32*half, rows (e&3)+8(e>>2)+4*half)
+// then gives every lane the 4 gates of the 4 CONSECUTIVE units 4*half .. 4*half+3 of one sequence,
+// so the cell update is lane-local and every global / exchange access is a 16-byte vector.
+#include "common.h"
+
+namespace {
+
+constexpr int KP = 304;              // padded reduction length (19 k-steps of 16)
+constexpr int KS = KP / 16;          // 19
+constexpr int UPW = 64;              // hidden units per workgroup
+constexpr int SEQS = 32;             // sequences per cluster
+constexpr int HPITCH = KP * 2 + 16;  // bytes per LDS row of bf16 h (624: 39 slots of 16 B, 39 odd)
+constexpr int SPIN_LIMIT = 1 << 21;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  lo = cvt_pk_bf16(a - ha, b - hb);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// Gate non-linearities on the hardware exp2 / reciprocal units (v_exp_f32, v_rcp_f32): a handful
+// of instructions instead of ~25-40 for the OCML expf / tanhf the other kernels use.  4 cells per
+// lane and step make the transcendental work visible here (~1.2 us of a 7 us step).  Relative error
+// ~2^-22 -- the same class as the split-bf16 product, two orders inside the 1e-3 parity bar.
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __frcp_rn(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // 1 - 2/(1 + e^{2x}); saturates correctly for large |x| (e^{2x} -> inf or 0)
+  return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+}
+#define SC1 16
+
+// ---- packed weights ------------------------------------------------------------------------
+// fwd: wf[dir][g][wave 8][ks 19][hl 2][lane 64] u32x4 : A fragment of k-step ks,
+//      lane (i = lane&31, kg = lane>>5): W_hh[gate*H + unit][16 ks + 8 kg + 0..7] as 8 bf16,
+//      row i = 4*rg + gate, unit = 64 g + 8 wave + 4*(rg&1) + (rg>>1)
+// bwd: wb[dir][g][wave 10][ks 16][hl 2][lane 64] u32x4 : A = W_hh^T tile, rows = OUTPUT units
+//      32*wave + i, k = own gate column 16 ks + 8 kg + j with column c = 4*ul + gate of unit 64g + ul
+__device__ __forceinline__ float w_at(const float* w, int H, int row, int col) {
+  return (row >= 0 && col < H) ? w[(int64_t)row * H + col] : 0.f;
+}
+__global__ void pack_onchip_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G,
+                                   u32x4* wf, u32x4* wb) {
+  const int64_t n_f = (int64_t)2 * G * 8 * KS * 2 * 64;
+  const int64_t n_b = (int64_t)2 * G * 10 * 16 * 2 * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_f + n_b;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float x[8];
+    int hl;
+    if (e < n_f) {
+      int64_t r = e;
+      const int lane = (int)(r & 63); r >>= 6;
+      hl = (int)(r & 1); r >>= 1;
+      const int ks = (int)(r % KS); r /= KS;
+      const int wave = (int)(r & 7); r >>= 3;
+      const int g = (int)(r % G);
+      const int d = (int)(r / G);
+      const int i = lane & 31, kg = lane >> 5;
+      const int rg = i >> 2, gate = i & 3;
+      const int unit = 64 * g + 8 * wave + 4 * (rg & 1) + (rg >> 1);
+      const float* w = d ? w_hh_r : w_hh_f;
+      for (int j = 0; j < 8; ++j)
+        x[j] = unit < H ? w_at(w, H, gate * H + unit, 16 * ks + 8 * kg + j) : 0.f;
+    } else {
+      int64_t r = e - n_f;
+      const int lane = (int)(r & 63); r >>= 6;
+      hl = (int)(r & 1); r >>= 1;
+      const int ks = (int)(r & 15); r >>= 4;
+      const int wave = (int)(r % 10); r /= 10;
+      const int g = (int)(r % G);
+      const int d = (int)(r / G);
+      const int i = lane & 31, kg = lane >> 5;
+      const int uo = 32 * wave + i;
+      const float* w = d ? w_hh_r : w_hh_f;
+      for (int j = 0; j < 8; ++j) {
+        const int c = 16 * ks + 8 * kg + j;          // own gate column: unit-local ul, gate
+        const int ui = 64 * g + (c >> 2), gate = c & 3;
+        x[j] = (ui < H && uo < H) ? w[(int64_t)(gate * H + ui) * H + uo] : 0.f;
+      }
+    }
+    unsigned h[4], l[4];
+    for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], h[j], l[j]);
+    const u32x4 v = hl ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{h[0], h[1], h[2], h[3]};
+    if (e < n_f) wf[e] = v; else wb[e - n_f] = v;
+  }
+}
+
+// exchange buffer layout (bytes), per work item (sequence group, direction):
+//   header (64 B, whole launch): ticket
+//   payload: [item][slot 2][G][SEQS][PW] 8-byte granules {tag, value}, zeroed every launch;
+//            PW = 64 (forward: own units) or 320 (backward: partial sums for every unit)
+struct XBuf {
+  unsigned* flags;
+  float* payload;
+};
+
+// Row of (sequence n, frame t) in the activation tensors.  layout 0: n*T + t (sequence-major, what
+// the GEMMs produce today); layout 1: time-major inside groups of 32 sequences,
+// (n/32)*T*32 + t*32 + n%32, so that the 32 sequences a cluster touches at one step are contiguous.
+#define ROW(n_, t_) (layout ? (((n_) >> 5) * T * 32 + (t_) * 32 + ((n_) & 31)) : ((n_) * T + (t_)))
+
+// ------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
+    float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
+    int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
+    unsigned* __restrict__ xflags, float* __restrict__ xpayload, int* __restrict__ err, int64_t N,
+    int64_t T, int H, int G, int nclusters, int layout) {
+  __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
+  __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
+  __shared__ int s_fail, s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    s_fail = 0;
+    s_ticket = (int)atomicAdd(xhead, 1u);
+  }
+  __syncthreads();
+  // wave-uniform by construction; readfirstlane makes it PROVABLY uniform so that the buffer
+  // descriptors below are built from SGPRs (no waterfall loops around the sc1 loads/stores)
+  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+  const int g = ticket % G, cid = ticket / G;
+  const int j = lane & 31, half = lane >> 5;
+  const int unit0 = 64 * g + 8 * wave + 4 * half;      // this lane's 4 consecutive units
+  const int64_t ngroups = (N + SEQS - 1) / SEQS;
+  const int foff = j * HPITCH + half * 16;             // B fragment offset (row = sequence j)
+  const bool vec_ok = ((H | ldo | dstride) & 3) == 0 && ((((uintptr_t)cell) | ((uintptr_t)hout)) & 15) == 0;
+
+  for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
+    const int dir = (int)(work & 1);
+    const int64_t seq0 = (work >> 1) * SEQS;
+    const int64_t n = seq0 + j;
+    const bool nvalid = n < N;
+    // stationary weights -> registers (A fragments, hi and lo)
+    u32x4 wh[KS], wl[KS];
+    {
+      const u32x4* wp = wf + ((((int64_t)(dir * G + g) * 8 + wave) * KS) * 2) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        wh[ks] = wp[(int64_t)(ks * 2 + 0) * 64];
+        wl[ks] = wp[(int64_t)(ks * 2 + 1) * 64];
+      }
+    }
+    for (int i = tid; i < SEQS * HPITCH / 4; i += 512) {
+      reinterpret_cast<unsigned*>(hs_hi)[i] = 0u;
+      reinterpret_cast<unsigned*>(hs_lo)[i] = 0u;
+    }
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    float* pl = xpayload + work * 2 * G * SEQS * UPW * 2;      // 8-byte granules
+    const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * UPW * 8, 0x00020000);
+    __syncthreads();
+
+    for (int64_t step = 0; step < T; ++step) {
+      const int64_t t = dir ? T - 1 - step : step;
+      // gate pre-activations of this lane's 4 cells (consumed after the k loop)
+      f32x4 gx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        gx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nvalid && unit0 + q < H)
+          gx[q] = *reinterpret_cast<const f32x4*>(
+              gates + ((ROW(n, t) * 2 + dir) * (int64_t)H + unit0 + q) * 4);
+      }
+      // ---- gather h_{t-1}: thread <-> (sequence s = tid/16, unit quad uq = tid%16) of every
+      // source workgroup; 2 granules per 16-byte load, all loads in flight at once
+      if (step > 0) {
+        const int slot = (int)((step - 1) & 1);
+        const unsigned want = (unsigned)step;
+        const int s = tid >> 4, uq = tid & 15;
+        u32x4 v[10];
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
+                                         prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, SC1)
+                                   : u32x4{want, 0u, want, 0u};
+        int spins = 0;
+        bool fail = false;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
+          if (ok) break;
+          if (++spins > SPIN_LIMIT) { fail = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int gs = 0; gs < 5; ++gs)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
+                v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
+                    prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, SC1);
+        }
+        if (fail) s_fail = 1;
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs) {
+          const int k = 64 * gs + 4 * uq;                      // column of h = unit index
+          if (gs < G && k < KP) {
+            unsigned h0, l0, h1, l1;
+            split2(__uint_as_float(v[2 * gs][1]), __uint_as_float(v[2 * gs][3]), h0, l0);
+            split2(__uint_as_float(v[2 * gs + 1][1]), __uint_as_float(v[2 * gs + 1][3]), h1, l1);
+            *reinterpret_cast<u32x2*>(hs_hi + s * HPITCH + 2 * k) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(hs_lo + s * HPITCH + 2 * k) = u32x2{l0, l1};
+          }
+        }
+        __syncthreads();
+        if (s_fail) {
+          if (tid == 0) atomicExch(err, 3);
+          return;
+        }
+      }
+      // ---- recurrent product for 32 gate rows x 32 sequences
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hs_hi + foff + ks * 32);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hs_lo + foff + ks * 32);
+        acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
+        acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
+        acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
+      }
+      // ---- lane-local cell update: acc[4q .. 4q+3] = gates (i,f,g,o) of unit unit0 + q
+      f32x4 hv, cv, act[4];
+      const int slot = (int)(step & 1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a0 = acc[4 * q + 0] + gx[q][0], a1 = acc[4 * q + 1] + gx[q][1];
+        const float a2 = acc[4 * q + 2] + gx[q][2], a3 = acc[4 * q + 3] + gx[q][3];
+        const float ig = fast_sigmoid(a0), fg = fast_sigmoid(a1);
+        const float gg = fast_tanh(a2), og = fast_sigmoid(a3);
+        const float cn = fg * c[q] + ig * gg;
+        c[q] = cn;
+        cv[q] = cn;
+        act[q] = f32x4{ig, fg, gg, og};
+        hv[q] = (unit0 + q < H) ? og * fast_tanh(cn) : 0.f;
+      }
+      // ---- publish h_t: two 16-byte write-through stores of 2 granules each (no drain, no flag)
+      {
+        const unsigned tag = (unsigned)(step + 1);
+        const int go = (((slot * G + g) * SEQS + j) * UPW + 8 * wave + 4 * half) * 8;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{tag, __float_as_uint(hv[0]), tag, __float_as_uint(hv[1])}, prs, go, 0, SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{tag, __float_as_uint(hv[2]), tag, __float_as_uint(hv[3])}, prs, go + 16, 0, SC1);
+      }
+      // ---- saved activations / output.  A lane owns 4 consecutive units of one sequence: gates
+      // 64 B (a lane pair completes a 128-B line, streamed non-temporal), cell and h 16 B each
+      // (plain stores: the 8 waves' pieces of a line are merged in L2).  Scalar 4-byte stores here
+      // were measured at +9 ms per launch at N = 1024 (64 different lines per instruction).
+      if (nvalid) {
+        const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
+        const int64_t h0 = ROW(n, t) * ldo + dir * dstride + unit0;
+        if (vec_ok && unit0 + 4 <= H) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4) = act[q];
+          *reinterpret_cast<f32x4*>(cell + cell0) = cv;
+          *reinterpret_cast<f32x4*>(hout + h0) = hv;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (unit0 + q < H) {
+              __builtin_nontemporal_store(act[q], reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4));
+              cell[cell0 + q] = cv[q];
+              hout[h0 + q] = hv[q];
+            }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int tssep_lstm_onchip_supported(int H) { return H > 0 && H <= KP ? 1 : 0; }
+
+extern "C" int64_t tssep_lstm_onchip_pack_floats(int H, int which) {
+  const int G = (H + UPW - 1) / UPW;
+  return which == 0 ? (int64_t)2 * G * 8 * KS * 2 * 64 * 4 : (int64_t)2 * G * 10 * 16 * 2 * 64 * 4;
+}
+
+extern "C" int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, int H, float* wf,
+                                      float* wb, void* stream) {
+  if (!w_hh_f || !w_hh_r || !wf || !wb) return TSSEP_E_NULL;
+  if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(wf) || !aligned16(wb)) return TSSEP_E_ALIGN;
+  const int G = (H + UPW - 1) / UPW;
+  const int64_t total = (tssep_lstm_onchip_pack_floats(H, 0) + tssep_lstm_onchip_pack_floats(H, 1)) / 4;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_onchip_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     w_hh_f, w_hh_r, H, G, (u32x4*)wf, (u32x4*)wb);
+  return tssep_launch_status();
+}
+
+// bytes: header 64 | flags (items*2*G*4, rounded to 64) | payload
+static void xbuf_layout(int64_t N, int G, int pw, int64_t* items, int64_t* flag_bytes,
+                        int64_t* payload_bytes) {
+  *items = 2 * ((N + SEQS - 1) / SEQS);
+  *flag_bytes = 0;
+  *payload_bytes = *items * 2 * G * SEQS * pw * 8;
+}
+
+extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) {
+  const int G = (H + UPW - 1) / UPW;
+  int64_t items, fb, pb;
+  xbuf_layout(N, G, backward ? G * UPW : UPW, &items, &fb, &pb);
+  return 64 + fb + pb;
+}
+
+extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, int64_t ldo,
+                                      int64_t dstride, const float* wf, void* xbuf, int* err,
+                                      int64_t N, int64_t T, int H, int max_wgs, int layout,
+                                      void* stream) {
+  if (!gates || !cell || !hout || !wf || !xbuf || !err) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
+  const int G = (H + UPW - 1) / UPW;
+  if (max_wgs < G) return TSSEP_E_SHAPE;
+  int64_t items, fb, pb;
+  xbuf_layout(N, G, UPW, &items, &fb, &pb);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(xbuf, 0, (size_t)(64 + fb + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  const int cap = max_wgs / G;
+  const int nc = (int)(items < cap ? items : cap);
+  char* base = (char*)xbuf;
+  hipLaunchKernelGGL(blstm_onchip_fwd_kernel, dim3((unsigned)(nc * G)), dim3(512), 0, s, gates, cell,
+                     hout, ldo, dstride, (const u32x4*)wf, (unsigned*)base, (unsigned*)(base + 64),
+                     (float*)(base + 64 + fb), err, N, T, H, G, nc, layout);
+  return tssep_launch_status();
+}

@@ -37,14 +37,18 @@ class _RNNP(torch.autograd.Function):
         Hp = _pad4(Hh)
         cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
         hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
+        kf, kb = H.recurrence_kernel(N, Hh, False), H.recurrence_kernel(N, Hh, True)
         cf = cb = None
-        if H.use_cluster(N, Hh, False) or H.use_cluster(N, Hh, True):
+        if "cluster" in (kf, kb):
             cf, cb = H.lstm_pack_cluster(w_hh, w_hh_r, Hh)
-        if H.use_cluster(N, Hh, False):
+        if kf == "cluster":
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
+        elif kf == "onchip":
+            wf3, _ = H.lstm_pack_onchip(w_hh, w_hh_r, Hh)
+            H.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf3, N, T, Hh)
         else:
             H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
-        pk["whh_cb"] = cb
+        pk["whh_cb"] = cb if kb == "cluster" else None
         # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
         wp = _proj_layout(w_proj, Hh, Hp)
         if combine:
@@ -118,7 +122,7 @@ class _RNNP(torch.autograd.Function):
         # ---- critical path: dhout, BPTT (gates <- d pre-activations)
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
         H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
-        if pk.get("whh_cb") is not None and H.use_cluster(N, Hh, True):
+        if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
         else:
             H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)

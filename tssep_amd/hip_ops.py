@@ -313,6 +313,26 @@ def n_cus(device):
     return torch.cuda.get_device_properties(device).multi_processor_count
 
 
+def recurrence_kernel(N, H, backward):
+    """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (measured on MI355X, H=300,
+    T=253, profiles/r1_recurrence_microbench.jsonl):
+      forward : fp32 cluster 1.5-2.0 ms up to 204 sequences; on-chip bf16x3 2.6-3.1 ms up to 816
+                (one resident round of 51 clusters x 32); streaming 4.8-6.3 ms beyond
+      backward: fp32 cluster 1.3-4.4 ms up to 160 sequences; streaming 6.0-6.5 ms beyond"""
+    L = _lib.lib()
+    if RECURRENCE in ("stream", "cluster", "onchip"):
+        ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)),
+              "onchip": bool(L.tssep_lstm_onchip_supported(H)) and not backward}[RECURRENCE]
+        return RECURRENCE if ok else "stream"
+    if H < 128:
+        return "stream"
+    if L.tssep_lstm_cluster_supported(H) and N <= (204 if not backward else 160):
+        return "cluster"
+    if not backward and L.tssep_lstm_onchip_supported(H) and N <= 816:
+        return "onchip"
+    return "stream"
+
+
 def use_cluster(N, H, backward):
     """Pick the recurrence kernel: per-step cost model fitted on MI355X."""
     if RECURRENCE == "stream" or not _lib.lib().tssep_lstm_cluster_supported(H) or H < 128:
@@ -355,6 +375,28 @@ def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H, ms=2):
         check(L.tssep_blstm_cluster_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_cb),
                                         _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus, ms,
                                         _stream()), "blstm_cluster_bwd")
+
+
+# on-chip-weights recurrence (bf16x3 MFMA, lstm_onchip.hip) -----------------------------------
+def lstm_pack_onchip(w_hh_f, w_hh_r, H):
+    L = _lib.lib()
+    nf, nb = int(L.tssep_lstm_onchip_pack_floats(H, 0)), int(L.tssep_lstm_onchip_pack_floats(H, 1))
+    buf = torch.empty(nf + nb, device=w_hh_f.device, dtype=torch.float32)
+    a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
+    check(L.tssep_lstm_pack_onchip(_p(a), _p(b), H, _p(buf[:nf]), _p(buf[nf:]), _stream()),
+          "lstm_pack_onchip")
+    return buf[:nf], buf[nf:]
+
+
+def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 0)) // 8 + 2, device=gates.device,
+                       dtype=torch.int64)
+    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_onchip_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf), _p(xbuf),
+                                       _p(_err_flag(gates.device)), N, T, H, cus, layout,
+                                       _stream()), "blstm_onchip_fwd")
 
 
 def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulate=False):
