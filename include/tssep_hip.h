@@ -194,7 +194,8 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
  * ceil(H/64) workgroups keeps W_hh on chip as split bf16 (hi+lo) and evaluates the recurrent
  * product as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class accuracy), 32 sequences per
  * cluster and step; h travels as fp32 through 16-byte write-through stores + epoch flags.
- * Same tensor layouts as tssep_blstm_fwd/bwd.  H <= 304. */
+ * Same tensor layouts as tssep_blstm_fwd/bwd (layout = 0; layout = 1 is an experimental
+ * time-major-in-groups-of-32 row order).  H <= 304. */
 int tssep_lstm_onchip_supported(int H);
 int64_t tssep_lstm_onchip_pack_floats(int H, int which /* 0: forward, 1: backward */);
 int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, int H, float* wf, float* wb,
@@ -203,6 +204,9 @@ int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward);
 int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
                            const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
                            int max_wgs, int layout, void* stream);
+int tssep_blstm_onchip_bwd(float* gates, const float* cell, const float* dhout, int64_t ldo,
+                           int64_t dstride, const float* wb, void* xbuf, int* err, int64_t N,
+                           int64_t T, int H, int max_wgs, int layout, void* stream);
 
 /* ---------------------------------------------------------- elementwise ------*/
 /* d(pre-tanh) = dy * (1 - y^2) for the Tanh between post-net layers (tssep/train/net.py:623-625).

@@ -441,8 +441,9 @@ def test_blstm_cluster_kernels(N, T, I, Hh, ms):
 
 @pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 40), (8, 9, 20, 64), (11, 5, 33, 300), (40, 7, 16, 300),
                                       (70, 4, 8, 130), (500, 3, 8, 300), (33, 12, 16, 256)])
-def test_blstm_onchip_forward(N, T, I, Hh):
-    """On-chip-weights recurrence on the bf16 MFMA (split hi+lo, fp32-class) == oracle."""
+def test_blstm_onchip_kernels(N, T, I, Hh):
+    """On-chip-weights recurrence on the bf16 MFMA (split hi+lo, fp32-class) == oracle, forward
+    and backward."""
     h = H()
     p, x = _lstm_case(N, T, I, Hh, 13)
     names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
@@ -459,7 +460,9 @@ def test_blstm_onchip_forward(N, T, I, Hh):
     hout = torch.zeros(N, T, 2 * Hp, device="cuda")
     h.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf, N, T, Hh)
     h.check_cluster_errors()
-    ref = ornnp.blstm(x, p, "")
+    pr = {k: v.clone().requires_grad_() for k, v in p.items()}
+    xr = x.clone().requires_grad_()
+    ref = ornnp.blstm(xr, pr, "")
     got = torch.cat([hout[..., :Hh], hout[..., Hp:Hp + Hh]], -1)
     close(got, ref, rtol=1e-4, atol=1e-5, name="onchip fwd")
     # saved activations agree with the exact-fp32 streaming kernel (backward consumes them)
@@ -467,3 +470,22 @@ def test_blstm_onchip_forward(N, T, I, Hh):
     h.blstm_fwd(g_stream, cell2, hout2, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
     close(gates, g_stream, rtol=1e-4, atol=1e-5, name="gates")
     close(cell, cell2, rtol=1e-4, atol=1e-5, name="cell")
+    # backward: d(gates) in place, then dx / db through the same GEMM + colsum as the other kernels
+    dh = torch.randn(N, T, 2 * Hh)
+    (ref * dh).sum().backward()
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = dh[..., :Hh].cuda(); dhd[..., Hp:Hp + Hh] = dh[..., Hh:].cuda()
+    h.blstm_onchip_bwd(gates, cell, dhd, 2 * Hp, Hp, wb, N, T, Hh)
+    h.check_cluster_errors()
+    R = N * T
+    dx = torch.empty(R, I, device="cuda")
+    h.gemm(gates, 8 * Hh, pk["wih_p"], pk["ld_i"], dx, I, R, I, 8 * Hh, b_kmajor=True)
+    close(dx.view(N, T, I), xr.grad, rtol=2e-4, atol=2e-6, name="onchip dx")
+    cs = h.colsum(gates, 8 * Hh, R, 8 * Hh)
+    bf = torch.empty(4 * Hh, device="cuda"); br = torch.empty(4 * Hh, device="cuda")
+    h.lstm_unpack(cs, 1, 1, 0, Hh, 1, bf, br)
+    close(bf, pr["bias_ih_l0"].grad, rtol=2e-4, atol=5e-6, name="onchip db")
+    close(br, pr["bias_hh_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="onchip db_reverse")
+    # and d(gates) against the exact-fp32 streaming backward on the same saved activations
+    h.blstm_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+    close(gates, g_stream, rtol=2e-4, atol=2e-6, name="dgates")

@@ -226,6 +226,37 @@ def test_full_size_properties(gemm_mode):
     assert float(t1) == pytest.approx(float(t2), rel=1e-3)
 
 
+def test_recurrence_kernels_interchangeable_at_full_size():
+    """The three recurrence kernels (streaming fp32, fp32 cluster, on-chip bf16x3) give the same
+    masks and parameter gradients through the whole mask estimator at cfg3 sizes."""
+    from tssep_amd.train import net
+    from tssep_amd import hip_ops as H
+    B, K, T = 3, 4, 253
+    torch.manual_seed(2)
+    me = net.MaskEstimator_v2(idim=553, odim=513, units=300, projs=320, combination="mul",
+                              aux_net_output_size=513, ts_vad=K, output_resolution="tf").cuda()
+    feat = torch.randn(B, T, 553, device="cuda")
+    aux = torch.rand(B, K, 513, device="cuda")
+    g = torch.randn(B, K, 1, T, 513, device="cuda") * 1e-3
+    res = {}
+    old = H.RECURRENCE
+    try:
+        for kind in ("stream", "cluster", "onchip"):
+            H.RECURRENCE = kind
+            me.zero_grad(set_to_none=True)
+            np.random.seed(3)
+            out = me(feat, aux)
+            (out.mask * g).sum().backward()
+            H.check_cluster_errors()
+            res[kind] = (out.mask.detach().clone(), [p.grad.clone() for p in me.parameters()])
+    finally:
+        H.RECURRENCE = old
+    for kind in ("cluster", "onchip"):
+        close(res[kind][0], res["stream"][0], rtol=1e-3, atol=1e-6, name=kind + " mask")
+        for (name, _), a, b in zip(me.named_parameters(), res[kind][1], res["stream"][1]):
+            close(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()) + 1e-9, name=kind + " " + name)
+
+
 def test_direct_grad_sink_matches_autograd():
     """Weight gradients accumulated straight into the GradBucket on the side stream equal the
     gradients returned through autograd (and accumulate over two backward passes)."""

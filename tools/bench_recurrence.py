@@ -42,7 +42,9 @@ for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
     g = g0.clone()
     res["onchip_fwd_ms"] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh)), 3)
     h.check_cluster_errors()
-    if N % 32 == 0:
-        res["onchip_fwd_timemajor_ms"] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh, 1)), 3)
-        h.check_cluster_errors()
+    res["onchip_bwd_ms"] = round(timeit(lambda: h.blstm_onchip_bwd(g, cell, dh, 2 * Hh, Hh, wb3, N, T, Hh)), 3)
+    h.check_cluster_errors()
+    for lay in [int(a) for a in os.environ.get("ABL", "").split(",") if a]:
+        res["onchip_bwd_abl%d_ms" % lay] = round(timeit(lambda: h.blstm_onchip_bwd(g, cell, dh, 2 * Hh, Hh, wb3, N, T, Hh, lay)), 3)
+        h._err_flag(g.device).zero_()
     print(json.dumps(res), flush=True)

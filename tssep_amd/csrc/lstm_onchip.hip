@@ -139,6 +139,7 @@ struct XBuf {
 #define ROW(n_, t_) (layout ? (((n_) >> 5) * T * 32 + (t_) * 32 + ((n_) & 31)) : ((n_) * T + (t_)))
 
 // ------------------------------------------------------------------------------- forward
+constexpr int PUBPITCH = UPW + 4;        // floats per LDS row of the publish transpose
 __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     int64_t T, int H, int G, int nclusters, int layout) {
   __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
+  __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];
   __shared__ int s_fail, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
@@ -275,14 +277,19 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         act[q] = f32x4{ig, fg, gg, og};
         hv[q] = (unit0 + q < H) ? og * fast_tanh(cn) : 0.f;
       }
-      // ---- publish h_t: two 16-byte write-through stores of 2 granules each (no drain, no flag)
+      // ---- publish h_t: transposed through LDS so that a wave instruction writes 4 runs of 512
+      // contiguous bytes (2 granules per lane and store) instead of 64 scattered 16-byte pieces
       {
+        *reinterpret_cast<f32x4*>(pub + j * PUBPITCH + 8 * wave + 4 * half) = hv;
+        __syncthreads();
         const unsigned tag = (unsigned)(step + 1);
-        const int go = (((slot * G + g) * SEQS + j) * UPW + 8 * wave + 4 * half) * 8;
+        const int s = tid >> 4, uq = tid & 15;
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
+        const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 8;
         __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(hv[0]), tag, __float_as_uint(hv[1])}, prs, go, 0, SC1);
+            u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, SC1);
         __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(hv[2]), tag, __float_as_uint(hv[3])}, prs, go + 16, 0, SC1);
+            u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, SC1);
       }
       // ---- saved activations / output.  A lane owns 4 consecutive units of one sequence: gates
       // 64 B (a lane pair completes a 128-B line, streamed non-temporal), cell and h 16 B each
@@ -309,6 +316,232 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------ backward
+// dh_{t-1} = dgates_t x W_hh as a reduce-scatter: workgroup g owns the 256 gate columns of its 64
+// units (the K slice: d(gate) values are produced locally by the lane-local cell backward) and
+// multiplies them into partial sums for ALL 320 output units; the owner of a unit adds the G
+// partials in a fixed order.  Output tiles (32 units) 0..7 belong to waves 0..7 (16 k-steps
+// each); tiles 8 and 9 are split over the 8 waves by k (4 k-steps of one of them each) and reduced
+// through LDS, so every wave issues 60 MFMAs per step and holds 160 stationary registers.  The
+// partials are transposed through LDS so that each publish instruction writes 1 KB contiguous
+// (scattered 32-byte pieces cost 3.7 us/step more, measured).
+constexpr int DPITCH = 256 * 2 + 16;     // bytes per LDS row of bf16 d(gates): 33 slots of 16 B
+constexpr int PPITCH = 5 * UPW + 4;      // floats per LDS row of partial dh (bank-skewed)
+
+__global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
+    float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dhout,
+    int64_t ldo, int64_t dstride, const u32x4* __restrict__ wb, unsigned* __restrict__ xhead,
+    float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G,
+    int nclusters, int layout) {
+  __shared__ __attribute__((aligned(16))) char dg_hi[SEQS * DPITCH];
+  __shared__ __attribute__((aligned(16))) char dg_lo[SEQS * DPITCH];
+  __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16];          // tiles 8/9 partials
+  __shared__ __attribute__((aligned(16))) float psum[SEQS * PPITCH];       // [seq][unit] partial dh
+  __shared__ u32x4 wl_sh[4 * 512];        // lo words of the shared-tile fragments (register relief)
+  __shared__ int s_fail, s_ticket;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    s_fail = 0;
+    s_ticket = (int)atomicAdd(xhead, 1u);
+  }
+  __syncthreads();
+  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+  const int g = ticket % G, cid = ticket / G;
+  const int j = lane & 31, half = lane >> 5;
+  const int s = tid >> 4, uq = tid & 15;                   // cell backward: sequence, unit quad
+  const int unit0 = 64 * g + 4 * uq;
+  const int Hp = G * UPW;
+  const int64_t ngroups = (N + SEQS - 1) / SEQS;
+  const int foff = j * DPITCH + half * 16;
+  const bool vec_ok = ((H | ldo | dstride) & 3) == 0 &&
+                      ((((uintptr_t)cell) | ((uintptr_t)dhout)) & 15) == 0;
+  const bool abl_pub = layout & 2, abl_ld = layout & 4;
+  layout &= 1;
+
+  for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
+    const int dir = (int)(work & 1);
+    const int64_t seq0 = (work >> 1) * SEQS;
+    const int64_t n = seq0 + s;
+    const bool nvalid = n < N;
+    // stationary W_hh^T fragments: own tile (16 k-steps) + k-steps {2w, 2w+1} of tiles 8 and 9
+    u32x4 wh[20], wl[16];
+    {
+      const u32x4* wbase = wb + ((int64_t)(dir * G + g) * 10) * 16 * 2 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        wh[ks] = wbase[(((int64_t)wave * 16 + ks) * 2 + 0) * 64];
+        wl[ks] = wbase[(((int64_t)wave * 16 + ks) * 2 + 1) * 64];
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int tile = 8 + (wave & 1), ks = 4 * (wave >> 1) + x;
+        wh[16 + x] = wbase[(((int64_t)tile * 16 + ks) * 2 + 0) * 64];
+        wl_sh[x * 512 + tid] = wbase[(((int64_t)tile * 16 + ks) * 2 + 1) * 64];
+      }
+    }
+    float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+    float* pl = xpayload + work * 2 * G * SEQS * Hp * 2;        // 8-byte granules
+    const __amdgpu_buffer_rsrc_t prs =
+        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 8, 0x00020000);
+    __syncthreads();
+
+    for (int64_t step = 0; step < T; ++step) {
+      const int64_t t = dir ? step : T - 1 - step;
+      const bool has_prev = step + 1 < T;
+      const int64_t tp = dir ? t + 1 : t - 1;
+      // ---- (1) this thread's saved activations (issued before waiting on the exchange)
+      f32x4 g4[4], ct = {0.f, 0.f, 0.f, 0.f}, cp = ct, dh = ct;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
+      const bool full = nvalid && unit0 + 4 <= H && vec_ok;
+      if (abl_ld && step > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+      } else if (full) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
+        ct = *reinterpret_cast<const f32x4*>(cell + cell0);
+        if (has_prev)
+          cp = *reinterpret_cast<const f32x4*>(cell + (ROW(n, tp) * 2 + dir) * (int64_t)H + unit0);
+        dh = *reinterpret_cast<const f32x4*>(dhout + ROW(n, t) * ldo + dir * dstride + unit0);
+      } else if (nvalid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (unit0 + q < H) {
+            g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
+            ct[q] = cell[cell0 + q];
+            if (has_prev) cp[q] = cell[(ROW(n, tp) * 2 + dir) * (int64_t)H + unit0 + q];
+            dh[q] = dhout[ROW(n, t) * ldo + dir * dstride + unit0 + q];
+          }
+      }
+      // ---- (2) reduce-scatter: add the G partial dh published with tag = step (fixed order)
+      if (step > 0 && !(abl_pub && (uq & 7) >= 2 && g < 4)) {
+        const int slot = (int)((step - 1) & 1);
+        const unsigned want = (unsigned)step;
+        u32x4 v[10];
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
+                                         prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, SC1)
+                                   : u32x4{want, 0u, want, 0u};
+        int spins = 0;
+        bool fail = false;
+        for (;;) {
+          bool ok = true;
+#pragma unroll
+          for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
+          if (ok) break;
+          if (++spins > SPIN_LIMIT) { fail = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+          for (int gs = 0; gs < 5; ++gs)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+              if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
+                v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
+                    prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, SC1);
+        }
+        if (fail) s_fail = 1;
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs) {
+          dh[0] += __uint_as_float(v[2 * gs][1]);
+          dh[1] += __uint_as_float(v[2 * gs][3]);
+          dh[2] += __uint_as_float(v[2 * gs + 1][1]);
+          dh[3] += __uint_as_float(v[2 * gs + 1][3]);
+        }
+      }
+      // ---- (3) cell backward; d(gates) -> global (in place) and LDS (bf16 hi+lo, MFMA B operand)
+      unsigned hi[8], lo[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid && unit0 + q < H) {
+          const float tc = fast_tanh(ct[q]);
+          const float d_o = dh[q] * tc;
+          const float dc = dh[q] * g4[q][3] * (1.f - tc * tc) + dcc[q];
+          dcc[q] = dc * g4[q][1];
+          d[0] = dc * g4[q][2] * g4[q][0] * (1.f - g4[q][0]);
+          d[1] = dc * cp[q] * g4[q][1] * (1.f - g4[q][1]);
+          d[2] = dc * g4[q][0] * (1.f - g4[q][2] * g4[q][2]);
+          d[3] = d_o * g4[q][3] * (1.f - g4[q][3]);
+          *reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4) = d;
+        }
+        split2(d[0], d[1], hi[2 * q], lo[2 * q]);
+        split2(d[2], d[3], hi[2 * q + 1], lo[2 * q + 1]);
+      }
+      {
+        const int o = s * DPITCH + 32 * uq;                 // 16 gate columns = 32 bytes of bf16
+        *reinterpret_cast<u32x4*>(dg_hi + o) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<u32x4*>(dg_hi + o + 16) = u32x4{hi[4], hi[5], hi[6], hi[7]};
+        *reinterpret_cast<u32x4*>(dg_lo + o) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<u32x4*>(dg_lo + o + 16) = u32x4{lo[4], lo[5], lo[6], lo[7]};
+      }
+      __syncthreads();
+      if (s_fail) {
+        if (tid == 0) atomicExch(err, 4);
+        return;
+      }
+      if (has_prev) {
+        // ---- (4) partial dh_prev: own output tile over all 16 k-steps; wave w also covers k-steps
+        //      4 (w>>1) .. +3 of shared tile 8 + (w&1)
+        f32x16 acc, accs;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32);
+          acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
+          acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
+          acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int ks = 4 * (wave >> 1) + x;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32);
+          accs = MFMA_BF16(as_bf16x8(wl_sh[x * 512 + tid]), bh, accs);
+          accs = MFMA_BF16(as_bf16x8(wh[16 + x]), bl, accs);
+          accs = MFMA_BF16(as_bf16x8(wh[16 + x]), bh, accs);
+        }
+        // own tile -> psum[seq][unit] (D rows (e&3) + 8 (e>>2) + 4 half); shared-tile partials -> red
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          *reinterpret_cast<f32x4*>(psum + j * PPITCH + 32 * wave + 8 * q + 4 * half) =
+              f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+          *reinterpret_cast<f32x4*>(red + ((wave * 4 + q) * 64 + lane) * 4) =
+              f32x4{accs[4 * q], accs[4 * q + 1], accs[4 * q + 2], accs[4 * q + 3]};
+        }
+        __syncthreads();
+        {   // wave w sums slice e4 = w & 3 of tile 8 + (w >> 2) over the 4 waves that hold it
+          const int tt = wave >> 2, e4 = wave & 3;
+          f32x4 sum = *reinterpret_cast<const f32x4*>(red + ((tt * 4 + e4) * 64 + lane) * 4);
+#pragma unroll
+          for (int ww = 1; ww < 4; ++ww)
+            sum += *reinterpret_cast<const f32x4*>(red + (((tt + 2 * ww) * 4 + e4) * 64 + lane) * 4);
+          *reinterpret_cast<f32x4*>(psum + j * PPITCH + 32 * (8 + tt) + 8 * e4 + 4 * half) = sum;
+        }
+        __syncthreads();
+        // ---- (5) publish: 2 granules per lane and store, 1 KB contiguous per wave instruction
+        const unsigned tag = (unsigned)(step + 1);
+        const int slot = (int)(step & 1);
+        const int npairs = SEQS * (Hp >> 1);
+        for (int pr = tid; pr < npairs; pr += 512) {
+          const int sq = pr / (Hp >> 1), up = pr - sq * (Hp >> 1);
+          const float2 v = *reinterpret_cast<const float2*>(psum + sq * PPITCH + 2 * up);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
+              (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, SC1);
+        }
+      }
+      // no barrier here: dg_* is rewritten after the next step's gather, psum/red after its barrier
+    }
   }
 }
 
@@ -370,5 +603,28 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   hipLaunchKernelGGL(blstm_onchip_fwd_kernel, dim3((unsigned)(nc * G)), dim3(512), 0, s, gates, cell,
                      hout, ldo, dstride, (const u32x4*)wf, (unsigned*)base, (unsigned*)(base + 64),
                      (float*)(base + 64 + fb), err, N, T, H, G, nc, layout);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const float* dhout,
+                                      int64_t ldo, int64_t dstride, const float* wb, void* xbuf,
+                                      int* err, int64_t N, int64_t T, int H, int max_wgs, int layout,
+                                      void* stream) {
+  if (!gates || !cell || !dhout || !wb || !xbuf || !err) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
+  const int G = (H + UPW - 1) / UPW;
+  if (max_wgs < G) return TSSEP_E_SHAPE;
+  int64_t items, fb, pb;
+  xbuf_layout(N, G, G * UPW, &items, &fb, &pb);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(xbuf, 0, (size_t)(64 + fb + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  const int cap = max_wgs / G;
+  const int nc = (int)(items < cap ? items : cap);
+  char* base = (char*)xbuf;
+  hipLaunchKernelGGL(blstm_onchip_bwd_kernel, dim3((unsigned)(nc * G)), dim3(512), 0, s, gates, cell,
+                     dhout, ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + 64 + fb),
+                     err, N, T, H, G, nc, layout);
   return tssep_launch_status();
 }

@@ -38,17 +38,19 @@ class _RNNP(torch.autograd.Function):
         cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
         hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
         kf, kb = H.recurrence_kernel(N, Hh, False), H.recurrence_kernel(N, Hh, True)
-        cf = cb = None
+        cf = cb = wf3 = wb3 = None
         if "cluster" in (kf, kb):
             cf, cb = H.lstm_pack_cluster(w_hh, w_hh_r, Hh)
+        if "onchip" in (kf, kb):
+            wf3, wb3 = H.lstm_pack_onchip(w_hh, w_hh_r, Hh)
         if kf == "cluster":
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
         elif kf == "onchip":
-            wf3, _ = H.lstm_pack_onchip(w_hh, w_hh_r, Hh)
             H.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf3, N, T, Hh)
         else:
             H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
         pk["whh_cb"] = cb if kb == "cluster" else None
+        pk["whh_ob"] = wb3 if kb == "onchip" else None
         # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
         wp = _proj_layout(w_proj, Hh, Hp)
         if combine:
@@ -124,6 +126,8 @@ class _RNNP(torch.autograd.Function):
         H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
+        elif pk.get("whh_ob") is not None:
+            H.blstm_onchip_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_ob"], N, T, Hh)
         else:
             H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
 

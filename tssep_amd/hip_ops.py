@@ -290,7 +290,7 @@ def blstm_bwd(gates, cell, dhout, ldo, dstride, whh_b, N, T, H):
 
 # cluster (W-stationary) recurrence ------------------------------------------------------------
 _ERR = {}
-RECURRENCE = "auto"          # "auto" | "stream" (lstm.hip) | "cluster" (lstm_cluster.hip)
+RECURRENCE = "auto"    # "auto" | "stream" (lstm.hip) | "cluster" (lstm_cluster.hip) | "onchip"
 
 
 def _err_flag(device):
@@ -314,35 +314,25 @@ def n_cus(device):
 
 
 def recurrence_kernel(N, H, backward):
-    """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (measured on MI355X, H=300,
-    T=253, profiles/r1_recurrence_microbench.jsonl):
-      forward : fp32 cluster 1.5-2.0 ms up to 204 sequences; on-chip bf16x3 2.6-3.1 ms up to 816
-                (one resident round of 51 clusters x 32); streaming 4.8-6.3 ms beyond
-      backward: fp32 cluster 1.3-4.4 ms up to 160 sequences; streaming 6.0-6.5 ms beyond"""
+    """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch measured on
+    MI355X at H=300, T=253, profiles/r1_recurrence_microbench.jsonl):
+      forward : fp32 cluster 1.5-2.05 up to 204 sequences; on-chip bf16x3 2.4-2.7 up to 800 (one
+                resident round: 2 directions x 25 groups of 32 on 51 clusters of 5 CUs) and 5.5
+                at 1024 (two rounds); streaming 4.8-6.2
+      backward: fp32 cluster 1.35 up to 32 sequences (2.1 at 64, 4.5 at 128); on-chip bf16x3
+                2.1-3.0 up to 800, 6.7 at 1024; streaming 6.0-6.5"""
     L = _lib.lib()
     if RECURRENCE in ("stream", "cluster", "onchip"):
         ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)),
-              "onchip": bool(L.tssep_lstm_onchip_supported(H)) and not backward}[RECURRENCE]
+              "onchip": bool(L.tssep_lstm_onchip_supported(H))}[RECURRENCE]
         return RECURRENCE if ok else "stream"
     if H < 128:
         return "stream"
-    if L.tssep_lstm_cluster_supported(H) and N <= (204 if not backward else 160):
+    if L.tssep_lstm_cluster_supported(H) and N <= (204 if not backward else 48):
         return "cluster"
-    if not backward and L.tssep_lstm_onchip_supported(H) and N <= 816:
+    if L.tssep_lstm_onchip_supported(H) and N <= (1600 if not backward else 800):
         return "onchip"
     return "stream"
-
-
-def use_cluster(N, H, backward):
-    """Pick the recurrence kernel: per-step cost model fitted on MI355X."""
-    if RECURRENCE == "stream" or not _lib.lib().tssep_lstm_cluster_supported(H) or H < 128:
-        return False
-    if RECURRENCE == "cluster":
-        return True
-    # measured on MI355X, H=300, T=253 (profiles/r1_recurrence_microbench.jsonl): the cluster
-    # kernels take ~6 us/step for up to ~200 sequences (one resident round) while the streaming
-    # kernels take 18-24 us/step for anything up to 1024 sequences
-    return N <= (384 if not backward else 160)
 
 
 def lstm_pack_cluster(w_hh_f, w_hh_r, H):
@@ -397,6 +387,17 @@ def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
         check(L.tssep_blstm_onchip_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf), _p(xbuf),
                                        _p(_err_flag(gates.device)), N, T, H, cus, layout,
                                        _stream()), "blstm_onchip_fwd")
+
+
+def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 1)) // 8 + 2, device=gates.device,
+                       dtype=torch.int64)
+    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_onchip_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(wb), _p(xbuf),
+                                       _p(_err_flag(gates.device)), N, T, H, cus, layout,
+                                       _stream()), "blstm_onchip_bwd")
 
 
 def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulate=False):
