@@ -6,8 +6,8 @@
 
 A step = STFT -> MFCC+log1p features -> RNNP pre-net -> 'mul' conditioning -> 3 RNNP post-net
 layers (TS-VAD speaker combination) -> mask head -> iSTFT -> LogMAE, then backward to every
-parameter and (N > 1) the all-reduce(SUM) of the flat gradient.  Inputs are synthetic and
-resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+parameter, (N > 1) the all-reduce(SUM) of the flat gradient, and the fused global-norm clip +
+Adam update.  Inputs are synthetic and resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -124,9 +124,6 @@ def main():
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
                     help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
-    ap.add_argument("--microbatches", type=int, default=int(os.environ.get("TSSEP_BENCH_MICROBATCHES", 1)),
-                    help="the batch is processed as this many micro-batches on separate HIP streams "
-                         "with gradient accumulation (the reference's virtual_minibatch_size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the secondary exact-fp32 measurement")
@@ -145,47 +142,28 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from tssep_amd import hip_ops as H
-    from tssep_amd.distributed import GradBucket
     H.GEMM_PRECISION = args.gemm
     model = build_model().to(dev)
-    S = max(1, args.microbatches)
     B = args.batch
-    assert B % S == 0, (B, S)
-    bucket = GradBucket(model.parameters(), replicas=S)
+    from tssep_amd.train.optimizer import Adam
+    opt = Adam(gradient_clipping=10.0, lr=1e-5)          # clipping as tssep/exp/init_cfg_common.yaml:85-94
+    opt.set_parameters(model.parameters())               # flat params + the flat gradient bucket
     obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, seed=rank)      # each rank its own shard
-    mb = B // S
-    exs = [dict(observation=torch.as_tensor(obs[i * mb:(i + 1) * mb]).to(dev),
-                auxInput=torch.as_tensor(aux[i * mb:(i + 1) * mb]).to(dev),
-                speaker_reverberation_early_ch0=torch.as_tensor(tgt[i * mb:(i + 1) * mb]).to(dev),
-                reference_channel=0, dataset=["bench"] * mb) for i in range(S)]
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
+               speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
+               reference_channel=0, dataset=["bench"] * B)
     np.random.seed(rank)
 
     def step():
-        """One optimizer-step worth of work: S micro-batches, forward + backward each on its own
-        stream (they overlap on the GPU: one micro-batch's T-sequential recurrences run beside the
-        other's GEMMs), gradients accumulated, then one all-reduce."""
-        main = streams[0]
-        bucket.zero()
-        outs, losses = [], []
-        for i, st in enumerate(streams):
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                ex = dict(exs[i])
-                out = model(ex)
-                losses.append(model.review(ex, out)["loss"])
-                outs.append(out)
-        for i, st in enumerate(streams):
-            H.ACTIVE_SINK = i
-            with torch.cuda.stream(st):
-                losses[i].backward()
-                H.join_side_stream(dev)
-        H.ACTIVE_SINK = 0
-        for st in streams[1:]:
-            main.wait_stream(st)
-        bucket.reduce_replicas()
-        bucket.all_reduce()
-        return outs[0]
+        """One training step: zero the flat gradient bucket, forward, LogMAE loss, backward (weight
+        gradients accumulate into the bucket on the side stream), gradient all-reduce over ranks
+        (RCCL), global-norm clipping + Adam in one fused launch."""
+        opt.zero_grad()
+        ex = dict(ex0)
+        out = model(ex)
+        model.review(ex, out)["loss"].backward()
+        opt.step()                   # joins the side stream, all-reduces, clips, updates
+        return out
 
     def barrier():
         if world > 1:
@@ -229,7 +207,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r1_traffic_pmc.json")) as f:
             tp = json.load(f)
         c = tp["config"]
-        if (c["batch_per_gpu"], c["gemm"], c["microbatches"]) == (B, args.gemm, S) and world == 1:
+        if (c["batch_per_gpu"], c["gemm"]) == (B, args.gemm) and world == 1:
             traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
     except (OSError, KeyError, ValueError):
         pass
@@ -270,7 +248,7 @@ def main():
             "config": {"workload": "TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])",
                        "speakers": K_SPK, "samples": N_SAMPLES, "frames_per_chunk": T,
                        "batch_per_gpu": B, "global_batch": B * world,
-                       "microbatches_per_gpu": S, "units": UNITS,
+                       "units": UNITS, "optimizer": "global-norm clip + Adam (fused), in the timed step",
                        "projs": PROJS, "parallelism": f"dp{world}",
                        "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate; recurrences exact fp32"
                                            if args.gemm == "bf16x3" else "exact fp32 MFMA"),
