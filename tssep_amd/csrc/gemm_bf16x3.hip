@@ -17,6 +17,7 @@
 // operands (lane = column) are both bank-conflict free.  k-major ("transposed") operands are read
 // from global memory lane = column (coalesced 4-byte loads), 16 consecutive k per lane, so the
 // transpose costs no extra LDS traffic.
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -258,6 +259,306 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
                       accumulate, sm, splitk == 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant: two LDS stages (separate arrays, so the compiler knows that the
+// fragment reads of stage t and the staging writes of stage t+1 never alias), ONE barrier per K
+// tile, and the split (VALU) + ds_write of tile t+1 and the global loads of tile t+2 interleaved
+// between the MFMAs of tile t by sched_group_barrier.  A 32x32x16 MFMA occupies the matrix pipe
+// for 32 cycles but its issue slot for 4: the ~110 VALU/LDS/VMEM instructions a wave needs per
+// tile fit in the shadow of its 24 MFMAs.
+__device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);          // v_cvt_pk_bf16_f32 (RNE)
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);     // v - hf is exact in fp32
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+template <int BK>
+__device__ __forceinline__ void row_store_n(char* hi, char* lo, int tid, const f32x4 (&v)[Cfg<BK>::NL]) {
+  constexpr int KQ = Cfg<BK>::KQ;
+#pragma unroll
+  for (int i = 0; i < Cfg<BK>::NL; ++i) {
+    const int off = (tid / KQ + (NTHREADS / KQ) * i) * Cfg<BK>::PITCH + ((tid % KQ) << 3);
+    unsigned h0, l0, h1, l1;
+    split2n(v[i][0], v[i][1], h0, l0);
+    split2n(v[i][2], v[i][3], h1, l1);
+    *reinterpret_cast<u32x2*>(hi + off) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(lo + off) = u32x2{l0, l1};
+  }
+}
+template <int BK>
+__device__ __forceinline__ void col_store_n(char* hi, char* lo, int tid, const float (&v)[Cfg<BK>::NC]) {
+  constexpr int NC = Cfg<BK>::NC;
+  const int off = (tid & 127) * Cfg<BK>::PITCH + (tid >> 7) * NC * 2;
+#pragma unroll
+  for (int c = 0; c < NC / 8; ++c) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2n(v[8 * c + 2 * e], v[8 * c + 2 * e + 1], h[e], l[e]);
+    *reinterpret_cast<u32x4*>(hi + off + 16 * c) = u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(lo + off + 16 * c) = u32x4{l[0], l[1], l[2], l[3]};
+  }
+}
+
+// ---- loads for the pipelined kernel: one uniform (SGPR) base per tile + 32-bit per-thread byte
+// offsets, so a load is `global_load v, voff, s[base]` with no 64-bit VALU address arithmetic
+template <int BK>
+struct RowLoadU {
+  const char* base;                 // P + r0 * ld   (uniform)
+  unsigned off[Cfg<BK>::NL];        // ((row_i clamped) - r0) * ld + kq, bytes
+  int kq;
+};
+template <int BK>
+__device__ __forceinline__ RowLoadU<BK> make_row_load_u(const float* P, int64_t ld, int64_t R,
+                                                        int64_t r0, int tid) {
+  constexpr int NL = Cfg<BK>::NL, KQ = Cfg<BK>::KQ;
+  RowLoadU<BK> d;
+  d.kq = (tid % KQ) << 2;
+  d.base = reinterpret_cast<const char*>(P + r0 * ld);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int64_t r = r0 + tid / KQ + (NTHREADS / KQ) * i;
+    r = r > R - 1 ? R - 1 : r;
+    d.off[i] = (unsigned)(((r - r0) * ld + d.kq) * 4);
+  }
+  return d;
+}
+template <int BK, bool TAIL>
+__device__ __forceinline__ void row_load_u(const RowLoadU<BK>& d, int64_t k0, int64_t K,
+                                           f32x4 (&v)[Cfg<BK>::NL]) {
+  const int64_t k = k0 + d.kq;
+  // (tail) a 16-byte load that starts at or beyond K would leave the row: read the row start
+  const char* b = d.base + ((!TAIL || k < K) ? k0 : -(int64_t)d.kq) * 4;
+#pragma unroll
+  for (int i = 0; i < Cfg<BK>::NL; ++i) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(b + d.off[i]);
+    if (TAIL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (k + e < K) ? x[e] : 0.f;
+    }
+    v[i] = x;
+  }
+}
+struct ColLoadU {
+  const char* base;        // P + c0   (uniform)
+  unsigned off;            // ((c clamped) - c0 + khalf * NC * ld) * 4
+  int khalf;
+  int ph0;                 // SHIFT: phase of this thread's first k of the NEXT tile to load
+  bool cvalid;
+};
+template <int BK>
+__device__ __forceinline__ ColLoadU make_col_load_u(const float* P, int64_t ld, int64_t C, int64_t c0,
+                                                    int tid, int64_t k_first, int64_t kperiod) {
+  ColLoadU d;
+  int64_t c = c0 + (tid & 127);
+  d.cvalid = c < C;
+  if (!d.cvalid) c = C - 1;
+  d.khalf = tid >> 7;
+  d.base = reinterpret_cast<const char*>(P + c0);
+  d.off = (unsigned)(((c - c0) + d.khalf * (Cfg<BK>::NC) * ld) * 4);
+  d.ph0 = kperiod > 0 ? (int)((k_first + d.khalf * Cfg<BK>::NC) % kperiod) : 0;
+  return d;
+}
+// tiles must be requested in increasing order, one call per tile (ph0 is advanced here)
+template <int BK, bool TAIL, bool SHIFT>
+__device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, int64_t K,
+                                           int kshift, int kperiod, float (&v)[Cfg<BK>::NC]) {
+  constexpr int NC = Cfg<BK>::NC;
+  if constexpr (TAIL) {           // last K tile only: per-thread 64-bit addresses, rows clamped
+    const char* col = d.base + (d.off - (unsigned)((int64_t)d.khalf * NC * ld * 4));
+    int ph = d.ph0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int64_t k = k0 + d.khalf * NC + i;
+      bool ok = d.cvalid && k < K;
+      int64_t kk = k < K ? k : 0;
+      if (SHIFT) {
+        const int q = ph + kshift;
+        const bool in = q >= 0 && q < kperiod;
+        if (ok && in) kk += kshift;
+        ok = ok && in;
+        ph = ph + 1 == kperiod ? 0 : ph + 1;
+      }
+      const float x = *reinterpret_cast<const float*>(col + kk * ld * 4);
+      v[i] = ok ? x : 0.f;
+    }
+  } else {
+    // uniform base biased by |kshift| rows so that the per-thread byte offset stays non-negative
+    const int64_t bias = SHIFT ? (int64_t)(kshift < 0 ? -kshift : kshift) * ld * 4 : 0;
+    const char* b = d.base + k0 * ld * 4 - bias;
+    const unsigned off0 = d.off + (unsigned)bias;
+    const unsigned off_in = (unsigned)((int64_t)off0 + (int64_t)kshift * ld * 4);
+    int ph = d.ph0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      bool ok = d.cvalid;
+      unsigned off = off0;
+      if (SHIFT) {
+        const int q = ph + kshift;
+        const bool in = q >= 0 && q < kperiod;
+        off = in ? off_in : off0;
+        ok = ok && in;
+        ph = ph + 1 == kperiod ? 0 : ph + 1;
+      }
+      const float x = *reinterpret_cast<const float*>(b + (int64_t)i * ld * 4 + off);
+      v[i] = ok ? x : 0.f;
+    }
+  }
+  if (SHIFT) d.ph0 = (d.ph0 + BK) % kperiod;
+}
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
+
+template <int BK, bool A_KMAJOR, bool B_KMAJOR, bool SHIFT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
+    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t b_kshift, int64_t kperiod,
+    const float* __restrict__ bias, int act, int accumulate, StoreMap sm, int splitk,
+    int64_t c_split_stride, TileMap tmap) {
+  static_assert(BK == 32, "the interleave pattern below is written for two 16-wide k-steps");
+  constexpr int PITCH = Cfg<BK>::PITCH, ARR = Cfg<BK>::ARR;
+  __shared__ __attribute__((aligned(16))) char lds0[4 * ARR];     // stage 0: A hi, A lo, B hi, B lo
+  __shared__ __attribute__((aligned(16))) char lds1[4 * ARR];     // stage 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+
+  const int64_t ktiles = (K + BK - 1) / BK;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  RowLoadU<BK> ra_d, rb_d;
+  ColLoadU ca_d, cb_d;
+  if (!A_KMAJOR) ra_d = make_row_load_u<BK>(A, lda, M, m0, tid);
+  else ca_d = make_col_load_u<BK>(A, lda, M, m0, tid, 0, 0);
+  if (!B_KMAJOR) rb_d = make_row_load_u<BK>(B, ldb, N, n0, tid);
+  else cb_d = make_col_load_u<BK>(B, ldb, N, n0, tid, kt_begin * BK, SHIFT ? kperiod : 0);
+  const int kshift = (int)b_kshift, kper = (int)kperiod;
+
+  // ONE register set for the raw (fp32) tile in flight: a second set (loads issued a whole
+  // iteration earlier) was measured 10-40 % slower -- the kernel is not load-latency bound and the
+  // extra 32 VGPRs cost more in schedule quality than the deeper prefetch returns.
+  f32x4 ra[Cfg<BK>::NL], rb[Cfg<BK>::NL];
+  float ca[Cfg<BK>::NC], cb[Cfg<BK>::NC];
+  auto gload_full = [&](int64_t kt) {
+    const int64_t k0 = kt * BK;
+    if (!A_KMAJOR) row_load_u<BK, false>(ra_d, k0, K, ra); else col_load_u<BK, false, false>(ca_d, lda, k0, K, 0, 1, ca);
+    if (!B_KMAJOR) row_load_u<BK, false>(rb_d, k0, K, rb); else col_load_u<BK, false, SHIFT>(cb_d, ldb, k0, K, kshift, kper, cb);
+  };
+  auto gload_any = [&](int64_t kt) {
+    const int64_t k0 = kt * BK;
+    if (kt < kt_full) {
+      gload_full(kt);
+    } else {
+      if (!A_KMAJOR) row_load_u<BK, true>(ra_d, k0, K, ra); else col_load_u<BK, true, false>(ca_d, lda, k0, K, 0, 1, ca);
+      if (!B_KMAJOR) row_load_u<BK, true>(rb_d, k0, K, rb); else col_load_u<BK, true, SHIFT>(cb_d, ldb, k0, K, kshift, kper, cb);
+    }
+  };
+  auto sstore = [&](char* st) {
+    if (!A_KMAJOR) row_store_n<BK>(st, st + ARR, tid, ra); else col_store_n<BK>(st, st + ARR, tid, ca);
+    if (!B_KMAJOR) row_store_n<BK>(st + 2 * ARR, st + 3 * ARR, tid, rb); else col_store_n<BK>(st + 2 * ARR, st + 3 * ARR, tid, cb);
+  };
+  const int foff = (lane & 31) * PITCH + (lane >> 5) * 16;
+  const int aoff = (wm * 64) * PITCH + foff, boff = 2 * ARR + (wn * 64) * PITCH + foff;
+  // 24 MFMAs of one K tile out of stage `st`; consecutive MFMAs hit different accumulators
+  auto compute = [&](const char* st) {
+    bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];            // [k-step][tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[ks][i] = *reinterpret_cast<const bf16x8*>(st + aoff + i * 32 * PITCH + ks * 32);
+        al[ks][i] = *reinterpret_cast<const bf16x8*>(st + ARR + aoff + i * 32 * PITCH + ks * 32);
+        bh[ks][i] = *reinterpret_cast<const bf16x8*>(st + boff + i * 32 * PITCH + ks * 32);
+        bl[ks][i] = *reinterpret_cast<const bf16x8*>(st + ARR + boff + i * 32 * PITCH + ks * 32);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  // steady state: compute tile kt (stage cur), stage tile kt+1 (registers -> nxt), fetch tile kt+2
+#define PIPE(cur, nxt, kt_, SID_)                                                               \
+  do {                                                                                          \
+    constexpr int SID = SID_;                                                                   \
+    compute(cur);                                                                               \
+    sstore(nxt);                                                                                \
+    gload_full((kt_) + 2);                                                                      \
+    SGB(0x100, 8);                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 5); SGB(0x200, 1); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x002, 5); SGB(0x200, 1); }               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x020, 4); }                              \
+    __syncthreads();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  if (kt_begin < kt_end) {
+    gload_any(kt_begin);
+    sstore(lds0);
+    if (kt_begin + 1 < kt_end) gload_any(kt_begin + 1);
+    __syncthreads();
+    int64_t kt = kt_begin;
+    // pipelined pairs while tiles kt+2 and kt+3 exist and are full
+    const int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    for (; kt < lim; kt += 2) {
+      PIPE(lds0, lds1, kt, 1);
+      PIPE(lds1, lds0, kt + 1, 2);
+    }
+    // drain (also the K tail): same stages, conditional work
+    for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
+      const char* cur = par ? lds1 : lds0;
+      char* nxt = par ? lds0 : lds1;
+      compute(cur);
+      if (kt + 1 < kt_end) sstore(nxt);
+      if (kt + 2 < kt_end) gload_any(kt + 2);
+      __syncthreads();
+    }
+  }
+#undef PIPE
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  if (!sm.remap) {
+    // both stages are free after the last barrier: waves 0,1 use stage 0, waves 2,3 stage 1
+    static_assert(2 * 64 * EPITCH * 4 <= 4 * ARR, "epilogue scratch must fit in one stage");
+    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+    gemm_epilogue_rows(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias,
+                       act, accumulate, sm.ldc, splitk == 1);
+    return;
+  }
+  gemm_epilogue<2, 2>(acc, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias, act,
+                      accumulate, sm, splitk == 1);
+}
+#undef SGB
+
 }  // namespace
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
@@ -279,6 +580,17 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     else LAUNCH(BKV, true, true, false);                                                         \
   } while (0)
   // BK = 64 was measured: no gain (the loop is bound by LDS traffic + MFMA, not by load latency)
+  static const bool pipe = [] { const char* e = getenv("TSSEP_GEMM_PIPE"); return !e || e[0] != '0'; }();
+  if (!pipe) {
+    DISPATCH(32);
+    return tssep_launch_status();
+  }
+#undef LAUNCH
+#define LAUNCH(BKV, AK, BKM, SH)                                                                 \
+  hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<BKV, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,    \
+                     g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
+                     g->kperiod, g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride,  \
+                     tmap)
   DISPATCH(32);
 #undef DISPATCH
 #undef LAUNCH

@@ -120,6 +120,57 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], float
   }
 }
 
+// Row-contiguous epilogue for a wave that owns a 64x64 block (2x2 MFMA tiles) and a private LDS
+// scratch of 64 x EPITCH floats: the accumulators are transposed through LDS so that every lane
+// stores 16 contiguous bytes and a wave instruction covers 4 rows x 256 B (the per-element variant
+// above writes 2 rows x 128 B per instruction with 4-byte lanes and measured 2.4 TB/s alone).
+// Plain row-major C only (no remap); falls back to scalar stores on ragged / unaligned edges.
+constexpr int EPITCH = 68;
+__device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], float* __restrict__ stage,
+                                                   float* __restrict__ Cz, int64_t M, int64_t N,
+                                                   int64_t mrow0, int64_t ncol0, int lane,
+                                                   const float* __restrict__ bias, int act,
+                                                   int accumulate, int64_t ldc, bool final_pass) {
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPITCH + j * 32 + col] = acc[i][j][e];
+  // same wave writes and reads: LDS operations of one wave complete in order
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const int64_t n = ncol0 + c4;
+  const bool vec = ((ldc & 3) == 0) && ((((uintptr_t)Cz) & 15) == 0) && n + 3 < N;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (final_pass && bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = n + q < N ? bias[n + q] : 0.f;
+  }
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int row = r * 4 + r0;
+    const int64_t m = mrow0 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * EPITCH + c4);
+    if (m >= M || n >= N) continue;
+    v += bv;
+    if (final_pass && act == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+    }
+    float* dst = Cz + m * ldc + n;
+    if (vec) {
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (n + q < N) dst[q] = accumulate ? dst[q] + v[q] : v[q];
+    }
+  }
+}
+
 }  // namespace gemm_detail
 
 // split-bf16 (bf16x3) variant, defined in gemm_bf16x3.hip
