@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): every measurement DESIGN.md cites, into gpurun_out/final/.
+# usage: bash tools/collect_profiles.sh [tag]
+set -u
+O=gpurun_out/final; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 > $O/recurrence_microbench.jsonl 2>/dev/null
+TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
+TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
+python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
+for b in 8 32 64 128 160 192 200 256 512; do
+  python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
+done > $O/batch_sweep.jsonl
+python bench.py > $O/bench_default.json 2>$O/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_write.log 2>&1
+find $O -name "*.csv" | head -20
+ls -la $O

@@ -413,12 +413,15 @@ _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 
 
+SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"
 ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
 
 
 def side_stream(device):
     """The weight-gradient stream paired with the CURRENT stream (one per compute stream)."""
     cur = torch.cuda.current_stream(device)
+    if not SIDE_STREAM:
+        return cur
     key = (str(device), cur.cuda_stream)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
