@@ -41,6 +41,8 @@ const char* tssep_arch(void);
  * Hardware self-checks used by tests: dump the lane<->element maps of the MFMA
  * instructions the kernels rely on.  out: device float[...] (see probe.hip). */
 int tssep_probe_mfma(float* out_4x4, float* out_32x32, void* stream);
+/* out[b] = XCD (HW_REG_XCC_ID) that ran workgroup b of an nblocks x 512-thread launch. */
+int tssep_probe_xcc(int* out, int nblocks, void* stream);
 
 /* ------------------------------------------------------------------- STFT ----
  * paderbox-semantics STFT (fading + end padding + periodic window + rfft, no

@@ -441,7 +441,8 @@ def test_blstm_cluster_kernels(N, T, I, Hh, ms):
 
 @pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 40), (8, 9, 20, 64), (11, 5, 33, 300), (40, 7, 16, 300),
                                       (70, 4, 8, 130), (500, 3, 8, 300), (33, 12, 16, 256)])
-def test_blstm_onchip_kernels(N, T, I, Hh):
+@pytest.mark.parametrize("mode", [0, 8], ids=["xcd_local", "cross_xcd"])
+def test_blstm_onchip_kernels(N, T, I, Hh, mode):
     """On-chip-weights recurrence on the bf16 MFMA (split hi+lo, fp32-class) == oracle, forward
     and backward."""
     h = H()
@@ -458,7 +459,7 @@ def test_blstm_onchip_kernels(N, T, I, Hh):
     Hp = h.round_up(Hh, 4)
     cell = torch.empty(N, T, 2, Hh, device="cuda")
     hout = torch.zeros(N, T, 2 * Hp, device="cuda")
-    h.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf, N, T, Hh)
+    h.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf, N, T, Hh, mode)
     h.check_cluster_errors()
     pr = {k: v.clone().requires_grad_() for k, v in p.items()}
     xr = x.clone().requires_grad_()
@@ -475,7 +476,7 @@ def test_blstm_onchip_kernels(N, T, I, Hh):
     (ref * dh).sum().backward()
     dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
     dhd[..., :Hh] = dh[..., :Hh].cuda(); dhd[..., Hp:Hp + Hh] = dh[..., Hh:].cuda()
-    h.blstm_onchip_bwd(gates, cell, dhd, 2 * Hp, Hp, wb, N, T, Hh)
+    h.blstm_onchip_bwd(gates, cell, dhd, 2 * Hp, Hp, wb, N, T, Hh, mode)
     h.check_cluster_errors()
     R = N * T
     dx = torch.empty(R, I, device="cuda")

@@ -27,6 +27,7 @@
 // u' = 4*(rg&1) + (rg>>1): the D layout (lane = sequence + 32*half, rows (e&3)+8(e>>2)+4*half)
 // then gives every lane the 4 gates of the 4 CONSECUTIVE units 4*half .. 4*half+3 of one sequence,
 // so the cell update is lane-local and every global / exchange access is a 16-byte vector.
+#include <atomic>
 #include "common.h"
 
 namespace {
@@ -68,6 +69,87 @@ __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
 }
 #define SC1 16
+#define SC0 1
+
+// ---- cluster membership and work distribution -------------------------------------------------
+// header words (zeroed before every launch): [0] arrivals (global ticket in the cross-XCD mode),
+// [1] next work item, [8..15] per-XCD tickets, [32..95] per-cluster claim {round+1, item}.
+constexpr int HDR_BYTES = 1024;
+constexpr int CL_PER_XCD = 8;          // cluster-id stride per XCD (32 CUs / G >= 5 -> at most 6)
+struct Membership { int g, cid, ok; };
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// XCD = false: clusters are G consecutive arrival tickets (workgroups of a cluster sit on different
+//   XCDs; the exchange must use agent-scope sc1 accesses that go through to the memory side).
+// XCD = true : clusters are formed from workgroups that run on the SAME XCD (HW_REG_XCC_ID), so the
+//   exchange is coherent in that XCD's L2: granules are stored with sc0 (written through the CU's
+//   L1 into the L2, where they stay) and gathered with sc1 loads (bypass the reader's L1, hit the
+//   L2) -- one L2 round trip per step instead of a trip through the fabric: 5.5 vs 6.8 us/step
+//   measured.  (sc0 LOADS do not work: outside tgsplit mode they may hit the reader's own L1 and a
+//   poll spins on its stale line; `buffer_inv sc0` does not help either -- both measured.)  No dispatch-order assumption: a cluster starts
+//   only once its G members have arrived, leftovers exit when every workgroup has taken a ticket,
+//   and work items are claimed dynamically, so any set of complete clusters finishes the job.
+//   (The verdict must be the same for all members of a cluster: "complete" is monotone and final
+//   once every workgroup has arrived.  An early exit on "all items already claimed" is NOT -- a
+//   member that left that way stranded its peers waiting for the leader's claim: removed.)
+template <bool XCD>
+__device__ __forceinline__ Membership join_cluster(unsigned* xhead, int G, int nitems, int* sh) {
+  if (threadIdx.x == 0) {
+    if (!XCD) {
+      const int t = (int)atomicAdd(xhead, 1u);
+      sh[0] = t % G; sh[1] = t / G; sh[2] = 1;
+    } else {
+      const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);      // XCC_ID[3:0]
+      const int t = (int)atomicAdd(xhead + 8 + xcd, 1u);
+      atomicAdd(xhead, 1u);
+      const int cl = t / G;
+      int ok = 0;
+      if (cl < CL_PER_XCD) {
+        for (;;) {
+          if ((int)ld_agent(xhead + 8 + xcd) >= (cl + 1) * G) { ok = 1; break; }
+          if (ld_agent(xhead) >= gridDim.x) { ok = (int)ld_agent(xhead + 8 + xcd) >= (cl + 1) * G; break; }
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      sh[0] = t % G; sh[1] = xcd * CL_PER_XCD + cl; sh[2] = ok;
+    }
+  }
+  __syncthreads();
+  Membership m;
+  m.g = __builtin_amdgcn_readfirstlane(sh[0]);
+  m.cid = __builtin_amdgcn_readfirstlane(sh[1]);
+  m.ok = __builtin_amdgcn_readfirstlane(sh[2]);
+  return m;
+}
+// work item of this cluster's `round`-th turn (>= nitems: done).  Every workgroup of the cluster
+// calls it; contains a barrier.
+template <bool XCD>
+__device__ __forceinline__ int64_t next_item(unsigned* xhead, const Membership& m, int round,
+                                             int nitems, int nclusters, int* sh) {
+  if (!XCD) return (int64_t)m.cid + (int64_t)round * nclusters;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* claim = xhead + 32 + m.cid;
+    unsigned item;
+    if (m.g == 0) {
+      item = atomicAdd(xhead + 1, 1u);
+      item = item < (unsigned)nitems ? item : 0xffffu;
+      __hip_atomic_store(claim, ((unsigned)(round + 1) << 16) | item, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      unsigned v;
+      int spins = 0;       // the leader claims within microseconds of finishing its previous item
+      while (((v = ld_agent(claim)) >> 16) != (unsigned)(round + 1) && ++spins < (SPIN_LIMIT << 3))
+        __builtin_amdgcn_s_sleep(2);
+      item = (v >> 16) == (unsigned)(round + 1) ? (v & 0xffffu) : 0xfffeu;     // 0xfffe: give up
+    }
+    sh[3] = item >= 0xfffeu ? nitems + (item == 0xfffeu) : (int)item;
+  }
+  __syncthreads();
+  return (int64_t)__builtin_amdgcn_readfirstlane(sh[3]);
+}
 
 // ---- packed weights ------------------------------------------------------------------------
 // fwd: wf[dir][g][wave 8][ks 19][hl 2][lane 64] u32x4 : A fragment of k-step ks,
@@ -125,7 +207,7 @@ __global__ void pack_onchip_kernel(const float* w_hh_f, const float* w_hh_r, int
 }
 
 // exchange buffer layout (bytes), per work item (sequence group, direction):
-//   header (64 B, whole launch): ticket
+//   header (HDR_BYTES, whole launch): see join_cluster
 //   payload: [item][slot 2][G][SEQS][PW] 8-byte granules {tag, value}, zeroed every launch;
 //            PW = 64 (forward: own units) or 320 (backward: partial sums for every unit)
 struct XBuf {
@@ -140,32 +222,36 @@ struct XBuf {
 
 // ------------------------------------------------------------------------------- forward
 constexpr int PUBPITCH = UPW + 4;        // floats per LDS row of the publish transpose
+template <bool XCD>
 __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
-    unsigned* __restrict__ xflags, float* __restrict__ xpayload, int* __restrict__ err, int64_t N,
-    int64_t T, int H, int G, int nclusters, int layout) {
+    float* __restrict__ xpayload, int* __restrict__ err, int64_t N,
+    int64_t T, int H, int G, int nclusters, int layout, unsigned tagbase) {
   __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];
-  __shared__ int s_fail, s_ticket;
+  __shared__ int s_fail, s_mem[4];
+  constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) {
-    s_fail = 0;
-    s_ticket = (int)atomicAdd(xhead, 1u);
-  }
-  __syncthreads();
-  // wave-uniform by construction; readfirstlane makes it PROVABLY uniform so that the buffer
-  // descriptors below are built from SGPRs (no waterfall loops around the sc1 loads/stores)
-  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-  const int g = ticket % G, cid = ticket / G;
+  if (tid == 0) s_fail = 0;
+  const int64_t ngroups = (N + SEQS - 1) / SEQS;
+  // (membership is wave-uniform by construction; join_cluster returns it through readfirstlane so
+  // that the buffer descriptors below are built from SGPRs, no waterfall loops around the loads)
+  const Membership mem = join_cluster<XCD>(xhead, G, (int)(2 * ngroups), s_mem);
+  if (!mem.ok) return;
+  const int g = mem.g;
   const int j = lane & 31, half = lane >> 5;
   const int unit0 = 64 * g + 8 * wave + 4 * half;      // this lane's 4 consecutive units
-  const int64_t ngroups = (N + SEQS - 1) / SEQS;
   const int foff = j * HPITCH + half * 16;             // B fragment offset (row = sequence j)
   const bool vec_ok = ((H | ldo | dstride) & 3) == 0 && ((((uintptr_t)cell) | ((uintptr_t)hout)) & 15) == 0;
 
-  for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
+  for (int round = 0;; ++round) {
+    const int64_t work = next_item<XCD>(xhead, mem, round, (int)(2 * ngroups), nclusters, s_mem);
+    if (work >= 2 * ngroups) {
+      if (work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed
+      break;
+    }
     const int dir = (int)(work & 1);
     const int64_t seq0 = (work >> 1) * SEQS;
     const int64_t n = seq0 + j;
@@ -205,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       // source workgroup; 2 granules per 16-byte load, all loads in flight at once
       if (step > 0) {
         const int slot = (int)((step - 1) & 1);
-        const unsigned want = (unsigned)step;
+        const unsigned want = tagbase | (unsigned)step;
         const int s = tid >> 4, uq = tid & 15;
         u32x4 v[10];
 #pragma unroll
@@ -213,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 #pragma unroll
           for (int p = 0; p < 2; ++p)
             v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                         prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, SC1)
+                                         prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL)
                                    : u32x4{want, 0u, want, 0u};
         int spins = 0;
         bool fail = false;
@@ -224,13 +310,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
           if (ok) break;
           if (++spins > SPIN_LIMIT) { fail = true; break; }
           __builtin_amdgcn_s_sleep(1);
-#pragma unroll
+  #pragma unroll
           for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
                 v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
-                    prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, SC1);
+                    prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL);
         }
         if (fail) s_fail = 1;
 #pragma unroll
@@ -282,14 +368,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       {
         *reinterpret_cast<f32x4*>(pub + j * PUBPITCH + 8 * wave + 4 * half) = hv;
         __syncthreads();
-        const unsigned tag = (unsigned)(step + 1);
+        const unsigned tag = tagbase | (unsigned)(step + 1);
         const int s = tid >> 4, uq = tid & 15;
         const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
         const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 8;
         __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, SC1);
+            u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, AUXS);
         __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, SC1);
+            u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, AUXS);
       }
       // ---- saved activations / output.  A lane owns 4 consecutive units of one sequence: gates
       // 64 B (a lane pair completes a 128-B line, streamed non-temporal), cell and h 16 B each
@@ -331,37 +417,39 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 constexpr int DPITCH = 256 * 2 + 16;     // bytes per LDS row of bf16 d(gates): 33 slots of 16 B
 constexpr int PPITCH = 5 * UPW + 4;      // floats per LDS row of partial dh (bank-skewed)
 
+template <bool XCD>
 __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
     float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dhout,
     int64_t ldo, int64_t dstride, const u32x4* __restrict__ wb, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G,
-    int nclusters, int layout) {
+    int nclusters, int layout, unsigned tagbase) {
   __shared__ __attribute__((aligned(16))) char dg_hi[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) char dg_lo[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16];          // tiles 8/9 partials
   __shared__ __attribute__((aligned(16))) float psum[SEQS * PPITCH];       // [seq][unit] partial dh
   __shared__ u32x4 wl_sh[4 * 512];        // lo words of the shared-tile fragments (register relief)
-  __shared__ int s_fail, s_ticket;
+  __shared__ int s_fail, s_mem[4];
+  constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) {
-    s_fail = 0;
-    s_ticket = (int)atomicAdd(xhead, 1u);
-  }
-  __syncthreads();
-  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-  const int g = ticket % G, cid = ticket / G;
+  if (tid == 0) s_fail = 0;
+  const int64_t ngroups = (N + SEQS - 1) / SEQS;
+  const Membership mem = join_cluster<XCD>(xhead, G, (int)(2 * ngroups), s_mem);
+  if (!mem.ok) return;
+  const int g = mem.g;
   const int j = lane & 31, half = lane >> 5;
   const int s = tid >> 4, uq = tid & 15;                   // cell backward: sequence, unit quad
   const int unit0 = 64 * g + 4 * uq;
   const int Hp = G * UPW;
-  const int64_t ngroups = (N + SEQS - 1) / SEQS;
   const int foff = j * DPITCH + half * 16;
   const bool vec_ok = ((H | ldo | dstride) & 3) == 0 &&
                       ((((uintptr_t)cell) | ((uintptr_t)dhout)) & 15) == 0;
-  const bool abl_pub = layout & 2, abl_ld = layout & 4;
-  layout &= 1;
 
-  for (int64_t work = cid; work < 2 * ngroups; work += nclusters) {
+  for (int round = 0;; ++round) {
+    const int64_t work = next_item<XCD>(xhead, mem, round, (int)(2 * ngroups), nclusters, s_mem);
+    if (work >= 2 * ngroups) {
+      if (work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed
+      break;
+    }
     const int dir = (int)(work & 1);
     const int64_t seq0 = (work >> 1) * SEQS;
     const int64_t n = seq0 + s;
@@ -398,10 +486,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
       const bool full = nvalid && unit0 + 4 <= H && vec_ok;
-      if (abl_ld && step > 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
-      } else if (full) {
+      if (full) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
         ct = *reinterpret_cast<const f32x4*>(cell + cell0);
@@ -419,16 +504,16 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           }
       }
       // ---- (2) reduce-scatter: add the G partial dh published with tag = step (fixed order)
-      if (step > 0 && !(abl_pub && (uq & 7) >= 2 && g < 4)) {
+      if (step > 0) {
         const int slot = (int)((step - 1) & 1);
-        const unsigned want = (unsigned)step;
+        const unsigned want = tagbase | (unsigned)step;
         u32x4 v[10];
 #pragma unroll
         for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
             v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                         prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, SC1)
+                                         prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL)
                                    : u32x4{want, 0u, want, 0u};
         int spins = 0;
         bool fail = false;
@@ -439,13 +524,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           if (ok) break;
           if (++spins > SPIN_LIMIT) { fail = true; break; }
           __builtin_amdgcn_s_sleep(1);
-#pragma unroll
+  #pragma unroll
           for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
             for (int p = 0; p < 2; ++p)
               if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
                 v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
-                    prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, SC1);
+                    prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL);
         }
         if (fail) s_fail = 1;
 #pragma unroll
@@ -529,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         }
         __syncthreads();
         // ---- (5) publish: 2 granules per lane and store, 1 KB contiguous per wave instruction
-        const unsigned tag = (unsigned)(step + 1);
+        const unsigned tag = tagbase | (unsigned)(step + 1);
         const int slot = (int)(step & 1);
         const int npairs = SEQS * (Hp >> 1);
         for (int pr = tid; pr < npairs; pr += 512) {
@@ -537,7 +622,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           const float2 v = *reinterpret_cast<const float2*>(psum + sq * PPITCH + 2 * up);
           __builtin_amdgcn_raw_buffer_store_b128(
               u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
-              (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, SC1);
+              (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, AUXS);
         }
       }
       // no barrier here: dg_* is rewritten after the next step's gather, psum/red after its barrier
@@ -569,18 +654,42 @@ extern "C" int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, 
 }
 
 // bytes: header 64 | flags (items*2*G*4, rounded to 64) | payload
-static void xbuf_layout(int64_t N, int G, int pw, int64_t* items, int64_t* flag_bytes,
-                        int64_t* payload_bytes) {
+static void xbuf_layout(int64_t N, int G, int pw, int64_t* items, int64_t* payload_bytes) {
   *items = 2 * ((N + SEQS - 1) / SEQS);
-  *flag_bytes = 0;
   *payload_bytes = *items * 2 * G * SEQS * pw * 8;
 }
 
 extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) {
   const int G = (H + UPW - 1) / UPW;
-  int64_t items, fb, pb;
-  xbuf_layout(N, G, backward ? G * UPW : UPW, &items, &fb, &pb);
-  return 64 + fb + pb;
+  int64_t items, pb;
+  xbuf_layout(N, G, backward ? G * UPW : UPW, &items, &pb);
+  return HDR_BYTES + pb;
+}
+
+// Granule tags are {launch epoch (15 bits, never 0) << 16 | step + 1}: a granule left in a cache or
+// in memory by an EARLIER launch over the same buffer can never satisfy a later launch's poll
+// (observed: with a second stream active, stale L2 lines of the previous launch carried tags that
+// matched the same step of the next one; consumers ran ahead and the two-slot protocol broke).
+static unsigned next_tagbase() {
+  static std::atomic<unsigned> epoch{0};
+  return (((epoch.fetch_add(1) % 0x7fffu) + 1u) << 16);
+}
+
+// grid: cross-XCD mode -> exactly the clusters wanted; XCD-local mode -> whole clusters per XCD
+// (workgroup b is observed on XCD b % 8; a cluster needs G workgroups of ONE XCD) plus one spare
+// workgroup per XCD for uneven dispatch.  Leftover workgroups exit (join_cluster).
+static unsigned onchip_grid(int64_t items, int G, int max_wgs, bool xcd, int* nclusters) {
+  if (!xcd) {
+    const int cap = max_wgs / G;
+    *nclusters = (int)(items < cap ? items : cap);
+    return (unsigned)(*nclusters * G);
+  }
+  const int per_xcd_cap = (max_wgs / 8) / G;                       // 32 CUs / 5 = 6
+  int per_xcd = (int)((items + 7) / 8);
+  if (per_xcd > per_xcd_cap) per_xcd = per_xcd_cap;
+  *nclusters = 8 * per_xcd;
+  int wgs = 8 * (per_xcd * G + 1);
+  return (unsigned)(wgs < max_wgs ? wgs : max_wgs);
 }
 
 extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, int64_t ldo,
@@ -592,17 +701,27 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
-  if (max_wgs < G) return TSSEP_E_SHAPE;
-  int64_t items, fb, pb;
-  xbuf_layout(N, G, UPW, &items, &fb, &pb);
+  if (max_wgs < 8 * (G + 1)) return TSSEP_E_SHAPE;
+  int64_t items, pb;
+  xbuf_layout(N, G, UPW, &items, &pb);
+  if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)(64 + fb + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
-  const int cap = max_wgs / G;
-  const int nc = (int)(items < cap ? items : cap);
+  if (hipMemsetAsync(xbuf, 0, (size_t)(HDR_BYTES + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
+  // (51 clusters) saves a whole resident round
+  const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
+  const bool xcd = !(layout & 8) && !(items > xcd_cap && items <= flat_cap);
+  int nc;
+  const unsigned grid = onchip_grid(items, G, max_wgs, xcd, &nc);
   char* base = (char*)xbuf;
-  hipLaunchKernelGGL(blstm_onchip_fwd_kernel, dim3((unsigned)(nc * G)), dim3(512), 0, s, gates, cell,
-                     hout, ldo, dstride, (const u32x4*)wf, (unsigned*)base, (unsigned*)(base + 64),
-                     (float*)(base + 64 + fb), err, N, T, H, G, nc, layout);
+  if (xcd)
+    hipLaunchKernelGGL(blstm_onchip_fwd_kernel<true>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
+                       ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
+                       N, T, H, G, nc, layout & 1, next_tagbase());
+  else
+    hipLaunchKernelGGL(blstm_onchip_fwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
+                       ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
+                       N, T, H, G, nc, layout & 1, next_tagbase());
   return tssep_launch_status();
 }
 
@@ -615,16 +734,26 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
-  if (max_wgs < G) return TSSEP_E_SHAPE;
-  int64_t items, fb, pb;
-  xbuf_layout(N, G, G * UPW, &items, &fb, &pb);
+  if (max_wgs < 8 * (G + 1)) return TSSEP_E_SHAPE;
+  int64_t items, pb;
+  xbuf_layout(N, G, G * UPW, &items, &pb);
+  if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)(64 + fb + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
-  const int cap = max_wgs / G;
-  const int nc = (int)(items < cap ? items : cap);
+  if (hipMemsetAsync(xbuf, 0, (size_t)(HDR_BYTES + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
+  // (51 clusters) saves a whole resident round
+  const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
+  const bool xcd = !(layout & 8) && !(items > xcd_cap && items <= flat_cap);
+  int nc;
+  const unsigned grid = onchip_grid(items, G, max_wgs, xcd, &nc);
   char* base = (char*)xbuf;
-  hipLaunchKernelGGL(blstm_onchip_bwd_kernel, dim3((unsigned)(nc * G)), dim3(512), 0, s, gates, cell,
-                     dhout, ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + 64 + fb),
-                     err, N, T, H, G, nc, layout);
+  if (xcd)
+    hipLaunchKernelGGL(blstm_onchip_bwd_kernel<true>, dim3(grid), dim3(512), 0, s, gates, cell, dhout,
+                       ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N,
+                       T, H, G, nc, layout & 1, next_tagbase());
+  else
+    hipLaunchKernelGGL(blstm_onchip_bwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, dhout,
+                       ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N,
+                       T, H, G, nc, layout & 1, next_tagbase());
   return tssep_launch_status();
 }

@@ -35,5 +35,17 @@ extern "C" int tssep_probe_mfma(float* out_4x4, float* out_32x32, void* stream) 
   return tssep_launch_status();
 }
 
+// XCD placement probe: out[b] = HW_REG_XCC_ID of workgroup b (the on-chip recurrence builds its
+// clusters from workgroups of one XCD and relies on nothing but this register).
+__global__ __launch_bounds__(512) void probe_xcc_kernel(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
+}
+extern "C" int tssep_probe_xcc(int* out, int nblocks, void* stream) {
+  if (!out) return TSSEP_E_NULL;
+  if (nblocks <= 0) return TSSEP_E_SHAPE;
+  hipLaunchKernelGGL(probe_xcc_kernel, dim3((unsigned)nblocks), dim3(512), 0, (hipStream_t)stream, out);
+  return tssep_launch_status();
+}
+
 extern "C" int tssep_abi_version(void) { return TSSEP_ABI_VERSION; }
 extern "C" const char* tssep_arch(void) { return "gfx950"; }

@@ -87,6 +87,12 @@ def padded(rows, cols, device, zero=False):
 
 
 # ----------------------------------------------------------------------------- probes
+def probe_xcc(nblocks=256):
+    out = torch.full((nblocks,), -1, device="cuda", dtype=torch.int32)
+    check(_lib.lib().tssep_probe_xcc(_p(out), nblocks, _stream()), "probe_xcc")
+    return out
+
+
 def probe_mfma():
     L = _lib.lib()
     o4 = torch.zeros(64, 4, device="cuda")
@@ -316,11 +322,12 @@ def n_cus(device):
 def recurrence_kernel(N, H, backward):
     """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch measured on
     MI355X at H=300, T=253, profiles/r1_recurrence_microbench.jsonl):
-      forward : fp32 cluster 1.5-2.05 up to 204 sequences; on-chip bf16x3 2.4-2.7 up to 800 (one
-                resident round: 2 directions x 25 groups of 32 on 51 clusters of 5 CUs) and 5.5
-                at 1024 (two rounds); streaming 4.8-6.2
-      backward: fp32 cluster 1.35 up to 32 sequences (2.1 at 64, 4.5 at 128); on-chip bf16x3
-                2.1-3.0 up to 800, 6.7 at 1024; streaming 6.0-6.5"""
+      forward : fp32 cluster 1.5-1.9 up to 128 sequences; on-chip bf16x3 2.0-2.5 up to 768 (one
+                resident round of 48 XCD-local clusters x 32), 4.5 at 1024, 6.9 at 2048;
+                streaming 4.8 (<= 512) .. 11.4 (2048)
+      backward: fp32 cluster 1.35-1.55 up to 32 sequences (2.9 at 96); on-chip bf16x3 1.7-2.9 up to
+                768, 5.4 at 1024, 8.2 at 2048; streaming 6.0 .. 12.5
+    The streaming kernels remain the path for H the W-stationary kernels do not support."""
     L = _lib.lib()
     if RECURRENCE in ("stream", "cluster", "onchip"):
         ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)),
@@ -328,9 +335,9 @@ def recurrence_kernel(N, H, backward):
         return RECURRENCE if ok else "stream"
     if H < 128:
         return "stream"
-    if L.tssep_lstm_cluster_supported(H) and N <= (204 if not backward else 48):
+    if L.tssep_lstm_cluster_supported(H) and N <= (128 if not backward else 32):
         return "cluster"
-    if L.tssep_lstm_onchip_supported(H) and N <= (1600 if not backward else 800):
+    if L.tssep_lstm_onchip_supported(H):
         return "onchip"
     return "stream"
 
