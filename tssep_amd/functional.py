@@ -123,7 +123,8 @@ class _RNNP(torch.autograd.Function):
             d_w_proj, d_b_proj = proj_wgrads()
         # ---- critical path: dhout, BPTT (gates <- d pre-activations)
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
-        H.gemm(dz, ld_dz, wp, 2 * Hp, dhout, 2 * Hp, R, 2 * Hp, hdim, b_kmajor=True)
+        wpT, ld_t = H.transposed(wp, hdim, 2 * Hp)
+        H.gemm(dz, ld_dz, wpT, ld_t, dhout, 2 * Hp, R, 2 * Hp, hdim)
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
         elif pk.get("whh_ob") is not None:
@@ -166,7 +167,8 @@ class _RNNP(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb, ld_dx = H.padded(R, I, dev, zero=True)
-            H.gemm(gates, G, pk["wih_p"], pk["ld_i"], dxb, ld_dx, R, I, G, b_kmajor=True)
+            wihT, ld_t = H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I)
+            H.gemm(gates, G, wihT, ld_t, dxb, ld_dx, R, I, G)
             dx = dxb[:, :I]
             if tuple(ctx.x_shape) != tuple(dx.shape):
                 dx = dx.reshape(ctx.x_shape)
@@ -293,7 +295,8 @@ class _Head(torch.autograd.Function):
             H.reduce_splits(part, S, Nout * P, dw)
             db = H.colsum(dv, ld_d, R, Nout)
         dxb, ld_dx = H.padded(R, P, dev, zero=True)
-        H.gemm(dv, ld_d, wv, ld_w, dxb, ld_dx, R, P, Nout, b_kmajor=True)
+        wvT, ld_t = H.transposed(wv, Nout, P)
+        H.gemm(dv, ld_d, wvT, ld_t, dxb, ld_dx, R, P, Nout)
         dx = dxb[:, :P]
         if tuple(ctx.x_shape) != tuple(dx.shape):
             dx = dx.reshape(ctx.x_shape)

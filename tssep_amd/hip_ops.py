@@ -220,6 +220,18 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
         check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
 
+def transposed(w, rows, cols):
+    """[rows, >= cols] weight view -> contiguous [cols, round_up(rows, 4)] copy (layout glue): the
+    dgrad GEMMs then read BOTH operands k-contiguous with 16-byte loads (the k-major path reads
+    4 bytes per lane: 242 vs ~300 TFLOP/s on the K = 2400 shapes)."""
+    ld = round_up(rows, 4)
+    if ld == rows:
+        return w[:rows, :cols].t().contiguous(), ld
+    out = torch.zeros(cols, ld, device=w.device, dtype=torch.float32)
+    out[:, :rows] = w[:rows, :cols].t()
+    return out, ld
+
+
 def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
