@@ -105,6 +105,29 @@ __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __res
     dz[e] = dy[src] * (1.0f - v * v);
   }
 }
+// P % 4 == 0 and 16-byte aligned buffers: one float4 per thread and iteration
+__global__ void tanh_bwd_v4_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y,
+                                   f32x4* __restrict__ dz, int64_t rows, int P4, int K, int T,
+                                   int combined) {
+  const int64_t total = rows * P4;
+  GRID_STRIDE(e, total) {
+    int64_t src = e;
+    if (combined) {
+      const int64_t row = e / P4;
+      const int p = (int)(e - row * P4);
+      const int64_t bk = row / T;
+      const int t = (int)(row - bk * T);
+      const int64_t b = bk / K;
+      const int k = (int)(bk - b * K);
+      src = ((b * T + t) * K + k) * P4 + p;
+    }
+    const f32x4 v = y[src], d = __builtin_nontemporal_load(dy + src);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = d[i] * (1.0f - v[i] * v[i]);
+    dz[e] = o;
+  }
+}
 
 // ---- column sums (bias gradients), deterministic two-pass ---------------------------------
 constexpr int CS_SLABS = 128;
@@ -118,8 +141,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int64_t m0 = (int64_t)blockIdx.y * per;
   const int64_t m1 = m0 + per < M ? m0 + per : M;
   float s = 0.f;
-  if (n < N)
-    for (int64_t m = m0 + ty; m < m1; m += 4) s += A[m * lda + n];
+  if (n < N) {
+    // 4 independent loads in flight per thread (one per loop trip left the slab latency-bound)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t m = m0 + ty;
+    for (; m + 12 < m1; m += 16) {
+      const float a0 = A[m * lda + n], a1 = A[(m + 4) * lda + n];
+      const float a2 = A[(m + 8) * lda + n], a3 = A[(m + 12) * lda + n];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; m < m1; m += 4) s0 += A[m * lda + n];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && n < N)
@@ -348,8 +381,13 @@ extern "C" int tssep_tanh_bwd(const float* dy, const float* y, float* dz, int64_
                               int64_t K, int64_t T, int combined_in, void* stream) {
   if (!dy || !y || !dz) return TSSEP_E_NULL;
   if (rows <= 0 || P <= 0 || K <= 0 || T <= 0 || rows % (K * T)) return TSSEP_E_SHAPE;
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(rows * P)), dim3(256), 0, S_, dy, y, dz, rows,
-                     P, K, T, combined_in);
+  if (P % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(dz))
+    hipLaunchKernelGGL(tanh_bwd_v4_kernel, dim3(grid_for(rows * P / 4)), dim3(256), 0, S_,
+                       (const f32x4*)dy, (const f32x4*)y, (f32x4*)dz, rows, (int)(P / 4), (int)K, (int)T,
+                       combined_in);
+  else
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(rows * P)), dim3(256), 0, S_, dy, y, dz, rows,
+                       P, K, T, combined_in);
   return tssep_launch_status();
 }
 extern "C" int64_t tssep_colsum_workspace_bytes(int64_t M, int64_t N) {

@@ -94,7 +94,7 @@ class _RNNP(torch.autograd.Function):
         sinks = [_grad_sink(p) for p in params]
         direct = all(s_ is not None for s_ in sinks) and H.OVERLAP_WGRAD
         main = torch.cuda.current_stream()
-        side = H.side_stream(dev) if direct else main
+        side = H.side_stream(dev, R) if direct else main
 
         # ---- projection weight / bias gradients (side stream when direct)
         def proj_wgrads():
@@ -280,7 +280,7 @@ class _Head(torch.autograd.Function):
         sw, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
         direct = sw is not None and sb is not None and H.OVERLAP_WGRAD
         if direct:
-            main, side = torch.cuda.current_stream(), H.side_stream(dev)
+            main, side = torch.cuda.current_stream(), H.side_stream(dev, R)
             side.wait_stream(main)
             for t_ in (dv, xv):
                 t_.record_stream(side)
