@@ -221,7 +221,23 @@ struct XBuf {
 #define ROW(n_, t_) (layout ? (((n_) >> 5) * T * 32 + (t_) * 32 + ((n_) & 31)) : ((n_) * T + (t_)))
 
 // ------------------------------------------------------------------------------- forward
-constexpr int PUBPITCH = UPW + 4;        // floats per LDS row of the publish transpose
+constexpr int PUBPITCH = UPW + 4;        // floats per LDS row of [seq][unit] scalars (h, c)
+constexpr int XPITCH = UPW * 4 + 4;      // floats per LDS row of [seq][unit][4 gates]
+
+// Wave roles.  All 8 waves hold W and run the MFMAs and the cell update of their unit slice.  Beyond
+// that, waves 0-3 ("exchange") do nothing but the inter-workgroup exchange and waves 4-7 ("io") do
+// nothing but HBM traffic, because a wave's vector-memory counter retires IN ORDER: with both kinds
+// of access in one wave, every gather of the exchange waited for the activation stores and gate
+// loads queued in front of it, and HBM time (19 MB per step at 768 sequences, ~4.3 us at the
+// achievable 4.5 TB/s) ADDED to the ~5 us exchange chain instead of overlapping it (measured by
+// ablation: 2.5 ms per launch with, 1.27 ms without the HBM traffic; re-ordering or delaying the
+// accesses inside one wave changed nothing).  With the roles split: 2.25 ms at 768 sequences,
+// 1.83 (was 2.07) at 192; the io arm (store acks + load latency, back to back) is what remains
+// exposed -- issuing the loads before the stores needs 32 more live registers and spilled.  Gate pre-activations therefore travel
+//   HBM -> io registers -> LDS xg[step&1] (two steps ahead) -> cell update (in place: activations)
+//   -> io waves -> HBM,
+// in a row-contiguous pattern (16 lanes x 16 B per sequence row), and the exchange waves gather
+// and publish for all 32 sequences (two halves of 16).
 template <bool XCD>
 __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
@@ -230,7 +246,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     int64_t T, int H, int G, int nclusters, int layout, unsigned tagbase) {
   __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
-  __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];
+  __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];      // h_t  [seq][unit]
+  __shared__ __attribute__((aligned(16))) float cellb[SEQS * PUBPITCH];    // c_t  [seq][unit]
+  __shared__ __attribute__((aligned(16))) float xg[2][SEQS * XPITCH];      // gates [seq][unit][4]
   __shared__ int s_fail, s_mem[4];
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,9 +260,17 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   if (!mem.ok) return;
   const int g = mem.g;
   const int j = lane & 31, half = lane >> 5;
-  const int unit0 = 64 * g + 8 * wave + 4 * half;      // this lane's 4 consecutive units
+  const int ul0 = 8 * wave + 4 * half;                 // this lane's 4 consecutive local units
+  const int unit0 = 64 * g + ul0;
   const int foff = j * HPITCH + half * 16;             // B fragment offset (row = sequence j)
   const bool vec_ok = ((H | ldo | dstride) & 3) == 0 && ((((uintptr_t)cell) | ((uintptr_t)hout)) & 15) == 0;
+  const bool io_wave = wave >= 4;
+  const int s2 = (tid & 255) >> 4, uq = tid & 15;      // exchange / io thread <-> rows s2, s2+16
+  // operand-image columns the gather never writes (k >= 64 G) must stay zero
+  for (int i = tid; i < SEQS * HPITCH / 4; i += 512) {
+    reinterpret_cast<unsigned*>(hs_hi)[i] = 0u;
+    reinterpret_cast<unsigned*>(hs_lo)[i] = 0u;
+  }
 
   for (int round = 0;; ++round) {
     const int64_t work = next_item<XCD>(xhead, mem, round, (int)(2 * ngroups), nclusters, s_mem);
@@ -254,8 +280,6 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     }
     const int dir = (int)(work & 1);
     const int64_t seq0 = (work >> 1) * SEQS;
-    const int64_t n = seq0 + j;
-    const bool nvalid = n < N;
     // stationary weights -> registers (A fragments, hi and lo)
     u32x4 wh[KS], wl[KS];
     {
@@ -266,68 +290,127 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         wl[ks] = wp[(int64_t)(ks * 2 + 1) * 64];
       }
     }
-    for (int i = tid; i < SEQS * HPITCH / 4; i += 512) {
-      reinterpret_cast<unsigned*>(hs_hi)[i] = 0u;
-      reinterpret_cast<unsigned*>(hs_lo)[i] = 0u;
-    }
     float c[4] = {0.f, 0.f, 0.f, 0.f};
     float* pl = xpayload + work * 2 * G * SEQS * UPW * 2;      // 8-byte granules
     const __amdgpu_buffer_rsrc_t prs =
         __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * UPW * 8, 0x00020000);
+
+    // ---- io waves: row-contiguous HBM access, thread <-> (rows s2 / s2+16, units 16 q + uq)
+    f32x4 rg[2][4];
+    auto io_load = [&](int64_t step_) {
+      const int64_t t_ = dir ? T - 1 - step_ : step_;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int64_t ns = seq0 + s2 + 16 * hf;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int u = 64 * g + 16 * q + uq;
+          rg[hf][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (ns < N && u < H)
+            rg[hf][q] = *reinterpret_cast<const f32x4*>(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4);
+        }
+      }
+    };
+    auto io_park = [&](int buf) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<f32x4*>(&xg[buf][(s2 + 16 * hf) * XPITCH + (16 * q + uq) * 4]) = rg[hf][q];
+    };
+    auto io_flush = [&](int64_t step_, int buf) {
+      const int64_t t_ = dir ? T - 1 - step_ : step_;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int s = s2 + 16 * hf;
+        const int64_t ns = seq0 + s;
+        if (ns >= N) continue;
+        const int64_t rowg = (ROW(ns, t_) * 2 + dir) * (int64_t)H;
+        const int64_t rowh = ROW(ns, t_) * ldo + dir * dstride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int u = 64 * g + 16 * q + uq;
+          if (u < H)
+            *reinterpret_cast<f32x4*>(gates + (rowg + u) * 4) =
+                *reinterpret_cast<const f32x4*>(&xg[buf][s * XPITCH + (16 * q + uq) * 4]);
+        }
+        const int u4 = 64 * g + 4 * uq;
+        const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s * PUBPITCH + 4 * uq);
+        const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
+        if (vec_ok && u4 + 4 <= H) {
+          *reinterpret_cast<f32x4*>(cell + rowg + u4) = cq;
+          *reinterpret_cast<f32x4*>(hout + rowh + u4) = hq;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (u4 + q < H) {
+              cell[rowg + u4 + q] = cq[q];
+              hout[rowh + u4 + q] = hq[q];
+            }
+        }
+      }
+    };
+    if (io_wave) {
+      io_load(0);
+      io_park(0);
+      if (T > 1) {
+        io_load(1);
+        io_park(1);
+      }
+    }
     __syncthreads();
 
     for (int64_t step = 0; step < T; ++step) {
-      const int64_t t = dir ? T - 1 - step : step;
-      // gate pre-activations of this lane's 4 cells (consumed after the k loop)
-      f32x4 gx[4];
+      const int buf = (int)(step & 1);
+      f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        gx[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nvalid && unit0 + q < H)
-          gx[q] = *reinterpret_cast<const f32x4*>(
-              gates + ((ROW(n, t) * 2 + dir) * (int64_t)H + unit0 + q) * 4);
-      }
-      // ---- gather h_{t-1}: thread <-> (sequence s = tid/16, unit quad uq = tid%16) of every
-      // source workgroup; 2 granules per 16-byte load, all loads in flight at once
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       if (step > 0) {
-        const int slot = (int)((step - 1) & 1);
-        const unsigned want = tagbase | (unsigned)step;
-        const int s = tid >> 4, uq = tid & 15;
-        u32x4 v[10];
+        // ---- exchange waves: gather h_{t-1} of every source workgroup, 16 sequences at a time
+        // (2 granules per 16-byte load, 10 loads in flight), into the bf16 hi+lo operand image
+        if (!io_wave) {
+          const int slot = (int)((step - 1) & 1);
+          const unsigned want = tagbase | (unsigned)step;
+#pragma unroll 1
+          for (int hf = 0; hf < 2; ++hf) {
+            const int s = s2 + 16 * hf;
+            u32x4 v[10];
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs)
+            for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
-          for (int p = 0; p < 2; ++p)
-            v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                         prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL)
-                                   : u32x4{want, 0u, want, 0u};
-        int spins = 0;
-        bool fail = false;
-        for (;;) {
-          bool ok = true;
+              for (int p = 0; p < 2; ++p)
+                v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
+                                             prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL)
+                                       : u32x4{want, 0u, want, 0u};
+            int spins = 0;
+            bool fail = false;
+            for (;;) {
+              bool ok = true;
 #pragma unroll
-          for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
-          if (ok) break;
-          if (++spins > SPIN_LIMIT) { fail = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-  #pragma unroll
-          for (int gs = 0; gs < 5; ++gs)
+              for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
+              if (ok) break;
+              if (++spins > SPIN_LIMIT) { fail = true; break; }
+              __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-              if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
-                v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
-                    prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL);
-        }
-        if (fail) s_fail = 1;
+              for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs) {
-          const int k = 64 * gs + 4 * uq;                      // column of h = unit index
-          if (gs < G && k < KP) {
-            unsigned h0, l0, h1, l1;
-            split2(__uint_as_float(v[2 * gs][1]), __uint_as_float(v[2 * gs][3]), h0, l0);
-            split2(__uint_as_float(v[2 * gs + 1][1]), __uint_as_float(v[2 * gs + 1][3]), h1, l1);
-            *reinterpret_cast<u32x2*>(hs_hi + s * HPITCH + 2 * k) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(hs_lo + s * HPITCH + 2 * k) = u32x2{l0, l1};
+                for (int p = 0; p < 2; ++p)
+                  if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
+                    v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
+                        prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL);
+            }
+            if (fail) s_fail = 1;
+#pragma unroll
+            for (int gs = 0; gs < 5; ++gs) {
+              const int k = 64 * gs + 4 * uq;                      // column of h = unit index
+              if (gs < G && k < KP) {
+                unsigned h0, l0, h1, l1;
+                split2(__uint_as_float(v[2 * gs][1]), __uint_as_float(v[2 * gs][3]), h0, l0);
+                split2(__uint_as_float(v[2 * gs + 1][1]), __uint_as_float(v[2 * gs + 1][3]), h1, l1);
+                *reinterpret_cast<u32x2*>(hs_hi + s * HPITCH + 2 * k) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(hs_lo + s * HPITCH + 2 * k) = u32x2{l0, l1};
+              }
+            }
           }
         }
         __syncthreads();
@@ -335,69 +418,63 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
           if (tid == 0) atomicExch(err, 3);
           return;
         }
-      }
-      // ---- recurrent product for 32 gate rows x 32 sequences
-      f32x16 acc;
+        // ---- recurrent product for 32 gate rows x 32 sequences (h_{-1} = 0: skipped at step 0)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hs_hi + foff + ks * 32);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hs_lo + foff + ks * 32);
-        acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
-        acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
-        acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(hs_hi + foff + ks * 32);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hs_lo + foff + ks * 32);
+          acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
+          acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
+          acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
+        }
       }
-      // ---- lane-local cell update: acc[4q .. 4q+3] = gates (i,f,g,o) of unit unit0 + q
-      f32x4 hv, cv, act[4];
-      const int slot = (int)(step & 1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a0 = acc[4 * q + 0] + gx[q][0], a1 = acc[4 * q + 1] + gx[q][1];
-        const float a2 = acc[4 * q + 2] + gx[q][2], a3 = acc[4 * q + 3] + gx[q][3];
-        const float ig = fast_sigmoid(a0), fg = fast_sigmoid(a1);
-        const float gg = fast_tanh(a2), og = fast_sigmoid(a3);
-        const float cn = fg * c[q] + ig * gg;
-        c[q] = cn;
-        cv[q] = cn;
-        act[q] = f32x4{ig, fg, gg, og};
-        hv[q] = (unit0 + q < H) ? og * fast_tanh(cn) : 0.f;
-      }
-      // ---- publish h_t: transposed through LDS so that a wave instruction writes 4 runs of 512
-      // contiguous bytes (2 granules per lane and store) instead of 64 scattered 16-byte pieces
+      // ---- lane-local cell update: acc[4q .. 4q+3] = gates (i,f,g,o) of unit unit0 + q; the
+      // pre-activations come from xg[buf] and the activations replace them in place
       {
-        *reinterpret_cast<f32x4*>(pub + j * PUBPITCH + 8 * wave + 4 * half) = hv;
-        __syncthreads();
-        const unsigned tag = tagbase | (unsigned)(step + 1);
-        const int s = tid >> 4, uq = tid & 15;
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
-        const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 8;
-        __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, AUXS);
-        __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, AUXS);
+        f32x4 hv, cv;
+        float* xrow = &xg[buf][j * XPITCH + ul0 * 4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 gx = *reinterpret_cast<const f32x4*>(xrow + 4 * q);
+          const float a0 = acc[4 * q + 0] + gx[0], a1 = acc[4 * q + 1] + gx[1];
+          const float a2 = acc[4 * q + 2] + gx[2], a3 = acc[4 * q + 3] + gx[3];
+          const float ig = fast_sigmoid(a0), fg = fast_sigmoid(a1);
+          const float gg = fast_tanh(a2), og = fast_sigmoid(a3);
+          const float cn = fg * c[q] + ig * gg;
+          c[q] = cn;
+          cv[q] = cn;
+          *reinterpret_cast<f32x4*>(xrow + 4 * q) = f32x4{ig, fg, gg, og};
+          hv[q] = (unit0 + q < H) ? og * fast_tanh(cn) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(pub + j * PUBPITCH + ul0) = hv;
+        *reinterpret_cast<f32x4*>(cellb + j * PUBPITCH + ul0) = cv;
       }
-      // ---- saved activations / output.  A lane owns 4 consecutive units of one sequence: gates
-      // 64 B (a lane pair completes a 128-B line, streamed non-temporal), cell and h 16 B each
-      // (plain stores: the 8 waves' pieces of a line are merged in L2).  Scalar 4-byte stores here
-      // were measured at +9 ms per launch at N = 1024 (64 different lines per instruction).
-      if (nvalid) {
-        const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
-        const int64_t h0 = ROW(n, t) * ldo + dir * dstride + unit0;
-        if (vec_ok && unit0 + 4 <= H) {
+      __syncthreads();
+      if (!io_wave) {
+        // ---- publish h_t: 2 granules per 16-byte store, 4 runs of 512 contiguous bytes per wave
+        // instruction (write-through; no drain, no flag -- the tag is the flag)
+        const unsigned tag = tagbase | (unsigned)(step + 1);
+        const int slot = (int)(step & 1);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4) = act[q];
-          *reinterpret_cast<f32x4*>(cell + cell0) = cv;
-          *reinterpret_cast<f32x4*>(hout + h0) = hv;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (unit0 + q < H) {
-              __builtin_nontemporal_store(act[q], reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4));
-              cell[cell0 + q] = cv[q];
-              hout[h0 + q] = hv[q];
-            }
+        for (int hf = 0; hf < 2; ++hf) {
+          const int s = s2 + 16 * hf;
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
+          const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 8;
+          __builtin_amdgcn_raw_buffer_store_b128(
+              u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, AUXS);
+          __builtin_amdgcn_raw_buffer_store_b128(
+              u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, AUXS);
+        }
+      } else {
+        // ---- io waves: activations / cell / h of this step -> HBM, then the pre-activations of
+        // step+2 into the buffer just flushed.  (Load and park stay in this arm so that the 32
+        // load registers are live only while these waves have nothing else to do -- held across
+        // the MFMA loop they spilled 29 VGPRs; the HBM latency is covered by the exchange waves'
+        // publish -> gather round trip that runs at the same time.)
+        io_flush(step, buf);
+        if (step + 2 < T) {
+          io_load(step + 2);
+          io_park(buf);
         }
       }
     }
