@@ -485,8 +485,9 @@ def test_blstm_onchip_kernels(N, T, I, Hh, mode):
     cs = h.colsum(gates, 8 * Hh, R, 8 * Hh)
     bf = torch.empty(4 * Hh, device="cuda"); br = torch.empty(4 * Hh, device="cuda")
     h.lstm_unpack(cs, 1, 1, 0, Hh, 1, bf, br)
-    close(bf, pr["bias_ih_l0"].grad, rtol=2e-4, atol=5e-6, name="onchip db")
-    close(br, pr["bias_hh_l0_reverse"].grad, rtol=2e-4, atol=5e-6, name="onchip db_reverse")
+    # (sums over N*T rows with cancellation: the absolute floor scales with the largest entry)
+    for got_, ref_, nm in ((bf, pr["bias_ih_l0"].grad, "onchip db"), (br, pr["bias_hh_l0_reverse"].grad, "onchip db_reverse")):
+        close(got_, ref_, rtol=2e-4, atol=5e-6 + 2e-6 * float(ref_.abs().max()), name=nm)
     # and d(gates) against the exact-fp32 streaming backward on the same saved activations
     h.blstm_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
     close(gates, g_stream, rtol=2e-4, atol=2e-6, name="dgates")

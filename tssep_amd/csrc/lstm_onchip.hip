@@ -652,26 +652,36 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       if (has_prev) {
         // ---- (4) partial dh_prev: own output tile over all 16 k-steps; wave w also covers k-steps
         //      4 (w>>1) .. +3 of shared tile 8 + (w&1)
-        f32x16 acc, accs;
+        // three accumulator chains round-robin (own tile even / odd k-steps, shared tile): MFMAs
+        // into one accumulator back to back wait for each other (the loop measured 2x issue-bound)
+        f32x16 acc, acc1, accs;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; accs[e] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32);
-          acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
-          acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
-          acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
-        }
+        for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc1[e] = 0.f; accs[e] = 0.f; }
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-          const int ks = 4 * (wave >> 1) + x;
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32);
-          accs = MFMA_BF16(as_bf16x8(wl_sh[x * 512 + tid]), bh, accs);
-          accs = MFMA_BF16(as_bf16x8(wh[16 + x]), bl, accs);
-          accs = MFMA_BF16(as_bf16x8(wh[16 + x]), bh, accs);
+          const int kx = 4 * (wave >> 1) + x;
+          const bf16x8 sh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + kx * 32);
+          const bf16x8 sl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + kx * 32);
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            const int ks = 4 * x + 2 * y;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32);
+            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(dg_hi + foff + ks * 32 + 32);
+            const bf16x8 cl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + ks * 32 + 32);
+            acc = MFMA_BF16(as_bf16x8(wl[ks]), bh, acc);
+            acc1 = MFMA_BF16(as_bf16x8(wl[ks + 1]), ch, acc1);
+            if (y == 0) accs = MFMA_BF16(as_bf16x8(wl_sh[x * 512 + tid]), sh, accs);
+            acc = MFMA_BF16(as_bf16x8(wh[ks]), bl, acc);
+            acc1 = MFMA_BF16(as_bf16x8(wh[ks + 1]), cl, acc1);
+            if (y == 0) accs = MFMA_BF16(as_bf16x8(wh[16 + x]), sl, accs);
+            acc = MFMA_BF16(as_bf16x8(wh[ks]), bh, acc);
+            acc1 = MFMA_BF16(as_bf16x8(wh[ks + 1]), ch, acc1);
+            if (y == 1) accs = MFMA_BF16(as_bf16x8(wh[16 + x]), sh, accs);
+          }
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += acc1[e];
         // own tile -> psum[seq][unit] (D rows (e&3) + 8 (e>>2) + 4 half); shared-tile partials -> red
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -693,13 +703,16 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         // ---- (5) publish: 2 granules per lane and store, 1 KB contiguous per wave instruction
         const unsigned tag = tagbase | (unsigned)(step + 1);
         const int slot = (int)(step & 1);
-        const int npairs = SEQS * (Hp >> 1);
-        for (int pr = tid; pr < npairs; pr += 512) {
-          const int sq = pr / (Hp >> 1), up = pr - sq * (Hp >> 1);
-          const float2 v = *reinterpret_cast<const float2*>(psum + sq * PPITCH + 2 * up);
-          __builtin_amdgcn_raw_buffer_store_b128(
-              u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
-              (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, AUXS);
+        // thread <-> (sequence s, pairs uq + 16 i): 16 lanes x 16 B = 256 contiguous bytes per row
+#pragma unroll
+        for (int i = 0; i < 2 * 5; ++i) {
+          const int up = uq + 16 * i;
+          if (2 * up < Hp) {
+            const float2 v = *reinterpret_cast<const float2*>(psum + s * PPITCH + 2 * up);
+            __builtin_amdgcn_raw_buffer_store_b128(
+                u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
+                (((slot * G + g) * SEQS + s) * Hp + 2 * up) * 8, 0, AUXS);
+          }
         }
       }
       // no barrier here: dg_* is rewritten after the next step's gather, psum/red after its barrier

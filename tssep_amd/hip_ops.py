@@ -334,9 +334,9 @@ def n_cus(device):
 def recurrence_kernel(N, H, backward):
     """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch measured on
     MI355X at H=300, T=253, profiles/r1_recurrence_microbench.jsonl):
-      forward : fp32 cluster 1.5-1.9 up to 128 sequences; on-chip bf16x3 2.0-2.5 up to 768 (one
-                resident round of 48 XCD-local clusters x 32), 4.5 at 1024, 6.9 at 2048;
-                streaming 4.8 (<= 512) .. 11.4 (2048)
+      forward : on-chip bf16x3 1.4 (8 sequences) .. 1.8 (192) .. 2.25 (768 = one resident round of
+                48 XCD-local clusters x 32), 4.5 at 1536; fp32 cluster 1.5-1.9 up to 128 (never
+                ahead); streaming 4.8 (<= 512) .. 11.4 (2048)
       backward: fp32 cluster 1.35-1.55 up to 32 sequences (2.9 at 96); on-chip bf16x3 1.7-2.9 up to
                 768, 5.4 at 1024, 8.2 at 2048; streaming 6.0 .. 12.5
     The streaming kernels remain the path for H the W-stationary kernels do not support."""
@@ -347,7 +347,7 @@ def recurrence_kernel(N, H, backward):
         return RECURRENCE if ok else "stream"
     if H < 128:
         return "stream"
-    if L.tssep_lstm_cluster_supported(H) and N <= (128 if not backward else 32):
+    if backward and L.tssep_lstm_cluster_supported(H) and N <= 32:
         return "cluster"
     if L.tssep_lstm_onchip_supported(H):
         return "onchip"
