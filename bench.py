@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 384)),
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
-                    help="arithmetic of the non-recurrent GEMMs (recurrences are always exact fp32)")
+                    help="arithmetic of the non-recurrent GEMMs (the recurrence kernel is chosen by hip_ops.recurrence_kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the secondary exact-fp32 measurement")
@@ -250,7 +250,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world,
                        "units": UNITS, "optimizer": "global-norm clip + Adam (fused), in the timed step",
                        "projs": PROJS, "parallelism": f"dp{world}",
-                       "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate; recurrences exact fp32"
+                       "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate, in the GEMMs and the W-stationary recurrences"
                                            if args.gemm == "bf16x3" else "exact fp32 MFMA"),
                        "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
             "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,

@@ -8,7 +8,7 @@ python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 > $O/recur
 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
 TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
-for b in 8 32 64 128 160 192 200 256 512; do
+for b in 8 32 64 128 160 192 256 384 512 768; do
   python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
 python bench.py > $O/bench_default.json 2>$O/bench_default.err
