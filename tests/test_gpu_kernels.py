@@ -76,7 +76,9 @@ def test_maskhead(B, K, T, F):
     close(h.maskhead_bwd(dest.cuda(), dmask.cuda(), mask, obs.cuda()), g2, rtol=1e-4, name="dlogit+dmask")
 
 
-GEMM_SHAPES = [(130, 70, 37), (257, 300, 553), (64, 129, 16), (1000, 2400, 513), (5, 3, 2)]
+GEMM_SHAPES = [(130, 70, 37), (257, 300, 553), (64, 129, 16), (1000, 2400, 513), (5, 3, 2),
+               # M >= 1024: the 256 x 128 'tall' tile of the split-bf16 row x row path (K tails, K < 16)
+               (1100, 200, 70), (2051, 390, 513), (1030, 131, 19), (1024, 128, 7)]
 
 
 @pytest.fixture(params=["f32", "bf16x3"])

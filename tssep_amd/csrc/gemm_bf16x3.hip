@@ -559,6 +559,182 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 }
 #undef SGB
 
+
+// ------------------------------------------------------------------------------------------------
+// "Tall" variant for row-major x row-major (both operands k-contiguous): 256 x 128 output tile,
+// wave tile 128 x 64 (4 x 2 MFMA tiles, 128 accumulator registers), K staged 16 at a time.  Per
+// MFMA it moves 25 % fewer operand bytes (global -> LDS -> fragments) and issues 25 % fewer
+// split / ds_write / ds_read instructions than the 128 x 128 kernel, with the same 24 MFMAs per
+// wave between barriers.  LDS rows are [row][16 bf16] with a 48-byte pitch (3 slots of 16 B: the 16
+// rows of a ds_read_b128 lane group land on 16 distinct slots).  Measured +3..15 % on the shapes of
+// the step.  Per-tile s_memtime profile at K = 320 (61 k cycles): prologue 4 %, K loop 54 % (1850
+// cycles per stage for 768 MFMA cycles per wave: two resident workgroups keep the matrix pipe 83 %
+// busy while both are in their loops), drain 5 %, epilogue 36 % (the 128 KB fp32 C tile: stores
+// back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing.
+constexpr int TBM = 256, TBK = 16, TPITCH = 48;
+constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
+constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
+    int64_t N, int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act,
+    int accumulate, StoreMap sm, TileMap tmap) {
+  __shared__ __attribute__((aligned(16))) char lds0[TSTAGE];
+  __shared__ __attribute__((aligned(16))) char lds1[TSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * TBM, n0 = (int64_t)nt * BN;
+  const int64_t ktiles = (K + TBK - 1) / TBK, kt_full = K / TBK;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // loads: thread <-> (row tid/4 + 64 i, 4 consecutive k at (tid%4)*4); uniform base + 32-bit offsets
+  const int kq = (tid & 3) << 2, lrow = tid >> 2;
+  const char* abase = reinterpret_cast<const char*>(A + m0 * lda);
+  const char* bbase = reinterpret_cast<const char*>(B + n0 * ldb);
+  unsigned aoffs[4], boffs[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int64_t r = m0 + lrow + 64 * i;
+    r = r > M - 1 ? M - 1 : r;
+    aoffs[i] = (unsigned)(((r - m0) * lda + kq) * 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int64_t r = n0 + lrow + 64 * i;
+    r = r > N - 1 ? N - 1 : r;
+    boffs[i] = (unsigned)(((r - n0) * ldb + kq) * 4);
+  }
+  f32x4 ra[4], rb[2];
+  auto gload = [&](int64_t kt, bool tail) {
+    const int64_t k0 = kt * TBK, k = k0 + kq;
+    // (tail) a 16-byte load that starts at or beyond K would leave the row: read the row start
+    const int64_t adj = (!tail || k < K) ? k0 : -(int64_t)kq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + adj * 4 + aoffs[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + adj * 4 + boffs[i]);
+    if (tail) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = k + e < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i][e] = ok ? ra[i][e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i][e] = ok ? rb[i][e] : 0.f;
+      }
+    }
+  };
+  const int soff = lrow * TPITCH + ((tid & 3) << 3);
+  auto sstore = [&](char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned h0, l0, h1, l1;
+      split2n(ra[i][0], ra[i][1], h0, l0);
+      split2n(ra[i][2], ra[i][3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soff + i * 64 * TPITCH) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + TARR_A + soff + i * 64 * TPITCH) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned h0, l0, h1, l1;
+      split2n(rb[i][0], rb[i][1], h0, l0);
+      split2n(rb[i][2], rb[i][3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + soff + i * 64 * TPITCH) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + TARR_B + soff + i * 64 * TPITCH) = u32x2{l0, l1};
+    }
+  };
+  const int foff = (lane & 31) * TPITCH + (lane >> 5) * 16;
+  const int aoff = (wm * 128) * TPITCH + foff, boff = 2 * TARR_A + (wn * 64) * TPITCH + foff;
+  auto compute = [&](const char* st) {
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(st + aoff + i * 32 * TPITCH);
+      al[i] = *reinterpret_cast<const bf16x8*>(st + TARR_A + aoff + i * 32 * TPITCH);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = *reinterpret_cast<const bf16x8*>(st + boff + j * 32 * TPITCH);
+      bl[j] = *reinterpret_cast<const bf16x8*>(st + TARR_B + boff + j * 32 * TPITCH);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+#define TPIPE(cur, nxt, kt_, SID_)                                                              \
+  do {                                                                                          \
+    constexpr int SID = SID_;                                                                   \
+    compute(cur);                                                                               \
+    sstore(nxt);                                                                                \
+    gload((kt_) + 2, false);                                                                    \
+    SGB(0x100, 6);                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x200, 1); }              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x020, 1); }                              \
+    __syncthreads();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  gload(0, 0 >= kt_full);
+  sstore(lds0);
+  if (1 < ktiles) gload(1, 1 >= kt_full);
+  __syncthreads();
+  int64_t kt = 0;
+  const int64_t lim = kt_full - 3;
+  for (; kt < lim; kt += 2) {
+    TPIPE(lds0, lds1, kt, 1);
+    TPIPE(lds1, lds0, kt + 1, 2);
+  }
+  for (int par = 0; kt < ktiles; ++kt, par ^= 1) {
+    const char* cur = par ? lds1 : lds0;
+    char* nxt = par ? lds0 : lds1;
+    compute(cur);
+    if (kt + 1 < ktiles) sstore(nxt);
+    if (kt + 2 < ktiles) gload(kt + 2, kt + 2 >= kt_full);
+    __syncthreads();
+  }
+#undef TPIPE
+  if (!sm.remap) {
+    static_assert(2 * 64 * EPITCH * 4 <= TSTAGE, "epilogue scratch must fit in one stage");
+    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      f32x16 a2[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
+      gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
+                         bias, act, accumulate, sm.ldc, true);
+    }
+    return;
+  }
+  gemm_epilogue<4, 2>(acc, C, M, N, m0 + (int64_t)wm * 128, n0 + (int64_t)wn * 64, lane, bias, act,
+                      accumulate, sm, true);
+}
+#undef SGB
+
 }  // namespace
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
@@ -581,6 +757,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   } while (0)
   // BK = 64 was measured: no gain (the loop is bound by LDS traffic + MFMA, not by load latency)
   static const bool pipe = [] { const char* e = getenv("TSSEP_GEMM_PIPE"); return !e || e[0] != '0'; }();
+  static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
+  if (tall && pipe && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+    const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
+    hipLaunchKernelGGL(gemm_bf16x3_tall_kernel, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
+                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
+                       g->accumulate, sm, tm2);
+    return tssep_launch_status();
+  }
   if (!pipe) {
     DISPATCH(32);
     return tssep_launch_status();
