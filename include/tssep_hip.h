@@ -195,9 +195,13 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
 /* On-chip-weights recurrence on the bf16 matrix cores (lstm_onchip.hip): a cluster of
  * ceil(H/64) workgroups keeps W_hh on chip as split bf16 (hi+lo) and evaluates the recurrent
  * product as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class accuracy), 32 sequences per
- * cluster and step; h travels as fp32 through 16-byte write-through stores + epoch flags.
- * Same tensor layouts as tssep_blstm_fwd/bwd (layout = 0; layout = 1 is an experimental
- * time-major-in-groups-of-32 row order).  H <= 304. */
+ * cluster and step; h / partial dh travel as fp32 in 8-byte {tag, value} granules (the tag carries
+ * a per-launch epoch and the step: the data is the flag).  Clusters are formed from workgroups of
+ * ONE XCD (HW_REG_XCC_ID), so the exchange stays in that XCD's L2.  Same tensor layouts as
+ * tssep_blstm_fwd/bwd.  `layout` bits: 1 = experimental time-major-in-groups-of-32 row order,
+ * 8 = force cross-XCD clusters (write-through exchange).  xbuf: caller-owned scratch of
+ * tssep_lstm_onchip_xbuf_bytes() bytes (zeroed by the call); err: device int, set non-zero if a
+ * bounded spin expired.  max_wgs: number of CUs the launch may occupy.  H <= 304. */
 int tssep_lstm_onchip_supported(int H);
 int64_t tssep_lstm_onchip_pack_floats(int H, int which /* 0: forward, 1: backward */);
 int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, int H, float* wf, float* wb,

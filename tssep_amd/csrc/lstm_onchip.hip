@@ -791,7 +791,7 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
-  if (max_wgs < 8 * (G + 1)) return TSSEP_E_SHAPE;
+  if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, UPW, &items, &pb);
   if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
@@ -800,7 +800,7 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
   // (51 clusters) saves a whole resident round
   const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
-  const bool xcd = !(layout & 8) && !(items > xcd_cap && items <= flat_cap);
+  const bool xcd = !(layout & 8) && xcd_cap > 0 && !(items > xcd_cap && items <= flat_cap);
   int nc;
   const unsigned grid = onchip_grid(items, G, max_wgs, xcd, &nc);
   char* base = (char*)xbuf;
@@ -824,7 +824,7 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   if (!tssep_lstm_onchip_supported(H)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
-  if (max_wgs < 8 * (G + 1)) return TSSEP_E_SHAPE;
+  if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, G * UPW, &items, &pb);
   if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
@@ -833,7 +833,7 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
   // (51 clusters) saves a whole resident round
   const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
-  const bool xcd = !(layout & 8) && !(items > xcd_cap && items <= flat_cap);
+  const bool xcd = !(layout & 8) && xcd_cap > 0 && !(items > xcd_cap && items <= flat_cap);
   int nc;
   const unsigned grid = onchip_grid(items, G, max_wgs, xcd, &nc);
   char* base = (char*)xbuf;
