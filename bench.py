@@ -26,6 +26,7 @@ K_SPK, N_SAMPLES, UNITS, PROJS, FBINS = 4, 64000, 300, 320, 513
 PEAK_F32_MFMA_TFLOPS = 157.3          # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1_16b)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; a bf16x3 GEMM issues 3 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0
+MEASURED_COPY_GBPS = 5300.0           # a plain copy of the mask head's bytes on this part (profiles/r1_maskhead_microbench.jsonl)
 
 
 def synth_batch(B, K, N, seed):
@@ -72,29 +73,67 @@ def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS):
     return pre + K * (b0 + b1) + b2 + 2 * P * F * K
 
 
-def cpu_baseline(seconds_budget=15.0):
+def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
     """The CPU oracle (a port of the reference's torch code path, pinned to it by tests) timed on
     this host: same model size and chunk length, a bounded sample.  Thread count: torch's CPU LSTM
     stops scaling (and collapses under oversubscription) well before the 256 hardware threads of
-    the GPU host, so the faster of 8 / 16 threads is reported together with the count used."""
+    the GPU host, so the faster of 8 / 16 threads is reported together with the count used, plus
+    the single-thread figure (the reference's CI setting, README.md:51-56).  With `hip_model` the
+    same 4 utterances and the same weights also go through the HIP path and the parity of masks,
+    loss and parameter gradients is asserted in this run."""
     from oracle import model as omodel
     torch.manual_seed(0)
     B = 4
     obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, 1234)
-    p = omodel.init_mask_estimator_params(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
-                                          combination="mul", aux_size=FBINS, ts_vad=K_SPK)
+    if hip_model is not None:
+        p = {"mask_estimator." + k: v.detach().cpu().clone()
+             for k, v in hip_model.mask_estimator.state_dict().items()}
+    else:
+        p = omodel.init_mask_estimator_params(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
+                                              combination="mul", aux_size=FBINS, ts_vad=K_SPK)
     for v in p.values():
         v.requires_grad_()
     cfg = dict(odim=FBINS, combination="mul", ts_vad=K_SPK, output_resolution="tf")
     x = [torch.as_tensor(a) for a in (obs, aux, tgt)]
 
-    def one_step():
+    def one_step(keep=False):
         t0 = time.time()
+        np.random.seed(4321)
         o = omodel.forward_loss(p, *x, cfg=cfg, fast=True)
         o["loss"].sum().backward()
+        dt_ = time.time() - t0
+        if not keep:
+            for v in p.values():
+                v.grad = None
+        return dt_, o
+
+    parity = None
+    if hip_model is not None:
+        dev = next(hip_model.parameters()).device
+        ex = dict(observation=x[0].to(dev), auxInput=x[1].to(dev),
+                  speaker_reverberation_early_ch0=x[2].to(dev), reference_channel=0,
+                  dataset=["parity"] * B)
+        opt.zero_grad()
+        np.random.seed(4321)
+        out = hip_model(ex)
+        loss = hip_model.review(ex, out)["loss"]
+        loss.backward()
+        opt.bucket.sync()
+        torch.cuda.synchronize()
+        _, o = one_step(keep=True)
+        merr = float((out.mask.cpu() - o["mask"]).abs().max())
+        lrel = abs(float(loss) - float(o["loss"].sum())) / max(abs(float(o["loss"].sum())), 1e-12)
+        grel = max(float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max()
+                         / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
+                   for k, v in hip_model.mask_estimator.named_parameters())
+        parity = dict(sample=f"batch {B} x 4 s, same weights, same np.random seed", max_abs_mask_err=merr,
+                      rel_loss_err=lrel, max_rel_grad_err=grel, bar_outputs=1e-3, bar_gradients=1e-2)
+        # the north star bounds the OUTPUTS (masks / posteriors) at 1e-3; gradients are reported,
+        # with the looser smoke-test bound (they carry 253 steps of split-bf16 rounding)
+        assert merr < 1e-3 and lrel < 1e-3 and grel < 1e-2, parity
         for v in p.values():
             v.grad = None
-        return time.time() - t0, o["mask"].shape[-2]
+        opt.zero_grad()
 
     best = None
     t_all = time.time()
@@ -102,17 +141,23 @@ def cpu_baseline(seconds_budget=15.0):
         torch.set_num_threads(nt)
         times = []
         while len(times) < 3 or (time.time() - t_all < seconds_budget / 2 and len(times) < 20):
-            dt_, T = one_step()
+            dt_, o = one_step()
             times.append(dt_)
             if time.time() - t_all > 4 * seconds_budget:        # hard stop on a slow host
                 break
-        cand = (min(times[1:]) if len(times) > 1 else times[0], nt, len(times), T)
+        cand = (min(times[1:]) if len(times) > 1 else times[0], nt, len(times), o["mask"].shape[-2])
         best = cand if best is None or cand[0] < best[0] else best
         t_all = time.time()
     step_s, nt, n, T = best
+    torch.set_num_threads(1)
+    one_step()
+    st_s, _ = one_step()
+    torch.set_num_threads(nt)
     return dict(value=round(B * T / step_s, 1), unit="frames/s", cores=nt, kind="port",
+                single_thread_value=round(B * T / st_s, 1),
                 sample=f"CPU oracle fwd+bwd, batch {B} x 4 s, best of {n} steps = {step_s:.3f} s, "
-                       f"torch {torch.__version__}, {nt} threads of {os.cpu_count()} logical CPUs")
+                       f"torch {torch.__version__}, {nt} threads of {os.cpu_count()} logical CPUs",
+                parity_vs_hip=parity)
 
 
 def main():
@@ -234,6 +279,7 @@ def main():
         gbps = by / (ms * 1e-3) / 1e9
         mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
                          peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
+                         frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
                          traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
                          avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l)
     if rank == 0:
@@ -254,7 +300,7 @@ def main():
                                            if args.gemm == "bf16x3" else "exact fp32 MFMA"),
                        "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
             "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(model, opt),
         }
         print(json.dumps(line), flush=True)
     if world > 1:
