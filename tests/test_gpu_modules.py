@@ -135,6 +135,52 @@ def test_model_end_to_end_against_oracle(res, loss_name, gemm_mode):
         close(v.grad, ref, rtol=1e-3, atol=1e-3 * scale + 1e-9, name="d" + k)
 
 
+def test_long_form_8_speakers_against_oracle():
+    """BASELINE configs[4] sizes: 8 speakers, 30 s @ 16 kHz (T = 1878 frames), units 300 / projs 320,
+    one utterance: the whole step (default split-bf16 GEMMs, on-chip recurrences at N = 8 and
+    T = 1878) against the CPU oracle -- masks, loss and every parameter gradient."""
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    from tssep_amd.data import DummyReader
+    from tssep_amd import hip_ops
+    B, K, N = 1, 8, 480000
+    obs, aux, tgt, _ = _example_batch(B, K, N, seed=2)
+    torch.manual_seed(4)
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=300, projs=320, combination="mul",
+                                            aux_net_output_size=513, ts_vad=K, output_resolution="tf"),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+    p = {"mask_estimator." + k: v.detach().cpu().clone().requires_grad_()
+         for k, v in m.mask_estimator.state_dict().items()}
+    np.random.seed(6)
+    o = omodel.forward_loss(p, obs, aux, tgt, cfg=dict(odim=513, combination="mul", ts_vad=K,
+                                                      output_resolution="tf"), fast=True)
+    o["loss"].sum().backward()
+    assert o["mask"].shape[-2] == 1878
+    ex = dict(observation=obs.cuda(), auxInput=aux.cuda(), reference_channel=0,
+              speaker_reverberation_early_ch0=tgt.cuda(), dataset=["long"] * B)
+    old = hip_ops.GEMM_PRECISION
+    hip_ops.GEMM_PRECISION = "bf16x3"
+    try:
+        np.random.seed(6)
+        out = m(ex)
+        summary = m.review(ex, out)
+        summary["loss"].backward()
+        hip_ops.check_cluster_errors()
+    finally:
+        hip_ops.GEMM_PRECISION = old
+    assert tuple(out.mask.shape) == (B, K, 1, 1878, 513)
+    close(out.mask, o["mask"], rtol=1e-3, atol=1e-5, name="mask @ cfg5")
+    close(summary["loss"], o["loss"].sum(), rtol=1e-4, atol=1e-6, name="loss @ cfg5")
+    for k, v in m.mask_estimator.named_parameters():
+        ref = p["mask_estimator." + k].grad
+        close(v.grad, ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()) + 1e-9, name="d" + k)
+
+
 def test_end_to_end_known_answer_of_the_reference():
     """tssep/train/model.py:552-575: validate_LogMAE = 0.74156505 / 0.744494 for the default
     Model config (Log1pMaxNormAbsSTFT, cat, 8 speakers, units 10 / projs 12), 114038 params."""
