@@ -9,27 +9,28 @@
 // of lo bound the per-product relative error by ~2^-16 -- three orders of magnitude inside the
 // 1e-3 parity bar, and unlike plain bf16 it does not eat the LSTM's dynamic range.
 //
-// Tiling: 128x128 output tile, BK = 32, 256 threads (waves 2x2, each 2x2 MFMA tiles -> 64
-// accumulator registers).  One LDS tile set (hi+lo, A+B = 40 KB -> 3 workgroups per CU) with
-// register prefetch of the next K tile: global loads of tile t+1 are issued before the MFMAs of
-// tile t and converted/stored after them.  LDS rows are [row][32 bf16] with an 80-byte pitch:
-// the 16-byte MFMA fragment reads (lane = row) and the 16-byte staging writes of the k-major
-// operands (lane = column) are both bank-conflict free.  k-major ("transposed") operands are read
-// from global memory lane = column (coalesced 4-byte loads), 16 consecutive k per lane, so the
-// transpose costs no extra LDS traffic.
+// Two kernels:
+//  * gemm_bf16x3_pipe_kernel -- 128x128 output tile, K staged 32 at a time, 256 threads (waves 2x2,
+//    each 2x2 MFMA tiles -> 64 accumulator registers), every operand layout (row-major, k-major,
+//    time-shifted k-major), split-K, all epilogues.
+//  * gemm_bf16x3_tall_kernel -- 256x128 tile for row-major x row-major with M >= 1024.
+// Both: two LDS stages (hi+lo, A+B), ONE barrier per K tile, register prefetch of the next-but-one
+// tile, and the split / ds_write / global loads interleaved between the MFMAs by
+// sched_group_barrier.  LDS rows are [row][BK bf16] with a pitch of 2*BK+16 bytes: the 16-byte MFMA
+// fragment reads (lane = row) and the staging writes are bank-conflict free.  k-major
+// ("transposed") operands are read from global memory lane = column (coalesced 4-byte loads), BK/2
+// consecutive k per lane, so the transpose costs no extra LDS traffic.
+// History (measured, profiles/r1_gemm_microbench_bf16x3.jsonl): a first version with one LDS
+// stage and two barriers per tile ran 113-267 TFLOP/s; BK = 64 and naive double buffering changed
+// nothing; the pipelined loop + row epilogue + tall tile run 190-320 TFLOP/s.
 #include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
 
 using namespace gemm_detail;
-// BK = 32 (pitch 80 B) or 64 (pitch 144 B): bytes per LDS row = 2*BK + 16; both pitches put the
-// 16 rows of a ds_read_b128 lane group on 16 distinct 16-byte slots (5r resp. 9r mod 16).
-// Measured (ablation, 64768x2400x513): MFMA + fragment reads alone 0.46 ms, loads + split + LDS
-// stores alone 0.13 ms, together 0.91 ms -- the shared LDS pipe (512 cycles of fragment reads +
-// ~770 cycles of ds_write per tile pair vs 1536 MFMA cycles) is the co-limiter; BK = 64 and a
-// double-buffered LDS were both tried and gave nothing.  The next step is operands pre-split by
-// their producers and staged with global_load_lds (no VALU, no ds_write).
+// bytes per LDS row = 2*BK + 16: the 16 rows of a ds_read_b128 lane group land on 16 distinct
+// 16-byte slots (5r mod 16 for BK = 32)
 template <int BK> struct Cfg {
   static constexpr int PITCH = 2 * BK + 16;
   static constexpr int ARR = BM * PITCH;
@@ -42,231 +43,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // lo half = bf16(a)
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-// split two floats: hi word = {bf16(a), bf16(b)}, lo word = {bf16(a - hi_a), bf16(b - hi_b)}
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  hi = cvt_pk_bf16(a, b);
-  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
-  lo = cvt_pk_bf16(a - ha, b - hb);
-}
-
-// ---- "row" operand (k contiguous): tile 128 rows x 32 k = 1024 float4, 4 per thread -----------
-template <int BK>
-struct RowLoad {
-  const float* p;                       // load 0
-  int64_t step[Cfg<BK>::NL - 1];        // element offsets of the other loads (row + 256/KQ*i, clamped)
-  int kq;
-};
-template <int BK>
-__device__ __forceinline__ RowLoad<BK> make_row_load(const float* P, int64_t ld, int64_t R,
-                                                     int64_t r0, int tid) {
-  constexpr int NL = Cfg<BK>::NL, KQ = Cfg<BK>::KQ;
-  RowLoad<BK> d;
-  d.kq = (tid % KQ) << 2;
-  int64_t rr[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    int64_t r = r0 + tid / KQ + (NTHREADS / KQ) * i;
-    rr[i] = r > R - 1 ? R - 1 : r;
-  }
-  d.p = P + rr[0] * ld + d.kq;
-#pragma unroll
-  for (int i = 0; i < NL - 1; ++i) d.step[i] = (rr[i + 1] - rr[0]) * ld;
-  return d;
-}
-template <int BK, bool TAIL>
-__device__ __forceinline__ void row_load(const RowLoad<BK>& d, int64_t k0, int64_t K,
-                                         f32x4 (&v)[Cfg<BK>::NL]) {
-  const int64_t k = k0 + d.kq;
-  // a 16-byte load that starts at or beyond K would leave the row: read the row start instead
-  const float* p = d.p + ((!TAIL || k < K) ? k0 : -(int64_t)d.kq);
-#pragma unroll
-  for (int i = 0; i < Cfg<BK>::NL; ++i) {
-    f32x4 x = *reinterpret_cast<const f32x4*>(i == 0 ? p : p + d.step[i - 1]);
-    if (TAIL) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = (k + e < K) ? x[e] : 0.f;
-    }
-    v[i] = x;
-  }
-}
-template <int BK>
-__device__ __forceinline__ void row_store(char* hi, char* lo, int tid,
-                                          const f32x4 (&v)[Cfg<BK>::NL]) {
-  constexpr int KQ = Cfg<BK>::KQ;
-#pragma unroll
-  for (int i = 0; i < Cfg<BK>::NL; ++i) {
-    const int off = (tid / KQ + (NTHREADS / KQ) * i) * Cfg<BK>::PITCH + ((tid % KQ) << 3);
-    unsigned h0, l0, h1, l1;
-    split2(v[i][0], v[i][1], h0, l0);
-    split2(v[i][2], v[i][3], h1, l1);
-    *reinterpret_cast<u32x2*>(hi + off) = u32x2{h0, h1};
-    *reinterpret_cast<u32x2*>(lo + off) = u32x2{l0, l1};
-  }
-}
-
-// ---- "col" operand (k-major): lane = column, BK/2 consecutive k per thread -------------------
-struct ColLoad {
-  const float* p;      // P + c (clamped)
-  int khalf;           // 0 / 1: k in [BK/2*khalf, BK/2*khalf + BK/2)
-  bool cvalid;
-};
-__device__ __forceinline__ ColLoad make_col_load(const float* P, int64_t C, int64_t c0, int tid) {
-  ColLoad d;
-  int64_t c = c0 + (tid & 127);
-  d.cvalid = c < C;
-  if (!d.cvalid) c = C - 1;
-  d.p = P + c;
-  d.khalf = tid >> 7;
-  return d;
-}
-template <int BK, bool TAIL, bool SHIFT>
-__device__ __forceinline__ void col_load(const ColLoad& d, int64_t ld, int64_t k0, int64_t K,
-                                         int64_t kshift, int64_t kperiod, float (&v)[Cfg<BK>::NC]) {
-  constexpr int NC = Cfg<BK>::NC;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int64_t k = k0 + d.khalf * NC + i;
-    bool ok = d.cvalid;
-    int64_t kk = k;
-    if (TAIL) {
-      if (k >= K) { ok = false; kk = 0; }
-    }
-    if (SHIFT) {
-      const int64_t ph = (k % kperiod) + kshift;
-      const bool in = ph >= 0 && ph < kperiod;
-      if (ok && in) kk = k + kshift;
-      ok = ok && in;
-    }
-    const float x = d.p[kk * ld];
-    v[i] = ok ? x : 0.f;
-  }
-}
-template <int BK>
-__device__ __forceinline__ void col_store(char* hi, char* lo, int tid, const float (&v)[Cfg<BK>::NC]) {
-  constexpr int NC = Cfg<BK>::NC;
-  const int off = (tid & 127) * Cfg<BK>::PITCH + (tid >> 7) * NC * 2;
-#pragma unroll
-  for (int c = 0; c < NC / 8; ++c) {             // 8 k = 16 bytes per store
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(v[8 * c + 2 * e], v[8 * c + 2 * e + 1], h[e], l[e]);
-    *reinterpret_cast<u32x4*>(hi + off + 16 * c) = u32x4{h[0], h[1], h[2], h[3]};
-    *reinterpret_cast<u32x4*>(lo + off + 16 * c) = u32x4{l[0], l[1], l[2], l[3]};
-  }
-}
-
-template <int BK, bool A_KMAJOR, bool B_KMAJOR, bool SHIFT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
-    int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t b_kshift, int64_t kperiod,
-    const float* __restrict__ bias, int act, int accumulate, StoreMap sm, int splitk,
-    int64_t c_split_stride, TileMap tmap) {
-  constexpr int PITCH = Cfg<BK>::PITCH, ARR = Cfg<BK>::ARR;
-  __shared__ __attribute__((aligned(16))) char lds[4 * ARR];      // A hi, A lo, B hi, B lo
-  char* const a_hi = lds;
-  char* const a_lo = lds + ARR;
-  char* const b_hi = lds + 2 * ARR;
-  char* const b_lo = lds + 3 * ARR;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int mt, nt, zsplit;
-  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
-  const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
-
-  const int64_t ktiles = (K + BK - 1) / BK;
-  const int64_t per = (ktiles + splitk - 1) / splitk;
-  const int64_t kt_begin = (int64_t)zsplit * per;
-  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
-  const int64_t kt_full = K / BK;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  RowLoad<BK> ra_d, rb_d;
-  ColLoad ca_d, cb_d;
-  if (!A_KMAJOR) ra_d = make_row_load<BK>(A, lda, M, m0, tid); else ca_d = make_col_load(A, M, m0, tid);
-  if (!B_KMAJOR) rb_d = make_row_load<BK>(B, ldb, N, n0, tid); else cb_d = make_col_load(B, N, n0, tid);
-
-  f32x4 ra[Cfg<BK>::NL], rb[Cfg<BK>::NL];
-  float ca[Cfg<BK>::NC], cb[Cfg<BK>::NC];
-  auto gload = [&](int64_t kt) {
-    const int64_t k0 = kt * BK;
-    if (kt < kt_full) {
-      if (!A_KMAJOR) row_load<BK, false>(ra_d, k0, K, ra); else col_load<BK, false, false>(ca_d, lda, k0, K, 0, 1, ca);
-      if (!B_KMAJOR) row_load<BK, false>(rb_d, k0, K, rb); else col_load<BK, false, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
-    } else {
-      if (!A_KMAJOR) row_load<BK, true>(ra_d, k0, K, ra); else col_load<BK, true, false>(ca_d, lda, k0, K, 0, 1, ca);
-      if (!B_KMAJOR) row_load<BK, true>(rb_d, k0, K, rb); else col_load<BK, true, SHIFT>(cb_d, ldb, k0, K, b_kshift, kperiod, cb);
-    }
-  };
-  auto sstore = [&]() {
-    if (!A_KMAJOR) row_store<BK>(a_hi, a_lo, tid, ra); else col_store<BK>(a_hi, a_lo, tid, ca);
-    if (!B_KMAJOR) row_store<BK>(b_hi, b_lo, tid, rb); else col_store<BK>(b_hi, b_lo, tid, cb);
-  };
-
-  if (kt_begin < kt_end) {
-    gload(kt_begin);
-    sstore();
-    __syncthreads();
-    // fragment byte offset of this lane inside a 32-row tile: row = lane&31, k group = lane>>5
-    const int foff = (lane & 31) * PITCH + (lane >> 5) * 16;
-    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = kt + 1 < kt_end;
-      if (more) gload(kt + 1);
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int o = (wm * 64 + i * 32) * PITCH + ks * 32 + foff;
-          ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + o);
-          al[i] = *reinterpret_cast<const bf16x8*>(a_lo + o);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int o = (wn * 64 + j * 32) * PITCH + ks * 32 + foff;
-          bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + o);
-          bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + o);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
-      }
-      __syncthreads();              // every wave is done reading this tile
-      if (more) {
-        sstore();
-        __syncthreads();
-      }
-    }
-  }
-  float* Cz = C + (int64_t)zsplit * c_split_stride;
-  gemm_epilogue<2, 2>(acc, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias, act,
-                      accumulate, sm, splitk == 1);
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined variant: two LDS stages (separate arrays, so the compiler knows that the
-// fragment reads of stage t and the staging writes of stage t+1 never alias), ONE barrier per K
-// tile, and the split (VALU) + ds_write of tile t+1 and the global loads of tile t+2 interleaved
-// between the MFMAs of tile t by sched_group_barrier.  A 32x32x16 MFMA occupies the matrix pipe
-// for 32 cycles but its issue slot for 4: the ~110 VALU/LDS/VMEM instructions a wave needs per
-// tile fit in the shadow of its 24 MFMAs.
+// Software pipeline: two LDS stages in SEPARATE arrays (so the compiler knows that the fragment
+// reads of stage t and the staging writes of stage t+1 never alias), one barrier per K tile, and
+// the split (VALU) + ds_write of tile t+1 and the global loads of tile t+2 interleaved between the
+// MFMAs of tile t.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but its issue slot for
+// 4: the ~110 VALU/LDS/VMEM instructions a wave needs per tile fit in the shadow of its 24 MFMAs.
 __device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned& lo) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -739,44 +521,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
                              void* stream) {
-  const TileMap tmap = make_tile_map((g->M + BM - 1) / BM, (g->N + BN - 1) / BN, splitk);
-  dim3 grid((unsigned)tile_map_blocks(tmap));
   hipStream_t s = (hipStream_t)stream;
   const bool shift = g->kperiod > 0;
-#define LAUNCH(BKV, AK, BKM, SH)                                                                 \
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<BKV, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s, g->A,   \
-                     g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod,      \
-                     g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride, tmap)
-#define DISPATCH(BKV)                                                                            \
-  do {                                                                                           \
-    if (!g->a_kmajor && !g->b_kmajor) LAUNCH(BKV, false, false, false);                          \
-    else if (!g->a_kmajor && shift) LAUNCH(BKV, false, true, true);                              \
-    else if (!g->a_kmajor) LAUNCH(BKV, false, true, false);                                      \
-    else if (shift) LAUNCH(BKV, true, true, true);                                               \
-    else LAUNCH(BKV, true, true, false);                                                         \
-  } while (0)
-  // BK = 64 was measured: no gain (the loop is bound by LDS traffic + MFMA, not by load latency)
-  static const bool pipe = [] { const char* e = getenv("TSSEP_GEMM_PIPE"); return !e || e[0] != '0'; }();
   static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
-  if (tall && pipe && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+  if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
     const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
     hipLaunchKernelGGL(gemm_bf16x3_tall_kernel, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
                        g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
                        g->accumulate, sm, tm2);
     return tssep_launch_status();
   }
-  if (!pipe) {
-    DISPATCH(32);
-    return tssep_launch_status();
-  }
-#undef LAUNCH
-#define LAUNCH(BKV, AK, BKM, SH)                                                                 \
-  hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<BKV, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,    \
+  const TileMap tmap = make_tile_map((g->M + BM - 1) / BM, (g->N + BN - 1) / BN, splitk);
+  dim3 grid((unsigned)tile_map_blocks(tmap));
+#define LAUNCH(AK, BKM, SH)                                                                      \
+  hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<32, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,     \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
                      g->kperiod, g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride,  \
                      tmap)
-  DISPATCH(32);
-#undef DISPATCH
+  if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false);
+  else if (!g->a_kmajor && shift) LAUNCH(false, true, true);
+  else if (!g->a_kmajor) LAUNCH(false, true, false);
+  else if (shift) LAUNCH(true, true, true);
+  else LAUNCH(true, true, false);
 #undef LAUNCH
   return tssep_launch_status();
 }
