@@ -129,6 +129,10 @@ typedef struct tssep_gemm_args {
    *     the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
    *     (per-product relative error <= ~2^-16, i.e. fp32-class for the 1e-3 parity bar). */
   int32_t precision;
+  /* k-major B only, precision 1 only: column N-1 of B is VIRTUAL and reads as 1.0 for every valid
+   * k, so column N-1 of C holds the column sums of A -- the bias gradient comes out of the
+   * weight-gradient GEMM that streams d(gates) anyway (B then has N-1 real columns). */
+  int32_t b_ones_col;
 } tssep_gemm_args;
 int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 

@@ -156,6 +156,25 @@ def test_gemm_tn_time_shift(gemm_precision):
         close(out.view(Mg, Hh), ref.float(), rtol=tol, atol=tol, name=f"shift {shift}")
 
 
+def test_gemm_wgrad_with_fused_column_sums():
+    """Split-bf16 weight-gradient GEMM with the virtual all-ones column: column N of the partials
+    is the column sum of dY (bias gradient), columns < N the weight gradient."""
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        torch.manual_seed(5)
+        for R, M, N in ((700, 40, 33), (5000, 260, 128), (3001, 130, 513)):
+            dy = torch.zeros(R, h.round_up(M, 4)); dy[:, :M] = torch.randn(R, M)
+            x = torch.zeros(R, h.round_up(N, 4)); x[:, :N] = torch.randn(R, N)
+            part, S = h.wgrad(dy.cuda(), dy.shape[1], x.cuda(), x.shape[1], M, N, R, with_colsum=True)
+            got = part.view(S, M, h.round_up(N + 1, 4)).sum(0)
+            close(got[:, :N], (dy[:, :M].double().t() @ x[:, :N].double()).float(), rtol=1e-4, atol=1e-3, name="dW")
+            close(got[:, N], dy[:, :M].double().sum(0).float(), rtol=1e-4, atol=1e-3, name="colsum")
+    finally:
+        h.GEMM_PRECISION = old
+
+
 def test_gemm_store_remaps(gemm_precision):
     tol = gemm_precision
     torch.manual_seed(4)

@@ -30,6 +30,7 @@ class GemmArgs(ctypes.Structure):
         ("c_perm", ctypes.c_void_p), ("c_perm_ld", ctypes.c_int64),
         ("splitk", ctypes.c_int32), ("c_split_stride", ctypes.c_int64),
         ("precision", ctypes.c_int32),
+        ("b_ones_col", ctypes.c_int32),
     ]
 
 

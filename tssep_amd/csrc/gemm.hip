@@ -260,7 +260,7 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
   sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
   if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
-  if (g->precision != 0) return TSSEP_E_UNSUPPORTED;
+  if (g->precision != 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
   hipStream_t s = (hipStream_t)stream;
   // columns [0, n_main) by 128-wide tiles; a remainder of <= 96 columns by 32-wide edge tiles

@@ -131,17 +131,22 @@ struct ColLoadU {
   int khalf;
   int ph0;                 // SHIFT: phase of this thread's first k of the NEXT tile to load
   bool cvalid;
+  bool ones;               // this thread's column is the virtual all-ones column
 };
 template <int BK>
 __device__ __forceinline__ ColLoadU make_col_load_u(const float* P, int64_t ld, int64_t C, int64_t c0,
-                                                    int tid, int64_t k_first, int64_t kperiod) {
+                                                    int tid, int64_t k_first, int64_t kperiod,
+                                                    bool ones_col = false) {
   ColLoadU d;
   int64_t c = c0 + (tid & 127);
   d.cvalid = c < C;
-  if (!d.cvalid) c = C - 1;
+  d.ones = ones_col && c == C - 1;
+  if (ones_col) C -= 1;                         // real columns of the matrix in memory
+  if (c > C - 1) c = C - 1;
   d.khalf = tid >> 7;
-  d.base = reinterpret_cast<const char*>(P + c0);
-  d.off = (unsigned)(((c - c0) + d.khalf * (Cfg<BK>::NC) * ld) * 4);
+  const int64_t cb = c0 < C ? c0 : C - 1;      // a tile may start AT the virtual column
+  d.base = reinterpret_cast<const char*>(P + cb);
+  d.off = (unsigned)(((c - cb) + d.khalf * (Cfg<BK>::NC) * ld) * 4);
   d.ph0 = kperiod > 0 ? (int)((k_first + d.khalf * Cfg<BK>::NC) % kperiod) : 0;
   return d;
 }
@@ -166,7 +171,7 @@ __device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, 
         ph = ph + 1 == kperiod ? 0 : ph + 1;
       }
       const float x = *reinterpret_cast<const float*>(col + kk * ld * 4);
-      v[i] = ok ? x : 0.f;
+      v[i] = d.ones ? (ok ? 1.f : 0.f) : (ok ? x : 0.f);
     }
   } else {
     // uniform base biased by |kshift| rows so that the per-thread byte offset stays non-negative
@@ -175,9 +180,10 @@ __device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, 
     const unsigned off0 = d.off + (unsigned)bias;
     const unsigned off_in = (unsigned)((int64_t)off0 + (int64_t)kshift * ld * 4);
     int ph = d.ph0;
+    const float fill = d.ones ? 1.f : 0.f;          // the virtual column: every valid k reads 1
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      bool ok = d.cvalid;
+      bool ok = d.cvalid && !d.ones;
       unsigned off = off0;
       if (SHIFT) {
         const int q = ph + kshift;
@@ -187,7 +193,7 @@ __device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, 
         ph = ph + 1 == kperiod ? 0 : ph + 1;
       }
       const float x = *reinterpret_cast<const float*>(b + (int64_t)i * ld * 4 + off);
-      v[i] = ok ? x : 0.f;
+      v[i] = ok ? x : fill;
     }
   }
   if (SHIFT) d.ph0 = (d.ph0 + BK) % kperiod;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t b_kshift, int64_t kperiod,
     const float* __restrict__ bias, int act, int accumulate, StoreMap sm, int splitk,
-    int64_t c_split_stride, TileMap tmap) {
+    int64_t c_split_stride, TileMap tmap, int b_ones_col) {
   static_assert(BK == 32, "the interleave pattern below is written for two 16-wide k-steps");
   constexpr int PITCH = Cfg<BK>::PITCH, ARR = Cfg<BK>::ARR;
   __shared__ __attribute__((aligned(16))) char lds0[4 * ARR];     // stage 0: A hi, A lo, B hi, B lo
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
   if (!A_KMAJOR) ra_d = make_row_load_u<BK>(A, lda, M, m0, tid);
   else ca_d = make_col_load_u<BK>(A, lda, M, m0, tid, 0, 0);
   if (!B_KMAJOR) rb_d = make_row_load_u<BK>(B, ldb, N, n0, tid);
-  else cb_d = make_col_load_u<BK>(B, ldb, N, n0, tid, kt_begin * BK, SHIFT ? kperiod : 0);
+  else cb_d = make_col_load_u<BK>(B, ldb, N, n0, tid, kt_begin * BK, SHIFT ? kperiod : 0, b_ones_col != 0);
   const int kshift = (int)b_kshift, kper = (int)kperiod;
 
   // ONE register set for the raw (fp32) tile in flight: a second set (loads issued a whole
@@ -523,6 +529,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
                              void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const bool shift = g->kperiod > 0;
+  if (g->b_ones_col && (!g->b_kmajor || shift || g->N < 2)) return TSSEP_E_UNSUPPORTED;
   static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
   if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
     const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
@@ -537,7 +544,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<32, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,     \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
                      g->kperiod, g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride,  \
-                     tmap)
+                     tmap, g->b_ones_col)
   if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false);
   else if (!g->a_kmajor && shift) LAUNCH(false, true, true);
   else if (!g->a_kmajor) LAUNCH(false, true, false);

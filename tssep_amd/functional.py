@@ -139,21 +139,28 @@ class _RNNP(torch.autograd.Function):
                 part, S = H.wgrad((gates, d * 4 * Hh), G, (hout, d * Hp), 2 * Hp, 4 * Hh, Hh, R,
                                   b_kshift=(-1 if d == 0 else 1), kperiod=T)
                 H.reduce_splits(part, S, 4 * Hh * Hh, dwhh[d])
-            part, S = H.wgrad(gates, G, xv, ld_x, G, I, R)
-            cs = H.colsum(gates, G, R, G)
+            # dW_ih and (split-bf16 GEMM) the bias gradient in ONE pass over dgates: a virtual ones
+            # column of x makes column I of the partials the column sums
+            fused = H.fused_colsum()
+            part, S = H.wgrad(gates, G, xv, ld_x, G, I, R, with_colsum=fused)
+            ldp = H.round_up(I + 1, 4) if fused else I
+            if fused:
+                cs, cs_ld, cs_S, cs_stride = (part, I), ldp, S, G * ldp
+            else:
+                cs, cs_ld, cs_S, cs_stride = H.colsum(gates, G, R, G), 1, 1, 0
             if direct:
                 H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, sinks[1], sinks[5], accumulate=True)
-                H.lstm_unpack(part, I, S, G * I, Hh, I, sinks[0], sinks[4], accumulate=True)
+                H.lstm_unpack(part, ldp, S, G * ldp, Hh, I, sinks[0], sinks[4], accumulate=True)
                 for a_, b_ in ((2, 6), (3, 7)):      # b_ih and b_hh receive the same gradient
-                    H.lstm_unpack(cs, 1, 1, 0, Hh, 1, sinks[a_], sinks[b_], accumulate=True)
+                    H.lstm_unpack(cs, cs_ld, cs_S, cs_stride, Hh, 1, sinks[a_], sinks[b_], accumulate=True)
                 return (None,) * 8
             new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)  # noqa: E731
             d_whh, d_whh_r = new(4 * Hh, Hh), new(4 * Hh, Hh)
             H.lstm_unpack(dwhh, Hh, 1, 0, Hh, Hh, d_whh, d_whh_r)
             d_wih, d_wih_r = new(4 * Hh, I), new(4 * Hh, I)
-            H.lstm_unpack(part, I, S, G * I, Hh, I, d_wih, d_wih_r)
+            H.lstm_unpack(part, ldp, S, G * ldp, Hh, I, d_wih, d_wih_r)
             d_b, d_b_r = new(4 * Hh), new(4 * Hh)
-            H.lstm_unpack(cs, 1, 1, 0, Hh, 1, d_b, d_b_r)
+            H.lstm_unpack(cs, cs_ld, cs_S, cs_stride, Hh, 1, d_b, d_b_r)
             return d_wih, d_whh, d_b, d_b.clone(), d_wih_r, d_whh_r, d_b_r, d_b_r.clone()
 
         if direct:

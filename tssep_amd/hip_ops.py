@@ -46,6 +46,9 @@ def kernel_time_summary():
 
 
 def _p(t):
+    """Device pointer of a tensor, or of (tensor, float_offset)."""
+    if isinstance(t, tuple):
+        return ctypes.c_void_p(t[0].data_ptr() + 4 * t[1])
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
@@ -189,7 +192,8 @@ _PREC = {"f32": 0, "bf16x3": 1}
 
 
 def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
-         accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0):
+         accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0,
+         b_ones_col=False):
     """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
     float_offset) tuples) whose data pointers are used as given."""
     L = _lib.lib()
@@ -216,6 +220,7 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
         g.c_perm_ld = remap.get("perm_ld", 0)
     g.splitk, g.c_split_stride = splitk, split_stride
     g.precision = _PREC[GEMM_PRECISION]
+    g.b_ones_col = int(b_ones_col)
     with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K):
         check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
@@ -241,14 +246,23 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     return min(s, 64)
 
 
-def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0):
-    """dW[M,N] = dY[R,M]^T X[R,N] by split-K partials -> (partials [S, M*N], S)."""
-    S = pick_splitk(M, N, R)
+def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False):
+    """dW[M,N] = dY[R,M]^T X[R,N] by split-K partials -> (partials [S, M*N], S).
+    with_colsum (split-bf16 GEMM only): partials are [S, M, round_up(N+1, 4)] and column N holds
+    the column sums of dY (the bias gradient), from a virtual all-ones column of X."""
+    Nc = N + 1 if with_colsum else N
+    ldp = round_up(Nc, 4) if with_colsum else N      # 16-byte rows keep the vector epilogue
+    S = pick_splitk(M, Nc, R)
     dev = dY[0].device if isinstance(dY, tuple) else dY.device
-    part = torch.empty(S, M * N, device=dev, dtype=torch.float32)
-    gemm(dY, ld_dy, X, ld_x, part, N, M, N, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
-         kperiod=kperiod, splitk=S, split_stride=M * N)
+    part = torch.empty(S, M * ldp, device=dev, dtype=torch.float32)
+    gemm(dY, ld_dy, X, ld_x, part, ldp, M, Nc, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
+         kperiod=kperiod, splitk=S, split_stride=M * ldp, b_ones_col=with_colsum)
     return part, S
+
+
+def fused_colsum():
+    """Whether weight-gradient GEMMs can also produce the bias gradient (b_ones_col)."""
+    return GEMM_PRECISION == "bf16x3"
 
 
 def reduce_splits(part, S, count, dst, accumulate=False):
