@@ -135,14 +135,15 @@ def test_gemm_nn_and_tn(M, N, K, gemm_precision):
           atol=tol, name=f"tn splitk={S}")
 
 
-def test_gemm_tn_time_shift(gemm_precision):
-    """dW_hh pairs dgates_t with h_{t-1} (shift -1) / h_{t+1} (shift +1) inside sequences of T."""
+@pytest.mark.parametrize("n,T,Mg,Hh", [(5, 7, 24, 12), (5, 40, 24, 12), (3, 253, 132, 44), (9, 33, 260, 300)])
+def test_gemm_tn_time_shift(n, T, Mg, Hh, gemm_precision):
+    """dW_hh pairs dgates_t with h_{t-1} (shift -1) / h_{t+1} (shift +1) inside sequences of T
+    (T < 32: generic phase arithmetic; T >= 32: the one-boundary-per-tile fast path)."""
     tol = gemm_precision
     torch.manual_seed(3)
     h = H()
-    n, T, Mg, Hh = 5, 7, 24, 12
     dg = torch.randn(n * T, Mg)
-    hh = torch.randn(n * T, Hh)
+    hh = torch.randn(n * T, Hh) / (n * T) ** 0.5       # keeps |result| ~ 1 for the absolute tolerance
     for shift in (-1, 1):
         hs = torch.zeros(n, T, Hh)
         if shift == -1:

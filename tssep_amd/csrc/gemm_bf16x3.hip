@@ -129,9 +129,11 @@ struct ColLoadU {
   const char* base;        // P + c0   (uniform)
   unsigned off;            // ((c clamped) - c0 + khalf * NC * ld) * 4
   int khalf;
-  int ph0;                 // SHIFT: phase of this thread's first k of the NEXT tile to load
+  int ph0;                 // SHIFT: phase (k % kperiod) of the first row of the NEXT tile to load
   bool cvalid;
   bool ones;               // this thread's column is the virtual all-ones column
+  int ph_tile;             // phase of the first row of the tile currently held in registers
+  bool premasked;          // that tile was masked while it was loaded (tail / generic shift)
 };
 template <int BK>
 __device__ __forceinline__ ColLoadU make_col_load_u(const float* P, int64_t ld, int64_t C, int64_t c0,
@@ -147,17 +149,25 @@ __device__ __forceinline__ ColLoadU make_col_load_u(const float* P, int64_t ld, 
   const int64_t cb = c0 < C ? c0 : C - 1;      // a tile may start AT the virtual column
   d.base = reinterpret_cast<const char*>(P + cb);
   d.off = (unsigned)(((c - cb) + d.khalf * (Cfg<BK>::NC) * ld) * 4);
-  d.ph0 = kperiod > 0 ? (int)((k_first + d.khalf * Cfg<BK>::NC) % kperiod) : 0;
+  d.ph0 = kperiod > 0 ? (int)(k_first % kperiod) : 0;      // phase of the tile's first row (uniform)
   return d;
 }
-// tiles must be requested in increasing order, one call per tile (ph0 is advanced here)
-template <int BK, bool TAIL, bool SHIFT>
+// tiles must be requested in increasing order, one call per tile (ph0 is advanced here).
+// SHIFT: 0 = none; 1 = generic time shift (any period, any shift); 2 = fast path for |kshift| = 1
+// and kperiod >= BK: a tile then holds at most ONE row whose shifted partner lies outside its
+// sequence, at the tile-uniform position rbad.
+// Full tiles without the generic shift are loaded RAW and masked by col_mask when they are staged
+// one iteration later: a select at load time sits on the loop-carried value and makes the wave wait
+// for its own prefetch inside the iteration that issued it (measured: the k-major GEMMs lost up to
+// half their rate to that wait).
+template <int BK, bool TAIL, int SHIFT>
 __device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, int64_t K,
                                            int kshift, int kperiod, float (&v)[Cfg<BK>::NC]) {
   constexpr int NC = Cfg<BK>::NC;
+  d.ph_tile = d.ph0;
   if constexpr (TAIL) {           // last K tile only: per-thread 64-bit addresses, rows clamped
     const char* col = d.base + (d.off - (unsigned)((int64_t)d.khalf * NC * ld * 4));
-    int ph = d.ph0;
+    int ph = SHIFT ? (d.ph0 + d.khalf * NC) % kperiod : 0;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int64_t k = k0 + d.khalf * NC + i;
@@ -173,35 +183,51 @@ __device__ __forceinline__ void col_load_u(ColLoadU& d, int64_t ld, int64_t k0, 
       const float x = *reinterpret_cast<const float*>(col + kk * ld * 4);
       v[i] = d.ones ? (ok ? 1.f : 0.f) : (ok ? x : 0.f);
     }
-  } else {
-    // uniform base biased by |kshift| rows so that the per-thread byte offset stays non-negative
-    const int64_t bias = SHIFT ? (int64_t)(kshift < 0 ? -kshift : kshift) * ld * 4 : 0;
-    const char* b = d.base + k0 * ld * 4 - bias;
+    d.premasked = true;
+  } else if constexpr (SHIFT == 1) {
+    // generic shift: the address depends on the row's phase, so the mask is known here anyway
+    const int64_t bias = (int64_t)(kshift < 0 ? -kshift : kshift) * ld * 4;
+    const char* b = d.base + k0 * ld * 4 - bias;          // keeps the lane offsets non-negative
     const unsigned off0 = d.off + (unsigned)bias;
     const unsigned off_in = (unsigned)((int64_t)off0 + (int64_t)kshift * ld * 4);
-    int ph = d.ph0;
-    const float fill = d.ones ? 1.f : 0.f;          // the virtual column: every valid k reads 1
+    int ph = (d.ph0 + d.khalf * NC) % kperiod;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      bool ok = d.cvalid && !d.ones;
-      unsigned off = off0;
-      if (SHIFT) {
-        const int q = ph + kshift;
-        const bool in = q >= 0 && q < kperiod;
-        off = in ? off_in : off0;
-        ok = ok && in;
-        ph = ph + 1 == kperiod ? 0 : ph + 1;
-      }
-      const float x = *reinterpret_cast<const float*>(b + (int64_t)i * ld * 4 + off);
-      v[i] = ok ? x : fill;
+      const int q = ph + kshift;
+      const bool in = q >= 0 && q < kperiod;
+      const float x = *reinterpret_cast<const float*>(b + (int64_t)i * ld * 4 + (in ? off_in : off0));
+      v[i] = (d.cvalid && in) ? x : 0.f;
+      ph = ph + 1 == kperiod ? 0 : ph + 1;
     }
+    d.premasked = true;
+  } else {
+    // raw: SHIFT == 2 reads every row at its shifted position (the caller -- the pipelined loop --
+    // only asks for tiles whose shifted rows all lie inside the matrix)
+    const char* p = d.base + (k0 + (SHIFT == 2 ? kshift : 0)) * ld * 4 + d.off;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) v[i] = *reinterpret_cast<const float*>(p + (int64_t)i * ld * 4);
+    d.premasked = false;
   }
   if (SHIFT) d.ph0 = (d.ph0 + BK) % kperiod;
+}
+// masks of a tile that was loaded raw (see col_load_u)
+template <int BK, int SHIFT>
+__device__ __forceinline__ void col_mask(const ColLoadU& d, int kshift, int kperiod,
+                                         float (&v)[Cfg<BK>::NC]) {
+  constexpr int NC = Cfg<BK>::NC;
+  const bool okc = d.cvalid && !d.ones;
+  const float fill = d.ones ? 1.f : 0.f;            // the virtual column: every valid k reads 1
+  // SHIFT == 2: position (relative to this lane's first row) of the tile's only bad row
+  const int rbad = SHIFT == 2 ? (kshift < 0 ? (kperiod - d.ph_tile) % kperiod : kperiod - 1 - d.ph_tile) -
+                                    d.khalf * NC
+                              : -1;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) v[i] = (okc && i != rbad) ? v[i] : fill;
 }
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
 
-template <int BK, bool A_KMAJOR, bool B_KMAJOR, bool SHIFT>
+template <int BK, bool A_KMAJOR, bool B_KMAJOR, int SHIFT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
     int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t b_kshift, int64_t kperiod,
@@ -244,23 +270,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
   // extra 32 VGPRs cost more in schedule quality than the deeper prefetch returns.
   f32x4 ra[Cfg<BK>::NL], rb[Cfg<BK>::NL];
   float ca[Cfg<BK>::NC], cb[Cfg<BK>::NC];
-  auto gload_full = [&](int64_t kt) {
+  auto gload_full = [&](int64_t kt) {           // steady state: raw tiles (masked when staged)
     const int64_t k0 = kt * BK;
-    if (!A_KMAJOR) row_load_u<BK, false>(ra_d, k0, K, ra); else col_load_u<BK, false, false>(ca_d, lda, k0, K, 0, 1, ca);
+    if (!A_KMAJOR) row_load_u<BK, false>(ra_d, k0, K, ra); else col_load_u<BK, false, 0>(ca_d, lda, k0, K, 0, 1, ca);
     if (!B_KMAJOR) row_load_u<BK, false>(rb_d, k0, K, rb); else col_load_u<BK, false, SHIFT>(cb_d, ldb, k0, K, kshift, kper, cb);
   };
+  constexpr int SHIFT_ANY = SHIFT == 2 ? 1 : SHIFT;      // prologue / drain: any tile, generic shift
   auto gload_any = [&](int64_t kt) {
     const int64_t k0 = kt * BK;
     if (kt < kt_full) {
-      gload_full(kt);
+      if (!A_KMAJOR) row_load_u<BK, false>(ra_d, k0, K, ra); else col_load_u<BK, false, 0>(ca_d, lda, k0, K, 0, 1, ca);
+      if (!B_KMAJOR) row_load_u<BK, false>(rb_d, k0, K, rb); else col_load_u<BK, false, SHIFT_ANY>(cb_d, ldb, k0, K, kshift, kper, cb);
     } else {
-      if (!A_KMAJOR) row_load_u<BK, true>(ra_d, k0, K, ra); else col_load_u<BK, true, false>(ca_d, lda, k0, K, 0, 1, ca);
-      if (!B_KMAJOR) row_load_u<BK, true>(rb_d, k0, K, rb); else col_load_u<BK, true, SHIFT>(cb_d, ldb, k0, K, kshift, kper, cb);
+      if (!A_KMAJOR) row_load_u<BK, true>(ra_d, k0, K, ra); else col_load_u<BK, true, 0>(ca_d, lda, k0, K, 0, 1, ca);
+      if (!B_KMAJOR) row_load_u<BK, true>(rb_d, k0, K, rb); else col_load_u<BK, true, SHIFT_ANY>(cb_d, ldb, k0, K, kshift, kper, cb);
     }
   };
-  auto sstore = [&](char* st) {
+  auto stage = [&](char* st) {
     if (!A_KMAJOR) row_store_n<BK>(st, st + ARR, tid, ra); else col_store_n<BK>(st, st + ARR, tid, ca);
     if (!B_KMAJOR) row_store_n<BK>(st + 2 * ARR, st + 3 * ARR, tid, rb); else col_store_n<BK>(st + 2 * ARR, st + 3 * ARR, tid, cb);
+  };
+  auto sstore_raw = [&](char* st) {             // tiles loaded by gload_full (never premasked
+    if (A_KMAJOR) col_mask<BK, 0>(ca_d, 0, 1, ca);                  // except the generic shift)
+    if (B_KMAJOR && SHIFT != 1) col_mask<BK, SHIFT>(cb_d, kshift, kper, cb);
+    stage(st);
+  };
+  auto sstore = [&](char* st) {                 // tiles loaded by gload_any
+    if (A_KMAJOR && !ca_d.premasked) col_mask<BK, 0>(ca_d, 0, 1, ca);
+    // (a raw B tile of a fast-shift kernel can only come from gload_full: gload_any premasks)
+    if (B_KMAJOR && !cb_d.premasked) col_mask<BK, (SHIFT == 1 ? 0 : SHIFT)>(cb_d, kshift, kper, cb);
+    stage(st);
   };
   const int foff = (lane & 31) * PITCH + (lane >> 5) * 16;
   const int aoff = (wm * 64) * PITCH + foff, boff = 2 * ARR + (wn * 64) * PITCH + foff;
@@ -300,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
   do {                                                                                          \
     constexpr int SID = SID_;                                                                   \
     compute(cur);                                                                               \
-    sstore(nxt);                                                                                \
+    sstore_raw(nxt);                                                                            \
     gload_full((kt_) + 2);                                                                      \
     SGB(0x100, 8);                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 5); SGB(0x200, 1); } \
@@ -317,7 +356,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
     __syncthreads();
     int64_t kt = kt_begin;
     // pipelined pairs while tiles kt+2 and kt+3 exist and are full
-    const int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    // fast shift: the pipelined loads read row k + kshift unconditionally, so they must stay clear
+    // of the matrix's last tile (they never see the first: they start at tile kt_begin + 2)
+    if (SHIFT == 2 && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
     for (; kt < lim; kt += 2) {
       PIPE(lds0, lds1, kt, 1);
       PIPE(lds1, lds0, kt + 1, 2);
@@ -545,11 +587,12 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
                      g->kperiod, g->bias, g->act, g->accumulate, sm, splitk, g->c_split_stride,  \
                      tmap, g->b_ones_col)
-  if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, false);
-  else if (!g->a_kmajor && shift) LAUNCH(false, true, true);
-  else if (!g->a_kmajor) LAUNCH(false, true, false);
-  else if (shift) LAUNCH(true, true, true);
-  else LAUNCH(true, true, false);
+  const bool fast = shift && g->kperiod >= 32 && (g->b_kshift == 1 || g->b_kshift == -1);
+  if (!g->a_kmajor && !g->b_kmajor) LAUNCH(false, false, 0);
+  else if (!g->a_kmajor && shift) { if (fast) LAUNCH(false, true, 2); else LAUNCH(false, true, 1); }
+  else if (!g->a_kmajor) LAUNCH(false, true, 0);
+  else if (shift) { if (fast) LAUNCH(true, true, 2); else LAUNCH(true, true, 1); }
+  else LAUNCH(true, true, 0);
 #undef LAUNCH
   return tssep_launch_status();
 }
