@@ -384,8 +384,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
                        act, accumulate, sm.ldc, splitk == 1);
     return;
   }
-  gemm_epilogue<2, 2>(acc, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias, act,
-                      accumulate, sm, splitk == 1);
+  {
+    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+    gemm_epilogue_rows_remap(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane,
+                             splitk == 1 ? bias : nullptr, splitk == 1 ? act : 0, accumulate, sm);
+  }
 }
 #undef SGB
 
@@ -560,8 +563,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
     }
     return;
   }
-  gemm_epilogue<4, 2>(acc, C, M, N, m0 + (int64_t)wm * 128, n0 + (int64_t)wn * 64, lane, bias, act,
-                      accumulate, sm, true);
+  {
+    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      f32x16 a2[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
+      gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                               lane, bias, act, accumulate, sm);
+    }
+  }
 }
 #undef SGB
 

@@ -171,6 +171,48 @@ __device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], fl
   }
 }
 
+// Same staging for the REMAPPED store (row m = (b*K + k)*T + t, column n = q*cm + r ->
+// b*sb + k*sk + t*st + perm(q)*co + r): a lane owns one column of the 64-wide block, so its column
+// decomposition (q, r) is computed once, the row decomposition once per row (wave-uniform), and a
+// wave instruction writes one row's 64 consecutive columns (runs of <= cm floats are contiguous in
+// the destination).  The per-element variant did two 64-bit divisions per element and ran the
+// logit GEMM at 111 TFLOP/s.
+__device__ __forceinline__ void gemm_epilogue_rows_remap(const f32x16 (&acc)[2][2], float* __restrict__ stage,
+                                                         float* __restrict__ Cz, int64_t M, int64_t N,
+                                                         int64_t mrow0, int64_t ncol0, int lane,
+                                                         const float* __restrict__ bias, int act,
+                                                         int accumulate, const StoreMap& sm) {
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPITCH + j * 32 + col] = acc[i][j][e];
+  const int64_t n = ncol0 + lane;
+  if (n >= N) return;
+  const int64_t cq = n / sm.cm, cr = n - cq * sm.cm;
+  const float bv = bias ? bias[n] : 0.f;
+  int64_t bprev = -1, coff = 0;
+  for (int row = 0; row < 64; ++row) {
+    const int64_t m = mrow0 + row;
+    if (m >= M) break;
+    const int64_t t = m % sm.T, q = m / sm.T;
+    const int64_t k = q % sm.K, b = q / sm.K;
+    if (b != bprev) {            // wave-uniform: the speaker permutation changes with the utterance
+      const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq] : cq;
+      coff = cqq * sm.co + cr;
+      bprev = b;
+    }
+    float v = stage[row * EPITCH + lane] + bv;
+    if (act == 1) v = tanhf(v);
+    float* dst = Cz + b * sm.sb + k * sm.sk + t * sm.st + coff;
+    if (accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 }  // namespace gemm_detail
 
 // split-bf16 (bf16x3) variant, defined in gemm_bf16x3.hip
