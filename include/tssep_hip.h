@@ -43,6 +43,9 @@ const char* tssep_arch(void);
 int tssep_probe_mfma(float* out_4x4, float* out_32x32, void* stream);
 /* out[b] = XCD (HW_REG_XCC_ID) that ran workgroup b of an nblocks x 512-thread launch. */
 int tssep_probe_xcc(int* out, int nblocks, void* stream);
+/* Shader clock under load: out[2b] = s_memtime ticks, out[2b+1] = 100 MHz reference ticks spent by
+ * block b in `iters` x 8 bf16 MFMAs per wave (heavy != 0) or as many s_sleep (heavy == 0). */
+int tssep_probe_clock(int64_t* out, int nblocks, int iters, int heavy, void* stream);
 
 /* ------------------------------------------------------------------- STFT ----
  * paderbox-semantics STFT (fading + end padding + periodic window + rfft, no

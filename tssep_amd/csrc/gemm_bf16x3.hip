@@ -403,7 +403,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // the step.  Per-tile s_memtime profile at K = 320 (61 k cycles): prologue 4 %, K loop 54 % (1850
 // cycles per stage for 768 MFMA cycles per wave: two resident workgroups keep the matrix pipe 83 %
 // busy while both are in their loops), drain 5 %, epilogue 36 % (the 128 KB fp32 C tile: stores
-// back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing.
+// back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing;
+// a persistent grid (512 workgroups walking the tile list) gained 5-9 % standalone on the K <= 600
+// shapes and nothing in the training step.
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
 constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B

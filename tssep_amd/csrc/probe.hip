@@ -47,5 +47,45 @@ extern "C" int tssep_probe_xcc(int* out, int nblocks, void* stream) {
   return tssep_launch_status();
 }
 
+// Shader clock under load: every wave runs `iters` x 8 back-to-back bf16 MFMAs (heavy = 1) or the
+// same number of s_sleep (heavy = 0) and reports s_memtime (shader clock) and wall_clock64 (the
+// constant 100 MHz reference) deltas.  out[2*b] = shader ticks, out[2*b+1] = 100 MHz ticks of block b.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void probe_clock_kernel(long long* out, int iters, int heavy) {
+  pf32x16 a0, a1, a2, a3;
+  for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; a3[e] = 0.f; }
+  pbf16x8 x, y;
+  for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(0.001f * (threadIdx.x + e)); y[e] = (__bf16)(0.002f * e); }
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+    if (heavy) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+    } else {
+      __builtin_amdgcn_s_sleep(16);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = wall_clock64();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = (long long)(t1 - t0) + (a0[0] + a1[1] + a2[2] + a3[3] == 12345.f ? 1 : 0);
+    out[2 * blockIdx.x + 1] = (long long)(w1 - w0);
+  }
+}
+extern "C" int tssep_probe_clock(int64_t* out_, int nblocks, int iters, int heavy, void* stream) {
+  long long* out = reinterpret_cast<long long*>(out_);
+  if (!out) return TSSEP_E_NULL;
+  if (nblocks <= 0 || iters <= 0) return TSSEP_E_SHAPE;
+  hipLaunchKernelGGL(probe_clock_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, out,
+                     iters, heavy);
+  return tssep_launch_status();
+}
+
 extern "C" int tssep_abi_version(void) { return TSSEP_ABI_VERSION; }
 extern "C" const char* tssep_arch(void) { return "gfx950"; }

@@ -96,6 +96,15 @@ def probe_xcc(nblocks=256):
     return out
 
 
+def probe_clock(heavy=True, nblocks=1024, iters=200000):
+    """-> (shader MHz, MFMA TFLOP/s of the probe) under that load."""
+    out = torch.zeros(2 * nblocks, device="cuda", dtype=torch.int64)
+    check(_lib.lib().tssep_probe_clock(_p(out), nblocks, iters, int(heavy), _stream()), "probe_clock")
+    o = out.cpu().view(nblocks, 2).double()
+    mhz = float((o[:, 0] / o[:, 1]).mean() * 100.0)
+    return mhz
+
+
 def probe_mfma():
     L = _lib.lib()
     o4 = torch.zeros(64, 4, device="cuda")
