@@ -405,7 +405,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // busy while both are in their loops), drain 5 %, epilogue 36 % (the 128 KB fp32 C tile: stores
 // back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing;
 // a persistent grid (512 workgroups walking the tile list) gained 5-9 % standalone on the K <= 600
-// shapes and nothing in the training step.
+// shapes and nothing in the training step; a BK = 16 variant of the 128 x 128 kernel at three
+// workgroups per CU (152 VGPRs, 48 KB LDS) was 0-10 % slower than BK = 32 at two.
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
 constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
