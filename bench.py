@@ -256,6 +256,18 @@ def main():
             traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
     except (OSError, KeyError, ValueError):
         pass
+    # MFMA-pipe busy share of the GEMM kernels from a rocprofv3 SQ-counter pass of this same command
+    # (profiles/r1_mfma_pmc.json): the measured counterpart of the algorithmic fraction below
+    mfma_busy = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_mfma_pmc.json")) as f:
+            mp = json.load(f)
+        if (mp["config"]["batch_per_gpu"], mp["config"]["gemm"]) == (B, args.gemm) and world == 1:
+            ks = [v for k, v in mp["kernels"].items() if k.startswith("gemm_")]
+            w = [v["raw"]["SQ_BUSY_CU_CYCLES"] * v["launches"] for v in ks]
+            mfma_busy = round(sum(v["mfma_busy_frac"] * wi for v, wi in zip(ks, w)) / sum(w), 4)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
     # dominant kernel (largest share of the step), timed live with HIP events on its launch stream
     ktimes = H.kernel_time_summary()
     roofline = mask_head = None
@@ -268,6 +280,7 @@ def main():
         roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
                         avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
+                        mfma_pipe_busy_frac_pmc=mfma_busy if name == "gemm_bf16x3" else None,
                         note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
                               "the bf16 MFMA, so frac <= 1/3" if name == "gemm_bf16x3" else
                               "exact fp32 MFMA"))
