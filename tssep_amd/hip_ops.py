@@ -459,7 +459,7 @@ SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"
 ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
 
 
-SIDE_STREAM_MAX_ROWS = 768 * 253     # beyond this the GEMMs of the two streams only slow each other
+SIDE_STREAM_MAX_ROWS = int(_os.environ.get("TSSEP_SIDE_STREAM_MAX_SEQS", 768)) * 253   # beyond this the GEMMs of the two streams only slow each other
 
 
 def side_stream(device, rows=0):
