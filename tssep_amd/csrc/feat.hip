@@ -21,41 +21,53 @@ __device__ __forceinline__ float unord(unsigned u) {
   return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+constexpr int MAXF = 1032;   // LDS line per wave / filter row pitch (F <= 1025)
+constexpr int GSLOTS = 64;   // the batch-global dB maximum is collected in 64 slots, merged by pass 2
+
 struct FeatWs {            // layout of the caller's workspace
-  unsigned* gmax;          // [1]   ordered bits of max dB
+  unsigned* gmax;          // [GSLOTS] ordered bits of max dB (a single address serialised 97 k atomics: 1 ms)
   unsigned* umax;          // [B]   ordered bits of max |X| per utterance
   int* range;              // [2*n_mels]
+  float* fbT;              // [n_mels][MAXF]  filterbank transposed (a filter's support contiguous)
   float* db;               // [B*T*n_mels]
 };
 __host__ __device__ inline FeatWs feat_ws(void* ws, int64_t B, int n_mels) {
   FeatWs w;
   char* p = (char*)ws;
   w.gmax = (unsigned*)p;
-  w.umax = (unsigned*)(p + 16);
-  const int64_t off1 = 16 + ((B * 4 + 15) / 16) * 16;
+  w.umax = (unsigned*)(p + GSLOTS * 4);
+  const int64_t off1 = GSLOTS * 4 + ((B * 4 + 15) / 16) * 16;
   w.range = (int*)(p + off1);
   const int64_t off2 = off1 + (((int64_t)2 * n_mels * 4 + 15) / 16) * 16;
-  w.db = (float*)(p + off2);
+  w.fbT = (float*)(p + off2);
+  w.db = (float*)(p + off2 + (int64_t)n_mels * MAXF * 4);
   return w;
 }
 
-__global__ void feat_init_kernel(void* ws, int64_t B, const float* __restrict__ fb, int F,
-                                 int n_mels) {
+// one wave per mel filter: support [lo,hi) of the filter and its transposed row; block 0 also
+// resets the maxima (a thread-per-filter serial scan of the dense matrix took 190 us)
+__global__ __launch_bounds__(64) void feat_init_kernel(void* ws, int64_t B, const float* __restrict__ fb,
+                                                       int F, int n_mels) {
   FeatWs w = feat_ws(ws, B, n_mels);
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0) *w.gmax = 0u;
-  for (int64_t b = tid; b < B; b += (int64_t)gridDim.x * blockDim.x) w.umax[b] = 0u;
-  if (tid < n_mels) {
-    int lo = F, hi = 0;
-    for (int f = 0; f < F; ++f)
-      if (fb[(int64_t)f * n_mels + tid] != 0.f) { if (f < lo) lo = f; hi = f + 1; }
-    if (hi == 0) lo = 0;
-    w.range[2 * tid] = lo;
-    w.range[2 * tid + 1] = hi;
+  const int lane = threadIdx.x, m = blockIdx.x;
+  if (m == 0) {
+    w.gmax[lane] = 0u;            // GSLOTS == 64 == wave size
+    for (int64_t b = lane; b < B; b += 64) w.umax[b] = 0u;
+  }
+  if (m >= n_mels) return;
+  float lo = (float)F, hi = 0.f;
+  for (int f = lane; f < F; f += 64) {
+    const float v = fb[(int64_t)f * n_mels + m];
+    w.fbT[(int64_t)m * MAXF + f] = v;
+    if (v != 0.f) { lo = fminf(lo, (float)f); hi = fmaxf(hi, (float)(f + 1)); }
+  }
+  lo = -wave_max(-lo);
+  hi = wave_max(hi);
+  if (lane == 0) {
+    w.range[2 * m] = hi == 0.f ? 0 : (int)lo;
+    w.range[2 * m + 1] = (int)hi;
   }
 }
-
-constexpr int MAXF = 1032;   // LDS line per wave (F <= 1025)
 
 __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restrict__ X, int64_t B,
                                                          int64_t T, int F,
@@ -81,17 +93,30 @@ __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restric
   amax = wave_max(amax);
   if (lane == 0) atomicMax(w.umax + frame / T, ord(amax));
   if (n_mfcc > 0) {
+    // all 64 lanes share every filter's band (fixed-order butterfly sum: deterministic); lane
+    // m % 64 keeps the result.  A lane per filter walked the widest band (~100 bins) serially
+    // through dependent, strided global loads of the filterbank.
     float dbmax = -INFINITY;
-    for (int m = lane; m < n_mels; m += 64) {
-      const int lo = w.range[2 * m], hi = w.range[2 * m + 1];
-      float s = 0.f;
-      for (int f = lo; f < hi; ++f) s = fmaf(pw[wave][f], fb[(int64_t)f * n_mels + m], s);
-      const float db = 10.0f * log10f(fmaxf(s, 1e-10f));
-      w.db[frame * n_mels + m] = db;
-      dbmax = fmaxf(dbmax, db);
+    for (int m0 = 0; m0 < n_mels; m0 += 64) {
+      float mine = 0.f;
+      const int mm = n_mels - m0 < 64 ? n_mels - m0 : 64;
+      for (int j = 0; j < mm; ++j) {
+        const int m = m0 + j;
+        const int lo = w.range[2 * m], hi = w.range[2 * m + 1];
+        const float* frow = w.fbT + (int64_t)m * MAXF;
+        float s = 0.f;
+        for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
+        s = wave_sum(s);
+        if (lane == j) mine = s;
+      }
+      if (lane < mm) {
+        const float db = 10.0f * log10f(fmaxf(mine, 1e-10f));
+        w.db[frame * n_mels + m0 + lane] = db;
+        dbmax = fmaxf(dbmax, db);
+      }
     }
     dbmax = wave_max(dbmax);
-    if (lane == 0) atomicMax(w.gmax, ord(dbmax));
+    if (lane == 0) atomicMax(w.gmax + (blockIdx.x & (GSLOTS - 1)), ord(dbmax));
   }
 }
 
@@ -108,7 +133,7 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
   const bool valid = frame < B * T;
   float* o = out + (valid ? frame : 0) * ld_out;
   if (n_mfcc > 0) {
-    const float floor_db = unord(*w.gmax) - top_db;
+    const float floor_db = wave_max(unord(w.gmax[lane])) - top_db;      // merge the 64 slots
     for (int m0 = 0; m0 < n_mels; m0 += 64) {   // n_mels <= 64 in every config; loop kept general
       if (valid && m0 + lane < n_mels)
         dbl[wave][lane] = fmaxf(w.db[frame * n_mels + m0 + lane], floor_db);
@@ -138,7 +163,7 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
 
 extern "C" int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels) {
   FeatWs w = feat_ws(nullptr, B, n_mels);
-  return (int64_t)((char*)w.db - (char*)nullptr) + B * T * (int64_t)n_mels * 4 + 16;
+  return (int64_t)((char*)w.db - (char*)nullptr) + B * T * (int64_t)n_mels * 4 + 16;       // incl. fbT
 }
 
 extern "C" int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F, const float* fb,
@@ -152,8 +177,7 @@ extern "C" int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F, const
   if ((((uintptr_t)X) & 7u) || (((uintptr_t)ws) & 15u)) return TSSEP_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int nm = n_mels > 0 ? n_mels : 1;
-  hipLaunchKernelGGL(feat_init_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, ws, B,
-                     fb, F, n_mels);
+  hipLaunchKernelGGL(feat_init_kernel, dim3((unsigned)nm), dim3(64), 0, s, ws, B, fb, F, n_mels);
   const unsigned blocks = (unsigned)((B * T + 3) / 4);
   hipLaunchKernelGGL(feat_pass1_kernel, dim3(blocks), dim3(256), 0, s, (const float2*)X, B, T, F,
                      fb, n_mels, n_mfcc, ws);
