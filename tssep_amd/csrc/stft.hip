@@ -21,6 +21,12 @@ namespace {
 constexpr int NH = 512;          // complex FFT length
 constexpr int LINE = NH + NH / 8;  // padded LDS line (float2)
 #define PADI(i) ((i) + ((i) >> 3))
+#define WAVE_SYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -48,16 +54,18 @@ __device__ __forceinline__ void fft8(float2 (&v)[8]) {
 }
 
 // 512-point forward FFT by one wave.  In: v[r] = z[lane + 64 r].  Out: buf[PADI(k)] = Z[k].
-// twl[k] = exp(-2 pi i k / 512) (LDS copy).  Every wave of the block must call it
-// (block-wide barriers keep the compiler from reordering the LDS hand-offs).
+// twl[k] = exp(-2 pi i k / 512) (LDS copy).  The line is private to the wave: LDS operations of one
+// wave execute in order, so the hand-offs between lanes need only a wave-level fence (the compiler
+// must not reorder them) -- block-wide barriers here coupled the 4 independent waves of a block
+// five times per frame.
 __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* buf, const float2* twl, int lane) {
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[PADI(8 * lane + r)] = v[r];
-  __syncthreads();
+  WAVE_SYNC();
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[PADI(lane + 64 * r)];
-  __syncthreads();
+  WAVE_SYNC();
   {
     const int k = lane & 7;
 #pragma unroll
@@ -67,16 +75,16 @@ __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* buf, const f
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf[PADI(d + 8 * r)] = v[r];
   }
-  __syncthreads();
+  WAVE_SYNC();
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[PADI(lane + 64 * r)];
-  __syncthreads();
+  WAVE_SYNC();
 #pragma unroll
   for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twl[lane * r]);
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[PADI(lane + 64 * r)] = v[r];
-  __syncthreads();
+  WAVE_SYNC();
 }
 
 // frames -> rfft.  Used as the STFT (window = analysis window, scales 1) and as the adjoint of
@@ -100,14 +108,23 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
     const int64_t t = valid ? fidx - row * T : 0;
     const int64_t base = t * shift - pad_left;
     const float* xr = x + row * N;
+    // (row * N + base) even and x 8-byte aligned -> the sample pair is one aligned float2
+    const bool pair_ok = (((row * N + base) & 1) == 0) && ((((uintptr_t)x) & 7u) == 0);
     float2 v[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int n2 = 2 * (lane + 64 * r);
       const int64_t i0 = base + n2;
-      const float a = (valid && i0 >= 0 && i0 < N) ? xr[i0] * window[n2] : 0.f;
-      const float b = (valid && i0 + 1 >= 0 && i0 + 1 < N) ? xr[i0 + 1] * window[n2 + 1] : 0.f;
-      v[r] = make_float2(a, b);
+      float a = 0.f, b = 0.f;
+      if (valid && pair_ok && i0 >= 0 && i0 + 1 < N) {            // both samples inside: one 8-byte load
+        const float2 xv = *reinterpret_cast<const float2*>(xr + i0);
+        a = xv.x; b = xv.y;
+      } else if (valid) {
+        if (i0 >= 0 && i0 < N) a = xr[i0];
+        if (i0 + 1 >= 0 && i0 + 1 < N) b = xr[i0 + 1];
+      }
+      const float2 wv = *reinterpret_cast<const float2*>(window + n2);
+      v[r] = make_float2(a * wv.x, b * wv.y);
     }
     float2* buf = line[wave];
     fft512_wave(v, buf, twl, lane);
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
         Xo[NH] = make_float2((z0.x - z0.y) * s_edge, 0.f);
       }
     }
-    __syncthreads();
+    WAVE_SYNC();          // the line is rewritten by this wave's next frame
   }
 }
 
