@@ -211,8 +211,9 @@ __global__ __launch_bounds__(256) void istft_kernel(
       const float2 w = *reinterpret_cast<const float2*>(wsyn + 2 * n);
       *reinterpret_cast<float2*>(&fr[lf][2 * n]) = make_float2(z.x * inv * w.x, -z.y * inv * w.y);
     }
-    __syncthreads();
+    WAVE_SYNC();          // the wave's line is reused by its next frame; fr rows are disjoint
   }
+  __syncthreads();        // all NFR windowed frames parked
   // overlap-add + un-fade + truncate
   const int64_t n0 = (int64_t)c * HC * 256;
   float* yr = y + row * N;
