@@ -27,17 +27,19 @@ __device__ __forceinline__ void cond_row(int64_t row, int64_t K, int64_t T, int 
   spk = k + tr;
   if (spk >= K) spk -= K;
 }
-__global__ void cond_mul_fwd_kernel(const float* __restrict__ pre, int64_t ld_pre,
-                                    const float* __restrict__ aux, int64_t ld_aux,
-                                    float* __restrict__ xs, int64_t ld_xs, int64_t B, int64_t K,
-                                    int64_t T, int F, int trials) {
-  const int64_t total = B * trials * K * T * F;
-  GRID_STRIDE(e, total) {
-    const int64_t row = e / F;
-    const int f = (int)(e - row * F);
+// one wave per output row: the row decomposition (3 divisions) once per row instead of per element
+__global__ __launch_bounds__(256) void cond_mul_fwd_kernel(
+    const float* __restrict__ pre, int64_t ld_pre, const float* __restrict__ aux, int64_t ld_aux,
+    float* __restrict__ xs, int64_t ld_xs, int64_t B, int64_t K, int64_t T, int F, int trials) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rows = B * trials * K * T;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
     int64_t b, t, spk;
     cond_row(row, K, T, trials, b, t, spk);
-    xs[row * ld_xs + f] = pre[(b * T + t) * ld_pre + f] * aux[(b * K + spk) * ld_aux + f];
+    const float* p = pre + (b * T + t) * ld_pre;
+    const float* a = aux + (b * K + spk) * ld_aux;
+    float* o = xs + row * ld_xs;
+    for (int f = lane; f < F; f += 64) o[f] = p[f] * a[f];
   }
 }
 __global__ void cond_mul_bwd_kernel(const float* __restrict__ dxs, int64_t ld_dxs,
@@ -291,27 +293,27 @@ __global__ void logit_map_fwd_kernel(const float* __restrict__ raw, MapArgs a,
     out[e] = a.trials == 1 ? acc : acc * inv;
   }
 }
-// draw (raw layout) <- dout [B,K,T,F]
-__global__ void logit_map_bwd_tf_kernel(const float* __restrict__ dout, MapArgs a,
-                                        float* __restrict__ draw) {
-  const int64_t total = a.B * a.trials * a.T * a.K * a.F;
+// draw (raw layout) <- dout [B,K,T,F]: one wave per run of F contiguous raw elements (one
+// (b, trial, t, k)); the index decomposition once per run instead of five divisions per element
+__global__ __launch_bounds__(256) void logit_map_bwd_tf_kernel(const float* __restrict__ dout, MapArgs a,
+                                                               float* __restrict__ draw) {
+  const int lane = threadIdx.x & 63;
+  const int64_t runs = a.B * a.trials * a.T * a.K;
   const float inv = 1.0f / (float)a.trials;
-  GRID_STRIDE(e, total) {
-    // decode e as raw index
-    int64_t b, t; int tr, k, f;
+  for (int64_t u = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); u < runs; u += (int64_t)gridDim.x * 4) {
+    int64_t b, t; int tr, k;
     if (a.spk_rows) {
-      const int64_t row = e / a.F; f = (int)(e - row * a.F);
-      t = row % a.T; const int64_t bk = row / a.T; k = (int)(bk % a.K); b = bk / a.K; tr = 0;
+      t = u % a.T; const int64_t bk = u / a.T; k = (int)(bk % a.K); b = bk / a.K; tr = 0;
     } else {
-      const int64_t row = e / (a.K * a.F); const int64_t c = e - row * (a.K * a.F);
-      k = (int)(c / a.F); f = (int)(c - (int64_t)k * a.F);
+      k = (int)(u % a.K); const int64_t row = u / a.K;
       t = row % a.T; const int64_t bt = row / a.T; tr = (int)(bt % a.trials); b = bt / a.trials;
     }
     int s = k + tr;
     if (s >= a.K) s -= (int)a.K;
     const int j = a.perm ? a.perm[b * a.K + s] : s;
-    const float v = dout[((b * a.K + j) * a.T + t) * a.F + f];
-    draw[e] = a.trials == 1 ? v : v * inv;
+    const float* src = dout + ((b * a.K + j) * a.T + t) * a.F;
+    float* dst = draw + u * a.F;
+    for (int f = lane; f < a.F; f += 64) dst[f] = a.trials == 1 ? src[f] : src[f] * inv;
   }
 }
 __global__ __launch_bounds__(256) void logit_map_bwd_t_kernel(const float* __restrict__ dout,
@@ -346,7 +348,7 @@ extern "C" int tssep_cond_mul_fwd(const float* pre, int64_t ld_pre, const float*
                                   int64_t T, int F, int trials, void* stream) {
   if (!pre || !aux || !xs) return TSSEP_E_NULL;
   if (B <= 0 || K <= 0 || T <= 0 || F <= 0 || trials <= 0 || trials > K) return TSSEP_E_SHAPE;
-  hipLaunchKernelGGL(cond_mul_fwd_kernel, dim3(grid_for(B * trials * K * T * F)), dim3(256), 0, S_,
+  hipLaunchKernelGGL(cond_mul_fwd_kernel, dim3(grid_for(B * trials * K * T * 64)), dim3(256), 0, S_,
                      pre, ld_pre, aux, ld_aux, xs, ld_xs, B, K, T, F, trials);
   return tssep_launch_status();
 }
@@ -497,7 +499,7 @@ extern "C" int tssep_logit_map_bwd(const float* dout, const int32_t* perm, const
     hipLaunchKernelGGL(logit_map_bwd_t_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, S_,
                        dout, a, draw);
   } else {
-    hipLaunchKernelGGL(logit_map_bwd_tf_kernel, dim3(grid_for(B * trials * T * K * F)), dim3(256),
+    hipLaunchKernelGGL(logit_map_bwd_tf_kernel, dim3(grid_for(B * trials * T * K * 64)), dim3(256),
                        0, S_, dout, a, draw);
   }
   return tssep_launch_status();
