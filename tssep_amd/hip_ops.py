@@ -84,8 +84,9 @@ def rows_view(t):
 def padded(rows, cols, device, zero=False):
     """[rows, cols] view of a buffer with leading dimension round_up(cols, 4)."""
     ld = round_up(cols, 4)
-    buf = (torch.zeros if zero or ld != cols else torch.empty)(rows, ld, device=device,
-                                                              dtype=torch.float32)
+    buf = torch.empty(rows, ld, device=device, dtype=torch.float32)
+    if ld != cols:            # only the pad columns need a defined value (the producers write the rest)
+        buf[:, cols:].zero_()
     return buf, ld
 
 
@@ -183,7 +184,9 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
         fb, dct = _f32(fb).contiguous(), _f32(dct).contiguous()
     D = n_mfcc + F
     ld = round_up(D, 4)
-    out = torch.zeros(B, T, ld, device=X.device, dtype=torch.float32)
+    out = torch.empty(B, T, ld, device=X.device, dtype=torch.float32)
+    if ld != D:
+        out[..., D:].zero_()
     ws = torch.empty(int(L.tssep_feat_workspace_bytes(B, T, max(n_mels, 1))) // 4 + 4,
                      device=X.device, dtype=torch.float32)
     check(L.tssep_feat_fwd(_p(Xr), B, T, F, _p(fb) if n_mfcc else None,
