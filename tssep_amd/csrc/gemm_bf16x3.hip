@@ -406,7 +406,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing;
 // a persistent grid (512 workgroups walking the tile list) gained 5-9 % standalone on the K <= 600
 // shapes and nothing in the training step; a BK = 16 variant of the 128 x 128 kernel at three
-// workgroups per CU (152 VGPRs, 48 KB LDS) was 0-10 % slower than BK = 32 at two.
+// workgroups per CU (152 VGPRs, 48 KB LDS) was 0-10 % slower than BK = 32 at two; half-width (128 x 64)
+// edge tiles for N = 513 / 514 / 300 (20-25 % of the columns of the last 128-wide tile are padding)
+// cost as much as the padding they remove -- as a second launch they also serialise behind the main
+// one (+5..12 % on the split-K shapes).
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
 constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
