@@ -197,8 +197,8 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
 
 # ------------------------------------------------------------------------------- GEMM
 # Arithmetic of the non-recurrent GEMMs: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 on the
-# bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The LSTM
-# recurrences always run exact fp32.
+# bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The recurrence
+# kernel (exact fp32 or split-bf16) is chosen separately by recurrence_kernel().
 GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
 _PREC = {"f32": 0, "bf16x3": 1}
 
