@@ -167,8 +167,8 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 384)),
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),

@@ -9,7 +9,7 @@ TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep na
 TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
 for b in 8 32 64 128 160 192 256 384 512 768; do
-  python bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
+  python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
 python bench.py > $O/bench_default.json 2>$O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 > $O/stats.log 2>&1
