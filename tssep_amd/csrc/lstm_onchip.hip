@@ -107,7 +107,10 @@ __device__ __forceinline__ Membership join_cluster(unsigned* xhead, int G, int n
       const int cl = t / G;
       int ok = 0;
       if (cl < CL_PER_XCD) {
-        for (;;) {
+        // bounded (~ seconds): two W-stationary launches running CONCURRENTLY could each hold CUs
+        // with half-formed clusters and starve the other's missing members; this library never
+        // does that (one compute stream), a caller who does gets ok = 0 / a peer timeout, not a hang
+        for (int spins = 0; spins < (SPIN_LIMIT << 1); ++spins) {
           if ((int)ld_agent(xhead + 8 + xcd) >= (cl + 1) * G) { ok = 1; break; }
           if (ld_agent(xhead) >= gridDim.x) { ok = (int)ld_agent(xhead + 8 + xcd) >= (cl + 1) * G; break; }
           __builtin_amdgcn_s_sleep(8);
