@@ -303,6 +303,50 @@ def test_recurrence_kernels_interchangeable_at_full_size():
             close(a, b, rtol=1e-3, atol=1e-3 * float(b.abs().max()) + 1e-9, name=kind + " " + name)
 
 
+def test_step_is_bitwise_reproducible():
+    """Same inputs, same seeds -> bit-identical masks and gradients, run after run (fixed-order
+    reductions everywhere: split-K partials, granule sums, ordered-bits atomic maxima; dynamic work
+    claiming and stream overlap do not touch the arithmetic)."""
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    from tssep_amd.data import DummyReader
+    from tssep_amd.distributed import GradBucket
+    from tssep_amd import hip_ops
+    B, K, N = 6, 4, 64000
+    obs, aux, tgt, _ = _example_batch(B, K, N, seed=9)
+    torch.manual_seed(9)
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=300, projs=320, combination="mul",
+                                            aux_net_output_size=513, ts_vad=K, output_resolution="tf"),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+    bucket = GradBucket(m.parameters())
+    ex0 = dict(observation=obs.cuda(), auxInput=aux.cuda(), reference_channel=0,
+               speaker_reverberation_early_ch0=tgt.cuda(), dataset=["r"] * B)
+    old = hip_ops.GEMM_PRECISION
+    hip_ops.GEMM_PRECISION = "bf16x3"
+    runs = []
+    try:
+        for _ in range(3):
+            bucket.zero()
+            np.random.seed(11)
+            ex = dict(ex0)
+            out = m(ex)
+            m.review(ex, out)["loss"].backward()
+            bucket.sync()
+            torch.cuda.synchronize()
+            hip_ops.check_cluster_errors()
+            runs.append((out.mask.detach().clone(), bucket.flat.clone()))
+    finally:
+        hip_ops.GEMM_PRECISION = old
+    for mask, flat in runs[1:]:
+        assert torch.equal(mask, runs[0][0])
+        assert torch.equal(flat, runs[0][1])
+
+
 def test_direct_grad_sink_matches_autograd():
     """Weight gradients accumulated straight into the GradBucket on the side stream equal the
     gradients returned through autograd (and accumulate over two backward passes)."""
