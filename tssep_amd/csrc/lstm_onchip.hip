@@ -251,7 +251,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];      // h_t  [seq][unit]
   __shared__ __attribute__((aligned(16))) float cellb[SEQS * PUBPITCH];    // c_t  [seq][unit]
-  __shared__ __attribute__((aligned(16))) float xg[2][SEQS * XPITCH];      // gates [seq][unit][4]
+  // gate tiles, three in rotation (step+2 arriving by LDS-DMA, step+1 waiting, step in use /
+  // being flushed).  The image is lane-linear, as global_load_lds writes it: f32x4 index
+  // ((s/16)*4 + unit/16)*256 + (s%16)*16 + ((unit%16) ^ (s%16)) -- the XOR is applied to the SOURCE
+  // address of the DMA so that the cell update's reads (fixed unit, 32 sequences) spread over the banks
+  __shared__ f32x4 xg[3][SEQS * UPW];
   __shared__ int s_fail, s_mem[4];
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,30 +302,26 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     const __amdgpu_buffer_rsrc_t prs =
         __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * UPW * 8, 0x00020000);
 
-    // ---- io waves: row-contiguous HBM access, thread <-> (rows s2 / s2+16, units 16 q + uq)
-    f32x4 rg[2][4];
-    auto io_load = [&](int64_t step_) {
+    // ---- io waves: row-contiguous HBM access, lane <-> (row s2 (+16), unit 16 q + (uq ^ s2))
+    const int iow = (tid & 255) >> 6;                    // io wave index 0..3 (rows 4 iow .. + 3)
+    const int usw = uq ^ s2;                             // this lane's unit within a 16-unit block
+    // asynchronous HBM -> LDS copy of the gate tile of step_ (no registers, returns immediately)
+    auto io_dma = [&](int64_t step_, int b_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int64_t ns = seq0 + s2 + 16 * hf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int u = 64 * g + 16 * q + uq;
-          rg[hf][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int u = 64 * g + 16 * q + usw;
           if (ns < N && u < H)
-            rg[hf][q] = *reinterpret_cast<const f32x4*>(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4),
+                (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64], 16, 0, 0);
         }
       }
     };
-    auto io_park = [&](int buf) {
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<f32x4*>(&xg[buf][(s2 + 16 * hf) * XPITCH + (16 * q + uq) * 4]) = rg[hf][q];
-    };
-    auto io_flush = [&](int64_t step_, int buf) {
+    auto io_flush = [&](int64_t step_, int b_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -332,10 +332,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         const int64_t rowh = ROW(ns, t_) * ldo + dir * dstride;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int u = 64 * g + 16 * q + uq;
-          if (u < H)
-            *reinterpret_cast<f32x4*>(gates + (rowg + u) * 4) =
-                *reinterpret_cast<const f32x4*>(&xg[buf][s * XPITCH + (16 * q + uq) * 4]);
+          const int u = 64 * g + 16 * q + usw;
+          if (u < H) *reinterpret_cast<f32x4*>(gates + (rowg + u) * 4) = xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane];
         }
         const int u4 = 64 * g + 4 * uq;
         const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s * PUBPITCH + 4 * uq);
@@ -353,18 +351,17 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         }
       }
     };
-    if (io_wave) {
-      io_load(0);
-      io_park(0);
-      if (T > 1) {
-        io_load(1);
-        io_park(1);
-      }
-    }
+    // cells outside H / N keep a defined (zero) pre-activation: the DMA skips them
+    for (int i = tid; i < 3 * SEQS * UPW; i += 512) (&xg[0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    if (io_wave) {
+      io_dma(0, 0);
+      if (T > 1) io_dma(1, 1);
+    }
+    __syncthreads();          // (a barrier drains the copies in flight: vmcnt(0))
+    int buf = 0;              // step % 3
 
     for (int64_t step = 0; step < T; ++step) {
-      const int buf = (int)(step & 1);
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -435,10 +432,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       // pre-activations come from xg[buf] and the activations replace them in place
       {
         f32x4 hv, cv;
-        float* xrow = &xg[buf][j * XPITCH + ul0 * 4];
+        f32x4* xrow = &xg[buf][((j >> 4) * 4 + (ul0 >> 4)) * 256 + (j & 15) * 16];
+        const int uq0 = ul0 & 15, sx = j & 15;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 gx = *reinterpret_cast<const f32x4*>(xrow + 4 * q);
+          const f32x4 gx = xrow[(uq0 + q) ^ sx];
           const float a0 = acc[4 * q + 0] + gx[0], a1 = acc[4 * q + 1] + gx[1];
           const float a2 = acc[4 * q + 2] + gx[2], a3 = acc[4 * q + 3] + gx[3];
           const float ig = fast_sigmoid(a0), fg = fast_sigmoid(a1);
@@ -446,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
           const float cn = fg * c[q] + ig * gg;
           c[q] = cn;
           cv[q] = cn;
-          *reinterpret_cast<f32x4*>(xrow + 4 * q) = f32x4{ig, fg, gg, og};
+          xrow[(uq0 + q) ^ sx] = f32x4{ig, fg, gg, og};
           hv[q] = (unit0 + q < H) ? og * fast_tanh(cn) : 0.f;
         }
         *reinterpret_cast<f32x4*>(pub + j * PUBPITCH + ul0) = hv;
@@ -469,17 +467,15 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
               u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, AUXS);
         }
       } else {
-        // ---- io waves: activations / cell / h of this step -> HBM, then the pre-activations of
-        // step+2 into the buffer just flushed.  (Load and park stay in this arm so that the 32
-        // load registers are live only while these waves have nothing else to do -- held across
-        // the MFMA loop they spilled 29 VGPRs; the HBM latency is covered by the exchange waves'
-        // publish -> gather round trip that runs at the same time.)
+        // ---- io waves: start the copy of step+2's pre-activations (into the tile flushed a step
+        // ago) BEFORE the stores of this step's activations / cell / h: the memory counter retires
+        // in order, so loads issued after the stores would also wait for their acknowledgements
+        int b2 = buf + 2;
+        if (b2 >= 3) b2 -= 3;
+        if (step + 2 < T) io_dma(step + 2, b2);
         io_flush(step, buf);
-        if (step + 2 < T) {
-          io_load(step + 2);
-          io_park(buf);
-        }
       }
+      buf = buf == 2 ? 0 : buf + 1;
     }
     __syncthreads();
   }
