@@ -300,6 +300,40 @@ int tssep_logit_map_bwd(const float* dout, const int32_t* perm, const int32_t* i
                         int trials, int64_t K, int64_t T, int F, int Fr, int spk_rows,
                         float* draw, void* stream);
 
+/* ------------------------------------------------- mask-based MVDR beamformer ----
+ * Eval-time enhancer TorchBF('mvdr_souden') of the reference, tssep/train/enhancer.py:140-265, in
+ * complex128 as there (the reference asserts Observation.dtype == complex128, :224):
+ *   psd_m[k,f]  = sum_t w_m[k,t,f] Y[:,t,f] Y[:,t,f]^H     w_0 = mask 0 (target),
+ *                                                          w_1 = mask 1, or 1 - mask 0 when M == 1
+ *   phi         = psd_1^-1 psd_0     (LU, partial pivoting = torch.linalg.solve / zgesv)
+ *   bf[k,f,:]   = phi[:, reference_channel] / max(Re trace(phi), eps)
+ *   enh[k,t,f]  = sum_d conj(bf[k,f,d]) Y[d,t,f]     (* max(mask 0, masking_eps) if masking)
+ * obs  [B,D,T,F] complex128 (interleaved re,im doubles), D <= 8
+ * masks [B,K,M,T,F] fp32 (mask_f64 = 0) or fp64 (mask_f64 = 1), M in {1,2}
+ * enh  [B,K,T,F] complex128.      eps: pass DBL_MIN for the reference's eps=None.
+ * info[0] (device int) receives the number of (b,k,f) systems with an exactly zero pivot
+ * (torch.linalg.solve raises for those; the host mirror does the same).
+ * Algorithmic HBM bytes: 2 * 16*D*T*F (Y for the statistics, Y again for the filtering)
+ *   + K*M*T*F*sizeof(mask) + 16*K*T*F, per batch element.
+ * The three stages are exported for tests and profiling; _souden_fwd runs them back to back on
+ * `stream` out of one caller-owned workspace of tssep_mvdr_workspace_bytes().  No host sync. */
+int64_t tssep_mvdr_partial_bytes(int64_t B, int K, int D, int64_t T, int F);
+int64_t tssep_mvdr_workspace_bytes(int64_t B, int K, int D, int64_t T, int F);
+int tssep_mvdr_psd(const double* obs, const void* masks, int mask_f64, double* partials,
+                   int64_t B, int K, int M, int D, int64_t T, int F, void* stream);
+/* wconj [B,K,D,F] complex128 = conj(bf), bin-contiguous.  Consumes `partials` (the chunk sums are
+ * formed in place).  masking_eps is compared in double: a caller that holds fp32 masks passes the
+ * fp32-rounded value to reproduce torch.clamp(mask_fp32, min=masking_eps) bit for bit. */
+int tssep_mvdr_weights(double* partials, double* wconj, int* info, int64_t B, int K, int D,
+                       int64_t T, int F, int reference_channel, double eps, void* stream);
+int tssep_mvdr_apply(const double* obs, const double* wconj, const void* masks, int mask_f64,
+                     double* enh, int64_t B, int K, int M, int D, int64_t T, int F, int masking,
+                     double masking_eps, void* stream);
+int tssep_mvdr_souden_fwd(const double* obs, const void* masks, int mask_f64, double* enh,
+                          void* workspace, int* info, int64_t B, int K, int M, int D, int64_t T,
+                          int F, int reference_channel, double eps, int masking,
+                          double masking_eps, void* stream);
+
 /* -------------------------------------------------------------- optimizer -----
  * One optimizer step on flat fp32 buffers: global-norm gradient clipping
  * (torch.nn.utils.clip_grad_norm_, max_norm <= 0 disables) + Adam (torch.optim.Adam update rule,

@@ -54,10 +54,39 @@ def npz(name, **arrays):
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def torch_bf_fixture(enhancer):
+    """(7) TorchBF('mvdr_souden'), enhancer.py:140-265: target+interference masks, target mask
+    only (batched), masking, explicit eps that clamps the trace."""
+    torch.manual_seed(7)
+    arrs = {}
+    cases = (
+        # tag, batch, K, M, D, T, F, mask dtype, ref, kwargs
+        ("a", None, 3, 2, 4, 20, 5, torch.float32, 1, {}),
+        ("b", 2, 2, 1, 6, 9, 66, torch.float64, 0, dict(masking=True, masking_eps=0.3)),
+        ("c", None, 2, 1, 3, 12, 7, torch.float32, 2, dict(eps=2.5)),
+        ("d", 1, 5, 2, 8, 17, 3, torch.float32, 7, dict(masking=True, masking_eps=0.0)),
+    )
+    for tag, b, K, M, D, T, F, mdt, ref, kw in cases:
+        lead = () if b is None else (b,)
+        Y = torch.randn(*lead, D, T, F, dtype=torch.complex128)
+        m = torch.rand(*lead, K, M, T, F, dtype=mdt)
+        out = enhancer.TorchBF(**kw)(m, {"Observation": Y, "reference_channel": ref}, None)
+        arrs.update({f"{tag}_Y": Y, f"{tag}_m": m, f"{tag}_out": out,
+                     f"{tag}_ref": np.array(ref),
+                     f"{tag}_kw": np.array([kw.get("eps", -1.0), float(kw.get("masking", False)),
+                                            kw.get("masking_eps", 0.0)])})
+    x = torch.arange(1.0, 10.0).view(3, 3)                      # trace doctest, enhancer.py:107-125
+    arrs["trace_3x3"] = enhancer.trace(x)
+    arrs["trace_axes"] = enhancer.trace(x.view(3, 1, 3), axis1=0, axis2=2)
+    npz("torch_bf", **arrs)
+
+
 def main():
     _stub_imports()
     from tssep.train import net, rnnp, loss, enhancer, init_ckpt
     from tssep.data import DummyReader
+    if sys.argv[1:] == ["torch_bf"]:
+        return torch_bf_fixture(enhancer)
 
     # ---- (1) RNNP_packed, 2/3/4-D inputs (rnnp.py:63-76) + gradients ---------
     torch.manual_seed(1)
@@ -177,6 +206,9 @@ def main():
             np.float64(ds16[i]["auxInput"].sum())])
     vad = r._get_vad(71, 8)
     npz("dummy_reader", vad71=vad, **arrs)
+
+    # ---- (7) TorchBF mask-based MVDR ------------------------------------------
+    torch_bf_fixture(enhancer)
 
 
 if __name__ == "__main__":

@@ -513,3 +513,111 @@ def test_blstm_onchip_kernels(N, T, I, Hh, mode):
     # and d(gates) against the exact-fp32 streaming backward on the same saved activations
     h.blstm_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
     close(gates, g_stream, rtol=2e-4, atol=2e-6, name="dgates")
+
+
+# ------------------------------------------------------------------ mask-based MVDR (TorchBF)
+def _bf_case(B, K, M, D, T, F, seed, mdt=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    Y = torch.randn(B, D, T, F, dtype=torch.complex128, generator=g)
+    m = torch.rand(B, K, M, T, F, dtype=mdt, generator=g)
+    return m, Y
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_mvdr_against_reference_fixture(golden, tag):
+    """C-ABI tssep_mvdr_souden_fwd vs outputs of the reference's TorchBF (enhancer.py:215-265)."""
+    from oracle import enhancer as oenh  # noqa: F401
+    g = golden("torch_bf")
+    eps, masking, masking_eps = g[tag + "_kw"]
+    m, Y = torch.as_tensor(g[tag + "_m"]), torch.as_tensor(g[tag + "_Y"])
+    batched = m.dim() == 5
+    if not batched:
+        m, Y = m[None], Y[None]
+    got = H().mvdr_souden(m.cuda(), Y.cuda(), int(g[tag + "_ref"]), eps=None if eps < 0 else float(eps),
+                          masking=bool(masking), masking_eps=float(masking_eps))
+    want = torch.as_tensor(g[tag + "_out"])
+    close(got if batched else got[0], want, rtol=1e-9, atol=1e-12, name="torch_bf " + tag)
+
+
+@pytest.mark.parametrize("B,K,M,D,T,F", [
+    (1, 1, 1, 1, 5, 3), (1, 2, 2, 2, 40, 64), (2, 3, 1, 3, 33, 65), (1, 4, 2, 4, 300, 129),
+    (1, 5, 1, 5, 17, 200), (2, 8, 2, 6, 100, 70), (1, 2, 1, 7, 64, 10), (1, 9, 2, 8, 50, 66)])
+def test_mvdr_against_oracle(B, K, M, D, T, F):
+    from oracle import enhancer as oenh
+    m, Y = _bf_case(B, K, M, D, T, F, seed=D * 100 + K, mdt=torch.float64 if D % 2 else torch.float32)
+    ref = D // 2
+    for masking, meps in ((False, 0.0), (True, 0.4)):
+        got = H().mvdr_souden(m.cuda(), Y.cuda(), ref, masking=masking, masking_eps=meps)
+        want = oenh.torch_bf(m.numpy(), Y.numpy(), ref, masking=masking, masking_eps=meps)
+        close(got, torch.as_tensor(want), rtol=1e-8, atol=1e-11, name=f"mvdr {masking}")
+
+
+def test_mvdr_stages_and_determinism():
+    """PSD partials summed = the einsum of the oracle; two runs are bit-identical."""
+    from oracle import enhancer as oenh
+    from tssep_amd import _lib
+    L = _lib.lib()
+    B, K, M, D, T, F = 1, 2, 2, 3, 700, 70
+    m, Y = _bf_case(B, K, M, D, T, F, 5)
+    md, Yd = m.cuda(), Y.cuda()
+    nb = L.tssep_mvdr_partial_bytes(B, K, D, T, F)
+    assert nb > 0 and nb % (8 * K * 2 * D * D * F) == 0
+    chunks = nb // (8 * B * K * 2 * D * D * F)
+    assert chunks > 1
+    part = torch.zeros(nb // 8, dtype=torch.float64, device="cuda")
+    st = L.tssep_mvdr_psd(Yd.data_ptr(), md.data_ptr(), 0, part.data_ptr(), B, K, M, D, T, F, None)
+    assert st == 0
+    torch.cuda.synchronize()
+    p = part.view(B, chunks, K, 2, D * D, F).sum(1).cpu().numpy()       # [B,K,2,DD,F]
+    want = np.stack([oenh.psd(m[:, :, i].numpy(), Y.numpy()) for i in range(2)], 2)  # [B,K,2,F,D,D]
+    for i in range(D):
+        np.testing.assert_allclose(p[:, :, :, i], want[..., i, i].real, rtol=1e-10)
+    q = 0
+    for i in range(D):
+        for j in range(i + 1, D):
+            np.testing.assert_allclose(p[:, :, :, D + 2 * q] + 1j * p[:, :, :, D + 2 * q + 1],
+                                       want[..., i, j], rtol=1e-9, atol=1e-10)
+            q += 1
+    a = H().mvdr_souden(md, Yd, 0)
+    b = H().mvdr_souden(md, Yd, 0)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_mvdr_errors_like_the_reference():
+    m, Y = _bf_case(1, 2, 2, 3, 20, 5, 1)
+    Hh = H()
+    with pytest.raises(torch.linalg.LinAlgError):               # torch.linalg.solve raises too
+        Hh.mvdr_souden(torch.zeros_like(m).cuda(), Y.cuda(), 0)
+    with pytest.raises(AssertionError):                         # enhancer.py:224
+        Hh.mvdr_souden(m.cuda(), Y.to(torch.complex64).cuda(), 0)
+    with pytest.raises(ValueError):                             # enhancer.py:251-252
+        Hh.mvdr_souden(torch.rand(1, 2, 3, 20, 5).cuda(), Y.cuda(), 0)
+    with pytest.raises(RuntimeError):                           # more than 8 channels
+        Hh.mvdr_souden(torch.rand(1, 2, 1, 4, 5).cuda(),
+                       torch.randn(1, 9, 4, 5, dtype=torch.complex128).cuda(), 0)
+    with pytest.raises(RuntimeError):                           # reference channel out of range
+        Hh.mvdr_souden(m.cuda(), Y.cuda(), 3)
+
+
+def test_mvdr_long_form_properties():
+    """cfg5-sized evaluation input (8 speakers, 6 channels, 1878 frames, 513 bins): the oracle on
+    a frequency slice, and size-independent properties on the whole output -- invariance to a
+    rescaling of either mask, channel-permutation equivariance, masking = elementwise product."""
+    from oracle import enhancer as oenh
+    B, K, M, D, T, F = 1, 8, 2, 6, 1878, 513
+    m, Y = _bf_case(B, K, M, D, T, F, 11)
+    md, Yd = m.cuda(), Y.cuda()
+    Hh = H()
+    base = Hh.mvdr_souden(md, Yd, 2)
+    sl = slice(250, 262)
+    want = oenh.torch_bf(m[..., sl].numpy(), Y[..., sl].numpy(), 2)
+    close(base[..., sl], torch.as_tensor(want), rtol=1e-8, atol=1e-11, name="slice")
+    m2 = md.double().clone()
+    m2[:, :, 0] *= 5.0
+    m2[:, :, 1] *= 0.125
+    close(Hh.mvdr_souden(m2, Yd, 2), base, rtol=1e-9, atol=1e-12, name="mask scale")
+    perm = torch.tensor([3, 0, 5, 2, 1, 4])
+    close(Hh.mvdr_souden(md, Yd[:, perm].contiguous(), int((perm == 2).nonzero())), base,
+          rtol=1e-8, atol=1e-11, name="channel permutation")
+    masked = Hh.mvdr_souden(md, Yd, 2, masking=True, masking_eps=0.5)
+    close(masked, base * md[:, :, 0].clamp(min=0.5), rtol=1e-14, atol=0, name="masking")

@@ -429,3 +429,36 @@ def test_toy_experiments_tsvad_then_tssep(tmp_path):
     eg3 = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck,
                          overrides=["eg.trainer.stop_trigger=[4,iteration]"] + fast[1:])
     assert eg3.trainer.iteration == 4
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_torch_bf_class_against_reference_fixture(golden, tag):
+    """tssep_amd.train.enhancer.TorchBF, same constructor / call as enhancer.py:140-265."""
+    from tssep_amd.train.enhancer import TorchBF
+    g = golden("torch_bf")
+    eps, masking, masking_eps = g[tag + "_kw"]
+    bf = TorchBF("mvdr_souden", masking=bool(masking), masking_eps=float(masking_eps),
+                 eps=None if eps < 0 else float(eps))
+    assert bf.name == "TorchBF"
+    ex = {"Observation": T_(g[tag + "_Y"]).cuda(), "reference_channel": int(g[tag + "_ref"])}
+    with torch.no_grad():
+        est = bf(T_(g[tag + "_m"]).cuda(), ex, None)
+    assert est.dtype == torch.complex128
+    close(est, g[tag + "_out"], rtol=1e-9, atol=1e-12, name=tag)
+
+
+def test_enhancer_classes_checks(golden):
+    from tssep_amd.train import enhancer as E
+    g = golden("torch_bf")
+    m, Y = T_(g["a_m"]).cuda(), T_(g["a_Y"]).cuda()
+    with pytest.raises(AssertionError):
+        E.TorchBF("gev")
+    with pytest.raises(AssertionError):
+        E.TorchBF()(m, {"Observation": Y.to(torch.complex64), "reference_channel": 0}, None)
+    with pytest.raises(NotImplementedError):
+        E.TorchBF()(m.clone().requires_grad_(), {"Observation": Y, "reference_channel": 0}, None)
+    assert E.Dummy()(m, {}, None) is None
+    out = E.Nothing()(m, {"Observation": Y, "reference_channel": 1}, None)
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(Y[1][None]))
+    x = torch.arange(1.0, 10.0).view(3, 3)
+    assert float(E.trace(x)) == 15.0 and E.trace(x.view(3, 1, 3), axis1=0, axis2=2).tolist() == [15.0]

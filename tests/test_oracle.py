@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import data as odata, features, loss as oloss, model as omodel, net as onet
-from oracle import rnnp as ornnp, stft as ostft
+from oracle import enhancer as oenh, rnnp as ornnp, stft as ostft
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 T = torch.as_tensor
@@ -106,6 +106,33 @@ def test_enhancer_and_losses_against_reference_fixture(golden):
     np.testing.assert_allclose(oloss.mae(T(g["e"]), T(g["t"])).numpy(), g["mae"], rtol=1e-6)
     np.testing.assert_allclose(oloss.vad_sigmoid_bce(T(g["logit"]), T(g["vad"])).numpy(), g["bce"],
                                rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_torch_bf_against_reference_fixture(golden, tag):
+    """TorchBF('mvdr_souden') of the reference (enhancer.py:215-265): target + interference masks,
+    target mask only (batched, masking), an eps that clamps the trace, 8 channels."""
+    g = golden("torch_bf")
+    eps, masking, masking_eps = g[tag + "_kw"]
+    got = oenh.torch_bf(g[tag + "_m"], g[tag + "_Y"], int(g[tag + "_ref"]),
+                        eps=None if eps < 0 else float(eps), masking=bool(masking),
+                        masking_eps=float(masking_eps))
+    assert got.dtype == np.complex128 and got.shape == g[tag + "_out"].shape
+    np.testing.assert_allclose(got, g[tag + "_out"], rtol=1e-9, atol=1e-12)
+
+
+def test_torch_bf_trace_and_invariances(golden):
+    g = golden("torch_bf")
+    x = np.arange(1.0, 10.0).reshape(3, 3)                       # enhancer.py:107-125
+    assert oenh.trace(x) == g["trace_3x3"] == 15.0
+    np.testing.assert_array_equal(oenh.trace(x.reshape(3, 1, 3), axis1=0, axis2=2), g["trace_axes"])
+    # Souden MVDR is invariant to a rescaling of either PSD matrix, i.e. of either mask
+    m, Y = g["a_m"].astype(np.float64), g["a_Y"]
+    base = oenh.torch_bf(m, Y, 1)
+    m2 = m.copy(); m2[:, 0] *= 3.0; m2[:, 1] *= 0.25
+    np.testing.assert_allclose(oenh.torch_bf(m2, Y, 1), base, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        oenh.torch_bf(np.ones((2, 3, 4, 5)), Y, 0)
 
 
 def test_loss_doctest_known_answers(golden):

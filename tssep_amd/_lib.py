@@ -40,7 +40,7 @@ class LstmSizes(ctypes.Structure):
 
 
 _SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
-            "float": ctypes.c_float}
+            "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 def _ctype(decl):

@@ -225,7 +225,6 @@ struct XBuf {
 
 // ------------------------------------------------------------------------------- forward
 constexpr int PUBPITCH = UPW + 4;        // floats per LDS row of [seq][unit] scalars (h, c)
-constexpr int XPITCH = UPW * 4 + 4;      // floats per LDS row of [seq][unit][4 gates]
 
 // Wave roles.  All 8 waves hold W and run the MFMAs and the cell update of their unit slice.  Beyond
 // that, waves 0-3 ("exchange") do nothing but the inter-workgroup exchange and waves 4-7 ("io") do

@@ -568,6 +568,52 @@ def mask_mul_bwd(dest, obs):
     return dmask
 
 
+# ----------------------------------------------------------------------------- beamformer
+def mvdr_souden(masks, obs, reference_channel, eps=None, masking=False, masking_eps=0.0,
+                check_singular=True):
+    """TorchBF('mvdr_souden'), tssep/train/enhancer.py:215-265.
+    masks [B,K,M,T,F] fp32|fp64 (M = 1|2), obs [B,D,T,F] complex128 -> enh [B,K,T,F] complex128.
+    eps None = torch.finfo(float64).tiny, as the reference.  Raises torch.linalg.LinAlgError for a
+    singular interference PSD like torch.linalg.solve does (one host sync; check_singular=False
+    skips it)."""
+    L = _lib.lib()
+    assert masks.is_cuda and obs.is_cuda, (masks.device, obs.device)
+    assert obs.dtype == torch.complex128, obs.dtype
+    if masks.dtype not in (torch.float32, torch.float64):
+        masks = masks.to(torch.float64)
+    B, K, M, T, F = masks.shape
+    Bo, D, To, Fo = obs.shape
+    assert (B, T, F) == (Bo, To, Fo), (masks.shape, obs.shape)
+    if M not in (1, 2):
+        raise ValueError(masks.shape)
+    masks = masks.contiguous()
+    obs_r = torch.view_as_real(obs.contiguous())
+    ws_bytes = L.tssep_mvdr_workspace_bytes(B, K, D, T, F)
+    if ws_bytes <= 0:
+        raise RuntimeError(f"mvdr_souden: unsupported shape masks {tuple(masks.shape)} "
+                           f"obs {tuple(obs.shape)} (at most 8 channels)")
+    ws = torch.empty(ws_bytes // 8 + 2, device=obs.device, dtype=torch.float64)
+    info = torch.empty(1, device=obs.device, dtype=torch.int32)
+    enh = torch.empty(B, K, T, F, 2, device=obs.device, dtype=torch.float64)
+    eps = float(torch.finfo(torch.float64).tiny) if eps is None else float(eps)
+    # torch.clamp(mask, min=masking_eps) compares in the mask's dtype (enhancer.py:261-263)
+    masking_eps = float(torch.tensor(float(masking_eps), dtype=masks.dtype))
+    msz = masks.element_size()
+    nbytes = B * T * F * (32 * D + K * M * msz + 16 * K + (K * msz if masking else 0))
+    with _timed("mvdr_souden", 0, nbytes):
+        check(L.tssep_mvdr_souden_fwd(_p(obs_r), _p(masks), int(masks.dtype == torch.float64),
+                                      _p(enh), _p(ws), _p(info), B, K, M, D, T, F,
+                                      int(reference_channel), eps, int(bool(masking)),
+                                      float(masking_eps), _stream()), "mvdr_souden")
+    if check_singular:
+        n = int(info.item())
+        if n:
+            raise torch.linalg.LinAlgError(
+                f"mvdr_souden: the solver failed because the interference PSD matrix is singular "
+                f"({n} of {B * K * F} (batch, speaker, frequency) systems)")
+    return torch.view_as_complex(enh)
+
+
 # ----------------------------------------------------------------------------- losses
 def logmae_fwd(est, tgt):
     L = _lib.lib()
