@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tssep_amd import _lib, hip_ops as H  # noqa: E402
 
 HBM_PEAK = 8000.0
+F64_VECTOR_PEAK = 78.6        # TFLOP/s: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 
 
 def ev_ms(fn, iters):
@@ -65,8 +66,14 @@ def main():
                "algorithmic_bytes": alg, "achieved_GBps": round(alg / total / 1e6, 1),
                "frac_of_hbm_peak": round(alg / total / 1e6 / HBM_PEAK, 4),
                "psd_ms": round(t_psd, 4), "psd_GBps": round(b_psd / t_psd / 1e6, 1),
+               # statistics pass: 7 D^2 fp64 flop per (frame, bin, speaker) -- pair products once,
+               # weighted into the target and the interference accumulators
+               "psd_f64_tflops": round(B * T * F * K * 7 * D * D / t_psd / 1e9, 2),
+               "psd_frac_of_f64_vector_peak": round(B * T * F * K * 7 * D * D / t_psd / 1e9 / F64_VECTOR_PEAK, 4),
                "weights_ms": round(t_w, 4), "apply_ms": round(t_app, 4),
-               "apply_GBps": round(b_app / t_app / 1e6, 1), "psd_partial_bytes": nb}
+               "apply_GBps": round(b_app / t_app / 1e6, 1),
+               "apply_frac_of_hbm_peak": round(b_app / t_app / 1e6 / HBM_PEAK, 4),
+               "psd_partial_bytes": nb}
         if not args.no_cpu and B == 1:
             from oracle import enhancer as oenh          # checker / CPU baseline only
             fs = 16

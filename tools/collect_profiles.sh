@@ -19,3 +19,6 @@ find $O -name "*.csv" | head -20
 ls -la $O
 # MFMA pipe and wave-state counters of the same command (own pass: SQ counters only)
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -o q -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_sq.log 2>&1
+# eval-time MVDR beamformer (TorchBF): microbench with the CPU oracle beside it + kernel stats
+python tools/bench_mvdr.py > $O/mvdr_microbench.jsonl 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvdr_stats -o m -- python3 tools/bench_mvdr.py --no-cpu --iters 10 > $O/mvdr_stats.log 2>&1

@@ -12,8 +12,17 @@ cp $F/maskhead_microbench.txt profiles/r1_maskhead_microbench.jsonl
 cp $F/batch_sweep.jsonl profiles/r1_batch_sweep_final.jsonl
 cp $F/bench_default.json profiles/r1_bench_default.json
 [ -f $F/gemm_in_step_b384.jsonl ] && cp $F/gemm_in_step_b384.jsonl profiles/r1_gemm_in_step_b384.jsonl
+[ -f $F/mvdr_microbench.jsonl ] && cp $F/mvdr_microbench.jsonl profiles/r1_mvdr_microbench.jsonl
 python - <<PY
-import csv
+import csv, os
+if os.path.exists('$F/mvdr_stats/m_kernel_stats.csv'):
+    rows = list(csv.DictReader(open('$F/mvdr_stats/m_kernel_stats.csv')))
+    with open('profiles/r1_kernel_stats_mvdr.txt', 'w') as f:
+        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_mvdr.py --no-cpu --iters 10   (4 configurations, see profiles/r1_mvdr_microbench.jsonl)\n")
+        f.write(f"{'Name':72s} {'Calls':>6s} {'TotalNs':>12s} {'AvgNs':>11s} {'Pct':>6s} {'MinNs':>9s} {'MaxNs':>9s}\n")
+        for r in rows:
+            n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+            f.write(f"{n[:72]:72s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
 rows = list(csv.DictReader(open('$F/stats/s_kernel_stats.csv')))
 with open('profiles/r1_kernel_stats_default_b${B}_${G}.txt', 'w') as f:
     f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32   (default config: batch $B, $G; 8 steps in total)\n")

@@ -7,10 +7,11 @@
 //
 // All of it is HBM-bound double-precision vector work (no matrix cores: D <= 8 channels), laid out
 // with lane = frequency bin so that every load and store of a wave is 512 B - 1 KB contiguous:
-//   1. mvdr_psd_kernel<D>     one wave per (64 bins, time chunk, speaker, target|interference);
-//                             D*D doubles of Hermitian accumulator per lane; the chunk partials go
+//   1. mvdr_psd_kernel<D>     one wave per (64 bins, time chunk, speaker): 2 D*D doubles of
+//                             Hermitian accumulators (target, interference) per lane; 4 speakers
+//                             per workgroup share the Y frames through LDS; the chunk partials go
 //                             to the workspace (fixed summation order -> run-to-run identical).
-//                             The 2K workgroups that share one Y tile are mapped to ONE XCD so the
+//                             The workgroups that share one Y tile are mapped to ONE XCD so the
 //                             tile is fetched from HBM once and served from that XCD's L2 after.
 //   2. mvdr_reduce_kernel     adds the chunk partials (into chunk 0), one lane per element;
 //      mvdr_solve_kernel<D>   one lane per (speaker, bin): LU with partial pivoting (LAPACK zgesv's
@@ -30,16 +31,24 @@ struct Plan {
   int chunks;      // time chunks of the PSD pass
   int64_t tchunk;  // frames per chunk
 };
-// enough workgroups to fill 256 CUs several times, chunks of at least 16 frames
+// Time chunks of the statistics pass: 512 workgroups are resident at once (2 per CU); pick the chunk
+// count that minimises (rounds of resident workgroups) x (frames per chunk) -- one workgroup more
+// than a round costs a whole extra round -- with a small charge per chunk for the partials' traffic.
 __host__ Plan make_plan(int64_t B, int K, int64_t T, int F) {
   Plan p;
   p.nf = (F + 63) / 64;
-  const int64_t per_chunk = B * p.nf * K * 2;
-  int64_t c = (4096 + per_chunk - 1) / per_chunk;
-  const int64_t cmax = (T + 15) / 16;
-  if (c > cmax) c = cmax;
-  if (c < 1) c = 1;
-  p.tchunk = (T + c - 1) / c;
+  const int64_t per_chunk = B * p.nf * ((K + 3) / 4);        // workgroups of 4 speakers
+  int64_t cmax = (T + 15) / 16;
+  if (cmax > 256) cmax = 256;
+  int64_t best_c = 1;
+  double best = 1e300;
+  for (int64_t c = 1; c <= cmax; ++c) {
+    const int64_t frames = (T + c - 1) / c;
+    const int64_t rounds = (per_chunk * c + 511) / 512;
+    const double cost = (double)rounds * (double)(frames + 8) + 0.5 * (double)c;
+    if (cost < best) { best = cost; best_c = c; }
+  }
+  p.tchunk = (T + best_c - 1) / best_c;
   p.chunks = (int)((T + p.tchunk - 1) / p.tchunk);
   return p;
 }
@@ -59,59 +68,129 @@ __device__ __forceinline__ bool xcd_tile(int64_t bid, int members, int64_t tiles
   return tile < tiles;
 }
 
-template <int D>
-__global__ __launch_bounds__(64) void mvdr_psd_kernel(
-    const double2* __restrict__ obs, const void* __restrict__ masks, int mask_f64,
-    double* __restrict__ part, int64_t B, int K, int M, int64_t T, int F, Plan plan) {
+// One workgroup = 4 waves = 4 speakers (target AND interference statistics each) of one
+// (64 bins, time chunk) tile.  Every wave fetches one frame of Y per step and shares it with the
+// other three through LDS (double buffered, one barrier per step), so Y crosses the L2 once per 4
+// speakers instead of once per (speaker, mask): a first version with one wave per (speaker, mask)
+// reading Y straight from L2 was L2-bandwidth bound (16 x 92 MB per 30-s utterance, 1.7 TB/s of
+// algorithmic traffic).
+constexpr int PW = 4;      // waves (= speakers) per workgroup
+template <typename MT> struct MaskRegs { MT w0[PW], w1[PW]; };
+
+template <int D, typename MT>
+__global__ __launch_bounds__(64 * PW, D <= 6 ? 2 : 1) void mvdr_psd_kernel(
+    const double2* __restrict__ obs, const MT* __restrict__ masks, double* __restrict__ part,
+    int64_t B, int K, int M, int64_t T, int F, Plan plan) {
+  // frames arrive by asynchronous global -> LDS copies (1 KB per wave instruction, lane-linear:
+  // exactly [channel][lane] of double2), no staging registers
+  __shared__ double2 ybuf[2][PW][D][64];
+  const int groups = (K + PW - 1) / PW;
   int64_t tile;
-  int km;
-  if (!xcd_tile(blockIdx.x, 2 * K, B * plan.chunks * plan.nf, tile, km)) return;
+  int grp;
+  if (!xcd_tile(blockIdx.x, groups, B * plan.chunks * plan.nf, tile, grp)) return;
   const int ft = (int)(tile % plan.nf);
   const int c = (int)((tile / plan.nf) % plan.chunks);
   const int64_t b = tile / ((int64_t)plan.nf * plan.chunks);
-  const int k = km >> 1, m = km & 1;
-  const int f = ft * 64 + threadIdx.x;
-  if (f >= F) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: uniform branches
+  const int k = grp * PW + wave;
+  const bool kvalid = k < K;
+  const int fraw = ft * 64 + lane;
+  const int f = fraw < F ? fraw : F - 1;
   const int64_t t0 = c * plan.tchunk;
   const int64_t t1 = t0 + plan.tchunk < T ? t0 + plan.tchunk : T;
+  const int steps = (int)((t1 - t0 + PW - 1) / PW);
   // target: mask 0.  interference: mask 1 if given, else 1 - mask 0 (enhancer.py:236-250)
-  const bool complement = m == 1 && M == 1;
-  const int64_t mbase = ((b * K + k) * M + (M == 2 ? m : 0)) * T * F + f;
+  const MT* mk0 = masks + ((b * K + (kvalid ? k : 0)) * M) * T * F + f;
+  const MT* mk1 = mk0 + (M == 2 ? T * (int64_t)F : 0);
   const double2* y0 = obs + b * D * T * F + f;
 
-  double diag[D];
-  double2 off[D * (D - 1) / 2 + 1];
+  double diag[2][D];
+  double2 off[2][D * (D - 1) / 2 + 1];
 #pragma unroll
-  for (int i = 0; i < D; ++i) diag[i] = 0.0;
+  for (int m = 0; m < 2; ++m) {
 #pragma unroll
-  for (int i = 0; i < D * (D - 1) / 2; ++i) off[i] = double2{0.0, 0.0};
-
-#pragma unroll 2
-  for (int64_t t = t0; t < t1; ++t) {
-    double w = load_mask(masks, mask_f64, mbase + t * F);
-    if (complement) w = 1.0 - w;
-    double2 y[D];
+    for (int i = 0; i < D; ++i) diag[m][i] = 0.0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) y[d] = y0[(d * T + t) * F];
-    int p = 0;
+    for (int i = 0; i < D * (D - 1) / 2; ++i) off[m][i] = double2{0.0, 0.0};
+  }
+  // wave w brings frame t0 + PW s + w of step s; frames past the chunk are zero-filled
+  auto fetch_y = [&](int s_) {
+    const int64_t t = t0 + (int64_t)s_ * PW + wave;
+    if (t < t1) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const double ur = w * y[i].x, ui = w * y[i].y;
-      diag[i] += ur * y[i].x + ui * y[i].y;
+      for (int d = 0; d < D; ++d)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(y0 + (d * T + t) * F),
+            (__attribute__((address_space(3))) void*)&ybuf[s_ & 1][wave][d][0], 16, 0, 0);
+    } else {
 #pragma unroll
-      for (int j = i + 1; j < D; ++j, ++p) {
-        off[p].x += ur * y[j].x + ui * y[j].y;       // u * conj(y_j)
-        off[p].y += ui * y[j].x - ur * y[j].y;
+      for (int d = 0; d < D; ++d) ybuf[s_ & 1][wave][d][lane] = double2{0.0, 0.0};
+    }
+  };
+  auto fetch_m = [&](int s_, MaskRegs<MT>& r) {
+    // unconditional loads (a branch per load would serialise them); frames past the chunk read
+    // the last frame's mask and meet zero-filled Y
+#pragma unroll
+    for (int fr = 0; fr < PW; ++fr) {
+      int64_t tt = t0 + (int64_t)s_ * PW + fr;
+      tt = tt < t1 ? tt : t1 - 1;
+      r.w0[fr] = mk0[tt * F];
+      r.w1[fr] = mk1[tt * F];
+    }
+  };
+  auto compute = [&](int s_, const MaskRegs<MT>& r) {
+#pragma unroll
+    for (int fr = 0; fr < PW; ++fr) {
+      double2 y[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) y[d] = ybuf[s_ & 1][fr][d][lane];
+      const double w0 = (double)r.w0[fr];
+      const double w1 = M == 2 ? (double)r.w1[fr] : 1.0 - w0;
+      // y_i conj(y_j) once, weighted into both accumulators
+      int p = 0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double pd = y[i].x * y[i].x + y[i].y * y[i].y;
+        diag[0][i] += w0 * pd;
+        diag[1][i] += w1 * pd;
+#pragma unroll
+        for (int j = i + 1; j < D; ++j, ++p) {
+          const double pr = y[i].x * y[j].x + y[i].y * y[j].y;
+          const double pi = y[i].y * y[j].x - y[i].x * y[j].y;
+          off[0][p].x += w0 * pr;
+          off[0][p].y += w0 * pi;
+          off[1][p].x += w1 * pr;
+          off[1][p].y += w1 * pi;
+        }
       }
     }
+  };
+  // one barrier per step: it drains the copies of step s (every wave waits for its own before
+  // arriving) and separates compute(s-1) from the copies of step s+1 into the same buffer
+  MaskRegs<MT> ra, rb;
+  fetch_y(0);
+  fetch_m(0, ra);
+  for (int s = 0; s < steps; s += 2) {
+    __syncthreads();
+    if (s + 1 < steps) { fetch_y(s + 1); fetch_m(s + 1, rb); }
+    if (kvalid) compute(s, ra);
+    if (s + 1 >= steps) break;
+    __syncthreads();
+    if (s + 2 < steps) { fetch_y(s + 2); fetch_m(s + 2, ra); }
+    if (kvalid) compute(s + 1, rb);
   }
-  double* out = part + ((((b * plan.chunks + c) * K + k) * 2 + m) * (int64_t)(D * D)) * F + f;
+  if (!kvalid || fraw >= F) return;
 #pragma unroll
-  for (int i = 0; i < D; ++i) out[(int64_t)i * F] = diag[i];
+  for (int m = 0; m < 2; ++m) {
+    double* out = part + ((((b * plan.chunks + c) * K + k) * 2 + m) * (int64_t)(D * D)) * F + f;
 #pragma unroll
-  for (int p = 0; p < D * (D - 1) / 2; ++p) {
-    out[(int64_t)(D + 2 * p) * F] = off[p].x;
-    out[(int64_t)(D + 2 * p + 1) * F] = off[p].y;
+    for (int i = 0; i < D; ++i) out[(int64_t)i * F] = diag[m][i];
+#pragma unroll
+    for (int p = 0; p < D * (D - 1) / 2; ++p) {
+      out[(int64_t)(D + 2 * p) * F] = off[m][p].x;
+      out[(int64_t)(D + 2 * p + 1) * F] = off[m][p].y;
+    }
   }
 }
 
@@ -390,9 +469,15 @@ template <int D>
 int launch_psd(const double* obs, const void* masks, int mask_f64, double* part, int64_t B, int K,
                int M, int64_t T, int F, const Plan& p, hipStream_t s) {
   const int64_t tiles = B * p.chunks * p.nf;
-  const int64_t grid = ((tiles + 7) / 8) * 8 * 2 * K;
-  hipLaunchKernelGGL(mvdr_psd_kernel<D>, dim3((unsigned)grid), dim3(64), 0, s,
-                     reinterpret_cast<const double2*>(obs), masks, mask_f64, part, B, K, M, T, F, p);
+  const int64_t grid = ((tiles + 7) / 8) * 8 * ((K + PW - 1) / PW);
+  if (mask_f64)
+    hipLaunchKernelGGL((mvdr_psd_kernel<D, double>), dim3((unsigned)grid), dim3(64 * PW), 0, s,
+                       reinterpret_cast<const double2*>(obs), static_cast<const double*>(masks), part,
+                       B, K, M, T, F, p);
+  else
+    hipLaunchKernelGGL((mvdr_psd_kernel<D, float>), dim3((unsigned)grid), dim3(64 * PW), 0, s,
+                       reinterpret_cast<const double2*>(obs), static_cast<const float*>(masks), part,
+                       B, K, M, T, F, p);
   return tssep_launch_status();
 }
 
