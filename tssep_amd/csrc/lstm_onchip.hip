@@ -546,6 +546,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       }
     }
     float dcc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 cnext = {0.f, 0.f, 0.f, 0.f};
     float* pl = xpayload + work * 2 * G * SEQS * Hp * 2;        // 8-byte granules
     const __amdgpu_buffer_rsrc_t prs =
         __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 8, 0x00020000);
@@ -556,7 +557,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       const bool has_prev = step + 1 < T;
       const int64_t tp = dir ? t + 1 : t - 1;
       // ---- (1) this thread's saved activations (issued before waiting on the exchange)
-      f32x4 g4[4], ct = {0.f, 0.f, 0.f, 0.f}, cp = ct, dh = ct;
+      // (the cell state of this step is the "previous cell state" the last step loaded)
+      f32x4 g4[4], ct = cnext, cp = {0.f, 0.f, 0.f, 0.f}, dh = cp;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       if (full) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
-        ct = *reinterpret_cast<const f32x4*>(cell + cell0);
+        if (step == 0) ct = *reinterpret_cast<const f32x4*>(cell + cell0);
         if (has_prev)
           cp = *reinterpret_cast<const f32x4*>(cell + (ROW(n, tp) * 2 + dir) * (int64_t)H + unit0);
         dh = *reinterpret_cast<const f32x4*>(dhout + ROW(n, t) * ldo + dir * dstride + unit0);
@@ -573,23 +575,28 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         for (int q = 0; q < 4; ++q)
           if (unit0 + q < H) {
             g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
-            ct[q] = cell[cell0 + q];
+            if (step == 0) ct[q] = cell[cell0 + q];
             if (has_prev) cp[q] = cell[(ROW(n, tp) * 2 + dir) * (int64_t)H + unit0 + q];
             dh[q] = dhout[ROW(n, t) * ldo + dir * dstride + unit0 + q];
           }
       }
+      cnext = cp;
       // ---- (2) reduce-scatter: add the G partial dh published with tag = step (fixed order)
       if (step > 0) {
         const int slot = (int)((step - 1) & 1);
         const unsigned want = tagbase | (unsigned)step;
         u32x4 v[10];
+        // this workgroup's own partial never leaves the CU: it is still in psum (rewritten only
+        // after this step's barrier) -- 1/G less exchange traffic, same summation order
+        const f32x4 own = *reinterpret_cast<const f32x4*>(psum + s * PPITCH + unit0);
 #pragma unroll
         for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
           for (int p = 0; p < 2; ++p)
-            v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                         prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL)
-                                   : u32x4{want, 0u, want, 0u};
+            v[2 * gs + p] = gs == g ? u32x4{want, __float_as_uint(own[2 * p]), want, __float_as_uint(own[2 * p + 1])}
+                            : gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
+                                           prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL)
+                                     : u32x4{want, 0u, want, 0u};
         int spins = 0;
         bool fail = false;
         for (;;) {
@@ -710,7 +717,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           const int dsq = 512 / hp2, dup = 512 - dsq * hp2;
           for (int pr = tid; pr < SEQS * hp2; pr += 512) {
             const float2 v = *reinterpret_cast<const float2*>(psum + sq * PPITCH + 2 * up);
-            __builtin_amdgcn_raw_buffer_store_b128(
+            if ((up >> 5) != g)                              // (own 64 units stay in psum)
+              __builtin_amdgcn_raw_buffer_store_b128(
                 u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
                 (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, AUXS);
             sq += dsq;
