@@ -4,7 +4,7 @@
 set -u
 O=gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 > $O/recurrence_microbench.jsonl 2>/dev/null
+python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 1536 2048 > $O/recurrence_microbench.jsonl 2>/dev/null
 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
 TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
