@@ -264,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   // that the buffer descriptors below are built from SGPRs, no waterfall loops around the loads)
   const Membership mem = join_cluster<XCD>(xhead, G, (int)(2 * ngroups), s_mem);
   if (!mem.ok) return;
-  const int g = mem.g;
+  const int g = __builtin_amdgcn_readfirstlane(mem.g);      // scalar: uniform branches, SGPR addressing
   const int j = lane & 31, half = lane >> 5;
   const int ul0 = 8 * wave + 4 * half;                 // this lane's 4 consecutive local units
   const int unit0 = 64 * g + ul0;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
   const int64_t ngroups = (N + SEQS - 1) / SEQS;
   const Membership mem = join_cluster<XCD>(xhead, G, (int)(2 * ngroups), s_mem);
   if (!mem.ok) return;
-  const int g = mem.g;
+  const int g = __builtin_amdgcn_readfirstlane(mem.g);      // scalar: uniform branches, SGPR addressing
   const int j = lane & 31, half = lane >> 5;
   const int s = tid >> 4, uq = tid & 15;                   // cell backward: sequence, unit quad
   const int unit0 = 64 * g + 4 * uq;
