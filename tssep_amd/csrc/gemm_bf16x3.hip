@@ -436,7 +436,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // loads: thread <-> (row tid/4 + 64 i, 4 consecutive k at (tid%4)*4); uniform base + 32-bit offsets
-  const int kq = (tid & 3) << 2, lrow = tid >> 2;
+  // rows of an 8-row block are visited 0,2,4,6,1,3,5,7: the 4 rows one ds_write_b64 lane group stages
+  // are then 96 B apart and cover all 32 banks once (consecutive rows at the 48-byte pitch overlap:
+  // SQ_LDS_BANK_CONFLICT was 11 % of the kernel's CU-busy cycles)
+  const int kq = (tid & 3) << 2;
+  const int lrow = ((tid >> 2) & ~7) | (((tid >> 2) & 3) << 1) | ((tid >> 4) & 1);
   const char* abase = reinterpret_cast<const char*>(A + m0 * lda);
   const char* bbase = reinterpret_cast<const char*>(B + n0 * ldb);
   unsigned aoffs[4], boffs[2];
