@@ -403,7 +403,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // the step.  Per-tile s_memtime profile at K = 320 (61 k cycles): prologue 4 %, K loop 54 % (1850
 // cycles per stage for 768 MFMA cycles per wave: two resident workgroups keep the matrix pipe 83 %
 // busy while both are in their loops), drain 5 %, epilogue 36 % (the 128 KB fp32 C tile: stores
-// back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing;
+// back-pressured by HBM).  De-phasing the two workgroups of a CU by a start delay changed nothing,
+// neither did starting the first resident round in 8 phases spread over one tile time chip-wide;
 // a persistent grid (512 workgroups walking the tile list) gained 5-9 % standalone on the K <= 600
 // shapes and nothing in the training step; a BK = 16 variant of the 128 x 128 kernel at three
 // workgroups per CU (152 VGPRs, 48 KB LDS) was 0-10 % slower than BK = 32 at two; half-width (128 x 64)
