@@ -266,7 +266,9 @@ int tssep_mask_mul_bwd(const float* dest, const float* obs, float* dmask,
  * LogMAE (tssep/train/loss.py:244-247): loss[b] = log10(sum_k mean_n |est-tgt|).
  * Deterministic two-stage reduction; `sums[b]` (the argument of the log) is kept for bwd.
  * tssep_logmae_finalize consumes the partial sums tssep_istft_fwd can emit
- * (partial [B*K, nchunks]).  bwd: dest = gout[b] * sign(est-tgt) / (N ln10 sums[b]). */
+ * (partial [B*K, nchunks]).  bwd: dest = gout[b] * sign(est-tgt) / (N ln10 sums[b]).
+ * MAE (tssep/train/loss.py:194-216) is the same reduction without the logarithm: its value is
+ * sums[b], and tssep_logmae_bwd with sums == NULL gives its gradient gout[b] * sign(est-tgt) / N. */
 int64_t tssep_logmae_chunks(int64_t N);
 int64_t tssep_logmae_workspace_bytes(int64_t B, int64_t K, int64_t N);
 int tssep_logmae_fwd(const float* est, const float* tgt, int64_t B, int64_t K, int64_t N,

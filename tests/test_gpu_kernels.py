@@ -621,3 +621,25 @@ def test_mvdr_long_form_properties():
           rtol=1e-8, atol=1e-11, name="channel permutation")
     masked = Hh.mvdr_souden(md, Yd, 2, masking=True, masking_eps=0.5)
     close(masked, base * md[:, :, 0].clamp(min=0.5), rtol=1e-14, atol=0, name="masking")
+
+
+def test_mae_loss(golden):
+    """MAE (tssep/train/loss.py:194-216): reference fixture, doctest value, gradient."""
+    from tssep_amd import functional as Fn
+    from tssep_amd.train.loss import MAE
+    g = golden("enh_loss")
+    e, t = torch.as_tensor(g["e"]).cuda(), torch.as_tensor(g["t"]).cuda()
+    close(MAE(pit=False)(e, t), g["mae"], rtol=1e-6, name="mae vs reference")
+    close(MAE()(e[0], t[0]), g["mae"][0], rtol=1e-6, name="mae unbatched")
+    torch.manual_seed(0)                                          # loss.py:198-204
+    t2 = torch.rand((2, 10000)); e2 = t2 + 0.5 * torch.rand((2, 10000))
+    assert float(MAE(pit=False)(e2.cuda(), t2.cuda())) == pytest.approx(0.5018, abs=5e-5)
+    assert float(MAE(pit=False)(t2.cuda(), t2.cuda())) == 0.0
+    torch.manual_seed(4)
+    tgt = torch.randn(3, 4, 5000)
+    est = (tgt + 0.5 * torch.randn(3, 4, 5000)).requires_grad_()
+    gout = torch.randn(3)
+    (oloss.mae(est, tgt) * gout).sum().backward()
+    ed = est.detach().cuda().requires_grad_()
+    (Fn.mae(ed, tgt.cuda()) * gout.cuda()).sum().backward()
+    close(ed.grad, est.grad, rtol=1e-6, atol=1e-12, name="mae grad")

@@ -210,7 +210,8 @@ __global__ void logmae_bwd_kernel(const float* __restrict__ est, const float* __
   const float ln10 = 2.30258509299404568402f;
   GRID_STRIDE(e, total) {
     const int64_t b = e / KN;
-    const float coef = gout[b] / ((float)N * ln10 * sums[b]);
+    // sums == NULL: plain MAE (tssep/train/loss.py:214-216), d/d est = gout sign(est - tgt) / N
+    const float coef = sums ? gout[b] / ((float)N * ln10 * sums[b]) : gout[b] / (float)N;
     const float d = est[e] - tgt[e];
     dest[e] = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
   }
@@ -439,7 +440,7 @@ extern "C" int tssep_logmae_fwd(const float* est, const float* tgt, int64_t B, i
 extern "C" int tssep_logmae_bwd(const float* est, const float* tgt, const float* sums,
                                 const float* gout, int64_t B, int64_t K, int64_t N, float* dest,
                                 void* stream) {
-  if (!est || !tgt || !sums || !gout || !dest) return TSSEP_E_NULL;
+  if (!est || !tgt || !gout || !dest) return TSSEP_E_NULL;      // sums may be NULL (MAE)
   if (B <= 0 || K <= 0 || N <= 0) return TSSEP_E_SHAPE;
   hipLaunchKernelGGL(logmae_bwd_kernel, dim3(grid_for(B * K * N)), dim3(256), 0, S_, est, tgt, sums,
                      gout, K * N, N, B * K * N, dest);

@@ -420,6 +420,25 @@ def log_mae(est, tgt):
     return _LogMAE.apply(est, tgt)
 
 
+class _MAE(torch.autograd.Function):
+    """sum_k mean_n |e - t| (loss.py:214-216): the argument of LogMAE's logarithm."""
+
+    @staticmethod
+    def forward(ctx, est, tgt):
+        _, sums = H.logmae_fwd(est, tgt)
+        ctx.save_for_backward(est, tgt)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        est, tgt = ctx.saved_tensors
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), None, g), None
+
+
+def mae(est, tgt):
+    return _MAE.apply(est, tgt)
+
+
 class _VadBCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logit, vad):

@@ -50,6 +50,14 @@ class LogMAE(TimeDomain):
         return Fn.log_mae(estimate, target)
 
 
+class MAE(TimeDomain):
+    def loss_fn(self, estimate, target):
+        """sum_k mean_n |e - t| -> [B]  (loss.py:194-216)"""
+        if estimate.dim() == 2:
+            return Fn.mae(estimate[None], target[None])[0]
+        return Fn.mae(estimate, target)
+
+
 class LogitsSTFTDomain(ABC):
     def from_ex_out(self, ex, out, model, summary):      # loss.py:122-146
         estimate = torch.squeeze(out.logit, dim=-3)
