@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 384)),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 768)),
                     help="utterances per GPU (weak scaling: global batch = batch * gpus)")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
                     help="arithmetic of the non-recurrent GEMMs (the recurrence kernel is chosen by hip_ops.recurrence_kernel)")

@@ -8,7 +8,7 @@ python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 1536 2048 
 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
 TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
-for b in 8 32 64 128 160 192 256 384 512 768; do
+for b in 8 32 64 128 160 192 256 384 512 768 1152 1536; do
   python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
 python bench.py > $O/bench_default.json 2>$O/bench_default.err
@@ -22,3 +22,4 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 # eval-time MVDR beamformer (TorchBF): microbench with the CPU oracle beside it + kernel stats
 python tools/bench_mvdr.py > $O/mvdr_microbench.jsonl 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvdr_stats -o m -- python3 tools/bench_mvdr.py --no-cpu --iters 10 > $O/mvdr_stats.log 2>&1
+python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null

@@ -6,7 +6,7 @@ import numpy as np, torch
 import bench
 from tssep_amd import hip_ops as H
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 384
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 H.GEMM_PRECISION = "bf16x3"
 calls = []
 orig = H.gemm

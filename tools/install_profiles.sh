@@ -2,7 +2,7 @@
 # Copies what tools/collect_profiles.sh wrote under gpurun_out/final/ into profiles/ (tracked).
 # usage: bash tools/install_profiles.sh <batch> <gemm>
 set -e
-F=gpurun_out/final; B=${1:-384}; G=${2:-bf16x3}
+F=gpurun_out/final; B=${1:-768}; G=${2:-bf16x3}
 python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G > profiles/r1_traffic_pmc.json
 python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G > profiles/r1_mfma_pmc.json
 cp $F/recurrence_microbench.jsonl profiles/r1_recurrence_microbench.jsonl
@@ -11,7 +11,7 @@ cp $F/gemm_microbench_f32.jsonl profiles/r1_gemm_microbench_f32.jsonl
 cp $F/maskhead_microbench.txt profiles/r1_maskhead_microbench.jsonl
 cp $F/batch_sweep.jsonl profiles/r1_batch_sweep_final.jsonl
 cp $F/bench_default.json profiles/r1_bench_default.json
-[ -f $F/gemm_in_step_b384.jsonl ] && cp $F/gemm_in_step_b384.jsonl profiles/r1_gemm_in_step_b384.jsonl
+[ -f $F/gemm_in_step_b$B.jsonl ] && cp $F/gemm_in_step_b$B.jsonl profiles/r1_gemm_in_step_b$B.jsonl
 [ -f $F/mvdr_microbench.jsonl ] && cp $F/mvdr_microbench.jsonl profiles/r1_mvdr_microbench.jsonl
 python - <<PY
 import csv, os

@@ -590,6 +590,222 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
 }
 #undef SGB
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient variant: C[M,N] = A^T B with BOTH operands k-major (A = dY [K, M], B = X [K, N],
+// rows = time steps).  The generic kernel above reads such operands lane = column with 4-byte loads
+// and transposes them in registers (32 scalar loads per wave and tile).  Here a tile is read the
+// way it lies in memory -- 16-byte loads along m / n, one k row per 32 lanes -- split, and written
+// UNTRANSPOSED to LDS as [k][m] bf16 rows (pitch 320 B: 4 consecutive k rows cover all 64 banks
+// once); the MFMA fragments (lane = m, 8 consecutive k) are produced by the LDS transpose read
+// ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 m] block, 4 contiguous m per lane, and lane
+// i receives column i (4 k values) -- two reads per 8-k fragment.  Masks (K tail, column tail, time
+// shift, virtual ones column) are applied when a tile is staged, never on the load path.
+// Time shift: row k of B is replaced by row k + kshift of the same period (zero outside it).
+constexpr int TNP = 320;                 // bytes per k row: 128 m x 2 B + 64
+constexpr int TNARR = 32 * TNP;          // one array (32 k rows) = 10 240 B
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * TNP));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
+template <bool SHIFT>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
+    int64_t N, int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate,
+    int64_t ldc, int splitk, int64_t c_split_stride, TileMap tmap, int b_ones_col) {
+  constexpr int BK = 32;
+  __shared__ __attribute__((aligned(16))) char lds0[4 * TNARR];     // A hi, A lo, B hi, B lo
+  __shared__ __attribute__((aligned(16))) char lds1[4 * TNARR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * BM, n0 = (int64_t)nt * BN;
+  const int64_t ktiles = (K + BK - 1) / BK;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // loads: thread <-> (k row tid/32 + 8 i, columns 4 (tid%32) .. +3)
+  const int krow = tid >> 5, cq = (tid & 31) << 2;
+  const int64_t Nreal = N - (b_ones_col ? 1 : 0);
+  // column starts clamped so that the 16-byte load stays inside the row (host: round_up(M,4) <= lda)
+  const int64_t Mp = (M + 3) & ~(int64_t)3, Np = (Nreal + 3) & ~(int64_t)3;
+  const int64_t ca = m0 + cq <= Mp - 4 ? m0 + cq : Mp - 4;
+  const int64_t cb = n0 + cq <= Np - 4 ? n0 + cq : Np - 4;
+  const char* abase = reinterpret_cast<const char*>(A);
+  const char* bbase = reinterpret_cast<const char*>(B);
+  const int64_t aoff0 = (krow * lda + ca) * 4, boff0 = (krow * ldb + cb) * 4;       // + k0 * ld * 4
+  // per-element column masks of this thread's four columns
+  bool am[4], bm[4], bone[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    am[e] = m0 + cq + e < M;
+    bm[e] = n0 + cq + e < Nreal;
+    bone[e] = b_ones_col && n0 + cq + e == N - 1;
+  }
+  // time shift: phase (k mod kperiod) of this thread's rows of the tile held in registers
+  int ph[4] = {0, 0, 0, 0};
+  const int phstep = SHIFT ? BK % kperiod : 0;
+  if (SHIFT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ph[i] = (int)((kt_begin * BK + krow + 8 * i) % kperiod);
+  }
+  bool kok[4] = {true, true, true, true};       // row < K, of the tile held in registers
+
+  f32x4 ra[4], rb[4];
+  // steady state: rows k0 .. k0+31 (and their shifted partners) all lie inside the matrix
+  auto gload_full = [&](int64_t kt) {
+    const char* pa = abase + kt * BK * lda * 4 + aoff0;
+    const char* pb = bbase + (kt * BK + (SHIFT ? kshift : 0)) * ldb * 4 + boff0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa + (int64_t)i * 8 * lda * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb + (int64_t)i * 8 * ldb * 4);
+  };
+  // prologue / drain: any tile; rows clamped into the matrix (the masks zero what was clamped)
+  auto gload_any = [&](int64_t kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = kt * BK + krow + 8 * i;
+      const int64_t ka = k < K ? k : K - 1;
+      int64_t kb = ka + (SHIFT ? kshift : 0);
+      kb = kb < 0 ? 0 : (kb > K - 1 ? K - 1 : kb);
+      ra[i] = *reinterpret_cast<const f32x4*>(abase + (ka * lda + ca) * 4);
+      rb[i] = *reinterpret_cast<const f32x4*>(bbase + (kb * ldb + cb) * 4);
+    }
+  };
+  // bookkeeping for the tile that was just requested (phases advance tile by tile)
+  int64_t held = kt_begin - 1;
+  auto note_tile = [&](int64_t kt, bool full) {
+    if (SHIFT && held >= kt_begin) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ph[i] += phstep; ph[i] = ph[i] >= kperiod ? ph[i] - kperiod : ph[i]; }
+    }
+    held = kt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kok[i] = full || kt * BK + krow + 8 * i < K;
+  };
+  const int soff = krow * TNP + (tid & 31) * 8;
+  auto stage = [&](char* st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool okb = kok[i];
+      if (SHIFT) { const int q = ph[i] + kshift; okb = okb && q >= 0 && q < kperiod; }
+      f32x4 a = ra[i], b = rb[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = (kok[i] && am[e]) ? a[e] : 0.f;
+        b[e] = (okb && bm[e]) ? b[e] : ((bone[e] && kok[i]) ? 1.f : 0.f);
+      }
+      unsigned h0, l0, h1, l1;
+      split2n(a[0], a[1], h0, l0);
+      split2n(a[2], a[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soff + i * 8 * TNP) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + TNARR + soff + i * 8 * TNP) = u32x2{l0, l1};
+      split2n(b[0], b[1], h0, l0);
+      split2n(b[2], b[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + 2 * TNARR + soff + i * 8 * TNP) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + 3 * TNARR + soff + i * 8 * TNP) = u32x2{l0, l1};
+    }
+  };
+  // fragment address of this lane: 16-lane group g2 covers 16 m, lane ii = 4 (k row) + m quad
+  const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
+  const int foff = (8 * hk + (ii >> 2)) * TNP + (16 * g2 + 4 * (ii & 3)) * 2;
+  const int aoff = foff + wm * 64 * 2, boff = 2 * TNARR + foff + wn * 64 * 2;
+  auto compute = [&](const char* st) {
+    bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];            // [k-step][tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[ks][i] = tr_frag(st + aoff + ks * 16 * TNP + i * 64);
+        al[ks][i] = tr_frag(st + TNARR + aoff + ks * 16 * TNP + i * 64);
+        bh[ks][i] = tr_frag(st + boff + ks * 16 * TNP + i * 64);
+        bl[ks][i] = tr_frag(st + TNARR + boff + ks * 16 * TNP + i * 64);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+  };
+#define TNPIPE(cur, nxt, kt_, SID_)                                                             \
+  do {                                                                                          \
+    constexpr int SID = SID_;                                                                   \
+    compute(cur);                                                                               \
+    stage(nxt);                                                                                 \
+    gload_full((kt_) + 2);                                                                      \
+    note_tile((kt_) + 2, true);                                                                 \
+    SGB(0x100, 16);                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x020, 1); }               \
+    __syncthreads();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  if (kt_begin < kt_end) {
+    gload_any(kt_begin);
+    note_tile(kt_begin, kt_begin < kt_full);
+    stage(lds0);
+    if (kt_begin + 1 < kt_end) { gload_any(kt_begin + 1); note_tile(kt_begin + 1, kt_begin + 1 < kt_full); }
+    __syncthreads();
+    int64_t kt = kt_begin;
+    int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    // the pipelined loads read row k + kshift unconditionally: stay clear of the matrix's last tiles
+    // (they never see the first ones: they start at tile kt_begin + 2)
+    if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
+    for (; kt < lim; kt += 2) {
+      TNPIPE(lds0, lds1, kt, 1);
+      TNPIPE(lds1, lds0, kt + 1, 2);
+    }
+    for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
+      const char* cur = par ? lds1 : lds0;
+      char* nxt = par ? lds0 : lds1;
+      compute(cur);
+      if (kt + 1 < kt_end) stage(nxt);
+      if (kt + 2 < kt_end) { gload_any(kt + 2); note_tile(kt + 2, kt + 2 < kt_full); }
+      __syncthreads();
+    }
+  }
+#undef TNPIPE
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  static_assert(2 * 64 * EPITCH * 4 <= 4 * TNARR, "epilogue scratch must fit in one stage");
+  float* stg = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+  gemm_epilogue_rows(acc, stg, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, nullptr, 0,
+                     accumulate, ldc, splitk == 1);
+}
+#undef SGB
+
 }  // namespace
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
@@ -607,6 +823,25 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   }
   const TileMap tmap = make_tile_map((g->M + BM - 1) / BM, (g->N + BN - 1) / BN, splitk);
   dim3 grid((unsigned)tile_map_blocks(tmap));
+  {
+    // weight gradients: both operands k-major, plain store, 16-byte rows (see gemm_bf16x3_tn_kernel)
+    static const bool tn = [] { const char* e = getenv("TSSEP_GEMM_TN"); return !e || e[0] != '0'; }();
+    const int64_t nreal = g->N - (g->b_ones_col ? 1 : 0);
+    const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
+    if (tn && g->a_kmajor && g->b_kmajor && !sm.remap && !g->bias && g->act == 0 && (g->lda & 3) == 0 &&
+        (g->ldb & 3) == 0 && aligned16(g->A) && aligned16(g->B) && ((g->M + 3) & ~(int64_t)3) <= g->lda &&
+        nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
+      if (shift)
+        hipLaunchKernelGGL(gemm_bf16x3_tn_kernel<true>, grid, dim3(NTHREADS), 0, s, g->A, g->B, g->C, g->M,
+                           g->N, g->K, g->lda, g->ldb, (int)g->b_kshift, (int)g->kperiod, g->accumulate,
+                           sm.ldc, splitk, g->c_split_stride, tmap, 0);
+      else
+        hipLaunchKernelGGL(gemm_bf16x3_tn_kernel<false>, grid, dim3(NTHREADS), 0, s, g->A, g->B, g->C, g->M,
+                           g->N, g->K, g->lda, g->ldb, 0, 1, g->accumulate, sm.ldc, splitk,
+                           g->c_split_stride, tmap, g->b_ones_col);
+      return tssep_launch_status();
+    }
+  }
 #define LAUNCH(AK, BKM, SH)                                                                      \
   hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<32, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,     \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
