@@ -462,13 +462,14 @@ SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"
 ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
 
 
-SIDE_STREAM_MAX_ROWS = int(_os.environ.get("TSSEP_SIDE_STREAM_MAX_SEQS", 768)) * 253   # beyond this the GEMMs of the two streams only slow each other
+SIDE_STREAM_MAX_ROWS = int(_os.environ.get("TSSEP_SIDE_STREAM_MAX_SEQS", 512)) * 253   # beyond this the GEMMs of the two streams only slow each other
 
 
 def side_stream(device, rows=0):
     """The weight-gradient stream paired with the CURRENT stream (one per compute stream).  Measured
     (batch sweep, MI355X): +7 % at batch 64, +2 % at 192, 0 at 384 -- where the uncontended GEMMs
-    run at 213 instead of 124 TFLOP/s -- so layers with more rows stay on the compute stream."""
+    run at 213 instead of 124 TFLOP/s --, -0.6 % for the 768-sequence layers of batch 768, so layers
+    with more than 512 sequences stay on the compute stream."""
     cur = torch.cuda.current_stream(device)
     if not SIDE_STREAM or rows > SIDE_STREAM_MAX_ROWS:
         return cur
