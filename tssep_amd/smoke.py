@@ -48,4 +48,16 @@ def run(verbose=True):
         print(f"smoke: loss {float(summary['loss']):.6f} (oracle {float(o['loss'].sum()):.6f}), "
               f"max |mask err| {merr:.2e}, max rel grad err {gerr:.2e}")
     assert merr < 1e-3 and lerr < 1e-3 and gerr < 1e-2, (merr, lerr, gerr)
-    return dict(mask_err=merr, loss_err=lerr, grad_err=gerr)
+    # evaluation-time enhancer: mask-based MVDR on 6 channels, complex128
+    from oracle import enhancer as oenh
+    g = torch.Generator().manual_seed(2)
+    Y = torch.randn(6, 40, 70, dtype=torch.complex128, generator=g)
+    mk = torch.rand(K, 2, 40, 70, generator=g)
+    with torch.no_grad():
+        est = enhancer.TorchBF()(mk.cuda(), {"Observation": Y.cuda(), "reference_channel": 0}, None)
+    want = oenh.torch_bf(mk.numpy(), Y.numpy(), 0)
+    berr = float(np.abs(est.cpu().numpy() - want).max() / np.abs(want).max())
+    if verbose:
+        print(f"smoke: MVDR beamformer max rel err {berr:.2e}")
+    assert berr < 1e-9, berr
+    return dict(mask_err=merr, loss_err=lerr, grad_err=gerr, mvdr_err=berr)
