@@ -48,3 +48,18 @@ def test_struct_layout_matches_c(tmp_path):
     import ctypes
     assert vals[:-1] == [getattr(_lib.GemmArgs, f).offset for f in fields]
     assert vals[-1] == ctypes.sizeof(_lib.GemmArgs)
+
+
+def test_mvdr_size_queries_are_host_only():
+    """tssep_mvdr_{partial,workspace}_bytes need no GPU: plan consistency and rejected shapes."""
+    L = _lib.lib()
+    for B, K, D, T, F in ((1, 4, 6, 253, 513), (1, 8, 6, 1878, 513), (8, 8, 6, 1878, 513), (2, 3, 1, 5, 3),
+                          (1, 9, 8, 50, 66)):
+        pb = L.tssep_mvdr_partial_bytes(B, K, D, T, F)
+        unit = 8 * B * K * 2 * D * D * F                 # one time chunk of Hermitian partials
+        assert pb > 0 and pb % unit == 0
+        chunks = pb // unit
+        assert 1 <= chunks <= (T + 15) // 16
+        assert L.tssep_mvdr_workspace_bytes(B, K, D, T, F) >= pb + 16 * B * K * D * F
+    assert L.tssep_mvdr_partial_bytes(1, 4, 9, 253, 513) == 0        # more than 8 channels
+    assert L.tssep_mvdr_workspace_bytes(1, 0, 6, 253, 513) == 0
