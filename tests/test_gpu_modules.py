@@ -462,3 +462,56 @@ def test_enhancer_classes_checks(golden):
     assert torch.equal(torch.view_as_real(out), torch.view_as_real(Y[1][None]))
     x = torch.arange(1.0, 10.0).view(3, 3)
     assert float(E.trace(x)) == 15.0 and E.trace(x.view(3, 1, 3), axis1=0, axis2=2).tolist() == [15.0]
+
+
+def test_device_loader_pinned_async_h2d():
+    """tssep_amd.dataset.DeviceLoader: batches arrive on the GPU bit-identical and in order, pinned staging
+    buffers are reused (depth + 1 allocations per key, not one per batch), errors of the producer surface."""
+    from tssep_amd import dataset as D
+    rng = np.random.RandomState(0)
+    host = [dict(observation=rng.randn(3, 1, 5000).astype(np.float32),
+                 auxInput=rng.rand(3, 4, 513).astype(np.float32), example_id=[f"e{i}"] * 3, reference_channel=0)
+            for i in range(9)]
+    dl = D.DeviceLoader(D.new(host), "cuda:0", ("observation", "auxInput"), depth=2)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                               # consumer on a non-default stream
+        got = [(ex["observation"].clone(), ex["auxInput"].clone(), ex["example_id"]) for ex in dl]
+    torch.cuda.synchronize()
+    assert len(got) == 9 and dl.stats["batches"] == 9
+    for (o, a, ids), h in zip(got, host):
+        assert o.is_cuda and torch.equal(o.cpu(), torch.as_tensor(h["observation"]))
+        assert torch.equal(a.cpu(), torch.as_tensor(h["auxInput"])) and ids == h["example_id"]
+    assert dl.stats["pinned_allocations"] == 2 * 3            # 2 keys x (depth + 1) slots
+    assert len(dl[:2]) == 2
+
+    def boom():
+        yield host[0]
+        raise RuntimeError("reader failed")
+    with pytest.raises(RuntimeError, match="reader failed"):
+        list(D.DeviceLoader(boom(), "cuda:0", ("observation",)))
+
+
+def test_training_through_the_input_pipeline():
+    """prepare_train_dataset(device=cuda) -> DeviceLoader -> Model.forward/review/backward."""
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    torch.manual_seed(0)
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(sample_rate=1600, train_examples=5, aux_size=513),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=8, projs=8, combination="mul",
+                                            aux_net_output_size=513, ts_vad=8, output_resolution="tf"),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+    m.train()
+    ds = m.prepare_train_dataset(device="cuda:0", batch_size=2)
+    losses = []
+    for ex in ds:
+        assert ex["observation"].is_cuda and ex["speaker_reverberation_early_ch0"].is_cuda
+        out = m(ex)
+        l = m.review(ex, out)["loss"]
+        l.backward()
+        losses.append(float(l))
+    assert len(losses) == 3 and all(np.isfinite(losses))

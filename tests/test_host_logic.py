@@ -2,6 +2,7 @@
 argument validation of the C ABI (status codes instead of launches)."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
@@ -59,4 +60,73 @@ def test_abi_argument_validation_without_gpu():
 
 
 def test_side_stream_rows_policy():
-    assert H.SIDE_STREAM_MAX_ROWS == 768 * 253
+    assert H.SIDE_STREAM_MAX_ROWS == 512 * 253
+
+
+def test_lazy_dataset_stages_and_threaded_prefetch():
+    """tssep_amd.dataset: the lazy_dataset calls of model.py:182-337 (map / shuffle(reshuffle) / batch /
+    prefetch / catch): order-preserving threads, a new order per pass, exceptions at their position."""
+    import time
+    import numpy as np
+    from tssep_amd import dataset as D
+    ds = D.new([{"i": i} for i in range(10)])
+    seen = []
+
+    def f(ex):
+        seen.append(ex["i"])
+        return {"i": ex["i"], "sq": ex["i"] ** 2}
+
+    chain = (ds.map(f).shuffle(reshuffle=True, rng=np.random.RandomState(0)).batch(3)
+             .map(lambda b: [e["sq"] for e in b]).prefetch(3, 6))
+    a, b = list(chain), list(chain)
+    assert [len(x) for x in a] == [3, 3, 3, 1] and len(chain) == 4
+    assert sorted(sum(a, [])) == sorted(sum(b, [])) == [i * i for i in range(10)] and a != b
+    assert chain[:1] and len(chain[:1]) == 1
+
+    def slow(ex):
+        time.sleep(0.02 * (5 - ex["i"] % 5))
+        return ex["i"]
+
+    t0 = time.time()
+    assert list(ds.map(slow).prefetch(4, 8)) == list(range(10))          # in order ...
+    assert time.time() - t0 < 0.45                                        # ... and in parallel (0.6 s serial)
+
+    def bad(ex):
+        if ex["i"] == 4:
+            raise D.FilterException()
+        if ex["i"] == 7:
+            raise ValueError("boom")
+        return ex["i"]
+
+    got = []
+    with pytest.raises(ValueError):
+        for v in ds.map(bad).prefetch(2, 4, catch_filter_exception=True):
+            got.append(v)
+    assert got == [0, 1, 2, 3, 5, 6]
+    assert list(ds.map(bad).catch((D.FilterException, ValueError))) == [0, 1, 2, 3, 5, 6, 8, 9]
+    with pytest.raises(TypeError):
+        len(ds.catch())
+    fixed = ds.shuffle(reshuffle=False, rng=np.random.RandomState(1))
+    assert list(fixed) == list(fixed)
+    assert [e["i"] for e in ds.sort(lambda e: -e["i"])] == list(range(9, -1, -1))
+
+
+def test_prepare_dataset_follows_the_reference_stages():
+    """Model.prepare_dataset (model.py:182-337) on the DummyReader: collate shapes, reshuffle per epoch
+    when training, sorted test run, unbatched validation examples."""
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, loss, model
+    m = model.Model(fe=None, reader=DummyReader(sample_rate=800, train_examples=7), mask_estimator=None,
+                    enhancer=enhancer.Masking(), loss=loss.LogMAE())
+    m.train()
+    np.random.seed(0)
+    ds = m.prepare_train_dataset(device=None, batch_size=3)
+    e1, e2 = [ex["example_id"] for ex in ds], [ex["example_id"] for ex in ds]
+    assert [len(b) for b in e1] == [3, 3, 1] and sorted(sum(e1, [])) == sorted(sum(e2, [])) and e1 != e2
+    ex = ds[:1][0]
+    assert ex["observation"].shape == (3, 1, 4000) and ex["speaker_reverberation_early_ch0"].shape == (3, 8, 4000)
+    assert ex["auxInput"].shape == (3, 8, 100) and ex["reference_channel"] == 0
+    val = m.prepare_validate_dataset(device=None, batch_size=None, prefetch=False)
+    assert [e["example_id"] for e in val] == [f"dummy_id_{i}" for i in range(4)]
+    srt = m.prepare_dataset("train", None, training=True, sort=True, batch_size=2, prefetch=False)
+    assert [e["example_id"] for e in srt][0] == ["dummy_id_0", "dummy_id_1"]

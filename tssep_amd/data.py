@@ -4,6 +4,7 @@ import dataclasses
 
 import numpy as np
 
+from . import dataset as lazy_dataset
 from .configurable import Configurable
 
 
@@ -57,9 +58,10 @@ class DummyReader(Configurable):
     def __call__(self, dataset_name, pre_load_apply=None, load_keys=("observation",)):
         n = self.train_examples if "train" in dataset_name else 4
         examples = [self.get_example(i, dataset_name, load_keys) for i in range(n)]
+        ds = lazy_dataset.new(examples)                       # data.py:141-144
         if pre_load_apply is not None:
-            examples = pre_load_apply(examples)
-        return examples
+            ds = pre_load_apply(ds)
+        return ds
 
     class data_hooks:
         @staticmethod

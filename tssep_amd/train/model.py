@@ -1,7 +1,9 @@
 """Model -- drop-in for tssep/train/model.py: ``forward`` (:465-536) and the loss part of
-``review`` (:653-690) on the HIP kernels; dataset helpers follow :182-370 in a reduced form
-(no lazy_dataset: plain lists, the reader is synthetic)."""
+``review`` (:653-690) on the HIP kernels; the dataset helpers follow :182-370 stage by stage on
+``tssep_amd.dataset`` (lazy map / shuffle / batch / threaded prefetch, pinned asynchronous H2D)."""
 import dataclasses
+import functools
+import os
 
 import numpy as np
 import torch
@@ -75,29 +77,95 @@ class Model(Configurable, torch.nn.Module):
                 ex[k] = torch.as_tensor(np.stack([np.asarray(v) for v in ex[k]]))
         return ex
 
-    def prepare_dataset(self, dataset_name, device, training=False, batch_size=None, **_):
-        load_keys = ["observation", *self.loss.targets(lower=True)]
-        out = []
-        for e in self.reader(dataset_name, pre_load_apply=None, load_keys=load_keys):
-            r = {"reference_channel": 0, "observation": e["audio_data"]["observation"]}
-            for t in self.loss.targets():
-                if t.lower() in e["audio_data"]:
-                    r[t.lower()] = e["audio_data"][t.lower()]
-            for k in ("example_id", "dataset", "auxInput", "vad"):
-                if k in e:
-                    r[k] = e[k]
-            out.append(r)
+    def prepare_dataset(self, dataset_name, device, training=False, review=True, batch_size=None,
+                        prefetch=True, reader=None, sort=False, verbose=False, load_keys=None):
+        """model.py:182-337, same stages in the same order: reader -> prepare -> shuffle(reshuffle) when
+        training -> batch + collate -> threaded prefetch -> device.  The device stage is a
+        ``DeviceLoader`` (pinned staging buffers, asynchronous H2D on a copy stream, 2 batches ahead)
+        instead of ``example_to_device`` in a prefetch thread."""
+        from .. import dataset as D
+        if reader is None:
+            reader = self.reader
+        pre_load_apply = None
+        if sort:                                            # longest first: an OOM shows up early
+            def get_num_samples(ex):
+                if "end" in ex and "start" in ex:
+                    return ex["end"] - ex["start"]
+                n = ex["num_samples"]
+                if isinstance(n, dict):
+                    return n["observation"] if "observation" in n else max(n["original_source"])
+                return n
+
+            def pre_load_apply(ds):
+                return D.new(ds).copy(freeze=True).sort(get_num_samples, reverse=True)
+        if load_keys is None:
+            load_keys = ["observation", *self.loss.targets(lower=True)]
+        ds = D.new(reader(dataset_name, pre_load_apply=pre_load_apply, load_keys=load_keys))
+
+        def prepare(ex):
+            r = {"reference_channel": 0}
+            try:
+                r["observation"] = ex["audio_data"]["observation"]
+            except KeyError:
+                if "Input" in ex:
+                    r["Input"] = ex["Input"]
+                else:
+                    raise
+            for target_name in self.loss.targets():
+                try:
+                    lower = target_name.lower()
+                    if lower in ex["audio_data"]:
+                        target = ex["audio_data"][lower]
+                        if isinstance(target, np.ndarray) and target.ndim == 3:
+                            target = target[:, r["reference_channel"]]
+                        r[lower] = target
+                    elif target_name in ["Vad"]:
+                        r[target_name] = ex["audio_data"][target_name]
+                    elif review:
+                        raise Exception(
+                            f"Either the reader has a bug and forgot to load {lower!r} or you don't need "
+                            "the\ntarget signal from the loss. To disable this error, set the review "
+                            "flag to False.")
+                except KeyError:
+                    if self.training:
+                        raise
+            for k in ("example_id", "dataset", "gender", "auxInput", "vad"):
+                if k in ex:
+                    r[k] = ex[k]
+            if verbose:
+                r["verbose"] = ex
+            return r
+
+        ds = ds.map(prepare)
+        if training and not sort:
+            ds = ds.shuffle(reshuffle=True)
         if batch_size is not None:
-            out = [self.collate_fn(out[i:i + batch_size]) for i in range(0, len(out), batch_size)]
+            ds = ds.batch(batch_size).map(self.collate_fn)
+        if prefetch:
+            threads = int(os.environ.get("SLURM_CPUS_PER_TASK", 6))
+            ds = ds.prefetch(threads, threads * 2, catch_filter_exception=True)
+        elif training:
+            ds = ds.catch()
         if device is not None:
-            out = [self.example_to_device(e, device) for e in out]
-        return out
+            keys = ("Input", "observation", "auxInput", "vad", *self.loss.targets(lower=True),
+                    *self.loss.targets())
+            if batch_size is None:                          # single examples: convert, then copy
+                ds = ds.map(lambda ex: {k: (torch.as_tensor(v) if isinstance(v, np.ndarray)
+                                            and v.dtype != object else v) for k, v in ex.items()})
+            if prefetch:
+                return D.DeviceLoader(ds, device, keys, depth=2)
+            ds = ds.map(functools.partial(self.example_to_device, device=device))
+        return ds
 
-    def prepare_train_dataset(self, device, batch_size=None, **kw):
-        return self.prepare_dataset(self.reader.train_dataset_name, device, True, batch_size)
+    def prepare_train_dataset(self, device, batch_size=None, prefetch=True, reader=None, sort=False):
+        return self.prepare_dataset(self.reader.train_dataset_name if reader is None
+                                    else reader.train_dataset_name, device, training=True,
+                                    batch_size=batch_size, prefetch=prefetch, reader=reader, sort=sort)
 
-    def prepare_validate_dataset(self, device, batch_size=None, **kw):
-        return self.prepare_dataset(self.reader.validate_dataset_name, device, False, batch_size)
+    def prepare_validate_dataset(self, device, batch_size=None, prefetch=True, reader=None, sort=False):
+        return self.prepare_dataset(self.reader.validate_dataset_name if reader is None
+                                    else reader.validate_dataset_name, device, training=False,
+                                    batch_size=batch_size, prefetch=prefetch, reader=reader, sort=sort)
 
     # ------------------------------------------------------------------------ forward
     @dataclasses.dataclass
