@@ -84,6 +84,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own libamdhip64.so, and the HIP runtime this library binds to must be
+    # the one torch's streams and allocations live in (loading ours first pulled /opt/rocm's copy into
+    # the process as a second runtime: every launch on a torch stream then failed)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. "

@@ -237,6 +237,8 @@ class DeviceLoader:
         self.copy_threads = int(copy_threads)
         if self.device.type != "cuda":
             raise RuntimeError("DeviceLoader needs a GPU device (tssep_amd has no CPU path)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.stats = collections.Counter()
 
     def __len__(self):
@@ -250,7 +252,12 @@ class DeviceLoader:
                     break
                 out.append(ex)
             return out
-        raise TypeError("DeviceLoader supports iteration and [:n] only")
+        if isinstance(item, int) and item >= 0:              # ds[i]: the reference indexes datasets too
+            for i, ex in enumerate(self):
+                if i == item:
+                    return ex
+            raise IndexError(item)
+        raise TypeError("DeviceLoader supports iteration, [:n] and [i >= 0]")
 
     def __iter__(self):
         q = queue.Queue(maxsize=self.depth)
