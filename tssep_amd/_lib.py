@@ -11,7 +11,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "tssep_hip.h")
-LIB_PATH = os.path.join(_HERE, "libtssep_hip.so")
+LIB_PATH = os.environ.get("TSSEP_HIP_LIB") or os.path.join(_HERE, "libtssep_hip.so")      # (override: kernel experiments)
 
 
 class GemmArgs(ctypes.Structure):

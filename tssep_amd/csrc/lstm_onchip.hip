@@ -304,7 +304,12 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     // ---- io waves: row-contiguous HBM access, lane <-> (row s2 (+16), unit 16 q + (uq ^ s2))
     const int iow = (tid & 255) >> 6;                    // io wave index 0..3 (rows 4 iow .. + 3)
     const int usw = uq ^ s2;                             // this lane's unit within a 16-unit block
-    // asynchronous HBM -> LDS copy of the gate tile of step_ (no registers, returns immediately)
+    // asynchronous HBM -> LDS copy of the gate tile of step_ (no registers, returns immediately).
+    // The streamed activations (this copy, the flush stores below) are non-temporal: every access is a
+    // full 1-KB run, touched once -- left to the normal policy they evict the exchange granules from
+    // the 4-MB L2 (PMC: the publishes were being written back to HBM, 9.3 GB per launch against 7 GB of
+    // activations); forward 4-6 % faster.  The backward's accesses are 16-B pieces at a 64-B stride
+    // (four instructions per line): the same hint makes them partial-line HBM transactions, 1.6x slower
     auto io_dma = [&](int64_t step_, int b_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
 #pragma unroll
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
           if (ns < N && u < H)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4),
-                (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64], 16, 0, 0);
+                (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64], 16, 0, 2);      // aux 2 = nt
         }
       }
     };
@@ -332,14 +337,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int u = 64 * g + 16 * q + usw;
-          if (u < H) *reinterpret_cast<f32x4*>(gates + (rowg + u) * 4) = xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane];
+          if (u < H) __builtin_nontemporal_store(xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane], reinterpret_cast<f32x4*>(gates + (rowg + u) * 4));
         }
         const int u4 = 64 * g + 4 * uq;
         const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s * PUBPITCH + 4 * uq);
         const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
         if (vec_ok && u4 + 4 <= H) {
-          *reinterpret_cast<f32x4*>(cell + rowg + u4) = cq;
-          *reinterpret_cast<f32x4*>(hout + rowh + u4) = hq;
+          __builtin_nontemporal_store(cq, reinterpret_cast<f32x4*>(cell + rowg + u4));
+          __builtin_nontemporal_store(hq, reinterpret_cast<f32x4*>(hout + rowh + u4));
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
