@@ -206,7 +206,9 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
  * a per-launch epoch and the step: the data is the flag).  Clusters are formed from workgroups of
  * ONE XCD (HW_REG_XCC_ID), so the exchange stays in that XCD's L2.  Same tensor layouts as
  * tssep_blstm_fwd/bwd.  `layout` bits: 1 = experimental time-major-in-groups-of-32 row order,
- * 8 = force cross-XCD clusters (write-through exchange).  xbuf: caller-owned scratch of
+ * 8 = force cross-XCD clusters (write-through exchange), 32 = forward only: keep the activation
+ * stream temporal (default: non-temporal from 160 sequences up, so that it does not evict the
+ * exchange granules from the L2).  xbuf: caller-owned scratch of
  * tssep_lstm_onchip_xbuf_bytes() bytes (zeroed by the call); err: device int, set non-zero if a
  * bounded spin expired.  max_wgs: number of CUs the launch may occupy.  H <= 304. */
 int tssep_lstm_onchip_supported(int H);

@@ -259,6 +259,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_fail = 0;
+  const bool stream_nt = (layout & 16) != 0;           // non-temporal activation stream (host: N >= 160)
+  layout &= 1;
   const int64_t ngroups = (N + SEQS - 1) / SEQS;
   // (membership is wave-uniform by construction; join_cluster returns it through readfirstlane so
   // that the buffer descriptors below are built from SGPRs, no waterfall loops around the loads)
@@ -305,11 +307,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     const int iow = (tid & 255) >> 6;                    // io wave index 0..3 (rows 4 iow .. + 3)
     const int usw = uq ^ s2;                             // this lane's unit within a 16-unit block
     // asynchronous HBM -> LDS copy of the gate tile of step_ (no registers, returns immediately).
-    // The streamed activations (this copy, the flush stores below) are non-temporal: every access is a
-    // full 1-KB run, touched once -- left to the normal policy they evict the exchange granules from
-    // the 4-MB L2 (PMC: the publishes were being written back to HBM, 9.3 GB per launch against 7 GB of
-    // activations); forward 4-6 % faster.  The backward's accesses are 16-B pieces at a 64-B stride
-    // (four instructions per line): the same hint makes them partial-line HBM transactions, 1.6x slower
+    // The streamed activations (this copy, the flush stores below) are non-temporal from 160 sequences
+    // up: every access is a full 1-KB run, touched once -- left to the normal policy they evict the
+    // exchange granules from the 4-MB L2 (PMC: the publishes were being written back to HBM, 9.3 GB per
+    // launch against 7 GB of activations).  Measured effect on the launch: +5 % between two processes on
+    // one box, 0-1 % toggled inside one process (layout bit 32) -- inside the pool's run-to-run spread;
+    // below 160 sequences (a few clusters, pure latency) the hint costs 10 % and is off.  The backward's
+    // accesses are 16-B pieces at a 64-B stride (four instructions per line): there the same hint makes
+    // partial-line HBM transactions, 1.2-1.6x slower.
     auto io_dma = [&](int64_t step_, int b_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
 #pragma unroll
@@ -318,10 +323,12 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int u = 64 * g + 16 * q + usw;
-          if (ns < N && u < H)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4),
-                (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64], 16, 0, 2);      // aux 2 = nt
+          if (ns < N && u < H) {
+            const auto* src = (const __attribute__((address_space(1))) void*)(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4);
+            auto* dst = (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64];
+            if (stream_nt) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);      // aux 2 = nt
+            else __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+          }
         }
       }
     };
@@ -337,14 +344,23 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int u = 64 * g + 16 * q + usw;
-          if (u < H) __builtin_nontemporal_store(xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane], reinterpret_cast<f32x4*>(gates + (rowg + u) * 4));
+          if (u < H) {
+            const f32x4 v = xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane];
+            f32x4* dst = reinterpret_cast<f32x4*>(gates + (rowg + u) * 4);
+            if (stream_nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+          }
         }
         const int u4 = 64 * g + 4 * uq;
         const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s * PUBPITCH + 4 * uq);
         const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
         if (vec_ok && u4 + 4 <= H) {
-          __builtin_nontemporal_store(cq, reinterpret_cast<f32x4*>(cell + rowg + u4));
-          __builtin_nontemporal_store(hq, reinterpret_cast<f32x4*>(hout + rowh + u4));
+          if (stream_nt) {
+            __builtin_nontemporal_store(cq, reinterpret_cast<f32x4*>(cell + rowg + u4));
+            __builtin_nontemporal_store(hq, reinterpret_cast<f32x4*>(hout + rowh + u4));
+          } else {
+            *reinterpret_cast<f32x4*>(cell + rowg + u4) = cq;
+            *reinterpret_cast<f32x4*>(hout + rowh + u4) = hq;
+          }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -821,14 +837,16 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   int nc;
   const unsigned grid = onchip_grid(items, G, max_wgs, xcd, &nc);
   char* base = (char*)xbuf;
+  // bit 4 of the kernel's layout word: non-temporal activation stream (layout bit 32 forces it off)
+  const int klayout = (layout & 1) | ((N >= 160 && !(layout & 32)) ? 16 : 0);
   if (xcd)
     hipLaunchKernelGGL(blstm_onchip_fwd_kernel<true>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
                        ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
-                       N, T, H, G, nc, layout & 1, next_tagbase());
+                       N, T, H, G, nc, klayout, next_tagbase());
   else
     hipLaunchKernelGGL(blstm_onchip_fwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
                        ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
-                       N, T, H, G, nc, layout & 1, next_tagbase());
+                       N, T, H, G, nc, klayout, next_tagbase());
   return tssep_launch_status();
 }
 
