@@ -24,6 +24,7 @@
 // stage and two barriers per tile ran 113-267 TFLOP/s; BK = 64 and naive double buffering changed
 // nothing; the pipelined loop + row epilogue + tall tile run 190-320 TFLOP/s.
 #include <cstdlib>
+#include <type_traits>
 #include "gemm_common.h"
 
 namespace {
@@ -703,16 +704,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
     for (int i = 0; i < 4; ++i) kok[i] = full || kt * BK + krow + 8 * i < K;
   };
   const int soff = krow * TNP + (tid & 31) * 8;
-  auto stage = [&](char* st) {
+  // EDGE = false: an interior tile in the steady state -- every row < K and every column valid, only
+  // the time shift still masks rows (64 selects per thread and tile less)
+  auto stage = [&](char* st, auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      bool okb = kok[i];
-      if (SHIFT) { const int q = ph[i] + kshift; okb = okb && q >= 0 && q < kperiod; }
       f32x4 a = ra[i], b = rb[i];
+      if constexpr (EDGE) {
+        bool okb = kok[i];
+        if (SHIFT) { const int q = ph[i] + kshift; okb = okb && q >= 0 && q < kperiod; }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = (kok[i] && am[e]) ? a[e] : 0.f;
-        b[e] = (okb && bm[e]) ? b[e] : ((bone[e] && kok[i]) ? 1.f : 0.f);
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (kok[i] && am[e]) ? a[e] : 0.f;
+          b[e] = (okb && bm[e]) ? b[e] : ((bone[e] && kok[i]) ? 1.f : 0.f);
+        }
+      } else if constexpr (SHIFT) {
+        const int q = ph[i] + kshift;
+        const bool okb = q >= 0 && q < kperiod;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = okb ? b[e] : 0.f;
       }
       unsigned h0, l0, h1, l1;
       split2n(a[0], a[1], h0, l0);
@@ -759,11 +770,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
     }
   };
-#define TNPIPE(cur, nxt, kt_, SID_)                                                             \
+#define TNPIPE(cur, nxt, kt_, SID_, EDGE_)                                                      \
   do {                                                                                          \
     constexpr int SID = SID_;                                                                   \
     compute(cur);                                                                               \
-    stage(nxt);                                                                                 \
+    stage(nxt, std::integral_constant<bool, EDGE_>{});                                          \
     gload_full((kt_) + 2);                                                                      \
     note_tile((kt_) + 2, true);                                                                 \
     SGB(0x100, 16);                                                                             \
@@ -776,7 +787,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
   if (kt_begin < kt_end) {
     gload_any(kt_begin);
     note_tile(kt_begin, kt_begin < kt_full);
-    stage(lds0);
+    stage(lds0, std::true_type{});
     if (kt_begin + 1 < kt_end) { gload_any(kt_begin + 1); note_tile(kt_begin + 1, kt_begin + 1 < kt_full); }
     __syncthreads();
     int64_t kt = kt_begin;
@@ -784,15 +795,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
     // the pipelined loads read row k + kshift unconditionally: stay clear of the matrix's last tiles
     // (they never see the first ones: they start at tile kt_begin + 2)
     if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
-    for (; kt < lim; kt += 2) {
-      TNPIPE(lds0, lds1, kt, 1);
-      TNPIPE(lds1, lds0, kt + 1, 2);
+    // (the tile staged first in the loop, kt + 1, was loaded by gload_any: rows < K there as well)
+    const bool edge = m0 + BM > M || n0 + BN > Nreal;
+    if (edge) {
+      for (; kt < lim; kt += 2) {
+        TNPIPE(lds0, lds1, kt, 1, true);
+        TNPIPE(lds1, lds0, kt + 1, 2, true);
+      }
+    } else {
+      for (; kt < lim; kt += 2) {
+        TNPIPE(lds0, lds1, kt, 3, false);
+        TNPIPE(lds1, lds0, kt + 1, 4, false);
+      }
     }
     for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
       const char* cur = par ? lds1 : lds0;
       char* nxt = par ? lds0 : lds1;
       compute(cur);
-      if (kt + 1 < kt_end) stage(nxt);
+      if (kt + 1 < kt_end) stage(nxt, std::true_type{});
       if (kt + 2 < kt_end) { gload_any(kt + 2); note_tile(kt + 2, kt + 2 < kt_full); }
       __syncthreads();
     }
