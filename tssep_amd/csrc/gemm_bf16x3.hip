@@ -603,6 +603,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
 // i receives column i (4 k values) -- two reads per 8-k fragment.  Masks (K tail, column tail, time
 // shift, virtual ones column) are applied when a tile is staged, never on the load path.
 // Time shift: row k of B is replaced by row k + kshift of the same period (zero outside it).
+// The loop body is left to the compiler's scheduler: a hand-written sched_group_barrier interleave
+// (MFMA / transpose read / 4 VALU / ds_write ...) measured 5-8 % SLOWER here in an alternating A/B of
+// two builds (three other interleaves 0-3 % slower than none).
 constexpr int TNP = 320;                 // bytes per k row: 128 m x 2 B + 64
 constexpr int TNARR = 32 * TNP;          // one array (32 k rows) = 10 240 B
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -772,14 +775,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
   };
 #define TNPIPE(cur, nxt, kt_, SID_, EDGE_)                                                      \
   do {                                                                                          \
-    constexpr int SID = SID_;                                                                   \
     compute(cur);                                                                               \
     stage(nxt, std::integral_constant<bool, EDGE_>{});                                          \
     gload_full((kt_) + 2);                                                                      \
     note_tile((kt_) + 2, true);                                                                 \
-    SGB(0x100, 16);                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x020, 1); }               \
     __syncthreads();                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
