@@ -24,3 +24,4 @@ python tools/bench_mvdr.py > $O/mvdr_microbench.jsonl 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvdr_stats -o m -- python3 tools/bench_mvdr.py --no-cpu --iters 10 > $O/mvdr_stats.log 2>&1
 python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null
 python tools/bench_input_pipeline.py 768 > $O/input_pipeline.jsonl 2>/dev/null; python tools/bench_input_pipeline.py 384 >> $O/input_pipeline.jsonl 2>/dev/null
+python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
