@@ -411,7 +411,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // workgroups per CU (152 VGPRs, 48 KB LDS) was 0-10 % slower than BK = 32 at two; half-width (128 x 64)
 // edge tiles for N = 513 / 514 / 300 (20-25 % of the columns of the last 128-wide tile are padding)
 // cost as much as the padding they remove -- as a second launch they also serialise behind the main
-// one (+5..12 % on the split-K shapes).
+// one (+5..12 % on the split-K shapes).  Skipping only the MFMAs of the padded 32 x 32 sub-tiles inside the
+// edge tile (N = 513: three quarters of its matrix work) changed nothing either (alternating A/B): an edge
+// workgroup still stages the full A panel, and the stage is bounded by staging and barriers, not by MFMA.
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
 constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
