@@ -605,9 +605,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
 // i receives column i (4 k values) -- two reads per 8-k fragment.  Masks (K tail, column tail, time
 // shift, virtual ones column) are applied when a tile is staged, never on the load path.
 // Time shift: row k of B is replaced by row k + kshift of the same period (zero outside it).
-// The loop body is left to the compiler's scheduler: a hand-written sched_group_barrier interleave
-// (MFMA / transpose read / 4 VALU / ds_write ...) measured 5-8 % SLOWER here in an alternating A/B of
-// two builds (three other interleaves 0-3 % slower than none).
+// The loop body of the unshifted variant is left to the compiler's scheduler: a hand-written
+// sched_group_barrier interleave (MFMA / transpose read / 4 VALU / ds_write ...) measured 5-8 % SLOWER
+// there in an alternating A/B of two builds (three other interleaves 0-3 % slower than none; MFMA busy
+// 44 -> 54 % in the step); the shifted variant keeps the interleave (44 % with, 40 % without).
 constexpr int TNP = 320;                 // bytes per k row: 128 m x 2 B + 64
 constexpr int TNARR = 32 * TNP;          // one array (32 k rows) = 10 240 B
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -781,6 +782,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
     stage(nxt, std::integral_constant<bool, EDGE_>{});                                          \
     gload_full((kt_) + 2);                                                                      \
     note_tile((kt_) + 2, true);                                                                 \
+    if constexpr (SHIFT) {     /* (the shifted variant: 44 % MFMA busy with this interleave, 40 % without) */ \
+      constexpr int SID = SID_;                                                                 \
+      SGB(0x100, 16);                                                                           \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x020, 1); }               \
+    }                                                                                           \
     __syncthreads();                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
@@ -797,7 +804,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
     // (they never see the first ones: they start at tile kt_begin + 2)
     if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
     // (the tile staged first in the loop, kt + 1, was loaded by gload_any: rows < K there as well)
-    const bool edge = m0 + BM > M || n0 + BN > Nreal;
+    // (the shifted variant always takes the masked loop: its second copy of the loop cost 3 points of
+    // MFMA-busy time -- code size -- and its row masks stay anyway)
+    const bool edge = SHIFT || m0 + BM > M || n0 + BN > Nreal;
     if (edge) {
       for (; kt < lim; kt += 2) {
         TNPIPE(lds0, lds1, kt, 1, true);
