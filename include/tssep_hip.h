@@ -338,6 +338,18 @@ int tssep_mvdr_souden_fwd(const double* obs, const void* masks, int mask_f64, do
                           int F, int reference_channel, double eps, int masking,
                           double masking_eps, void* stream);
 
+/* ------------------------------------------------ experimental GEMM probes ----
+ * Round-1 probe for the next GEMM design (DESIGN.md "Next" 1), not on the product path: operands
+ * pre-split into bf16 hi / lo planes [rows][Kp], Kp = K rounded up to 16 (zero padded), staged by
+ * asynchronous global -> LDS copies through a ring of `ring` (2 or 3) LDS stages.  Same tile and
+ * MFMA order as the production split-bf16 kernel: C = A B^T bit-identical to tssep_gemm_f32 with
+ * precision 1 (plain store, no bias / activation). */
+int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi, void* lo,
+                             void* stream);
+int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
+                              float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int ring,
+                              void* stream);
+
 /* -------------------------------------------------------------- optimizer -----
  * One optimizer step on flat fp32 buffers: global-norm gradient clipping
  * (torch.nn.utils.clip_grad_norm_, max_norm <= 0 disables) + Adam (torch.optim.Adam update rule,

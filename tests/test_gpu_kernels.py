@@ -643,3 +643,42 @@ def test_mae_loss(golden):
     ed = est.detach().cuda().requires_grad_()
     (Fn.mae(ed, tgt.cuda()) * gout.cuda()).sum().backward()
     close(ed.grad, est.grad, rtol=1e-6, atol=1e-12, name="mae grad")
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 300, 70), (2051, 390, 513), (300, 513, 33)])
+def test_presplit_gemm_probe_is_bit_identical(M, N, K):
+    """Experimental probe (csrc/gemm_presplit.hip): pre-split bf16 planes staged by asynchronous
+    global -> LDS copies, 256x128 / 256x256 tiles, 2- and 3-stage rings -- same MFMA order as the
+    production split-bf16 GEMM, so the results must be bit-identical to it."""
+    from tssep_amd import _lib
+    h, L = H(), _lib.lib()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        torch.manual_seed(0)
+        Kp4, Kp = h.round_up(K, 4), h.round_up(K, 16)
+        A = torch.zeros(M, Kp4, device="cuda"); A[:, :K] = torch.randn(M, K, device="cuda")
+        W = torch.zeros(N, Kp4, device="cuda"); W[:, :K] = torch.randn(N, K, device="cuda")
+        C0 = torch.empty(M, N, device="cuda")
+        if M >= 1024:
+            h.gemm(A, Kp4, W, Kp4, C0, N, M, N, K)              # the tall kernel: same tile, same order
+        planes = [torch.empty(r, Kp, device="cuda", dtype=torch.bfloat16) for r in (M, M, N, N)]
+        st = torch.cuda.current_stream().cuda_stream
+        h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), st), "split")
+        h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), st), "split")
+        hi, lo = planes[0].float(), planes[1].float()
+        assert float((hi[:, :K] + lo[:, :K] - A[:, :K]).abs().max()) <= float(A.abs().max()) * 2 ** -16
+        assert float(hi[:, K:].abs().max() if Kp > K else 0) == 0
+        ref = (A[:, :K].double() @ W[:, :K].double().t()).float()
+        outs = []
+        for ring in (2, 3, 12, 13):
+            C = torch.full((M, N), float("nan"), device="cuda")
+            h.check(L.tssep_probe_gemm_presplit(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
+                                                planes[3].data_ptr(), C.data_ptr(), M, N, K, N, ring, st), "probe")
+            close(C, ref, rtol=2e-4, atol=2e-4 * K ** 0.5, name=f"ring {ring}")
+            outs.append(C)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        if M >= 1024:
+            assert torch.equal(outs[0], C0)
+    finally:
+        h.GEMM_PRECISION = old

@@ -1,0 +1,202 @@
+// EXPERIMENT (round-1 probe for the next GEMM design, see DESIGN.md "Next" 1): split-bf16 GEMM whose
+// operands arrive PRE-SPLIT (bf16 hi and lo planes, [rows][Kp] with Kp = K rounded up to 16, zero padded),
+// so that a K tile is staged by asynchronous global -> LDS copies only: no split VALU, no ds_write, no
+// staging registers, and a three-deep LDS ring at the same 72 KB per workgroup the production kernel
+// uses for two stages.  Same tile (256 x 128 x 16, 4 waves, wave tile 128 x 64) and the same MFMA order
+// as gemm_bf16x3_tall_kernel, so the results are bit-identical to it.
+//
+// LDS image of one plane: rows of 16 bf16 = 32 B, two 16-B slots per row; a copy instruction moves 1 KB
+// = 32 rows lane-linearly, so the layout is fixed -- the slot order inside a row is XOR-swizzled with
+// bit 3 of the row ON THE SOURCE SIDE so that the 16 rows of a ds_read_b128 lane group hit 16 distinct
+// 16-byte bank groups.
+// The copies are issued with inline asm (the compiler orders every LDS read behind any copy it knows of
+// with vmcnt(0), which would serialise the ring) and waited for with an explicit vmcnt(6): the six
+// copies of the NEXT tile may stay in flight.
+#include "gemm_common.h"
+
+namespace {
+using namespace gemm_detail;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PBM = 256, PBK = 16;
+constexpr int PA = PBM * 32;                           // bytes of one A plane of one stage
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t rows,
+                                                           int64_t K, int64_t ld, int64_t Kp,
+                                                           __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * Kp) return;
+  const int64_t r = i / Kp, k = i - r * Kp;
+  const float v = k < K ? x[r * ld + k] : 0.f;
+  const __bf16 h = (__bf16)v;
+  hi[i] = h;
+  lo[i] = (__bf16)(v - (float)h);
+}
+
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
+  // 64 lanes x 16 B -> LDS [lds_addr, lds_addr + 1024), lane-linear
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_addr) : "memory");
+}
+
+// WN = 2: 256 x 128 tile, 4 waves, two workgroups per CU.  WN = 4: 256 x 256 tile, 8 waves, one workgroup per
+// CU (32 KB per stage: 33 % fewer operand bytes per MFMA).
+template <int WN>
+__global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kernel(
+    const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al, const __bf16* __restrict__ Bh,
+    const __bf16* __restrict__ Bl, float* __restrict__ C, int64_t M, int64_t N, int64_t Kp,
+    int64_t ldc, TileMap tmap, int ring) {
+  constexpr int PBN = 64 * WN, PB = PBN * 32, PSTAGE = 2 * PA + 2 * PB, NW = 2 * WN;
+  constexpr int NPIECE = PSTAGE / 1024, PPW = NPIECE / NW;     // copies per stage, per wave
+  constexpr int EPI = NW * 64 * EPITCH * 4;
+  __shared__ __attribute__((aligned(1024))) char lds[3 * PSTAGE > EPI ? 3 * PSTAGE : EPI];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * PBM, n0 = (int64_t)nt * PBN;
+  const int64_t ktiles = Kp / PBK;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // copies of this wave: pieces p = wave + 4 q (q = 0..5) of the stage's 24 KB; piece p covers 32 rows
+  // of plane {A hi: 0-7, A lo: 8-15, B hi: 16-19, B lo: 20-23}; lane l fetches row l/2, 16-B slot
+  // (l&1) ^ bit3(row)
+  const char* src[PPW];
+  unsigned dst[PPW];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = wave + NW * q;
+    const bool isA = p < 16;
+    const int blk = isA ? (p & 7) : ((p - 16) % (2 * WN));
+    const bool lo = isA ? p >= 8 : p >= 16 + 2 * WN;
+    const int r = blk * 32 + (lane >> 1);
+    const int h = (lane & 1) ^ ((r >> 3) & 1);
+    int64_t grow = (isA ? m0 : n0) + r;
+    const int64_t lim = (isA ? M : N) - 1;
+    grow = grow > lim ? lim : grow;
+    const __bf16* plane = isA ? (lo ? Al : Ah) : (lo ? Bl : Bh);
+    src[q] = reinterpret_cast<const char*>(plane + grow * Kp) + h * 16;
+    dst[q] = (unsigned)((isA ? (lo ? PA : 0) : 2 * PA + (lo ? PB : 0)) + blk * 1024);
+  }
+  auto issue = [&](int64_t kt, int stage) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) dma16(src[q] + kt * (PBK * 2), lds_base + stage * PSTAGE + dst[q]);
+  };
+  // fragment slots of this lane
+  const int fr = lane & 31, fh = lane >> 5;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 128 + i * 32 + fr;
+    aoff[i] = (2 * r + (fh ^ ((r >> 3) & 1))) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wn * 64 + j * 32 + fr;
+    boff[j] = 2 * PA + (2 * r + (fh ^ ((r >> 3) & 1))) * 16;
+  }
+  auto compute = [&](const char* st) {
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const bf16x8*>(st + aoff[i]);
+      al[i] = *reinterpret_cast<const bf16x8*>(st + PA + aoff[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = *reinterpret_cast<const bf16x8*>(st + boff[j]);
+      bl[j] = *reinterpret_cast<const bf16x8*>(st + PB + boff[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+
+  // ring of `ring` stages (2 or 3): tile kt lives in stage kt % ring; `ring - 1` tiles are in flight
+  issue(0, 0);
+  if (ring == 3 && ktiles > 1) issue(1, 1);
+  int cur = 0;
+  for (int64_t kt = 0; kt < ktiles; ++kt) {
+    const int64_t nxt_tile = kt + ring - 1;
+    // tile kt has landed when at most the copies of the younger in-flight tile are outstanding
+    if (ring == 3 && kt + 1 < ktiles) {
+      if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // every wave's copies of tile kt are in; every wave is done with tile kt - 1
+    if (nxt_tile < ktiles) {
+      int st = cur + ring - 1;
+      st = st >= ring ? st - ring : st;
+      issue(nxt_tile, st);
+    }
+    compute(lds + cur * PSTAGE);
+    cur = cur + 1 == ring ? 0 : cur + 1;
+  }
+  __syncthreads();
+  float* stage = reinterpret_cast<float*>(lds) + wave * 64 * EPITCH;
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    f32x16 a2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
+    gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
+                       nullptr, 0, 0, ldc, true);
+  }
+}
+
+}  // namespace
+
+extern "C" int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi,
+                                        void* lo, void* stream) {
+  if (!x || !hi || !lo) return TSSEP_E_NULL;
+  if (rows <= 0 || K <= 0 || ld < K) return TSSEP_E_SHAPE;
+  const int64_t Kp = (K + 15) / 16 * 16;
+  const int64_t n = rows * Kp;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, rows, K, ld, Kp, (__bf16*)hi, (__bf16*)lo);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_hi,
+                                         const void* b_lo, float* C, int64_t M, int64_t N, int64_t K,
+                                         int64_t ldc, int ring, void* stream) {
+  if (!a_hi || !a_lo || !b_hi || !b_lo || !C) return TSSEP_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || ldc < N || (ring != 2 && ring != 3 && ring != 12 && ring != 13)) return TSSEP_E_SHAPE;
+  if (!aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) || !aligned16(b_lo)) return TSSEP_E_ALIGN;
+  const int64_t Kp = (K + 15) / 16 * 16;
+  // ring 2 / 3: 256 x 128 tile (4 waves); ring 12 / 13: 256 x 256 tile (8 waves), ring 2 / 3
+  if (ring >= 12) {
+    const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 255) / 256, 1);
+    hipLaunchKernelGGL(gemm_presplit_kernel<4>, dim3((unsigned)tile_map_blocks(tm)), dim3(512), 0,
+                       (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
+                       (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring - 10);
+    return tssep_launch_status();
+  }
+  const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 127) / 128, 1);
+  hipLaunchKernelGGL(gemm_presplit_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
+                     (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
+                     (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring);
+  return tssep_launch_status();
+}
