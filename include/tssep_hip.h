@@ -343,9 +343,11 @@ int tssep_mvdr_souden_fwd(const double* obs, const void* masks, int mask_f64, do
  * pre-split into bf16 hi / lo planes [rows][Kp], Kp = K rounded up to 16 (zero padded), staged by
  * asynchronous global -> LDS copies through a ring of `ring` (2 or 3) LDS stages.  Same tile and
  * MFMA order as the production split-bf16 kernel: C = A B^T bit-identical to tssep_gemm_f32 with
- * precision 1 (plain store, no bias / activation). */
+ * precision 1 (plain store, no bias / activation).  ring: 2 | 3 (256 x 128 tile) or 12 | 13 (256 x 256,
+ * 8 waves), + 4096 when the planes are k-tile-major ([K/16][rows][16], ktile_major = 1 in the split),
+ * + ablation flags 256 / 512 / 1024 / 2048 (timing experiments, see the source). */
 int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi, void* lo,
-                             void* stream);
+                             int ktile_major, void* stream);
 int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                               float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int ring,
                               void* stream);

@@ -664,8 +664,8 @@ def test_presplit_gemm_probe_is_bit_identical(M, N, K):
             h.gemm(A, Kp4, W, Kp4, C0, N, M, N, K)              # the tall kernel: same tile, same order
         planes = [torch.empty(r, Kp, device="cuda", dtype=torch.bfloat16) for r in (M, M, N, N)]
         st = torch.cuda.current_stream().cuda_stream
-        h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), st), "split")
-        h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), st), "split")
+        h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), 0, st), "split")
+        h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), 0, st), "split")
         hi, lo = planes[0].float(), planes[1].float()
         assert float((hi[:, :K] + lo[:, :K] - A[:, :K]).abs().max()) <= float(A.abs().max()) * 2 ** -16
         assert float(hi[:, K:].abs().max() if Kp > K else 0) == 0

@@ -37,26 +37,26 @@ for name, M, N, K in (("small", 1000, 300, 70), ("birnn1 in", 388608, 2400, 320)
     h.gemm(A, Kp4, W, Kp4, C0, N, M, N, K)
     planes = [torch.empty(r, Kp, device="cuda", dtype=torch.bfloat16) for r in (M, M, N, N)]
 
-    def split():
-        h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), st()), "split")
-        h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), st()), "split")
-    split()
     row = {"name": name, "M": M, "N": N, "K": K}
-    for ring in (2, 3, 12, 13):
-        C = torch.full((M, N), float("nan"), device="cuda")
+    for KTM, tag in ((0, "rowmajor"), (1, "ktile")):
+        def split():
+            h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), KTM, st()), "split")
+            h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), KTM, st()), "split")
+        split()
+        for ring in (2, 3, 12, 13):
+            C = torch.full((M, N), float("nan"), device="cuda")
 
-        def run():
-            h.check(L.tssep_probe_gemm_presplit(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                                                planes[3].data_ptr(), C.data_ptr(), M, N, K, N, ring, st()), "presplit")
-        run()
-        torch.cuda.synchronize()
-        row[f"ring{ring}_max_abs_diff"] = float((C - C0).abs().max())
-        row[f"ring{ring}_bit_identical"] = bool(torch.equal(C, C0))
-        ms = timeit(run)
-        row[f"ring{ring}_ms"] = round(ms, 4)
-        row[f"ring{ring}_tflops"] = round(2 * M * N * K / ms / 1e9, 1)
+            def run():
+                h.check(L.tssep_probe_gemm_presplit(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
+                                                    planes[3].data_ptr(), C.data_ptr(), M, N, K, N, ring | (4096 * KTM), st()), "presplit")
+            run()
+            torch.cuda.synchronize()
+            row[f"{tag}_ring{ring}_bit_identical"] = bool(torch.equal(C, C0))
+            ms = timeit(run)
+            row[f"{tag}_ring{ring}_ms"] = round(ms, 4)
+            row[f"{tag}_ring{ring}_tflops"] = round(2 * M * N * K / ms / 1e9, 1)
+        row[f"{tag}_split_ms"] = round(timeit(split), 4)
     ms0 = timeit(lambda: h.gemm(A, Kp4, W, Kp4, C0, N, M, N, K))
     row["production_ms"], row["production_tflops"] = round(ms0, 4), round(2 * M * N * K / ms0 / 1e9, 1)
-    row["split_ms"] = round(timeit(split), 4)
     print(json.dumps(row), flush=True)
     del A, W, C0, planes

@@ -21,16 +21,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PBM = 256, PBK = 16;
 constexpr int PA = PBM * 32;                           // bytes of one A plane of one stage
 
+// ktile_major: element (r, k) at ((k / 16) * rows + r) * 16 + k % 16 -- the 32 rows x 16 k of one copy
+// instruction are then 1 KB CONTIGUOUS (whole cache lines), instead of 32-byte pieces of 32 different lines
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t rows,
                                                            int64_t K, int64_t ld, int64_t Kp,
-                                                           __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+                                                           __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                           int ktile_major) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * Kp) return;
   const int64_t r = i / Kp, k = i - r * Kp;
   const float v = k < K ? x[r * ld + k] : 0.f;
   const __bf16 h = (__bf16)v;
-  hi[i] = h;
-  lo[i] = (__bf16)(v - (float)h);
+  const int64_t o = ktile_major ? ((k >> 4) * rows + r) * 16 + (k & 15) : i;
+  hi[o] = h;
+  lo[o] = (__bf16)(v - (float)h);
 }
 
 __device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
@@ -44,7 +48,12 @@ template <int WN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kernel(
     const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al, const __bf16* __restrict__ Bh,
     const __bf16* __restrict__ Bl, float* __restrict__ C, int64_t M, int64_t N, int64_t Kp,
-    int64_t ldc, TileMap tmap, int ring) {
+    int64_t ldc, TileMap tmap, int ring_flags) {
+  // ablation flags (timing experiments only, results are then wrong): 256 = no MFMA, 512 = no fragment
+  // reads, 1024 = no copies, 2048 = no barriers
+  const int ring = ring_flags & 255;
+  const bool ktm = ring_flags & 4096;       // planes are k-tile-major
+  const bool no_mfma = ring_flags & 256, no_frag = ring_flags & 512, no_dma = ring_flags & 1024, no_bar = ring_flags & 2048;
   constexpr int PBN = 64 * WN, PB = PBN * 32, PSTAGE = 2 * PA + 2 * PB, NW = 2 * WN;
   constexpr int NPIECE = PSTAGE / 1024, PPW = NPIECE / NW;     // copies per stage, per wave
   constexpr int EPI = NW * 64 * EPITCH * 4;
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
   // of plane {A hi: 0-7, A lo: 8-15, B hi: 16-19, B lo: 20-23}; lane l fetches row l/2, 16-B slot
   // (l&1) ^ bit3(row)
   const char* src[PPW];
+  int64_t kstride[PPW];
   unsigned dst[PPW];
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 #pragma unroll
@@ -82,12 +92,14 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
     const int64_t lim = (isA ? M : N) - 1;
     grow = grow > lim ? lim : grow;
     const __bf16* plane = isA ? (lo ? Al : Ah) : (lo ? Bl : Bh);
-    src[q] = reinterpret_cast<const char*>(plane + grow * Kp) + h * 16;
+    src[q] = reinterpret_cast<const char*>(plane + (ktm ? grow * 16 : grow * Kp)) + h * 16;
+    kstride[q] = ktm ? (isA ? M : N) * 32 : PBK * 2;
     dst[q] = (unsigned)((isA ? (lo ? PA : 0) : 2 * PA + (lo ? PB : 0)) + blk * 1024);
   }
   auto issue = [&](int64_t kt, int stage) {
+    if (no_dma) return;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) dma16(src[q] + kt * (PBK * 2), lds_base + stage * PSTAGE + dst[q]);
+    for (int q = 0; q < PPW; ++q) dma16(src[q] + kt * kstride[q], lds_base + stage * PSTAGE + dst[q]);
   };
   // fragment slots of this lane
   const int fr = lane & 31, fh = lane >> 5;
@@ -102,8 +114,17 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
     const int r = wn * 64 + j * 32 + fr;
     boff[j] = 2 * PA + (2 * r + (fh ^ ((r >> 3) & 1))) * 16;
   }
+  bf16x8 kfrag;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) kfrag[e] = (__bf16)(0.001f * (lane + e));
   auto compute = [&](const char* st) {
     bf16x8 ah[4], al[4], bh[2], bl[2];
+    if (no_frag) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ah[i] = kfrag; al[i] = kfrag; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { bh[j] = kfrag; bl[j] = kfrag; }
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       ah[i] = *reinterpret_cast<const bf16x8*>(st + aoff[i]);
@@ -113,6 +134,11 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
     for (int j = 0; j < 2; ++j) {
       bh[j] = *reinterpret_cast<const bf16x8*>(st + boff[j]);
       bl[j] = *reinterpret_cast<const bf16x8*>(st + PB + boff[j]);
+    }
+    }
+    if (no_mfma) {
+      acc[0][0][0] += (float)ah[0][0] + (float)al[3][1] + (float)bh[1][2] + (float)bl[0][3] + (float)ah[2][4] + (float)bh[0][5];
+      return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -143,7 +169,7 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // every wave's copies of tile kt are in; every wave is done with tile kt - 1
+    if (!no_bar) __syncthreads();          // every wave's copies of tile kt are in; every wave is done with tile kt - 1
     if (nxt_tile < ktiles) {
       int st = cur + ring - 1;
       st = st >= ring ? st - ring : st;
@@ -169,13 +195,13 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
 }  // namespace
 
 extern "C" int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi,
-                                        void* lo, void* stream) {
+                                        void* lo, int ktile_major, void* stream) {
   if (!x || !hi || !lo) return TSSEP_E_NULL;
   if (rows <= 0 || K <= 0 || ld < K) return TSSEP_E_SHAPE;
   const int64_t Kp = (K + 15) / 16 * 16;
   const int64_t n = rows * Kp;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, rows, K, ld, Kp, (__bf16*)hi, (__bf16*)lo);
+                     (hipStream_t)stream, x, rows, K, ld, Kp, (__bf16*)hi, (__bf16*)lo, ktile_major);
   return tssep_launch_status();
 }
 
@@ -183,6 +209,8 @@ extern "C" int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, con
                                          const void* b_lo, float* C, int64_t M, int64_t N, int64_t K,
                                          int64_t ldc, int ring, void* stream) {
   if (!a_hi || !a_lo || !b_hi || !b_lo || !C) return TSSEP_E_NULL;
+  const int flags = ring & ~255;
+  ring &= 255;
   if (M <= 0 || N <= 0 || K <= 0 || ldc < N || (ring != 2 && ring != 3 && ring != 12 && ring != 13)) return TSSEP_E_SHAPE;
   if (!aligned16(a_hi) || !aligned16(a_lo) || !aligned16(b_hi) || !aligned16(b_lo)) return TSSEP_E_ALIGN;
   const int64_t Kp = (K + 15) / 16 * 16;
@@ -191,12 +219,12 @@ extern "C" int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, con
     const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 255) / 256, 1);
     hipLaunchKernelGGL(gemm_presplit_kernel<4>, dim3((unsigned)tile_map_blocks(tm)), dim3(512), 0,
                        (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                       (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring - 10);
+                       (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, (ring - 10) | flags);
     return tssep_launch_status();
   }
   const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 127) / 128, 1);
   hipLaunchKernelGGL(gemm_presplit_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
                      (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                     (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring);
+                     (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring | flags);
   return tssep_launch_status();
 }
