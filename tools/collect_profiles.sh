@@ -25,3 +25,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvdr_stats -o m -- py
 python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null
 python tools/bench_input_pipeline.py 768 > $O/input_pipeline.jsonl 2>/dev/null; python tools/bench_input_pipeline.py 384 >> $O/input_pipeline.jsonl 2>/dev/null
 python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
+# experimental GEMM probes (pre-split planes + asynchronous copies) and their ablations
+python tools/probe_presplit.py > $O/gemm_presplit_probe.jsonl 2>/dev/null
+python tools/probe_presplit_ablation.py > $O/gemm_presplit_ablation.jsonl 2>/dev/null
