@@ -414,6 +414,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // one (+5..12 % on the split-K shapes).  Skipping only the MFMAs of the padded 32 x 32 sub-tiles inside the
 // edge tile (N = 513: three quarters of its matrix work) changed nothing either (alternating A/B): an edge
 // workgroup still stages the full A panel, and the stage is bounded by staging and barriers, not by MFMA.
+// A K tile of 32 (whole 128-byte lines instead of half lines: half the L2 -> L1 line traffic) with ONE LDS
+// stage of 61 KB and two barriers per tile (48 MFMAs between them, 246 VGPRs, no spills) measured 3-10 %
+// SLOWER on the N = 2400 shapes and equal on the rest (alternating A/B): the second barrier costs more than the
+// line traffic saves.
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
 constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
