@@ -351,6 +351,13 @@ int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld
 int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                               float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int ring,
                               void* stream);
+/* weight-gradient counterpart: C[M,N] (split-K partials [splitk][c_split_stride]) = A^T B with A = dY
+ * [K rows][M], B = X [K rows][N] given as k-tile-major planes (tssep_probe_split_planes with
+ * ktile_major = 1 on the [K][M] / [K][N] matrices); K must be a multiple of 32. */
+int tssep_probe_gemm_presplit_tn(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
+                                 float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int splitk,
+                                 int64_t c_split_stride, int ring, void* stream);
+
 
 /* -------------------------------------------------------------- optimizer -----
  * One optimizer step on flat fp32 buffers: global-norm gradient clipping

@@ -682,3 +682,35 @@ def test_presplit_gemm_probe_is_bit_identical(M, N, K):
             assert torch.equal(outs[0], C0)
     finally:
         h.GEMM_PRECISION = old
+
+
+@pytest.mark.parametrize("M,N,R", [(260, 130, 3200), (24, 12, 64), (513, 600, 960)])
+def test_presplit_tn_probe_is_bit_identical(M, N, R):
+    """Experimental plane-fed weight-gradient probe: same k-tile-major planes as the nt probe, fragments
+    by LDS transpose reads; split-K partials bit-identical to the production transpose-read kernel."""
+    from tssep_amd import _lib
+    h, L = H(), _lib.lib()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        torch.manual_seed(1)
+        dY = torch.zeros(R, h.round_up(M, 4), device="cuda"); dY[:, :M] = torch.randn(R, M, device="cuda") / R ** 0.5
+        X = torch.zeros(R, h.round_up(N, 4), device="cuda"); X[:, :N] = torch.randn(R, N, device="cuda")
+        part, S = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R)
+        st = torch.cuda.current_stream().cuda_stream
+        Mp, Np = h.round_up(M, 16), h.round_up(N, 16)
+        planes = [torch.empty((Mp // 16) * R * 16, device="cuda", dtype=torch.bfloat16) for _ in range(2)] + \
+                 [torch.empty((Np // 16) * R * 16, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
+        h.check(L.tssep_probe_split_planes(dY.data_ptr(), R, M, dY.shape[1], planes[0].data_ptr(), planes[1].data_ptr(), 1, st), "split")
+        h.check(L.tssep_probe_split_planes(X.data_ptr(), R, N, X.shape[1], planes[2].data_ptr(), planes[3].data_ptr(), 1, st), "split")
+        ref = (dY[:, :M].double().t() @ X[:, :N].double()).float()
+        for ring in (2, 3):
+            C = torch.full((S, M * N), float("nan"), device="cuda")
+            h.check(L.tssep_probe_gemm_presplit_tn(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
+                                                   planes[3].data_ptr(), C.data_ptr(), M, N, R, N, S, M * N, ring, st), "probe")
+            assert torch.equal(C.view(S, M, N), part.view(S, M, N)), ring
+            close(C.view(S, M, N).sum(0), ref, rtol=2e-4, atol=2e-4, name=f"tn ring {ring}")
+        assert L.tssep_probe_gemm_presplit_tn(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
+                                              planes[3].data_ptr(), C.data_ptr(), M, N, R + 1, N, S, M * N, 2, st) != 0
+    finally:
+        h.GEMM_PRECISION = old

@@ -28,3 +28,4 @@ python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
 # experimental GEMM probes (pre-split planes + asynchronous copies) and their ablations
 python tools/probe_presplit.py > $O/gemm_presplit_probe.jsonl 2>/dev/null
 python tools/probe_presplit_ablation.py > $O/gemm_presplit_ablation.jsonl 2>/dev/null
+python tools/probe_presplit_tn.py > $O/gemm_presplit_tn_probe.jsonl 2>/dev/null

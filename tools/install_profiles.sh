@@ -13,7 +13,7 @@ cp $F/batch_sweep.jsonl profiles/r1_batch_sweep_final.jsonl
 cp $F/bench_default.json profiles/r1_bench_default.json
 [ -f $F/gemm_in_step_b$B.jsonl ] && cp $F/gemm_in_step_b$B.jsonl profiles/r1_gemm_in_step_b$B.jsonl
 [ -f $F/mvdr_microbench.jsonl ] && cp $F/mvdr_microbench.jsonl profiles/r1_mvdr_microbench.jsonl
-for f in input_pipeline.jsonl gemm_presplit_probe.jsonl gemm_presplit_ablation.jsonl; do [ -s $F/$f ] && cp $F/$f profiles/r1_$f; done
+for f in input_pipeline.jsonl gemm_presplit_probe.jsonl gemm_presplit_ablation.jsonl gemm_presplit_tn_probe.jsonl; do [ -s $F/$f ] && cp $F/$f profiles/r1_$f; done
 [ -s $F/step_clock.json ] && cp $F/step_clock.json profiles/r1_step_clock.json
 python - <<PY
 import csv, os

@@ -192,6 +192,129 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
   }
 }
 
+
+// ---- weight-gradient counterpart: C[M,N] = A^T B, A = dY [K rows][M], B = X [K rows][N], both given as
+// planes [cols/16][K][16] (the SAME k-tile-major planes the forward / dgrad GEMMs of the same tensors would
+// read).  A K tile of 32 rows of a 16-column chunk is 1 KB contiguous: one copy instruction; in LDS it stays
+// [chunk][32 rows][16 cols] and the MFMA fragments come from ds_read_b64_tr_b16 exactly as in
+// gemm_bf16x3_tn_kernel (a 16-lane group reads 4 rows x 16 columns = 128 contiguous bytes).  Same tile
+// (128 x 128 x 32), split-K and MFMA order as that kernel -> bit-identical partials.
+typedef short s16x4p __attribute__((ext_vector_type(4)));
+typedef short s16x8p __attribute__((ext_vector_type(8)));
+constexpr int QCH = 1024 + 128;               // LDS stride of a chunk (the pad separates the two 16-lane groups)
+constexpr int QPLANE = 8 * QCH, QSTAGE = 4 * QPLANE;      // A hi, A lo, B hi, B lo = 36 864 B
+
+__device__ __forceinline__ bf16x8 tr_frag_p(const char* p) {
+  const s16x4p a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4p*)(p));
+  const s16x4p b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4p*)(p + 4 * 32));
+  const s16x8p v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int RING>
+__global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void gemm_presplit_tn_kernel(
+    const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al, const __bf16* __restrict__ Bh,
+    const __bf16* __restrict__ Bl, float* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t ldc,
+    int splitk, int64_t c_split_stride, TileMap tmap) {
+  constexpr int ring = RING;
+  __shared__ __attribute__((aligned(1024))) char lds[RING * QSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * 128, n0 = (int64_t)nt * 128;
+  const int64_t ktiles = K / 32;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // copies of this wave: pieces p = wave + 4 q (q = 0..7); piece p = plane p / 8, chunk p % 8
+  const char* src[8];
+  unsigned dst[8];
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int64_t mchunks = (M + 15) / 16, nchunks = (N + 15) / 16;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int p = wave + 4 * q, plane = p >> 3, ch = p & 7;
+    const bool isA = plane < 2;
+    int64_t c = (isA ? m0 : n0) / 16 + ch;
+    const int64_t cl = (isA ? mchunks : nchunks) - 1;
+    c = c > cl ? cl : c;
+    const __bf16* base = plane == 0 ? Ah : plane == 1 ? Al : plane == 2 ? Bh : Bl;
+    src[q] = reinterpret_cast<const char*>(base + (c * K) * 16) + lane * 16;          // + k0 * 32 bytes per tile row
+    dst[q] = (unsigned)(plane * QPLANE + ch * QCH);
+  }
+  auto issue = [&](int64_t kt, int stage) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma16(src[q] + kt * (32 * 32), lds_base + stage * QSTAGE + dst[q]);
+  };
+  const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
+  const int foff = (8 * hk + (ii >> 2)) * 32 + (ii & 3) * 8;
+  auto compute = [&](const char* st) {
+    bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ca = (wm * 4 + 2 * i + g2) * QCH + ks * 16 * 32 + foff;
+        const int cb = (wn * 4 + 2 * i + g2) * QCH + ks * 16 * 32 + foff;
+        ah[ks][i] = tr_frag_p(st + ca);
+        al[ks][i] = tr_frag_p(st + QPLANE + ca);
+        bh[ks][i] = tr_frag_p(st + 2 * QPLANE + cb);
+        bl[ks][i] = tr_frag_p(st + 3 * QPLANE + cb);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if (kt_begin < kt_end) {
+    issue(kt_begin, 0);
+    if (ring == 3 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
+    int cur = 0;
+    for (int64_t kt = kt_begin; kt < kt_end; ++kt) {
+      if (ring == 3 && kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int64_t nxt = kt + ring - 1;
+      if (nxt < kt_end) {
+        int stg = cur + ring - 1;
+        stg = stg >= ring ? stg - ring : stg;
+        issue(nxt, stg);
+      }
+      compute(lds + cur * QSTAGE);
+      cur = cur + 1 == ring ? 0 : cur + 1;
+    }
+  }
+  __syncthreads();
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  float* stage = reinterpret_cast<float*>(lds) + wave * 64 * EPITCH;
+  static_assert(4 * 64 * EPITCH * 4 <= RING * QSTAGE, "epilogue scratch");
+  gemm_epilogue_rows(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, nullptr, 0, 0, ldc,
+                     splitk == 1);
+}
+
 }  // namespace
 
 extern "C" int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi,
@@ -226,5 +349,23 @@ extern "C" int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, con
   hipLaunchKernelGGL(gemm_presplit_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
                      (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
                      (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring | flags);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_probe_gemm_presplit_tn(const void* a_hi, const void* a_lo, const void* b_hi,
+                                            const void* b_lo, float* C, int64_t M, int64_t N, int64_t K,
+                                            int64_t ldc, int splitk, int64_t c_split_stride, int ring,
+                                            void* stream) {
+  if (!a_hi || !a_lo || !b_hi || !b_lo || !C) return TSSEP_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || ldc < N || splitk < 1 || (ring != 2 && ring != 3)) return TSSEP_E_SHAPE;
+  const TileMap tm = make_tile_map((M + 127) / 128, (N + 127) / 128, splitk);
+  if (ring == 2)
+    hipLaunchKernelGGL(gemm_presplit_tn_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
+                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, tm);
+  else
+    hipLaunchKernelGGL(gemm_presplit_tn_kernel<3>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
+                       (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
+                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, tm);
   return tssep_launch_status();
 }
