@@ -357,6 +357,13 @@ int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_
 int tssep_probe_gemm_presplit_tn(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                                  float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int splitk,
                                  int64_t c_split_stride, int ring, void* stream);
+/* The plane GEMMs behind the production argument block (groundwork for round 2, not yet called by the
+ * product): g->A / g->B = HI planes, a_lo / b_lo = LO planes, k-tile-major (ktile_major = 1 above); lda / ldb
+ * are ignored.  a_kmajor = b_kmajor = 0: C = epilogue(A B^T) with bias / tanh / accumulate / store remap as
+ * tssep_gemm_f32.  a_kmajor = b_kmajor = 1: split-K partials of A^T B (K % 32 == 0, accumulate only).
+ * Bit-identical to tssep_gemm_f32 with precision 1 on the same values. */
+int tssep_gemm_planes(const tssep_gemm_args* g, const void* a_lo, const void* b_lo, void* stream);
+
 
 
 /* -------------------------------------------------------------- optimizer -----

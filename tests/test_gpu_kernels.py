@@ -714,3 +714,56 @@ def test_presplit_tn_probe_is_bit_identical(M, N, R):
                                               planes[3].data_ptr(), C.data_ptr(), M, N, R + 1, N, S, M * N, 2, st) != 0
     finally:
         h.GEMM_PRECISION = old
+
+
+def test_gemm_planes_matches_production_gemm_feature_by_feature():
+    """tssep_gemm_planes (round-2 groundwork): plane operands behind the production argument block --
+    bias, tanh, accumulate, both store remaps and split-K weight gradients agree with h.gemm in split-bf16
+    arithmetic (bit-identical where production takes the same tile: M >= 1024 for nt, every tn shape)."""
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        torch.manual_seed(6)
+        # ---- nt: bias + tanh, then accumulate
+        M, N, K = 2051, 390, 513
+        A = torch.zeros(M, h.round_up(K, 4), device="cuda"); A[:, :K] = torch.randn(M, K, device="cuda")
+        W = torch.zeros(N, h.round_up(K, 4), device="cuda"); W[:, :K] = torch.randn(N, K, device="cuda") / K ** 0.5
+        bias = torch.randn(N, device="cuda")
+        Ap, Wp = h.split_planes(A, M, K), h.split_planes(W, N, K)
+        for kw in (dict(bias=bias), dict(bias=bias, act=1), dict(accumulate=True)):
+            C0 = torch.ones(M, N, device="cuda"); C1 = torch.ones(M, N, device="cuda")
+            h.gemm(A, A.shape[1], W, W.shape[1], C0, N, M, N, K, **kw)
+            h.gemm_planes(Ap, Wp, C1, N, M, N, K, **kw)
+            assert torch.equal(C0, C1), kw
+        # ---- nt: the two store remaps of the model (small M: numerically equal, other tile)
+        B, Kk, T, P, F = 2, 3, 5, 8, 9
+        A = torch.randn(B * Kk * T, 12, device="cuda"); W = torch.randn(P, 12, device="cuda"); bias = torch.randn(P, device="cuda")
+        rm = dict(T=T, K=Kk, sb=T * Kk * P, sk=P, st=Kk * P)
+        C0 = torch.full((B, T, Kk * P), float("nan"), device="cuda"); C1 = C0.clone()
+        h.gemm(A, 12, W, 12, C0, 0, B * Kk * T, P, 12, bias=bias, act=1, remap=rm)
+        h.gemm_planes(h.split_planes(A, B * Kk * T, 12), h.split_planes(W, P, 12), C1, 0, B * Kk * T, P, 12, bias=bias, act=1, remap=rm)
+        close(C1, C0, rtol=1e-5, atol=1e-5, name="combine remap")
+        A = torch.randn(B * T, 12, device="cuda"); W = torch.randn(Kk * F, 12, device="cuda"); bias = torch.randn(Kk * F, device="cuda")
+        perm = torch.stack([torch.randperm(Kk) for _ in range(B)]).int().cuda()
+        rm = dict(T=T, K=1, sb=Kk * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=Kk)
+        C0 = torch.full((B, Kk, T, F), float("nan"), device="cuda"); C1 = C0.clone()
+        h.gemm(A, 12, W, 12, C0, 0, B * T, Kk * F, 12, bias=bias, remap=rm)
+        h.gemm_planes(h.split_planes(A, B * T, 12), h.split_planes(W, Kk * F, 12), C1, 0, B * T, Kk * F, 12, bias=bias, remap=rm)
+        close(C1, C0, rtol=1e-5, atol=1e-5, name="logit remap")
+        # ---- tn: split-K partials, then accumulate into them
+        M, N, R = 260, 130, 3200
+        dY = torch.randn(R, M, device="cuda") / R ** 0.5
+        X = torch.zeros(R, h.round_up(N, 4), device="cuda"); X[:, :N] = torch.randn(R, N, device="cuda")
+        part, S = h.wgrad(dY, M, X, X.shape[1], M, N, R)
+        dYp, Xp = h.split_planes(dY, R, M), h.split_planes(X, R, N, ld=X.shape[1])
+        C1 = torch.full((S, M * N), float("nan"), device="cuda")
+        h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N)
+        assert torch.equal(C1, part.view(S, M * N))
+        h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N, accumulate=True)
+        assert torch.equal(C1, 2 * part.view(S, M * N))
+        with pytest.raises(RuntimeError):                          # time shift: not in the plane kernels yet
+            h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N,
+                          b_kshift=1, kperiod=100)
+    finally:
+        h.GEMM_PRECISION = old

@@ -253,12 +253,7 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (splitk > 1 && (g->bias || g->act || g->c_remap)) return TSSEP_E_UNSUPPORTED;
   if (g->a_kmajor && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
   if (g->kperiod > 0 && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
-  StoreMap sm;
-  sm.ldc = g->ldc; sm.remap = g->c_remap;
-  sm.T = g->c_T > 0 ? g->c_T : 1; sm.K = g->c_K > 0 ? g->c_K : 1;
-  sm.sb = g->c_sb; sm.sk = g->c_sk; sm.st = g->c_st;
-  sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
-  sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
+  const StoreMap sm = make_store_map(g);
   if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
   if (g->precision != 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);

@@ -58,6 +58,16 @@ struct StoreMap {
   const int32_t* perm; int64_t perm_ld;
 };
 
+inline StoreMap make_store_map(const tssep_gemm_args* g) {
+  StoreMap sm;
+  sm.ldc = g->ldc; sm.remap = g->c_remap;
+  sm.T = g->c_T > 0 ? g->c_T : 1; sm.K = g->c_K > 0 ? g->c_K : 1;
+  sm.sb = g->c_sb; sm.sk = g->c_sk; sm.st = g->c_st;
+  sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
+  sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
+  return sm;
+}
+
 // Epilogue for a wave that owns TM x TN MFMA 32x32 tiles starting at (mrow0, ncol0):
 // D[i][j] of a tile: lane holds column j = lane&31, rows (e&3)+8*(e>>2)+4*(lane>>5).
 // bias / tanh only on the final (non split-K) pass; optional accumulate; optional layout remap

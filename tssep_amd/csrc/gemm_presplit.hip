@@ -48,7 +48,7 @@ template <int WN>
 __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kernel(
     const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al, const __bf16* __restrict__ Bh,
     const __bf16* __restrict__ Bl, float* __restrict__ C, int64_t M, int64_t N, int64_t Kp,
-    int64_t ldc, TileMap tmap, int ring_flags) {
+    StoreMap sm, const float* __restrict__ bias, int act, int accumulate, TileMap tmap, int ring_flags) {
   // ablation flags (timing experiments only, results are then wrong): 256 = no MFMA, 512 = no fragment
   // reads, 1024 = no copies, 2048 = no barriers
   const int ring = ring_flags & 255;
@@ -187,8 +187,12 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
-    gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
-                       nullptr, 0, 0, ldc, true);
+    if (!sm.remap)
+      gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
+                         bias, act, accumulate, sm.ldc, true);
+    else
+      gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                               lane, bias, act, accumulate, sm);
   }
 }
 
@@ -215,7 +219,7 @@ template <int RING>
 __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void gemm_presplit_tn_kernel(
     const __bf16* __restrict__ Ah, const __bf16* __restrict__ Al, const __bf16* __restrict__ Bh,
     const __bf16* __restrict__ Bl, float* __restrict__ C, int64_t M, int64_t N, int64_t K, int64_t ldc,
-    int splitk, int64_t c_split_stride, TileMap tmap) {
+    int splitk, int64_t c_split_stride, int accumulate, TileMap tmap) {
   constexpr int ring = RING;
   __shared__ __attribute__((aligned(1024))) char lds[RING * QSTAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -311,8 +315,15 @@ __global__ __launch_bounds__(256, RING == 2 ? 2 : 1) void gemm_presplit_tn_kerne
   float* Cz = C + (int64_t)zsplit * c_split_stride;
   float* stage = reinterpret_cast<float*>(lds) + wave * 64 * EPITCH;
   static_assert(4 * 64 * EPITCH * 4 <= RING * QSTAGE, "epilogue scratch");
-  gemm_epilogue_rows(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, nullptr, 0, 0, ldc,
-                     splitk == 1);
+  gemm_epilogue_rows(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, nullptr, 0,
+                     accumulate, ldc, splitk == 1);
+}
+
+StoreMap plain_map(int64_t ldc, int64_t N) {
+  StoreMap sm;
+  sm.ldc = ldc; sm.remap = 0; sm.T = 1; sm.K = 1; sm.sb = 0; sm.sk = 0; sm.st = 0; sm.cm = N > 0 ? N : 1; sm.co = 0;
+  sm.perm = nullptr; sm.perm_ld = 0;
+  return sm;
 }
 
 }  // namespace
@@ -342,13 +353,13 @@ extern "C" int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, con
     const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 255) / 256, 1);
     hipLaunchKernelGGL(gemm_presplit_kernel<4>, dim3((unsigned)tile_map_blocks(tm)), dim3(512), 0,
                        (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                       (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, (ring - 10) | flags);
+                       (const __bf16*)b_lo, C, M, N, Kp, plain_map(ldc, N), nullptr, 0, 0, tm, (ring - 10) | flags);
     return tssep_launch_status();
   }
   const TileMap tm = make_tile_map((M + PBM - 1) / PBM, (N + 127) / 128, 1);
   hipLaunchKernelGGL(gemm_presplit_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
                      (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                     (const __bf16*)b_lo, C, M, N, Kp, ldc, tm, ring | flags);
+                     (const __bf16*)b_lo, C, M, N, Kp, plain_map(ldc, N), nullptr, 0, 0, tm, ring | flags);
   return tssep_launch_status();
 }
 
@@ -362,10 +373,42 @@ extern "C" int tssep_probe_gemm_presplit_tn(const void* a_hi, const void* a_lo, 
   if (ring == 2)
     hipLaunchKernelGGL(gemm_presplit_tn_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
                        (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, tm);
+                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, 0, tm);
   else
     hipLaunchKernelGGL(gemm_presplit_tn_kernel<3>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0,
                        (hipStream_t)stream, (const __bf16*)a_hi, (const __bf16*)a_lo, (const __bf16*)b_hi,
-                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, tm);
+                       (const __bf16*)b_lo, C, M, N, K, ldc, splitk, c_split_stride, 0, tm);
+  return tssep_launch_status();
+}
+
+// GEMM on plane operands with the production argument block (groundwork for round 2: producers emit the
+// planes, this replaces tssep_gemm_f32 precision 1).  g->A / g->B are the HI planes, a_lo / b_lo the LO
+// planes; lda / ldb are ignored (the planes are k-tile-major, see tssep_probe_split_planes).
+//   a_kmajor = b_kmajor = 0: C = epilogue(A B^T), planes [K/16][M][16] and [K/16][N][16]: bias, tanh,
+//                            accumulate, store remap as in tssep_gemm_f32.
+//   a_kmajor = b_kmajor = 1: C (split-K partials) = A^T B, planes [M/16][K][16] and [N/16][K][16], K % 32 == 0
+//                            (producers pad the rows with zeros), accumulate; no time shift, no virtual
+//                            ones column (the producer writes a real one).
+extern "C" int tssep_gemm_planes(const tssep_gemm_args* g, const void* a_lo, const void* b_lo, void* stream) {
+  if (!g || !g->A || !g->B || !g->C || !a_lo || !b_lo) return TSSEP_E_NULL;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return TSSEP_E_SHAPE;
+  if (!aligned16(g->A) || !aligned16(g->B) || !aligned16(a_lo) || !aligned16(b_lo)) return TSSEP_E_ALIGN;
+  if (g->kperiod > 0 || g->b_ones_col || g->a_kmajor != g->b_kmajor) return TSSEP_E_UNSUPPORTED;
+  const int splitk = g->splitk > 1 ? g->splitk : 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (!g->a_kmajor) {
+    if (splitk > 1) return TSSEP_E_UNSUPPORTED;
+    const int64_t Kp = (g->K + 15) / 16 * 16;
+    const TileMap tm = make_tile_map((g->M + PBM - 1) / PBM, (g->N + 127) / 128, 1);
+    hipLaunchKernelGGL(gemm_presplit_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0, s,
+                       (const __bf16*)g->A, (const __bf16*)a_lo, (const __bf16*)g->B, (const __bf16*)b_lo, g->C,
+                       g->M, g->N, Kp, make_store_map(g), g->bias, g->act, g->accumulate, tm, 2 | 4096);
+    return tssep_launch_status();
+  }
+  if ((g->K & 31) || g->bias || g->act || g->c_remap) return TSSEP_E_UNSUPPORTED;
+  const TileMap tm = make_tile_map((g->M + 127) / 128, (g->N + 127) / 128, splitk);
+  hipLaunchKernelGGL(gemm_presplit_tn_kernel<2>, dim3((unsigned)tile_map_blocks(tm)), dim3(256), 0, s,
+                     (const __bf16*)g->A, (const __bf16*)a_lo, (const __bf16*)g->B, (const __bf16*)b_lo, g->C, g->M,
+                     g->N, g->K, g->ldc, splitk, g->c_split_stride, g->accumulate, tm);
   return tssep_launch_status();
 }

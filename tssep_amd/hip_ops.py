@@ -203,13 +203,9 @@ GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
 _PREC = {"f32": 0, "bf16x3": 1}
 
 
-def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
-         accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0,
-         b_ones_col=False):
-    """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
-    float_offset) tuples) whose data pointers are used as given."""
-    L = _lib.lib()
-
+def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
+               accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0,
+               b_ones_col=False):
     def ptr(x):
         if isinstance(x, tuple):
             return x[0].data_ptr() + 4 * x[1]
@@ -233,8 +229,37 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=N
     g.splitk, g.c_split_stride = splitk, split_stride
     g.precision = _PREC[GEMM_PRECISION]
     g.b_ones_col = int(b_ones_col)
+    return g
+
+
+def gemm(A, lda, B, ldb, C, ldc, M, N, K, **kw):
+    """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
+    float_offset) tuples) whose data pointers are used as given.  Keywords: a_kmajor, b_kmajor, bias, act,
+    accumulate, b_kshift, kperiod, remap, splitk, split_stride, b_ones_col."""
+    g = _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, **kw)
     with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K):
-        check(L.tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
+        check(_lib.lib().tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
+
+
+def split_planes(x, rows, cols, ld=None, ktile_major=True):
+    """fp32 [rows, >= cols] -> (hi, lo) bf16 planes, k-tile-major [ceil(cols/16)][rows][16] (round-2 groundwork:
+    in production the planes will come from the producer kernels, this pass is for tests and probes)."""
+    ld = x.shape[-1] if ld is None else ld
+    n = round_up(cols, 16) * rows
+    hi = torch.empty(n, device=x.device, dtype=torch.bfloat16)
+    lo = torch.empty(n, device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().tssep_probe_split_planes(_p(x), rows, cols, ld, _p(hi), _p(lo), int(ktile_major), _stream()),
+          "split_planes")
+    return hi, lo
+
+
+def gemm_planes(A, B, C, ldc, M, N, K, **kw):
+    """The split-bf16 GEMM on plane operands (A, B = (hi, lo) pairs from split_planes / producer kernels);
+    same keywords and results as gemm() with GEMM_PRECISION = 'bf16x3' (bit-identical).  Not yet on the
+    product path."""
+    g = _gemm_args(A[0], 0, B[0], 0, C, ldc, M, N, K, **kw)
+    with _timed("gemm_planes", 2 * M * N * K):
+        check(_lib.lib().tssep_gemm_planes(ctypes.byref(g), _p(A[1]), _p(B[1]), _stream()), "gemm_planes")
 
 
 def transposed(w, rows, cols):
