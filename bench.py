@@ -21,7 +21,22 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-K_SPK, N_SAMPLES, UNITS, PROJS, FBINS = 4, 64000, 300, 320, 513
+UNITS, PROJS, FBINS = 300, 320, 513
+# Workloads (BASELINE.json configs): the headline metric is quoted on cfg3 (configs[2]); cfg4 is the
+# per-GPU shard of configs[3] (global batch 64 over 8 GPUs); cfg5 is configs[4]'s chunk shape (8
+# speakers, 30 s), the HBM-bound mask-head stress.  `batch` = utterances per GPU (weak scaling).
+WORKLOADS = {
+    "cfg3": dict(K=4, N=64000, batch=768,
+                 metric="frames/sec fwd+bwd, 4-spk TS-SEP, 16kHz 4s chunks",
+                 name="TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])"),
+    "cfg4": dict(K=4, N=64000, batch=8,
+                 metric="frames/sec fwd+bwd, 4-spk TS-SEP, 16kHz 4s chunks",
+                 name="TS-SEP 4-speaker, 4 s @ 16 kHz, the 8-utterance per-GPU shard of configs[3] (global batch 64 on 8 GPUs)"),
+    "cfg5": dict(K=8, N=480000, batch=96,
+                 metric="frames/sec fwd+bwd, 8-spk TS-SEP, 16kHz 30s chunks",
+                 name="TS-SEP 8-speaker long-form, 30 s chunks @ 16 kHz, 513-bin STFT (configs[4])"),
+}
+K_SPK, N_SAMPLES = WORKLOADS["cfg3"]["K"], WORKLOADS["cfg3"]["N"]
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
 PEAK_F32_MFMA_TFLOPS = 157.3          # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1_16b)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; a bf16x3 GEMM issues 3 MFMA flops per algorithmic flop
@@ -47,7 +62,7 @@ def synth_batch(B, K, N, seed):
     return obs, aux, tgt
 
 
-def build_model():
+def build_model(K=None):
     from tssep_amd.data import DummyReader
     from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
     torch.manual_seed(0)
@@ -59,7 +74,7 @@ def build_model():
         reader=DummyReader(),
         mask_estimator=net.MaskEstimator_v2(idim=553, odim=FBINS, units=UNITS, projs=PROJS,
                                             combination="mul", aux_net_output_size=FBINS,
-                                            ts_vad=K_SPK, output_resolution="tf",
+                                            ts_vad=K or K_SPK, output_resolution="tf",
                                             random_speaker_order=True, num_averaged_permutations=1),
         enhancer=enhancer.Masking(), loss=loss.LogMAE())
 
@@ -71,6 +86,38 @@ def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS):
     b1 = 16 * H * (P + H) + 2 * 2 * H * P
     b2 = 16 * H * (P * K + H) + 2 * 2 * H * P
     return pre + K * (b0 + b1) + b2 + 2 * P * F * K
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, as fresh
+    child processes of a parent that has not touched the GPU (no HIP call has been made at this point:
+    importing torch and counting devices does not initialise it).  The child command is the contract's
+    own: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
@@ -157,11 +204,23 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
     one_step()
     st_s, _ = one_step()
     torch.set_num_threads(nt)
-    return dict(value=round(B * T / step_s, 1), unit="frames/s", cores=nt, kind="port",
+    return dict(value=round(B * T / step_s, 1), unit="frames/s", cores=nt, kind="port", cpu_model=cpu_model(),
                 single_thread_value=round(B * T / st_s, 1),
                 sample=f"CPU oracle fwd+bwd, batch {B} x 4 s, best of {n} steps = {step_s:.3f} s, "
                        f"torch {torch.__version__}, {nt} threads of {os.cpu_count()} logical CPUs",
                 parity_vs_hip=parity)
+
+
+def newest_profile(suffix):
+    """profiles/r<N>_<suffix> of the latest round that has one (PMC passes are collected per round)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}")):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
 
 
 def main():
@@ -169,38 +228,57 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 768)),
-                    help="utterances per GPU (weak scaling: global batch = batch * gpus)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3",
+                    help="cfg3 = the headline configuration (BASELINE configs[2]); cfg4 = its 8-utterance "
+                         "per-GPU shard of configs[3]; cfg5 = 8 speakers x 30 s (configs[4])")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 0)),
+                    help="utterances per GPU (weak scaling: global batch = batch * gpus); 0 = the workload's default")
     ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
-                    help="arithmetic of the non-recurrent GEMMs (the recurrence kernel is chosen by hip_ops.recurrence_kernel)")
+                    help="arithmetic of the non-recurrent GEMMs")
+    ap.add_argument("--recurrence", choices=["auto", "stream", "cluster", "onchip"], default="auto",
+                    help="recurrence kernel: auto = hip_ops.recurrence_kernel's policy (split-bf16 W-stationary "
+                         "for H >= 128); stream / cluster = exact fp32")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step as a captured hipGraph (auto: small batches, where launches dominate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
-                    help="skip the secondary exact-fp32 measurement")
+                    help="skip the secondary fp32-GEMM measurement")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no torchrun around us: become the launcher (before anything initialises the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
+    wl = WORKLOADS[args.workload]
+    K, N_s = wl["K"], wl["N"]
+    B = args.batch or wl["batch"]
     from tssep_amd import hip_ops as H
     H.GEMM_PRECISION = args.gemm
-    model = build_model().to(dev)
-    B = args.batch
+    H.RECURRENCE = args.recurrence
+    model = build_model(K).to(dev)
     from tssep_amd.train.optimizer import Adam
     opt = Adam(gradient_clipping=10.0, lr=1e-5)          # clipping as tssep/exp/init_cfg_common.yaml:85-94
     opt.set_parameters(model.parameters())               # flat params + the flat gradient bucket
-    obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, seed=rank)      # each rank its own shard
+    if world > 1:                                        # identical replicas, as Trainer.train does
+        dist.broadcast(opt.flat_param, src=0)
+    obs, aux, tgt = synth_batch(B, K, N_s, seed=rank)    # each rank its own shard
     ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
                speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
                reference_channel=0, dataset=["bench"] * B)
+    del obs, aux, tgt
     np.random.seed(rank)
 
     def step():
@@ -225,99 +303,117 @@ def main():
             out = step()
         H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear()
         H.KERNEL_TIMING = True
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for i in range(steps):
             out = step()
+            marks[i + 1].record()
         barrier()
         dt_ = time.perf_counter() - t0
         H.KERNEL_TIMING = False
+        per_step = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))      # device-side ms per step
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax), int(out.mask.shape[-2])
+        return float(tmax), int(out.mask.shape[-2]), float(np.median(per_step))
+
+    def rooflines(dt, gemm_name):
+        """Live HIP-event timings of this run -> (dominant MFMA kernel, mask head)."""
+        traffic, mfma_busy = {}, None
+        try:      # HBM bytes per launch from rocprofv3 PMC passes of this same command (separate --pmc runs)
+            with open(newest_profile("traffic_pmc.json")) as f:
+                tp = json.load(f)
+            c = tp["config"]
+            if (c["batch_per_gpu"], c["gemm"], c.get("workload", "cfg3")) == (B, gemm_name, args.workload) and world == 1:
+                traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+        try:      # MFMA-pipe busy share of the GEMM kernels from an SQ-counter pass of this same command
+            with open(newest_profile("mfma_pmc.json")) as f:
+                mp = json.load(f)
+            c = mp["config"]
+            if (c["batch_per_gpu"], c["gemm"], c.get("workload", "cfg3")) == (B, gemm_name, args.workload) and world == 1:
+                ks = [v for k, v in mp["kernels"].items() if k.startswith("gemm_")]
+                w = [v["raw"]["SQ_BUSY_CU_CYCLES"] * v["launches"] for v in ks]
+                mfma_busy = round(sum(v["mfma_busy_frac"] * wi for v, wi in zip(ks, w)) / sum(w), 4)
+        except (OSError, KeyError, ValueError, ZeroDivisionError, TypeError):
+            pass
+        ktimes = H.kernel_time_summary()
+        roofline = mask_head = None
+        mfma = {k: v for k, v in ktimes.items() if H.KERNEL_FLOPS.get(k, 0) > 0}
+        if mfma:
+            name, (n_launch, total_ms) = max(mfma.items(), key=lambda kv: kv[1][1])
+            avg_ms = total_ms / n_launch
+            ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
+            split = name in ("gemm_bf16x3", "gemm_planes", "blstm_onchip_fwd", "blstm_onchip_bwd")
+            peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
+                            avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
+                            mfma_pipe_busy_frac_pmc=mfma_busy if name.startswith("gemm_") else None,
+                            note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
+                                  "the bf16 MFMA, so frac <= 1/3" if split else "exact fp32 MFMA"))
+        hb = [(k, ktimes[k]) for k in ("maskhead_fwd", "maskhead_bwd") if k in ktimes]
+        if hb:       # the mask head is the HBM-bound kernel the north star singles out
+            n_l = sum(v[0] for _, v in hb)
+            ms = sum(v[1] for _, v in hb)
+            by = sum(H.KERNEL_BYTES[k] for k, _ in hb)
+            gbps = by / (ms * 1e-3) / 1e9
+            mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
+                             peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
+                             frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
+                             traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
+                             avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l,
+                             note="bytes = (16 K F + 8 F) per frame and direction: the UNFUSED chain of "
+                                  "net.py:983 + enhancer.py:98-100, whatever the kernels actually move")
+        return roofline, mask_head
+
+    def arithmetic(gemm_name):
+        rec = ("split-bf16 (hi+lo) MFMA W-stationary recurrence" if args.recurrence in ("auto", "onchip")
+               else f"exact fp32 {args.recurrence} recurrence")
+        g = ("split-bf16 (hi+lo) MFMA GEMMs, fp32 accumulate" if gemm_name == "bf16x3" else "exact fp32 MFMA GEMMs")
+        return f"{g}; {rec}"
 
     exact = None
-    if args.gemm != "f32" and world == 1 and not args.no_exact_f32:
-        # secondary line: the same step with every GEMM in exact fp32 (reference arithmetic)
+    if args.gemm != "f32" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3":
+        # secondary line, first-class: the same step with every GEMM in exact fp32 (the reference's GEMM
+        # arithmetic), same steps / warm-up, its own roofline
         H.GEMM_PRECISION = "f32"
-        dt_e, T_e = timed_run(max(2, args.steps // 3), 1)
-        n_e = max(2, args.steps // 3)
-        exact = dict(value=round(B * T_e * n_e / dt_e, 1), unit="frames/s",
-                     ms_per_step=round(dt_e / n_e * 1e3, 3), steps=n_e, dtype="f32")
+        dt_e, T_e, med_e = timed_run(args.steps, args.warmup)
+        roof_e, mh_e = rooflines(dt_e, "f32")
+        exact = dict(value=round(B * T_e * args.steps / dt_e, 1), unit="frames/s",
+                     ms_per_step=round(dt_e / args.steps * 1e3, 3), ms_per_step_median=round(med_e, 3),
+                     steps=args.steps, warmup=args.warmup, dtype="f32 GEMMs" + ("" if args.recurrence in ("stream", "cluster") else " + bf16x3 recurrence"),
+                     arithmetic=arithmetic("f32"), roofline=roof_e, roofline_mask_head=mh_e)
         H.GEMM_PRECISION = args.gemm
-    dt, T = timed_run(args.steps, args.warmup)
+    dt, T, med = timed_run(args.steps, args.warmup)
     H.check_cluster_errors(dev)
+    roofline, mask_head = rooflines(dt, args.gemm)
 
-    # HBM traffic per launch from rocprofv3 PMC passes of this same command (separate --pmc runs,
-    # see profiles/r1_traffic_pmc.json); only used when it was collected for this configuration
-    traffic = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic_pmc.json")) as f:
-            tp = json.load(f)
-        c = tp["config"]
-        if (c["batch_per_gpu"], c["gemm"]) == (B, args.gemm) and world == 1:
-            traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
-    except (OSError, KeyError, ValueError):
-        pass
-    # MFMA-pipe busy share of the GEMM kernels from a rocprofv3 SQ-counter pass of this same command
-    # (profiles/r1_mfma_pmc.json): the measured counterpart of the algorithmic fraction below
-    mfma_busy = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_mfma_pmc.json")) as f:
-            mp = json.load(f)
-        if (mp["config"]["batch_per_gpu"], mp["config"]["gemm"]) == (B, args.gemm) and world == 1:
-            ks = [v for k, v in mp["kernels"].items() if k.startswith("gemm_")]
-            w = [v["raw"]["SQ_BUSY_CU_CYCLES"] * v["launches"] for v in ks]
-            mfma_busy = round(sum(v["mfma_busy_frac"] * wi for v, wi in zip(ks, w)) / sum(w), 4)
-    except (OSError, KeyError, ValueError, ZeroDivisionError):
-        pass
-    # dominant kernel (largest share of the step), timed live with HIP events on its launch stream
-    ktimes = H.kernel_time_summary()
-    roofline = mask_head = None
-    mfma = {k: v for k, v in ktimes.items() if H.KERNEL_FLOPS.get(k, 0) > 0}
-    if mfma:
-        name, (n_launch, total_ms) = max(mfma.items(), key=lambda kv: kv[1][1])
-        avg_ms = total_ms / n_launch
-        ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
-        peak = PEAK_BF16_MFMA_TFLOPS if name == "gemm_bf16x3" else PEAK_F32_MFMA_TFLOPS
-        roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
-                        avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
-                        mfma_pipe_busy_frac_pmc=mfma_busy if name == "gemm_bf16x3" else None,
-                        note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
-                              "the bf16 MFMA, so frac <= 1/3" if name == "gemm_bf16x3" else
-                              "exact fp32 MFMA"))
-    hb = [(k, ktimes[k]) for k in ("maskhead_fwd", "maskhead_bwd") if k in ktimes]
-    if hb:       # the mask head is the HBM-bound kernel the north star singles out
-        n_l = sum(v[0] for _, v in hb)
-        ms = sum(v[1] for _, v in hb)
-        by = sum(H.KERNEL_BYTES[k] for k, _ in hb)
-        gbps = by / (ms * 1e-3) / 1e9
-        mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
-                         peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
-                         frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
-                         traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
-                         avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l)
     if rank == 0:
         frames = B * world * T * args.steps
         line = {
-            "metric": "frames/sec fwd+bwd, 4-spk TS-SEP, 16kHz 4s chunks",
+            "metric": wl["metric"],
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_median": round(med, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16x3+f32" if args.gemm == "bf16x3" else "f32"),
+            "dtype": ("bf16x3+f32" if args.gemm == "bf16x3" else
+                      "f32" if args.recurrence in ("stream", "cluster") else "f32 GEMMs + bf16x3 recurrence"),
             "data": "synthetic",
-            "config": {"workload": "TS-SEP 4-speaker synthetic mixtures, 4 s @ 16 kHz (configs[2])",
-                       "speakers": K_SPK, "samples": N_SAMPLES, "frames_per_chunk": T,
+            "config": {"workload": wl["name"], "workload_key": args.workload,
+                       "speakers": K, "samples": N_s, "frames_per_chunk": T,
                        "batch_per_gpu": B, "global_batch": B * world,
                        "units": UNITS, "optimizer": "global-norm clip + Adam (fused), in the timed step",
                        "projs": PROJS, "parallelism": f"dp{world}",
-                       "gemm_arithmetic": ("split-bf16 (hi+lo) MFMA, fp32 accumulate, in the GEMMs and the W-stationary recurrences"
-                                           if args.gemm == "bf16x3" else "exact fp32 MFMA"),
-                       "gemm_tflops_per_step": round(3 * flops_per_frame(K_SPK) * B * T / 1e12, 4)},
+                       "collective": ("one RCCL all-reduce(SUM) of the flat fp32 gradient per step" if world > 1 else None),
+                       "arithmetic": arithmetic(args.gemm), "recurrence": args.recurrence,
+                       "gemm_tflops_per_step": round(3 * flops_per_frame(K) * B * T / 1e12, 4)},
             "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(model, opt),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload != "cfg3")
+            else cpu_baseline(model, opt),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

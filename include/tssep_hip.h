@@ -185,8 +185,19 @@ int tssep_lstm_unpack(const float* src, int64_t ld, int nsplit, int64_t split_st
  * the call by a memset node on `stream`).  `max_wgs` = number of CUs (sizes the grid so that
  * neighbouring clusters hide each other's exchange latency; cluster membership is taken by
  * arrival ticket, so correctness does not depend on residency or dispatch order).
- * `ms` = sequences per cluster / 4: 2, 4, or 0 = automatic.  `err` (device int, caller zeroes it
- * once) is set non-zero if a bounded spin timed out.  H <= 304. */
+ * `ms` = sequences per cluster / 4: 2, 4, or 0 = automatic.  H <= 304, T < 65535.
+ *
+ * `err` (both W-stationary families, cluster and on-chip): device int[4], zeroed ONCE by the caller
+ * and then owned by the library: err[0] is set non-zero when a bounded spin timed out (the workgroup
+ * gives up and the outputs of that launch are garbage: the caller MUST read err[0] before it trusts
+ * or checkpoints anything computed from them); err[1] is the launch epoch the granule tags carry,
+ * advanced on the device in front of every launch (so captured hipGraphs replay with fresh epochs).
+ *
+ * CONCURRENCY CONTRACT: at most ONE W-stationary launch (tssep_blstm_cluster_* / tssep_blstm_onchip_*)
+ * may be in flight per device at any time, across all streams and processes that share `err`: the
+ * clusters are formed from the workgroups of one launch by arrival ticket and spin on their peers,
+ * and two such grids competing for CUs can starve each other into the timeout.  Launch them on one
+ * stream (other kernels may run concurrently on other streams). */
 int tssep_lstm_cluster_supported(int H);
 int64_t tssep_lstm_cluster_pack_floats(int H, int which /* 0: whh_cf, 1: whh_cb */);
 int tssep_lstm_pack_cluster(const float* w_hh_f, const float* w_hh_r, int H,
@@ -208,9 +219,10 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
  * tssep_blstm_fwd/bwd.  `layout` bits: 1 = experimental time-major-in-groups-of-32 row order,
  * 8 = force cross-XCD clusters (write-through exchange), 32 = forward only: keep the activation
  * stream temporal (default: non-temporal from 160 sequences up, so that it does not evict the
- * exchange granules from the L2).  xbuf: caller-owned scratch of
- * tssep_lstm_onchip_xbuf_bytes() bytes (zeroed by the call); err: device int, set non-zero if a
- * bounded spin expired.  max_wgs: number of CUs the launch may occupy.  H <= 304. */
+ * exchange granules from the L2).  xbuf: caller-owned 16-byte-aligned scratch of
+ * tssep_lstm_onchip_xbuf_bytes() bytes (zeroed by the call); err: device int[4] and the concurrency
+ * contract as stated for the cluster kernels above.  max_wgs: number of CUs the launch may occupy.
+ * H <= 304. */
 int tssep_lstm_onchip_supported(int H);
 int64_t tssep_lstm_onchip_pack_floats(int H, int which /* 0: forward, 1: backward */);
 int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, int H, float* wf, float* wb,

@@ -1,15 +1,23 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the gradient bucket (SUM all-reduce) and the
-utterance sharding.  Utterances are independent, so summed shard gradients must equal the
-gradient of the concatenated batch (checked here on the oracle's loss, which is summed over the
-batch like tssep/train/model.py:669)."""
+"""N > 1 path on CPU: world_size-2 ``gloo`` runs of the flat gradient bucket (one all-reduce(SUM)) and of
+the utterance sharding.
+
+* ``test_gradient_sum_allreduce_world2``: the bucket mechanics on a small ``nn.Linear``.
+* ``test_model_level_data_parallel_equivalence``: the REAL TS-SEP step (STFT -> features -> RNNP stack ->
+  mask head -> iSTFT -> LogMAE, the CPU oracle's restatement of tssep/train/model.py:465-536, 653-669) on
+  two ranks, each with its shard of the utterances: because the loss is SUMMED over the batch
+  (model.py:669) and utterances are independent, the all-reduced flat gradient must equal the
+  single-process gradient of the concatenated batch.  (The same statement on the HIP path, two processes
+  on one GPU: tests/test_gpu_modules.py::test_data_parallel_hip_step_matches_single_process.)
+"""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tssep_amd.distributed import GradBucket, shard_range
+from tssep_amd.distributed import GradBucket, equal_shard, shard_range
 
 
 def _free_port():
@@ -18,6 +26,19 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _spawn(worker, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q, *args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    return res
 
 
 def _worker(rank, world, port, q):
@@ -43,16 +64,31 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
+def test_equal_shard_gives_every_rank_the_same_number_of_steps():
+    for n, w in ((10, 2), (10, 4), (64, 8), (9, 8)):
+        spans = [equal_shard(n, r, w) for r in range(w)]
+        assert len({hi - lo for lo, hi in spans}) == 1 and spans[-1][1] <= n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    try:
+        equal_shard(3, 0, 8)
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("3 examples over 8 ranks must be refused")
+
+
+def test_dataset_shard_stage():
+    from tssep_amd import dataset as D
+    ds = D.new([{"i": i} for i in range(10)]).map(lambda e: e["i"] * 10)
+    assert list(ds.shard(0, 1)) == list(ds)
+    a, b = list(ds.shard(0, 2)), list(ds.shard(1, 2))
+    assert a == [0, 10, 20, 30, 40] and b == [50, 60, 70, 80, 90]
+    assert [len(list(ds.shard(r, 4))) for r in range(4)] == [2, 2, 2, 2]
+    assert [len(b_) for b_ in ds.shard(1, 2).batch(2)] == [2, 2, 1]
+
+
 def test_gradient_sum_allreduce_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
-    for p in procs:
-        p.join(30)
+    res = _spawn(_worker, 2)
     torch.manual_seed(0)
     lin = torch.nn.Linear(6, 3)
     x = torch.arange(8 * 6, dtype=torch.float32).view(8, 6) / 10
@@ -61,6 +97,62 @@ def test_gradient_sum_allreduce_world2():
     for _, flat, norm in res:
         torch.testing.assert_close(flat, ref)
         assert abs(norm - float(ref.norm())) < 1e-4
+
+
+# ---- the real model --------------------------------------------------------------------------------
+_CFG = dict(odim=33, combination="mul", ts_vad=4, output_resolution="tf", random_speaker_order=False)
+_DIMS = dict(idim=33, odim=33, units=6, projs=7, combination="mul", aux_size=33, ts_vad=4)
+_B, _K, _N = 4, 4, 400
+
+
+def _toy_batch():
+    rng = np.random.RandomState(7)
+    tgt = 0.1 * rng.randn(_B, _K, _N).astype(np.float32)
+    obs = tgt.sum(1, keepdims=True) + 0.01 * rng.rand(_B, 1, _N).astype(np.float32)
+    aux = rng.rand(_B, _K, 33).astype(np.float32)
+    return [torch.as_tensor(a) for a in (obs, aux, tgt)]
+
+
+def _oracle_params():
+    from oracle import model as omodel
+    torch.manual_seed(3)
+    p = omodel.init_mask_estimator_params(**_DIMS)
+    return [v.requires_grad_() for v in p.values()], p
+
+
+def _oracle_loss(p, obs, aux, tgt):
+    from oracle import model as omodel
+    # log1p features only: the MFCC dB floor is taken over the LOCAL batch, which couples
+    # the utterances of a shard on purpose -- DP then equals per-shard reference runs, not one big batch
+    return omodel.forward_loss(p, obs, aux, tgt, cfg=_CFG, mfcc=False, size=64, shift=16)["loss"].sum()
+
+
+def _model_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    leaves, p = _oracle_params()
+    bucket = GradBucket(leaves)
+    lo, hi = shard_range(_B, rank, world)
+    obs, aux, tgt = (t[lo:hi] for t in _toy_batch())
+    bucket.zero()
+    loss = _oracle_loss(p, obs, aux, tgt)
+    loss.backward()
+    bucket.all_reduce()
+    q.put((rank, bucket.flat.clone(), float(loss)))
+    dist.destroy_process_group()
+
+
+def test_model_level_data_parallel_equivalence():
+    res = _spawn(_model_worker, 2)
+    leaves, p = _oracle_params()
+    loss = _oracle_loss(p, *_toy_batch())
+    loss.backward()
+    ref = torch.cat([v.grad.flatten() for v in leaves])
+    assert float(ref.abs().max()) > 1e-4
+    for _, flat, _ in res:
+        torch.testing.assert_close(flat, ref, rtol=2e-4, atol=2e-6 * float(ref.abs().max()) + 1e-9)
+    torch.testing.assert_close(torch.tensor(sum(r[2] for r in res)), torch.tensor(float(loss.detach())), rtol=1e-5, atol=1e-6)
 
 
 def test_bucket_grads_are_views():

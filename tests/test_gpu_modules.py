@@ -406,29 +406,40 @@ def test_fused_adam_matches_torch_adam_with_clipping():
 
 
 def test_toy_experiments_tsvad_then_tssep(tmp_path):
-    """BASELINE configs[0]/[1]: the toy TS-VAD run (8 speakers, 2 averaged permutations), then
-    TS-SEP initialised from its checkpoint (tssep/exp/run_tsvad.py, run_tssep.py; the reference's
-    tests/test_exp.py:135-162 asserts the same flow does not raise)."""
+    """BASELINE configs[0]/[1]: the toy TS-VAD run (8 speakers, 2 averaged permutations), then TS-SEP
+    initialised from its checkpoint, each as the reference's two child processes -- ``init with ...`` then
+    ``with config.yaml`` inside the storage dir (tssep/exp/run_tsvad.py:54-71, run_tssep.py:56-74; the
+    reference's tests/test_exp.py:135-162 asserts the same flow does not raise)."""
+    import json
+    import subprocess
+    import sys
     from tssep_amd.exp import run_tsvad, run_tssep
     fast = ["eg.trainer.stop_trigger=[3,iteration]", "eg.trainer.checkpoint_trigger=[3,iteration]",
             "eg.trainer.summary_trigger=[1,iteration]"]
-    np.random.seed(0)
-    torch.manual_seed(0)
-    eg = run_tsvad.main(storage_dir=tmp_path / "tsvad", overrides=fast)
-    hist = eg.trainer.history
-    assert len(hist) == 3 and all(np.isfinite(l) for _, l in hist)
-    ck = tmp_path / "tsvad" / "checkpoints" / "ckpt_best_loss.pth"
-    assert ck.exists() and (tmp_path / "tsvad" / "config.yaml").exists()
+    vad_dir = run_tsvad.main(storage_dir=tmp_path / "tsvad", overrides=fast)
+    hist = json.loads((vad_dir / "log" / "history.json").read_text())
+    assert hist["iteration"] == 3 and len(hist["loss"]) == 3 and all(np.isfinite(l) for _, l in hist["loss"])
+    ck = vad_dir / "checkpoints" / "ckpt_best_loss.pth"
+    for f in ("config.yaml", "Makefile", "python_history.txt", "log/model.txt"):
+        assert (vad_dir / f).exists(), f
     sd = torch.load(ck, map_location="cpu")
     assert sd["model"]["mask_estimator.post_net.linear2.weight"].shape == (8, 42)
-    eg2 = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck, overrides=fast)
-    w = eg2.trainer.model.mask_estimator.post_net.linear2.weight
-    assert w.shape == (8 * 513, 42)
-    assert len(eg2.trainer.history) == 3 and all(np.isfinite(l) for _, l in eg2.trainer.history)
-    # resume: a second call continues from ckpt_latest instead of re-initialising
-    eg3 = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck,
-                         overrides=["eg.trainer.stop_trigger=[4,iteration]"] + fast[1:])
-    assert eg3.trainer.iteration == 4
+    assert "fe.fe1.mel_scale.fb" in sd["model"] and "fe.fe1.dct_mat" in sd["model"]      # reference keys
+    sep_dir = run_tssep.main(storage_dir=tmp_path / "tssep", checkpoint=ck, overrides=fast)
+    hist2 = json.loads((sep_dir / "log" / "history.json").read_text())
+    assert hist2["iteration"] == 3 and all(np.isfinite(l) for _, l in hist2["loss"])
+    sd2 = torch.load(sep_dir / "checkpoints" / "ckpt_latest.pth", map_location="cpu")
+    assert sd2["model"]["mask_estimator.post_net.linear2.weight"].shape == (8 * 513, 42)
+    # a second call finds config.yaml, skips init and resumes from ckpt_latest: nothing left to do
+    run_tssep.main(storage_dir=sep_dir, checkpoint=ck, overrides=fast)
+    assert json.loads((sep_dir / "log" / "history.json").read_text())["iteration"] == 3
+    # the Makefile's `run` with one override: continues from iteration 3 to 4 instead of re-initialising
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-m", "tssep_amd.train.run", "with", "config.yaml",
+                    "eg.trainer.stop_trigger=[4,iteration]"], cwd=sep_dir, check=True,
+                   env=dict(os.environ, PYTHONPATH=root))
+    assert json.loads((sep_dir / "log" / "history.json").read_text())["iteration"] == 4
+    assert any((sep_dir / "backup").iterdir())                      # the changed config.yaml was backed up
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
@@ -491,6 +502,32 @@ def test_device_loader_pinned_async_h2d():
         list(D.DeviceLoader(boom(), "cuda:0", ("observation",)))
 
 
+def test_device_loader_large_batches_survive_queued_steps():
+    """The >= 32 MB branch of DeviceLoader (every real training batch): the host runs several steps ahead
+    of the GPU (Trainer.train has no per-step sync) and drops each batch right after queueing its kernels.
+    The device block must not be recycled for a later batch's DMA while queued kernels still read it:
+    every batch is summed AFTER a long queued delay and the sums must be those of the host data."""
+    from tssep_amd import dataset as D
+    rows, cols = 24, 400_000                                  # 38.4 MB per batch, 24 >= 2 * copy_threads
+    host = [dict(observation=np.full((rows, cols), float(i + 1), dtype=np.float32), reference_channel=0)
+            for i in range(8)]
+    for i, h in enumerate(host):
+        h["observation"][:, ::7] += 0.25 * i
+    dl = D.DeviceLoader(D.new(host), "cuda:0", ("observation",), depth=2)
+    busy = torch.randn(4096, 4096, device="cuda")
+    sums = []
+    for ex in dl:
+        x = ex["observation"]
+        for _ in range(12):                                   # ~ tens of ms of queued work per "step"
+            busy = torch.tanh(busy @ busy) * 0.5
+        sums.append(x.double().sum() + 0 * busy[0, 0].double())
+        del x, ex                                             # the step's only reference goes away here
+    torch.cuda.synchronize()
+    want = [float(h["observation"].astype(np.float64).sum()) for h in host]
+    got = [float(v) for v in sums]
+    assert got == want, (got, want)
+
+
 def test_training_through_the_input_pipeline():
     """prepare_train_dataset(device=cuda) -> DeviceLoader -> Model.forward/review/backward."""
     from tssep_amd.data import DummyReader
@@ -515,3 +552,85 @@ def test_training_through_the_input_pipeline():
         l.backward()
         losses.append(float(l))
     assert len(losses) == 3 and all(np.isfinite(losses))
+
+
+# ---- data parallel on the HIP path: two processes on ONE GPU --------------------------------------------
+def _dp_model():
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    torch.manual_seed(11)
+    # units < 128 -> streaming recurrence: no W-stationary launches, which two processes sharing a GPU
+    # must not run concurrently (include/tssep_hip.h).  log1p features only: the MFCC dB floor is over the
+    # LOCAL batch by design and would couple the utterances of a shard.
+    return model.Model(
+        fe=fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"), reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=513, odim=513, units=16, projs=12, combination="mul",
+                                            aux_net_output_size=513, ts_vad=4, output_resolution="tf",
+                                            random_speaker_order=False),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+
+
+def _dp_batch(lo, hi):
+    rng = np.random.RandomState(5)
+    tgt = 0.1 * rng.randn(4, 4, 6000).astype(np.float32)
+    obs = tgt.sum(1, keepdims=True) + 0.01 * rng.rand(4, 1, 6000).astype(np.float32)
+    aux = rng.rand(4, 4, 513).astype(np.float32)
+    return dict(observation=torch.as_tensor(obs[lo:hi]).cuda(), auxInput=torch.as_tensor(aux[lo:hi]).cuda(),
+                speaker_reverberation_early_ch0=torch.as_tensor(tgt[lo:hi]).cuda(), reference_channel=0,
+                dataset=["dp"] * (hi - lo))
+
+
+def _dp_step(lo, hi):
+    from tssep_amd.train.optimizer import Adam
+    m = _dp_model()
+    opt = Adam(gradient_clipping=10.0)
+    opt.set_parameters(m.parameters())
+    opt.zero_grad()
+    ex = _dp_batch(lo, hi)
+    loss = m.review(ex, m(ex))["loss"]
+    loss.backward()
+    opt.bucket.all_reduce()              # joins the side stream; SUM over ranks when a group exists
+    torch.cuda.synchronize()
+    return opt.bucket.flat.cpu(), float(loss)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from tssep_amd.distributed import shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat, loss = _dp_step(*shard_range(4, rank, world))
+        q.put((rank, flat, loss))
+    except BaseException as e:           # surface the failure in the parent instead of a queue timeout
+        q.put((rank, repr(e), None))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_hip_step_matches_single_process():
+    """SURVEY 8e on the product path: each of two ranks runs the HIP forward + backward on its half of the
+    utterances, GradBucket.all_reduce sums the flat gradients; the result is the single-process gradient
+    of the whole batch (loss summed over the batch, tssep/train/model.py:669)."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(60)
+    for r in res:
+        assert r[2] is not None, r[1]
+    ref, loss = _dp_step(0, 4)
+    scale = float(ref.abs().max())
+    assert scale > 1e-6
+    for _, flat, _ in res:
+        assert float((flat - ref).abs().max()) <= 2e-5 * scale, float((flat - ref).abs().max()) / scale
+    assert abs(res[0][2] + res[1][2] - loss) <= 1e-5 * abs(loss)

@@ -96,7 +96,8 @@ def test_mask_estimator_consumes_np_random_like_reference(golden):
 
 # generation order of make_golden.py (seed = 100 + case index)
 ME_CASES_ORDER = [f"me_{c}_{v}_{r}_{n}" for c in ("mul", "cat") for v in (False, 3, 4)
-                  for r in ("t", "tf") for n in (1, 2) if not (v is False and n != 1)]
+                  for r in ("t", "tf") for n in (1, 2) if not (v is False and n != 1)] + \
+                 [f"me_{c}_8_{r}_{n}" for c in ("mul", "cat") for r in ("t", "tf") for n in (1, 2)]
 
 
 def test_enhancer_and_losses_against_reference_fixture(golden):

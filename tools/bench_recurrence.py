@@ -47,7 +47,7 @@ for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
     for lay in [int(a) for a in os.environ.get("LAYOUTS", "").split(",") if a]:
         g = g0.clone()
         res["onchip_fwd_lay%d_ms" % lay] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh, lay)), 3)
-        res["err%d" % lay] = int(h._err_flag(g.device).item()); h._err_flag(g.device).zero_()
+        res["err%d" % lay] = int(h._err_flag(g.device)[0].item()); h._err_flag(g.device)[0].zero_()
     if os.environ.get("CROSS_XCD"):
         g = g0.clone()
         res["onchip_crossxcd_fwd_ms"] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh, 8)), 3)

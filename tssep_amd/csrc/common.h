@@ -29,3 +29,17 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ---- launch epoch of the W-stationary recurrences (lstm_cluster.hip, lstm_onchip.hip) -------------
+// Granule tags are {launch epoch (15 bits, never 0) << 16 | step + 1}: a granule left in a cache or in
+// memory by an EARLIER launch over the same buffer can never satisfy a later launch's poll (observed:
+// with a second stream active, stale L2 lines of the previous launch carried tags that matched the same
+// step of the next one; consumers ran ahead and the two-slot protocol broke).  The epoch lives in DEVICE
+// memory (err[1], next to the error flag err[0]) and is advanced by the reset kernel that zeroes the
+// exchange buffer in front of every launch, so a captured hipGraph replays with fresh epochs too (a
+// host-side counter would be frozen into the captured kernel arguments).
+int tssep_xbuf_reset(void* xbuf, size_t bytes, int* err, hipStream_t s);
+__device__ __forceinline__ unsigned tssep_load_tagbase(const int* err) {
+  const unsigned e = (unsigned)__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(((e % 0x7fffu) + 1u) << 16));
+}

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_fwd_kern
   __shared__ int s_fail, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ub = wave >> 1, kh = wave & 1;
+  const unsigned tagbase = tssep_load_tagbase(err);
   // Cluster membership by arrival ticket: the first G workgroups that START form cluster 0, the
   // next G cluster 1, ...  A cluster therefore only ever waits for workgroups that are already
   // running or will be scheduled as soon as a complete (running) cluster retires -- no assumption
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_fwd_kern
           off[r] = ok ? s * KROW + uu : -1;
         }
         float v[CH];
-        if (!gather_granules<CH>(p, (unsigned)step, v)) s_fail = 1;
+        if (!gather_granules<CH>(p, tagbase | (unsigned)step, v)) s_fail = 1;
 #pragma unroll
         for (int r = 0; r < CH; ++r)
           if (off[r] >= 0) hs[off[r]] = v[r];
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_fwd_kern
         const int s = 4 * (kh * HQ + q) + j;
         const int64_t n = seq0 + s;
         if (uvalid) {
-          granule_store(dst + (int64_t)s * Hp + unit, (unsigned)(step + 1), h);
+          granule_store(dst + (int64_t)s * Hp + unit, tagbase | (unsigned)(step + 1), h);
           if (n < N) {
             const int64_t cellidx = ((n * T + t) * 2 + dir) * (int64_t)H + unit;
             *reinterpret_cast<f32x4*>(gates + cellidx * 4) = f32x4{ig, fg, gg, og};
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_bwd_kern
   __shared__ int s_fail, s_ticket;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ub = wave >> 1, kh = wave & 1;
+  const unsigned tagbase = tssep_load_tagbase(err);
   if (tid == 0) {
     s_fail = 0;
     s_ticket = (int)atomicAdd(reinterpret_cast<unsigned*>(xbuf), 1u);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_bwd_kern
               p[q * GMAX + gs] = gs < G ? src + (int64_t)gs * M * Hp : nullptr;
           }
           float v[GMAX * HQ];
-          if (!gather_granules<GMAX * HQ>(p, (unsigned)step, v)) s_fail = 1;
+          if (!gather_granules<GMAX * HQ>(p, tagbase | (unsigned)step, v)) s_fail = 1;
 #pragma unroll
           for (int q = 0; q < HQ; ++q)
 #pragma unroll
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, (MS == 2 ? 2 : 1)) void blstm_cluster_bwd_kern
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (uo0 + i < H)
-              granule_store(dst + (int64_t)(4 * q + j) * Hp + uo0 + i, (unsigned)(step + 1), sum[i]);
+              granule_store(dst + (int64_t)(4 * q + j) * Hp + uo0 + i, tagbase | (unsigned)(step + 1), sum[i]);
         }
       }
       __syncthreads();      // dgs / part are rewritten by the next step
@@ -452,6 +454,24 @@ static void cluster_plan(int64_t N, int G, int max_wgs, int ms_req, int* ms, int
   *nclusters = (int)(work < cap ? work : cap);
 }
 
+// ---- exchange-buffer reset + launch epoch (common.h) ------------------------------------------------
+__global__ __launch_bounds__(256) void xbuf_reset_kernel(uint4* __restrict__ p, int64_t n16,
+                                                         int* __restrict__ err) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+    p[i] = uint4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && threadIdx.x == 0) err[1] = (int)(((unsigned)err[1] + 1u) & 0x3fffffffu);
+}
+
+int tssep_xbuf_reset(void* xbuf, size_t bytes, int* err, hipStream_t s) {
+  const int64_t n16 = (int64_t)((bytes + 15) / 16);          // callers size the buffer in 16-byte units
+  int64_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(xbuf_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)xbuf, n16, err);
+  return tssep_launch_status();
+}
+
 extern "C" int64_t tssep_lstm_cluster_xbuf_bytes(int64_t N, int H, int backward, int max_wgs,
                                                  int ms_req) {
   const int G = (H + UPW - 1) / UPW;
@@ -470,14 +490,15 @@ extern "C" int tssep_blstm_cluster_fwd(float* gates, float* cell, float* hout, i
   if (!gates || !cell || !hout || !whh_cf || !xbuf || !err) return TSSEP_E_NULL;
   if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!tssep_lstm_cluster_supported(H)) return TSSEP_E_UNSUPPORTED;
-  if (!aligned16(gates) || (((uintptr_t)xbuf) & 7u)) return TSSEP_E_ALIGN;
+  if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int ms, nc;
   cluster_plan(N, G, max_wgs, ms_req, &ms, &nc);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 0, max_wgs, ms_req), s) !=
-      hipSuccess)
+  if (T >= 0xffff) return TSSEP_E_SHAPE;                      // the step shares the tag with the epoch
+  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 0, max_wgs, ms_req), err, s) !=
+      TSSEP_OK)
     return TSSEP_E_LAUNCH;
   dim3 grid((unsigned)(nc * G));
   if (ms == 2)
@@ -496,14 +517,15 @@ extern "C" int tssep_blstm_cluster_bwd(float* gates, const float* cell, const fl
   if (!gates || !cell || !dhout || !whh_cb || !xbuf || !err) return TSSEP_E_NULL;
   if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!tssep_lstm_cluster_supported(H)) return TSSEP_E_UNSUPPORTED;
-  if (!aligned16(gates) || (((uintptr_t)xbuf) & 7u)) return TSSEP_E_ALIGN;
+  if (!aligned16(gates) || !aligned16(xbuf)) return TSSEP_E_ALIGN;
   const int G = (H + UPW - 1) / UPW;
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int ms, nc;
   cluster_plan(N, G, max_wgs, ms_req, &ms, &nc);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 1, max_wgs, ms_req), s) !=
-      hipSuccess)
+  if (T >= 0xffff) return TSSEP_E_SHAPE;                      // the step shares the tag with the epoch
+  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_cluster_xbuf_bytes(N, H, 1, max_wgs, ms_req), err, s) !=
+      TSSEP_OK)
     return TSSEP_E_LAUNCH;
   dim3 grid((unsigned)(nc * G));
   if (ms == 2)

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N,
-    int64_t T, int H, int G, int nclusters, int layout, unsigned tagbase) {
+    int64_t T, int H, int G, int nclusters, int layout) {
+  const unsigned tagbase = tssep_load_tagbase(err);
   __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];      // h_t  [seq][unit]
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
     float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dhout,
     int64_t ldo, int64_t dstride, const u32x4* __restrict__ wb, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G,
-    int nclusters, int layout, unsigned tagbase) {
+    int nclusters, int layout) {
+  const unsigned tagbase = tssep_load_tagbase(err);
   __shared__ __attribute__((aligned(16))) char dg_hi[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) char dg_lo[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16];          // tiles 8/9 partials
@@ -789,14 +791,7 @@ extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) 
   return HDR_BYTES + pb;
 }
 
-// Granule tags are {launch epoch (15 bits, never 0) << 16 | step + 1}: a granule left in a cache or
-// in memory by an EARLIER launch over the same buffer can never satisfy a later launch's poll
-// (observed: with a second stream active, stale L2 lines of the previous launch carried tags that
-// matched the same step of the next one; consumers ran ahead and the two-slot protocol broke).
-static unsigned next_tagbase() {
-  static std::atomic<unsigned> epoch{0};
-  return (((epoch.fetch_add(1) % 0x7fffu) + 1u) << 16);
-}
+// (granule tags carry a per-launch epoch kept in device memory: common.h, tssep_load_tagbase)
 
 // grid: cross-XCD mode -> exactly the clusters wanted; XCD-local mode -> whole clusters per XCD
 // (workgroup b is observed on XCD b % 8; a cluster needs G workgroups of ONE XCD) plus one spare
@@ -829,7 +824,7 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   xbuf_layout(N, G, UPW, &items, &pb);
   if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)(HDR_BYTES + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
   // (51 clusters) saves a whole resident round
   const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
@@ -842,11 +837,11 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   if (xcd)
     hipLaunchKernelGGL(blstm_onchip_fwd_kernel<true>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
                        ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
-                       N, T, H, G, nc, klayout, next_tagbase());
+                       N, T, H, G, nc, klayout);
   else
     hipLaunchKernelGGL(blstm_onchip_fwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, hout,
                        ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err,
-                       N, T, H, G, nc, klayout, next_tagbase());
+                       N, T, H, G, nc, klayout);
   return tssep_launch_status();
 }
 
@@ -864,7 +859,7 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   xbuf_layout(N, G, G * UPW, &items, &pb);
   if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(xbuf, 0, (size_t)(HDR_BYTES + pb), s) != hipSuccess) return TSSEP_E_LAUNCH;
+  if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
   // (51 clusters) saves a whole resident round
   const int xcd_cap = 8 * ((max_wgs / 8) / G), flat_cap = max_wgs / G;
@@ -875,10 +870,10 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   if (xcd)
     hipLaunchKernelGGL(blstm_onchip_bwd_kernel<true>, dim3(grid), dim3(512), 0, s, gates, cell, dhout,
                        ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N,
-                       T, H, G, nc, layout & 1, next_tagbase());
+                       T, H, G, nc, layout & 1);
   else
     hipLaunchKernelGGL(blstm_onchip_bwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, dhout,
                        ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N,
-                       T, H, G, nc, layout & 1, next_tagbase());
+                       T, H, G, nc, layout & 1);
   return tssep_launch_status();
 }

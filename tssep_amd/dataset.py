@@ -53,6 +53,16 @@ class Dataset:
     def copy(self, freeze=False):
         return Dataset(list(self)) if freeze else Dataset(self._source, self._stages)
 
+    def shard(self, rank, world):
+        """The rank's share of the SOURCE examples for data-parallel training (equal shares, remainder
+        dropped: tssep_amd.distributed.equal_shard); later stages see only that share."""
+        if world == 1:
+            return self
+        from .distributed import equal_shard
+        items = list(self._source)
+        lo, hi = equal_shard(len(items), rank, world)
+        return Dataset(items[lo:hi], self._stages)
+
     def batch(self, batch_size, drop_last=False):
         return self._with(("batch", int(batch_size), bool(drop_last)))
 
@@ -281,7 +291,13 @@ class DeviceLoader:
                 # large tensors: the pageable -> pinned copy is the slow leg (one core moves ~8 GB/s, a
                 # batch of 768 utterances is 1 GB); chunks along the batch axis on a few threads
                 # (Tensor.copy_ releases the GIL), each chunk's DMA issued as soon as it is staged
-                dev = torch.empty(t.shape, dtype=t.dtype, device=self.device)
+                # allocated UNDER the copy stream: the block then belongs to that stream's pool, so the
+                # allocator cannot hand it out again (to the next batch's DMA) while kernels of a step the
+                # host has already queued still read it -- the consumer's record_stream(cur) below defers
+                # the reuse until its stream has passed this point.  (Allocated on the default stream the
+                # block was recycled at once and the next DMA overwrote a batch still in use.)
+                with torch.cuda.stream(copy_stream):
+                    dev = torch.empty(t.shape, dtype=t.dtype, device=self.device)
                 bounds = np.linspace(0, t.shape[0], self.copy_threads + 1).astype(int)
 
                 def chunk(i):

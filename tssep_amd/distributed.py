@@ -53,11 +53,61 @@ class GradBucket:
     def all_reduce(self, group=None, async_op=False):
         self.sync()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+                # debugging / test configuration (several ranks on one GPU, where RCCL refuses to
+                # run): stage through the host.  Production is nccl = RCCL over xGMI, in place.
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host)
+                return None
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
     def global_norm(self):
         return torch.linalg.vector_norm(self.flat)
+
+
+def env_rank():
+    """(rank, world, local_rank) of this process from the torchrun environment (1 process = 1 GPU)."""
+    import os
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
+            int(os.environ.get("LOCAL_RANK", 0)))
+
+
+def init_from_env(backend=None):
+    """Join the job the environment describes (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*): select the
+    rank's GPU and, for WORLD_SIZE > 1, create the process group (``nccl`` = RCCL when a GPU is
+    present, ``gloo`` otherwise).  Idempotent.  -> (rank, world, local_rank)."""
+    import os
+    rank, world, local_rank = env_rank()
+    on_gpu = torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if on_gpu else "gloo")
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def equal_shard(n_items, rank, world):
+    """[lo, hi) of the rank's TRAINING shard: every rank gets floor(n / world) units (the remainder is
+    dropped), because all ranks must run the same number of optimizer steps -- a rank with one batch
+    more would wait for ever in the gradient all-reduce."""
+    per = n_items // world
+    if per == 0:
+        raise ValueError(f"{n_items} training examples cannot be sharded over {world} ranks")
+    return rank * per, (rank + 1) * per
 
 
 def shard_range(n_items, rank, world):

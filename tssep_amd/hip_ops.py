@@ -365,16 +365,17 @@ RECURRENCE = "auto"    # "auto" | "stream" (lstm.hip) | "cluster" (lstm_cluster.
 def _err_flag(device):
     key = str(device)
     if key not in _ERR:
-        _ERR[key] = torch.zeros(1, device=device, dtype=torch.int32)
+        # [0] error flag, [1] launch epoch of the W-stationary kernels (library-maintained), [2..3] spare
+        _ERR[key] = torch.zeros(4, device=device, dtype=torch.int32)
     return _ERR[key]
 
 
 def check_cluster_errors(device="cuda"):
     """Synchronising check of the cluster kernels' timeout flag (tests / end of a bench run)."""
     f = _err_flag(torch.device(device) if not isinstance(device, torch.device) else device)
-    v = int(f.item())
+    v = int(f[0].item())
     if v:
-        f.zero_()
+        f[0].zero_()
         raise RuntimeError(f"cluster recurrence kernel timed out waiting for a peer (code {v})")
 
 

@@ -38,9 +38,13 @@ class Experiment(Configurable):
 
     @property
     def device(self):
+        """experiment.py:166-191 picks the single visible GPU and refuses more; here every process owns
+        the GPU torchrun assigned to it (LOCAL_RANK), one process per GPU."""
         if not torch.cuda.is_available():
             raise RuntimeError("tssep_amd needs an MI355X: there is no CPU path")
-        return torch.cuda.current_device()
+        from .. import distributed as _dist
+        _, _, local_rank = _dist.init_from_env()
+        return local_rank
 
     def load_model_state_dict(self, ckpt, strict=True):     # experiment.py:199-206
         ckpt = Path(ckpt)
@@ -62,7 +66,7 @@ class Experiment(Configurable):
         resume = (t.checkpoint_dir / "ckpt_latest.pth").exists()
         if not resume:
             self.init_ckpt(self)
-        dev = self.device
+        dev = self.device                                    # joins the torchrun job when there is one
         model.to(torch.device("cuda", dev))
         val = model.prepare_validate_dataset(device=dev, batch_size=self.validation_batchsize)
         train = model.prepare_train_dataset(device=dev, batch_size=self.train_batchsize)

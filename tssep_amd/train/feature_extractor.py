@@ -71,9 +71,9 @@ class STFT(Configurable):
         return self.stft_to_feature(self.stft(signal))
 
     def sample_index_to_frame_index(self, sample_index):
-        """paderbox STFT.sample_index_to_frame_index: frame whose centre covers the sample."""
-        pad = self.window_length - self.shift if self.fading else 0
-        return max(0, (int(sample_index) + pad - self.window_length // 2) // self.shift)
+        """paderbox STFT.sample_index_to_frame_index (feature_extractor.py:208,306)."""
+        from ..util.utils import sample_index_to_stft_frame_index
+        return sample_index_to_stft_frame_index(sample_index, self.window_length, self.shift, self.fading)
 
 
 class Log1pMaxNormAbsSTFT(STFT):
@@ -112,8 +112,17 @@ class TorchMFCC(STFT, torch.nn.Module):
             f_max = sample_rate + f_max                       # :57-58
         self.f_max, self.n_mels = f_max, n_mels
         self.dct_norm, self.mel_norm, self.top_db, self.log_mels = dct_norm, mel_norm, 80, log_mels
-        self.register_buffer("fb", _melscale_fbanks(size // 2 + 1, f_min, f_max, n_mels, sample_rate))
+        # module tree of the reference (feature_extractor_torchaudio.py:69-85): a parameter-free
+        # ``amplitude_to_DB``, ``mel_scale`` holding the persistent buffer ``fb`` and the buffer
+        # ``dct_mat`` -> checkpoint keys ``<fe>.dct_mat`` and ``<fe>.mel_scale.fb``, so a checkpoint the
+        # reference wrote loads with strict=True (init_cfg_tssep.yaml:22)
+        self.amplitude_to_DB = _AmplitudeToDB("power", self.top_db)
+        self.mel_scale = _MelScale(n_mels, sample_rate, f_min, f_max, size // 2 + 1)
         self.register_buffer("dct_mat", _create_dct(n_mfcc, n_mels))
+
+    @property
+    def fb(self):
+        return self.mel_scale.fb
 
     def _get_output_size(self, output_size):
         return self.n_mfcc if output_size is None else output_size
@@ -125,6 +134,24 @@ class TorchMFCC(STFT, torch.nn.Module):
         assert X.dim() == 3, X.shape
         out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self.top_db)
         return out[..., :self.n_mfcc]
+
+
+class _MelScale(torch.nn.Module):
+    """Holder of the mel filterbank under torchaudio's key (``MelScale.fb``, a persistent buffer
+    [n_freqs, n_mels]); the filtering itself runs inside tssep_feat_fwd."""
+
+    def __init__(self, n_mels, sample_rate, f_min, f_max, n_stft):
+        super().__init__()
+        self.n_mels, self.sample_rate, self.f_min, self.f_max = n_mels, sample_rate, f_min, f_max
+        self.register_buffer("fb", _melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate))
+
+
+class _AmplitudeToDB(torch.nn.Module):
+    """Parameter- and buffer-free, like torchaudio's; keeps the attribute name of the reference."""
+
+    def __init__(self, stype, top_db):
+        super().__init__()
+        self.stype, self.top_db = stype, top_db
 
 
 def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):

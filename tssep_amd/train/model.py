@@ -101,37 +101,49 @@ class Model(Configurable, torch.nn.Module):
         if load_keys is None:
             load_keys = ["observation", *self.loss.targets(lower=True)]
         ds = D.new(reader(dataset_name, pre_load_apply=pre_load_apply, load_keys=load_keys))
+        if training:            # data parallel: one process per GPU, each trains on its share of the utterances
+            from .. import distributed as _dist
+            ds = ds.shard(_dist.get_rank(), _dist.world_size())
+
+        targets = tuple(self.loss.targets())
+        passthrough = ("example_id", "dataset", "gender", "auxInput", "vad", "framewise_embeddings",
+                       "framewise_embeddings_stride")
+
+        def pick_target(audio, name):
+            """The loss target `name` out of the loaded audio (model.py:254-283): signals are stored
+            under the lower-case key (multi-channel ones reduced to the reference channel), the
+            frame-level 'Vad' under its own name; (None, None) when the reader did not load it."""
+            key = name.lower()
+            if key in audio:
+                value = audio[key]
+                if isinstance(value, np.ndarray) and value.ndim == 3:
+                    value = value[:, 0]
+                return key, value
+            if name == "Vad" and name in audio:
+                return name, audio[name]
+            return None, None
 
         def prepare(ex):
+            audio = ex.get("audio_data")
             r = {"reference_channel": 0}
-            try:
-                r["observation"] = ex["audio_data"]["observation"]
-            except KeyError:
-                if "Input" in ex:
-                    r["Input"] = ex["Input"]
-                else:
-                    raise
-            for target_name in self.loss.targets():
-                try:
-                    lower = target_name.lower()
-                    if lower in ex["audio_data"]:
-                        target = ex["audio_data"][lower]
-                        if isinstance(target, np.ndarray) and target.ndim == 3:
-                            target = target[:, r["reference_channel"]]
-                        r[lower] = target
-                    elif target_name in ["Vad"]:
-                        r[target_name] = ex["audio_data"][target_name]
-                    elif review:
-                        raise Exception(
-                            f"Either the reader has a bug and forgot to load {lower!r} or you don't need "
-                            "the\ntarget signal from the loss. To disable this error, set the review "
-                            "flag to False.")
-                except KeyError:
-                    if self.training:
-                        raise
-            for k in ("example_id", "dataset", "gender", "auxInput", "vad"):
-                if k in ex:
-                    r[k] = ex[k]
+            if audio is not None and "observation" in audio:
+                r["observation"] = audio["observation"]
+            elif "Input" in ex:
+                r["Input"] = ex["Input"]
+            else:
+                raise KeyError("observation")
+            for name in targets:
+                key, value = pick_target(audio or {}, name)
+                if key is not None:
+                    r[key] = value
+                elif audio is None or name == "Vad":
+                    if self.training:                      # a missing entry only passes outside training
+                        raise KeyError(name if audio is not None else "audio_data")
+                elif review:
+                    raise Exception(
+                        f"The reader did not load {name.lower()!r} although the loss asks for it; load it, "
+                        "or call prepare_dataset(review=False) when the target is not needed.")
+            r.update((k, ex[k]) for k in passthrough if k in ex)
             if verbose:
                 r["verbose"] = ex
             return r
@@ -230,11 +242,13 @@ class Model(Configurable, torch.nn.Module):
         summary.add_to_loss(loss_value.sum())                            # model.py:669
         with torch.no_grad():
             name = self.loss.name
-            if loss_value.ndim == 0:
+            if loss_value.ndim == 0:                                      # model.py:672-679
                 summary.add_scalar(f'{ex["dataset"]}_{name}', loss_value)
-            elif loss_value.ndim == 1:
+                summary.add_histogram(f'hist_{ex["dataset"]}_{name}', loss_value)
+            elif loss_value.ndim == 1:                                    # model.py:680-686
                 for dataset_name, lv in zip(ex["dataset"], loss_value):
                     summary.add_scalar(f"{dataset_name}_{name}", lv)
+                    summary.add_histogram(f"hist_{dataset_name}_{name}", lv)
             else:
                 raise NotImplementedError(loss_value.ndim, loss_value.shape)
         return summary

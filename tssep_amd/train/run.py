@@ -3,6 +3,7 @@
     python -m tssep_amd.train.run init with a.yaml b.yaml eg.trainer.storage_dir=/path key=value
     python -m tssep_amd.train.run with config.yaml          (== train; run inside storage_dir)
     python -m tssep_amd.train.run print_config with config.yaml
+    python -m tssep_amd.train.run makefile with config.yaml  (re-writes storage_dir/Makefile)
 
 YAML files are merged left to right, then ``key=value`` overrides (dotted paths, YAML values)."""
 import datetime
@@ -53,13 +54,34 @@ def dump_config(storage_dir, cfg):                      # run.py:138-151 (+ back
     path.write_text(text)
 
 
+def makefile(cfg, dump=True):
+    """storage_dir/Makefile with the targets of tssep/train/makefile.py:10-32 (help, init, run, makefile),
+    each re-entering this module with the frozen config.yaml."""
+    mod = "tssep_amd.train.run"
+    targets = [("help", ["cat Makefile"]),
+               ("init", ["# Update config.yaml and Makefile. Print config.", f"python -m {mod} init with config.yaml"]),
+               ("run", [f"python -m {mod} with config.yaml"]),
+               ("makefile", ["@# Update this makefile.", f"python -m {mod} makefile with config.yaml"])]
+    text = "SHELL := /bin/bash\n"
+    for name, recipe in targets:
+        text += f"\n.PHONY: {name}\n{name}:\n" + "".join(f"\t{line}\n" for line in recipe)
+    if dump:
+        (Path(cfg["eg"]["trainer"]["storage_dir"]) / "Makefile").write_text(text)
+    return text
+
+
 def init(cfg):
     storage_dir = Path(cfg["eg"]["trainer"]["storage_dir"])
     storage_dir.mkdir(exist_ok=True, parents=True)
     with open(storage_dir / "python_history.txt", "a") as fd:      # run.py:159-165
         print(f"{shlex.join(sys.argv)}  # {datetime.datetime.today():%Y.%m.%d %H:%M:%S}  # {Path.cwd()}",
               file=fd)
+    cwd = Path.cwd()                                   # run.py:167-172: a sibling directory of the
+    if cwd.parts[:-1] == storage_dir.parts[:-1]:       # storage dir is almost certainly a mistake
+        assert cwd == storage_dir, (cwd, storage_dir)
     dump_config(storage_dir, cfg)
+    print(yaml.safe_dump(cfg, sort_keys=False))
+    makefile(cfg)
     eg = Experiment.from_config(cfg["eg"])
     eg.add_log_files()
     print(f"Initialized {storage_dir}")
@@ -69,7 +91,7 @@ def init(cfg):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     command = "train"
-    if argv and argv[0] in ("init", "train", "print_config"):
+    if argv and argv[0] in ("init", "train", "print_config", "makefile"):
         command = argv.pop(0)
     if argv and argv[0] == "with":
         argv.pop(0)
@@ -78,6 +100,9 @@ def main(argv=None):
         cfg["eg"]["trainer"]["storage_dir"] = str(Path.cwd())
     if command == "print_config":
         print(yaml.safe_dump(cfg, sort_keys=False))
+        return cfg
+    if command == "makefile":
+        makefile(cfg)
         return cfg
     eg = init(cfg)
     if command == "train":

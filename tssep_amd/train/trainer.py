@@ -3,12 +3,20 @@
 ``loss.backward()``, optimizer step every ``virtual_minibatch_size`` examples, validation +
 checkpoints every ``checkpoint_trigger`` iterations (``checkpoints/ckpt_<iter>.pth`` with the
 ``model`` / ``optimizer`` / ``iteration`` / ``epoch`` keys, ``ckpt_latest.pth`` and
-``ckpt_best_loss.pth`` links), resume from ``ckpt_latest.pth``."""
+``ckpt_best_loss.pth`` links), resume from ``ckpt_latest.pth``.
+
+Data parallel (new here; the reference refuses more than one GPU, experiment.py:181-184): one process per
+GPU under torchrun.  Every rank trains on its share of the utterances (``Dataset.shard``), the flat
+gradient is all-reduced (SUM, the loss is summed over the batch: model.py:669) inside ``optimizer.step()``
+on the last micro-step of a virtual minibatch, parameters start from rank 0's values, and only rank 0
+validates and writes checkpoints."""
 import os
 from pathlib import Path
 
+import numpy as np
 import torch
 
+from .. import distributed as _dist
 from ..configurable import Configurable
 
 
@@ -51,6 +59,15 @@ class Trainer(Configurable):
         n, unit = trigger
         return unit == "iteration" and self.iteration % n == 0
 
+    def check_device_errors(self):
+        """Raise if a W-stationary recurrence launch gave up on a peer (include/tssep_hip.h: err[0]):
+        everything computed since is garbage and must not be trained on or checkpointed.  One host
+        sync; called where the loop synchronises anyway (summary scalars, validation, checkpoints)."""
+        p = next(self.model.parameters(), None)
+        if p is not None and p.is_cuda:
+            from .. import hip_ops
+            hip_ops.check_cluster_errors(p.device)
+
     def validate(self):
         self.model.eval()
         losses = []
@@ -58,9 +75,12 @@ class Trainer(Configurable):
             for ex in self.validation_dataset:
                 losses.append(self.model.review(ex, self.model(ex))["loss"].detach())
         self.model.train()
-        return float(torch.stack(losses).mean()) if losses else float("nan")
+        value = float(torch.stack(losses).mean()) if losses else float("nan")
+        self.check_device_errors()
+        return value
 
     def save_checkpoint(self, val_loss):
+        self.check_device_errors()
         self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
         path = self.checkpoint_dir / f"ckpt_{self.iteration}.pth"
         torch.save({"model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
@@ -90,6 +110,15 @@ class Trainer(Configurable):
         self.optimizer.set_parameters(self.model.parameters())
         if resume:
             self.load_checkpoint(self.checkpoint_dir / "ckpt_latest.pth")
+        rank, world = _dist.get_rank(), _dist.world_size()
+        if world > 1:
+            # identical replicas: rank 0's parameters (and, after a resume, its Adam moments); a speaker
+            # permutation / shuffle stream of its own per rank, derived from the current state so that a
+            # seeded run stays reproducible
+            for t in (self.optimizer.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
+                torch.distributed.broadcast(t, src=0)
+            np.random.seed((int(np.random.get_state()[1][0]) + 7919 * rank) & 0x7FFFFFFF)
+        chief = rank == 0
         stop_n, stop_unit = self.stop_trigger
         assert stop_unit == "iteration", self.stop_trigger
         self.optimizer.zero_grad()
@@ -99,15 +128,24 @@ class Trainer(Configurable):
                 summary["loss"].backward()
                 self.iteration += 1
                 if self.iteration % self.virtual_minibatch_size == 0:
-                    self.optimizer.step()
+                    self.optimizer.step()            # all-reduce(SUM) over ranks, clip, Adam
                     self.optimizer.zero_grad()
                 if self._triggered(self.summary_trigger):
-                    self.history.append((self.iteration, float(summary["loss"])))
-                if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None:
+                    self.history.append((self.iteration, float(summary["loss"])))     # host sync
+                    self.check_device_errors()
+                if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None and chief:
                     self.save_checkpoint(self.validate())
                 if self.iteration >= stop_n:
                     break
             self.epoch += 1
-        if self.validation_dataset is not None and not (self.checkpoint_dir / "ckpt_latest.pth").exists():
+        self.check_device_errors()
+        if chief and self.validation_dataset is not None and not (self.checkpoint_dir / "ckpt_latest.pth").exists():
             self.save_checkpoint(self.validate())
+        if chief:                                    # the summary scalars, for runs driven as child processes
+            import json
+            (self.storage_dir / "log").mkdir(parents=True, exist_ok=True)
+            (self.storage_dir / "log" / "history.json").write_text(json.dumps(
+                dict(iteration=self.iteration, epoch=self.epoch, loss=self.history)))
+        if world > 1:
+            torch.distributed.barrier()              # nobody leaves before rank 0 has written its files
         return self.history
