@@ -281,14 +281,25 @@ def main():
     del obs, aux, tgt
     np.random.seed(rank)
 
-    def step():
+    graphed = args.graph == "on" or (args.graph == "auto" and B <= 32)
+    gstep = None
+    if graphed:
+        from tssep_amd.train.graph import GraphedStep
+        gstep = GraphedStep(model, opt, adopt_inputs=True)
+
+    def step(eager=False):
         """One training step: zero the flat gradient bucket, forward, LogMAE loss, backward (weight
         gradients accumulate into the bucket on the side stream), gradient all-reduce over ranks
-        (RCCL), global-norm clipping + Adam in one fused launch."""
-        opt.zero_grad()
-        ex = dict(ex0)
-        out = model(ex)
-        model.review(ex, out)["loss"].backward()
+        (RCCL), global-norm clipping + Adam in one fused launch.  Small batches replay the device work
+        of everything up to the optimizer as one captured hipGraph (tssep_amd/train/graph.py); the
+        speaker permutations are still drawn per step on the host."""
+        if gstep is not None and not eager:
+            out, _ = gstep(dict(ex0))
+        else:
+            opt.zero_grad()
+            ex = dict(ex0)
+            out = model(ex)
+            model.review(ex, out)["loss"].backward()
         opt.step()                   # joins the side stream, all-reduces, clips, updates
         return out
 
@@ -302,7 +313,7 @@ def main():
         for _ in range(warmup):
             out = step()
         H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear()
-        H.KERNEL_TIMING = True
+        H.KERNEL_TIMING = gstep is None      # events cannot be read back out of a graph replay: see below
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
         t0 = time.perf_counter()
@@ -313,6 +324,12 @@ def main():
         barrier()
         dt_ = time.perf_counter() - t0
         H.KERNEL_TIMING = False
+        if gstep is not None:                # per-kernel roofline timings: an eager pass after the timed region
+            H.KERNEL_TIMING = True
+            for _ in range(min(steps, 10)):
+                out = step(eager=True)
+            torch.cuda.synchronize()
+            H.KERNEL_TIMING = False
         per_step = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))      # device-side ms per step
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
         if world > 1:
@@ -410,9 +427,11 @@ def main():
                        "projs": PROJS, "parallelism": f"dp{world}",
                        "collective": ("one RCCL all-reduce(SUM) of the flat fp32 gradient per step" if world > 1 else None),
                        "arithmetic": arithmetic(args.gemm), "recurrence": args.recurrence,
+                       "hip_graph": ("forward + loss + backward replayed as one captured hipGraph; optimizer eager; "
+                                     "roofline timings from an eager pass after the timed region") if graphed else None,
                        "gemm_tflops_per_step": round(3 * flops_per_frame(K) * B * T / 1e12, 4)},
             "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload != "cfg3")
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload == "cfg5")
             else cpu_baseline(model, opt),
         }
         print(json.dumps(line), flush=True)

@@ -591,7 +591,7 @@ def _dp_step(lo, hi):
     loss.backward()
     opt.bucket.all_reduce()              # joins the side stream; SUM over ranks when a group exists
     torch.cuda.synchronize()
-    return opt.bucket.flat.cpu(), float(loss)
+    return opt.bucket.flat.cpu().numpy(), float(loss.detach())       # numpy: picklable by value through the queue
 
 
 def _dp_worker(rank, world, port, q):
@@ -629,8 +629,82 @@ def test_data_parallel_hip_step_matches_single_process():
     for r in res:
         assert r[2] is not None, r[1]
     ref, loss = _dp_step(0, 4)
-    scale = float(ref.abs().max())
+    scale = float(np.abs(ref).max())
     assert scale > 1e-6
     for _, flat, _ in res:
-        assert float((flat - ref).abs().max()) <= 2e-5 * scale, float((flat - ref).abs().max()) / scale
+        assert float(np.abs(flat - ref).max()) <= 2e-5 * scale, float(np.abs(flat - ref).max()) / scale
     assert abs(res[0][2] + res[1][2] - loss) <= 1e-5 * abs(loss)
+
+
+@pytest.mark.parametrize("units", [16, 128])
+def test_graphed_step_replays_the_eager_step(units):
+    """tssep_amd.train.graph.GraphedStep: forward + loss + backward replayed as one hipGraph gives the eager
+    step's loss, masks and flat gradient -- for the streaming (units 16) and the W-stationary (units 128:
+    device-side launch epoch) recurrences, on the side stream too -- and the speaker permutation is NOT
+    frozen into the graph: every replay consumes np.random exactly like an eager forward (net.py:824-826)."""
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    from tssep_amd.train.graph import GraphedStep
+    from tssep_amd.train.optimizer import Adam
+    from tssep_amd import hip_ops as H
+    torch.manual_seed(2)
+    m = model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"), size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=513, units=units, projs=24, combination="mul",
+                                            aux_net_output_size=513, ts_vad=4, output_resolution="tf",
+                                            random_speaker_order=True),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+    m.train()
+    opt = Adam(gradient_clipping=10.0)
+    opt.set_parameters(m.parameters())
+    rng = np.random.RandomState(9)
+    B, K, N = 3, 4, 5000
+    tgt = 0.1 * rng.randn(B, K, N).astype(np.float32)
+    ex = dict(observation=T_(tgt.sum(1, keepdims=True) + 0.01 * rng.rand(B, 1, N).astype(np.float32)).cuda(),
+              auxInput=T_(rng.rand(B, K, 513).astype(np.float32)).cuda(),
+              speaker_reverberation_early_ch0=T_(tgt).cuda(), reference_channel=0, dataset=["g"] * B)
+
+    def eager(seed):
+        np.random.seed(seed)
+        opt.zero_grad()
+        out = m(dict(ex))
+        l = m.review(dict(ex), out)["loss"]
+        l.backward()
+        opt.bucket.sync()
+        torch.cuda.synchronize()
+        return float(l.detach()), out.mask.detach().clone(), opt.bucket.flat.clone()
+
+    ref5, ref6 = eager(5), eager(6)
+    assert float((ref5[1] - ref6[1]).abs().max()) > 1e-4           # the permutation matters (ts_vad layer)
+    g = GraphedStep(m, opt)
+    g(dict(ex))                                                    # warm-up, capture, first replay
+    for seed, ref in ((5, ref5), (6, ref6), (5, ref5)):
+        np.random.seed(seed)
+        out, summary = g(dict(ex))
+        state = np.random.get_state()[1][:4].copy()
+        torch.cuda.synchronize()
+        np.random.seed(seed)
+        net.MaskEstimator_v2.draw_permutations(B, K)
+        assert (np.random.get_state()[1][:4] == state).all()       # one draw of B permutations per replay
+        assert float(summary["loss"]) == pytest.approx(ref[0], rel=1e-6)
+        close(out.mask, ref[1].detach().cpu().numpy(), rtol=1e-5, atol=1e-6, name="mask")
+        scale = float(ref[2].abs().max())
+        assert float((opt.bucket.flat - ref[2]).abs().max()) <= 1e-5 * scale
+    H.check_cluster_errors("cuda")
+    assert g.replays == 4 and len(g._graphs) == 1
+    # a new input shape is a new graph; new DATA in the same shape is copied into the static inputs
+    ex2 = {k: (v[:2] if isinstance(v, torch.Tensor) else v) for k, v in ex.items()}
+    ex2["dataset"] = ["g"] * 2
+    g(ex2)
+    assert len(g._graphs) == 2
+    ex3 = dict(ex, observation=ex["observation"] * 0.5)
+    np.random.seed(5)
+    out3, s3 = g(ex3)
+    l3 = float(s3["loss"])
+    np.random.seed(5)
+    opt.zero_grad()
+    l3e = float(m.review(dict(ex3), m(dict(ex3)))["loss"])
+    assert l3 == pytest.approx(l3e, rel=1e-6) and abs(l3 - ref5[0]) > 1e-4

@@ -11,11 +11,11 @@
 // H=300 LSTM the split adds < 4e-6 to the fp32 rounding noise of h -- far inside the 1e-3 bar.
 // Per step: ~1.7 us of MFMA for 32 sequences + one exchange of h between the G workgroups.
 //
-// Exchange (MI355X_MICROARCH.md "valid forms", recipe R2 -- the data is the flag): every fp32
-// value travels as an 8-byte granule {tag = step+1, value}; a lane writes its 4 values as TWO
-// 16-byte sc1 (write-through) stores = 2 granules each, and the consumer reads 2 granules per
-// 16-byte sc1 load.  Only the 8-byte halves need to be untorn (each carries its own tag), which is
-// what aligned dwordx4 accesses give.  One memory hop per step: no drain, no barrier, no flag
+// Exchange (MI355X_MICROARCH.md "valid forms", recipe R2 -- the data is the flag): values travel in
+// 8-byte granules {16-bit tag = epoch | step+1, two values rounded to 24 bits} ("compact granules"
+// below); a lane writes its 4 values as ONE 16-byte (write-through) store = 2 granules, and the
+// consumer reads 2 granules per 16-byte sc1 load.  Only the 8-byte halves need to be untorn (each
+// carries its own tag), which is what aligned dwordx4 accesses give.  One memory hop per step: no drain, no barrier, no flag
 // (a flag-based protocol was measured first: 3 hops, 8 us/step, collapsing under load).
 // Two slots alternate by step parity (a slot is rewritten only after every workgroup consumed it:
 // publishing step t+2 transitively requires everyone to have gathered step t).  All granules are
@@ -70,6 +70,30 @@ __device__ __forceinline__ float fast_tanh(float x) {
 }
 #define SC1 16
 #define SC0 1
+
+// ---- compact exchange granules ---------------------------------------------------------------------
+// One naturally aligned 8-byte granule carries TWO values and a 16-bit tag:
+//     word0 = tag16 | a24[15:0] << 16,   word1 = a24[23:16] | b24 << 8,
+// a24 / b24 = the fp32 value rounded to its upper 24 bits (sign, exponent, 15 mantissa bits: 2^-16
+// relative -- what the split-bf16 MFMA operand keeps of it anyway: hi 8 + lo 8 significant bits).
+// tag16 = {launch epoch 1..31} << 11 | step + 1 (T <= 2046).  Against the {32-bit tag, fp32 value}
+// granule of round 1 this halves every byte of the exchange: the forward gather moves 41 instead of
+// 82 KB per workgroup and step (both sequence halves now fit into ONE round trip of ten 16-byte
+// loads), and the backward's exchange working set per XCD drops from 4.9 MB -- more than the 4-MB L2:
+// every publish was written back to HBM and every gather missed (PMC round 1: 14 GB written per
+// launch for 4.7 GB of d(gates)) -- to 2.5 MB.
+__device__ __forceinline__ unsigned tag16_base(const int* err) {
+  const unsigned e = (unsigned)__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(((e % 31u) + 1u) << 11));
+}
+__device__ __forceinline__ u32x2 pack_granule(unsigned tag16, float a, float b) {
+  const unsigned ua = __float_as_uint(a) + 0x80u, ub = __float_as_uint(b) + 0x80u;   // round to 24 bits
+  return u32x2{tag16 | ((ua & 0x00ffff00u) << 8), (ua >> 24) | (ub & 0xffffff00u)};
+}
+__device__ __forceinline__ float granule_a(unsigned w0, unsigned w1) {
+  return __uint_as_float(((w0 >> 8) & 0x00ffff00u) | (w1 << 24));
+}
+__device__ __forceinline__ float granule_b(unsigned w1) { return __uint_as_float(w1 & 0xffffff00u); }
 
 // ---- cluster membership and work distribution -------------------------------------------------
 // header words (zeroed before every launch): [0] arrivals (global ticket in the cross-XCD mode),
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N,
     int64_t T, int H, int G, int nclusters, int layout) {
-  const unsigned tagbase = tssep_load_tagbase(err);
+  const unsigned tagbase = tag16_base(err);
   __shared__ __attribute__((aligned(16))) char hs_hi[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) char hs_lo[SEQS * HPITCH];
   __shared__ __attribute__((aligned(16))) float pub[SEQS * PUBPITCH];      // h_t  [seq][unit]
@@ -300,9 +324,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       }
     }
     float c[4] = {0.f, 0.f, 0.f, 0.f};
-    float* pl = xpayload + work * 2 * G * SEQS * UPW * 2;      // 8-byte granules
+    float* pl = xpayload + work * 2 * G * SEQS * UPW;          // 8-byte granules of 2 values: 4 B per value
     const __amdgpu_buffer_rsrc_t prs =
-        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * UPW * 8, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * UPW * 4, 0x00020000);
 
     // ---- io waves: row-contiguous HBM access, lane <-> (row s2 (+16), unit 16 q + (uq ^ s2))
     const int iow = (tid & 255) >> 6;                    // io wave index 0..3 (rows 4 iow .. + 3)
@@ -387,47 +411,49 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       if (step > 0) {
-        // ---- exchange waves: gather h_{t-1} of every source workgroup, 16 sequences at a time
-        // (2 granules per 16-byte load, 10 loads in flight), into the bf16 hi+lo operand image
+        // ---- exchange waves: gather h_{t-1} of every source workgroup for BOTH sequence halves in one
+        // round trip: ten 16-byte loads in flight, each two granules = the 4 units 4 uq .. + 3 of one
+        // (source workgroup, sequence); then into the bf16 hi+lo operand image
         if (!io_wave) {
           const int slot = (int)((step - 1) & 1);
           const unsigned want = tagbase | (unsigned)step;
-#pragma unroll 1
-          for (int hf = 0; hf < 2; ++hf) {
-            const int s = s2 + 16 * hf;
-            u32x4 v[10];
+          u32x4 v[10];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
             for (int gs = 0; gs < 5; ++gs)
+              v[5 * hf + gs] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
+                                            prs, (((slot * G + gs) * SEQS + s2 + 16 * hf) * UPW + 4 * uq) * 4, 0, AUXL)
+                                      : u32x4{want, 0u, want, 0u};
+          int spins = 0;
+          bool fail = false;
+          for (;;) {
+            bool ok = true;
 #pragma unroll
-              for (int p = 0; p < 2; ++p)
-                v[2 * gs + p] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                             prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL)
-                                       : u32x4{want, 0u, want, 0u};
-            int spins = 0;
-            bool fail = false;
-            for (;;) {
-              bool ok = true;
+            for (int i = 0; i < 10; ++i) ok = ok && (v[i][0] & 0xffffu) == want && (v[i][2] & 0xffffu) == want;
+            if (ok) break;
+            if (++spins > SPIN_LIMIT) { fail = true; break; }
+            __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-              for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
-              if (ok) break;
-              if (++spins > SPIN_LIMIT) { fail = true; break; }
-              __builtin_amdgcn_s_sleep(1);
+            for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
               for (int gs = 0; gs < 5; ++gs)
+                if (gs < G && !((v[5 * hf + gs][0] & 0xffffu) == want && (v[5 * hf + gs][2] & 0xffffu) == want))
+                  v[5 * hf + gs] = __builtin_amdgcn_raw_buffer_load_b128(
+                      prs, (((slot * G + gs) * SEQS + s2 + 16 * hf) * UPW + 4 * uq) * 4, 0, AUXL);
+          }
+          if (fail) s_fail = 1;
 #pragma unroll
-                for (int p = 0; p < 2; ++p)
-                  if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
-                    v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
-                        prs, (((slot * G + gs) * SEQS + s) * UPW + 4 * uq + 2 * p) * 8, 0, AUXL);
-            }
-            if (fail) s_fail = 1;
+          for (int hf = 0; hf < 2; ++hf) {
+            const int s = s2 + 16 * hf;
 #pragma unroll
             for (int gs = 0; gs < 5; ++gs) {
               const int k = 64 * gs + 4 * uq;                      // column of h = unit index
               if (gs < G && k < KP) {
+                const u32x4 w = v[5 * hf + gs];
                 unsigned h0, l0, h1, l1;
-                split2(__uint_as_float(v[2 * gs][1]), __uint_as_float(v[2 * gs][3]), h0, l0);
-                split2(__uint_as_float(v[2 * gs + 1][1]), __uint_as_float(v[2 * gs + 1][3]), h1, l1);
+                split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
+                split2(granule_a(w[2], w[3]), granule_b(w[3]), h1, l1);
                 *reinterpret_cast<u32x2*>(hs_hi + s * HPITCH + 2 * k) = u32x2{h0, h1};
                 *reinterpret_cast<u32x2*>(hs_lo + s * HPITCH + 2 * k) = u32x2{l0, l1};
               }
@@ -473,19 +499,17 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       }
       __syncthreads();
       if (!io_wave) {
-        // ---- publish h_t: 2 granules per 16-byte store, 4 runs of 512 contiguous bytes per wave
-        // instruction (write-through; no drain, no flag -- the tag is the flag)
+        // ---- publish h_t: 2 granules = 4 units per 16-byte store, 256-byte runs per sequence row
+        // (write-through; no drain, no flag -- the tag is the flag)
         const unsigned tag = tagbase | (unsigned)(step + 1);
         const int slot = (int)(step & 1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int s = s2 + 16 * hf;
           const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
-          const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 8;
-          __builtin_amdgcn_raw_buffer_store_b128(
-              u32x4{tag, __float_as_uint(pv[0]), tag, __float_as_uint(pv[1])}, prs, go, 0, AUXS);
-          __builtin_amdgcn_raw_buffer_store_b128(
-              u32x4{tag, __float_as_uint(pv[2]), tag, __float_as_uint(pv[3])}, prs, go + 16, 0, AUXS);
+          const int go = (((slot * G + g) * SEQS + s) * UPW + 4 * uq) * 4;
+          const u32x2 ga = pack_granule(tag, pv[0], pv[1]), gb = pack_granule(tag, pv[2], pv[3]);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs, go, 0, AUXS);
         }
       } else {
         // ---- io waves: start the copy of step+2's pre-activations (into the tile flushed a step
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
     int64_t ldo, int64_t dstride, const u32x4* __restrict__ wb, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G,
     int nclusters, int layout) {
-  const unsigned tagbase = tssep_load_tagbase(err);
+  const unsigned tagbase = tag16_base(err);
   __shared__ __attribute__((aligned(16))) char dg_hi[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) char dg_lo[SEQS * DPITCH];
   __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16];          // tiles 8/9 partials
@@ -570,9 +594,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
     }
     float dcc[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 cnext = {0.f, 0.f, 0.f, 0.f};
-    float* pl = xpayload + work * 2 * G * SEQS * Hp * 2;        // 8-byte granules
+    float* pl = xpayload + work * 2 * G * SEQS * Hp;            // 8-byte granules of 2 values: 4 B per value
     const __amdgpu_buffer_rsrc_t prs =
-        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 8, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 4, 0x00020000);
     __syncthreads();
 
     for (int64_t step = 0; step < T; ++step) {
@@ -608,42 +632,42 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       if (step > 0) {
         const int slot = (int)((step - 1) & 1);
         const unsigned want = tagbase | (unsigned)step;
-        u32x4 v[10];
+        u32x4 v[5];
         // this workgroup's own partial never leaves the CU: it is still in psum (rewritten only
-        // after this step's barrier) -- 1/G less exchange traffic, same summation order
+        // after this step's barrier) -- 1/G less exchange traffic, same summation order.  One 16-byte
+        // load = 2 granules = this thread's 4 units from one source workgroup.
         const f32x4 own = *reinterpret_cast<const f32x4*>(psum + s * PPITCH + unit0);
 #pragma unroll
         for (int gs = 0; gs < 5; ++gs)
-#pragma unroll
-          for (int p = 0; p < 2; ++p)
-            v[2 * gs + p] = gs == g ? u32x4{want, __float_as_uint(own[2 * p]), want, __float_as_uint(own[2 * p + 1])}
-                            : gs < G ? __builtin_amdgcn_raw_buffer_load_b128(
-                                           prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL)
-                                     : u32x4{want, 0u, want, 0u};
+          v[gs] = (gs < G && gs != g) ? __builtin_amdgcn_raw_buffer_load_b128(
+                                            prs, (((slot * G + gs) * SEQS + s) * Hp + unit0) * 4, 0, AUXL)
+                                      : u32x4{want, 0u, want, 0u};
         int spins = 0;
         bool fail = false;
         for (;;) {
           bool ok = true;
 #pragma unroll
-          for (int i = 0; i < 10; ++i) ok = ok && v[i][0] == want && v[i][2] == want;
+          for (int i = 0; i < 5; ++i) ok = ok && (v[i][0] & 0xffffu) == want && (v[i][2] & 0xffffu) == want;
           if (ok) break;
           if (++spins > SPIN_LIMIT) { fail = true; break; }
           __builtin_amdgcn_s_sleep(1);
-  #pragma unroll
-          for (int gs = 0; gs < 5; ++gs)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-              if (gs < G && !(v[2 * gs + p][0] == want && v[2 * gs + p][2] == want))
-                v[2 * gs + p] = __builtin_amdgcn_raw_buffer_load_b128(
-                    prs, (((slot * G + gs) * SEQS + s) * Hp + unit0 + 2 * p) * 8, 0, AUXL);
+          for (int gs = 0; gs < 5; ++gs)
+            if (gs < G && gs != g && !((v[gs][0] & 0xffffu) == want && (v[gs][2] & 0xffffu) == want))
+              v[gs] = __builtin_amdgcn_raw_buffer_load_b128(
+                  prs, (((slot * G + gs) * SEQS + s) * Hp + unit0) * 4, 0, AUXL);
         }
         if (fail) s_fail = 1;
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs) {
-          dh[0] += __uint_as_float(v[2 * gs][1]);
-          dh[1] += __uint_as_float(v[2 * gs][3]);
-          dh[2] += __uint_as_float(v[2 * gs + 1][1]);
-          dh[3] += __uint_as_float(v[2 * gs + 1][3]);
+        for (int gs = 0; gs < 5; ++gs) {             // fixed order gs = 0..G-1 (own partial in its place)
+          if (gs == g) {
+            dh[0] += own[0]; dh[1] += own[1]; dh[2] += own[2]; dh[3] += own[3];
+          } else if (gs < G) {
+            dh[0] += granule_a(v[gs][0], v[gs][1]);
+            dh[1] += granule_b(v[gs][1]);
+            dh[2] += granule_a(v[gs][2], v[gs][3]);
+            dh[3] += granule_b(v[gs][3]);
+          }
         }
       }
       // ---- (3) cell backward; d(gates) -> global (in place) and LDS (bf16 hi+lo, MFMA B operand)
@@ -731,22 +755,23 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         // ---- (5) publish: 2 granules per lane and store, 1 KB contiguous per wave instruction
         const unsigned tag = tagbase | (unsigned)(step + 1);
         const int slot = (int)(step & 1);
-        // pair index pr = tid + 512 i walks the [seq][Hp/2] array linearly: a wave instruction
-        // writes 1 KB contiguous (4 x 256-byte runs per instruction measured 3x slower under load);
-        // (seq, pair) advance incrementally -- no divisions
+        // quad index qd = tid + 512 i walks the [seq][Hp/4] array linearly: a wave instruction writes
+        // 1 KB contiguous (4 x 256-byte runs per instruction measured 3x slower under load); one
+        // 16-byte store = 2 granules = 4 units; (seq, quad) advance incrementally -- no divisions
         {
-          const int hp2 = Hp >> 1;
-          int sq = tid / hp2, up = tid - sq * hp2;
-          const int dsq = 512 / hp2, dup = 512 - dsq * hp2;
-          for (int pr = tid; pr < SEQS * hp2; pr += 512) {
-            const float2 v = *reinterpret_cast<const float2*>(psum + sq * PPITCH + 2 * up);
-            if ((up >> 5) != g)                              // (own 64 units stay in psum)
-              __builtin_amdgcn_raw_buffer_store_b128(
-                u32x4{tag, __float_as_uint(v.x), tag, __float_as_uint(v.y)}, prs,
-                (((slot * G + g) * SEQS + sq) * Hp + 2 * up) * 8, 0, AUXS);
+          const int hp4 = Hp >> 2;
+          int sq = tid / hp4, uq4 = tid - sq * hp4;
+          const int dsq = 512 / hp4, duq = 512 - dsq * hp4;
+          for (int qd = tid; qd < SEQS * hp4; qd += 512) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(psum + sq * PPITCH + 4 * uq4);
+            if ((uq4 >> 4) != g) {                           // (own 64 units stay in psum)
+              const u32x2 ga = pack_granule(tag, v[0], v[1]), gb = pack_granule(tag, v[2], v[3]);
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
+                                                     (((slot * G + g) * SEQS + sq) * Hp + 4 * uq4) * 4, 0, AUXS);
+            }
             sq += dsq;
-            up += dup;
-            if (up >= hp2) { up -= hp2; ++sq; }
+            uq4 += duq;
+            if (uq4 >= hp4) { uq4 -= hp4; ++sq; }
           }
         }
       }
@@ -781,7 +806,7 @@ extern "C" int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, 
 // bytes: header 64 | flags (items*2*G*4, rounded to 64) | payload
 static void xbuf_layout(int64_t N, int G, int pw, int64_t* items, int64_t* payload_bytes) {
   *items = 2 * ((N + SEQS - 1) / SEQS);
-  *payload_bytes = *items * 2 * G * SEQS * pw * 8;
+  *payload_bytes = *items * 2 * G * SEQS * pw * 4;      // compact granules: 4 bytes per value
 }
 
 extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) {
@@ -791,7 +816,7 @@ extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) 
   return HDR_BYTES + pb;
 }
 
-// (granule tags carry a per-launch epoch kept in device memory: common.h, tssep_load_tagbase)
+// (granule tags carry a per-launch epoch kept in device memory: common.h; tag16_base above)
 
 // grid: cross-XCD mode -> exactly the clusters wanted; XCD-local mode -> whole clusters per XCD
 // (workgroup b is observed on XCD b % 8; a cluster needs G workgroups of ONE XCD) plus one spare
@@ -822,7 +847,7 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, UPW, &items, &pb);
-  if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
+  if (items >= 0xffff || T > 2046) return TSSEP_E_SHAPE;     // the step shares 16 tag bits with the epoch
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
@@ -857,7 +882,7 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, G * UPW, &items, &pb);
-  if (items >= 0xffff || T >= 0xffff) return TSSEP_E_SHAPE;
+  if (items >= 0xffff || T > 2046) return TSSEP_E_SHAPE;     // the step shares 16 tag bits with the epoch
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing

@@ -31,18 +31,19 @@ class _RNNP(torch.autograd.Function):
         xv, ld_x = H.rows_view(x)
         R = N * T
         assert xv.shape[0] == R and xv.shape[1] >= I, (xv.shape, R, I)
-        pk = H.lstm_pack([w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r], Hh, I)
+        lstm_params = [w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r]
+        pk = dict(H.derived("lstm_pack", lstm_params, lambda: H.lstm_pack(lstm_params, Hh, I)))
         gates = torch.empty(R, 8 * Hh, device=dev, dtype=torch.float32)
         H.gemm(xv, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, R, 8 * Hh, I, bias=pk["bias_p"])
         Hp = _pad4(Hh)
         cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
         hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
-        kf, kb = H.recurrence_kernel(N, Hh, False), H.recurrence_kernel(N, Hh, True)
+        kf, kb = H.recurrence_kernel(N, Hh, False, T), H.recurrence_kernel(N, Hh, True, T)
         cf = cb = wf3 = wb3 = None
         if "cluster" in (kf, kb):
-            cf, cb = H.lstm_pack_cluster(w_hh, w_hh_r, Hh)
+            cf, cb = H.derived("pack_cluster", [w_hh, w_hh_r], lambda: H.lstm_pack_cluster(w_hh, w_hh_r, Hh))
         if "onchip" in (kf, kb):
-            wf3, wb3 = H.lstm_pack_onchip(w_hh, w_hh_r, Hh)
+            wf3, wb3 = H.derived("pack_onchip", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip(w_hh, w_hh_r, Hh))
         if kf == "cluster":
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
         elif kf == "onchip":
@@ -52,7 +53,7 @@ class _RNNP(torch.autograd.Function):
         pk["whh_cb"] = cb if kb == "cluster" else None
         pk["whh_ob"] = wb3 if kb == "onchip" else None
         # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
-        wp = _proj_layout(w_proj, Hh, Hp)
+        wp = H.derived("proj_layout", [w_proj], lambda: _proj_layout(w_proj, Hh, Hp))
         if combine:
             K = combine
             B = N // K
@@ -123,7 +124,7 @@ class _RNNP(torch.autograd.Function):
             d_w_proj, d_b_proj = proj_wgrads()
         # ---- critical path: dhout, BPTT (gates <- d pre-activations)
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
-        wpT, ld_t = H.transposed(wp, hdim, 2 * Hp)
+        wpT, ld_t = H.derived("proj_T", [params[8]], lambda: H.transposed(wp, hdim, 2 * Hp))
         H.gemm(dz, ld_dz, wpT, ld_t, dhout, 2 * Hp, R, 2 * Hp, hdim)
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
@@ -174,7 +175,8 @@ class _RNNP(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dxb, ld_dx = H.padded(R, I, dev, zero=True)
-            wihT, ld_t = H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I)
+            wihT, ld_t = H.derived("wih_T", [params[0], params[4]],
+                                   lambda: H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I))
             H.gemm(gates, G, wihT, ld_t, dxb, ld_dx, R, I, G)
             dx = dxb[:, :I]
             if tuple(ctx.x_shape) != tuple(dx.shape):
@@ -302,7 +304,7 @@ class _Head(torch.autograd.Function):
             H.reduce_splits(part, S, Nout * P, dw)
             db = H.colsum(dv, ld_d, R, Nout)
         dxb, ld_dx = H.padded(R, P, dev, zero=True)
-        wvT, ld_t = H.transposed(wv, Nout, P)
+        wvT, ld_t = H.derived("head_T", [ctx.params[0]], lambda: H.transposed(wv, Nout, P))
         H.gemm(dv, ld_d, wvT, ld_t, dxb, ld_dx, R, P, Nout)
         dx = dxb[:, :P]
         if tuple(ctx.x_shape) != tuple(dx.shape):

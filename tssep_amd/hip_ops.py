@@ -320,6 +320,40 @@ def colsum(A, lda, M, N, out=None, accumulate=False):
     return out
 
 
+# ---- derived weight layouts, cached across the micro-steps of a virtual minibatch ------------------
+# Packed / transposed weight copies (lstm_pack, the W-stationary packs, dgrad transposes) are functions of
+# the parameters only.  With virtual_minibatch_size = v (the reference's default is 12,
+# tssep/train/experiment.py:135) the parameters change once per v forward/backward passes, so the copies
+# are rebuilt once per optimizer step instead of once per pass.  Validity: a parameter changes either
+# through torch (its ``_version`` counter moves: load_state_dict, copy_) or through the fused Adam kernel
+# (raw pointer: ``weights_changed()`` is called by the optimizer).  Never used while a stream is being
+# captured: a graph must contain the pack kernels, the weights differ at every replay.
+WEIGHTS_VERSION = 0
+
+
+def weights_changed():
+    global WEIGHTS_VERSION
+    WEIGHTS_VERSION += 1
+
+
+def derived(tag, params, build):
+    """build() -> any structure of tensors derived from `params`; memoised until a parameter changes.
+    The memo lives ON the first parameter object (it dies with the module: a recycled device address of
+    another model can never hit it) and is stamped with every parameter's address and version, the global
+    update counter and the stream it was built on."""
+    if torch.cuda.is_current_stream_capturing():
+        return build()
+    memo = params[0].__dict__.setdefault("_tssep_derived", {})
+    stamp = (WEIGHTS_VERSION, torch.cuda.current_stream().cuda_stream,
+             tuple((id(p), p.data_ptr(), p._version) for p in params))
+    hit = memo.get(tag)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    val = build()
+    memo[tag] = (stamp, val)
+    return val
+
+
 # ------------------------------------------------------------------------------ BLSTM
 def lstm_sizes(H, I, ld_i):
     sz = LstmSizes()
@@ -383,7 +417,10 @@ def n_cus(device):
     return torch.cuda.get_device_properties(device).multi_processor_count
 
 
-def recurrence_kernel(N, H, backward):
+ONCHIP_MAX_T = 2046       # the on-chip kernels' 16-bit granule tag holds the step in 11 bits
+
+
+def recurrence_kernel(N, H, backward, T=0):
     """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch measured on
     MI355X at H=300, T=253, profiles/r1_recurrence_microbench.jsonl):
       forward : on-chip bf16x3 1.4 (8 sequences) .. 1.8 (192) .. 2.25 (768 = one resident round of
@@ -393,15 +430,15 @@ def recurrence_kernel(N, H, backward):
                 768, 5.4 at 1024, 8.2 at 2048; streaming 6.0 .. 12.5
     The streaming kernels remain the path for H the W-stationary kernels do not support."""
     L = _lib.lib()
+    onchip_ok = bool(L.tssep_lstm_onchip_supported(H)) and T <= ONCHIP_MAX_T
     if RECURRENCE in ("stream", "cluster", "onchip"):
-        ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)),
-              "onchip": bool(L.tssep_lstm_onchip_supported(H))}[RECURRENCE]
+        ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)), "onchip": onchip_ok}[RECURRENCE]
         return RECURRENCE if ok else "stream"
     if H < 128:
         return "stream"
     if backward and L.tssep_lstm_cluster_supported(H) and N <= 32:
         return "cluster"
-    if L.tssep_lstm_onchip_supported(H):
+    if onchip_ok:
         return "onchip"
     return "stream"
 
@@ -506,10 +543,13 @@ def side_stream(device, rows=0):
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for all gradient work queued on the side streams."""
-    for (dev, _), st in _SIDE.items():
-        if device is None or dev == str(device):
-            torch.cuda.current_stream().wait_stream(st)
+    """Make the current stream wait for the gradient work queued on ITS side stream (the pairing is per
+    compute stream, so a stream that is being captured into a hipGraph only ever joins the stream it
+    forked itself)."""
+    cur = torch.cuda.current_stream(device)
+    st = _SIDE.get((str(cur.device), cur.cuda_stream))
+    if st is not None:
+        cur.wait_stream(st)
 
 
 # ------------------------------------------------------------------------ elementwise

@@ -1,0 +1,129 @@
+"""hipGraph replay of the training step's device work for the launch-bound regime.
+
+At 8 utterances per GPU (the per-GPU shard of BASELINE configs[3]) a step is ~170 kernel launches, most of
+them far shorter than the time the host needs to issue one; the T-sequential recurrences aside, the GPU
+waits for Python.  ``GraphedStep`` captures
+
+    zero the flat gradient -> Model.forward -> Model.review (loss) -> backward -> join the side stream
+
+ONCE per input signature into a hipGraph (torch.cuda.CUDAGraph: stream capture of every launch the C ABI
+makes on torch's current stream, including the forked weight-gradient stream) and replays it per step.
+The optimizer step (gradient all-reduce over ranks, global-norm clip + Adam: two launches) stays outside
+the graph: its bias correction depends on the host-side step count and the all-reduce belongs to RCCL.
+
+What would otherwise be frozen into the graph is routed through device memory:
+  * the speaker permutations of ``random_speaker_order`` (net.py:821-831) are still drawn from the global
+    ``np.random`` on the host -- one permutation per batch entry and step, the reference's consumption
+    order -- and copied into a static device buffer before each replay
+    (``MaskEstimator_v2.permutation_source``);
+  * the W-stationary recurrences take their launch epoch from device memory (csrc/common.h);
+  * inputs live in static device tensors (a batch that already IS the static tensor is not copied).
+"""
+import numpy as np
+import torch
+
+from .. import hip_ops as H
+
+_INPUT_KEYS = ("observation", "auxInput", "Input", "Vad", "vad")
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer, warmup=2, adopt_inputs=False):
+        """adopt_inputs: the tensors of the first batch of a signature BECOME the static inputs (no
+        clone, no per-step copy while the caller keeps passing the same tensors -- benchmarks)."""
+        self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
+        self.adopt_inputs = bool(adopt_inputs)
+        self._graphs = {}
+        self.replays = 0
+
+    # ------------------------------------------------------------------------------ helpers
+    def _tensor_keys(self, ex):
+        keys = [k for k in (*_INPUT_KEYS, *self.model.loss.targets(lower=True), *self.model.loss.targets())
+                if isinstance(ex.get(k), torch.Tensor)]
+        return tuple(dict.fromkeys(keys))
+
+    def _signature(self, ex):
+        return tuple((k, tuple(ex[k].shape), ex[k].dtype) for k in self._tensor_keys(ex)) + \
+            (("training", self.model.training),)
+
+    def _eager(self, ex):
+        self.optimizer.zero_grad()
+        out = self.model(ex)
+        summary = self.model.review(ex, out)
+        summary["loss"].backward()
+        self.optimizer.bucket.sync()
+        return out, summary
+
+    # ------------------------------------------------------------------------------ capture
+    def _capture(self, ex):
+        if H.KERNEL_TIMING:
+            raise RuntimeError("per-kernel event timing cannot be captured into a graph")
+        me = self.model.mask_estimator
+        dev = next(self.model.parameters()).device
+        st = {"keys": self._tensor_keys(ex)}
+        st["static"] = {k: (ex[k].detach() if self.adopt_inputs else ex[k].detach().clone()) for k in st["keys"]}
+        st["rest"] = {k: v for k, v in ex.items() if k not in st["static"]}
+        B = ex["auxInput"].shape[0] if isinstance(ex.get("auxInput"), torch.Tensor) and ex["auxInput"].dim() == 3 else 1
+        K = ex["auxInput"].shape[-2]
+        shuffled = bool(getattr(me, "random_speaker_order", False))
+        if shuffled:
+            st["perm_dev"] = torch.zeros(2, B, K, device=dev, dtype=torch.int32)
+            st["perm_pinned"] = [torch.zeros(2, B, K, dtype=torch.int32).pin_memory() for _ in range(4)]
+            st["perm_events"] = [None] * 4
+            st["perm_shape"] = (B, K)
+            # warm-up and capture read the static buffer; a valid permutation must be in it
+            st["perm_dev"].copy_(torch.as_tensor(me.draw_permutations(B, K)))
+
+            def source(b, k, d, _p=st["perm_dev"]):
+                assert (b, k) == tuple(_p.shape[1:]), ((b, k), _p.shape)
+                return _p[0], _p[1]
+            st["source"] = source
+
+        def run():
+            return self._eager({**st["rest"], **st["static"]})
+
+        prev = me.permutation_source
+        if shuffled:
+            me.permutation_source = st["source"]
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):       # same stream as the capture: side stream, caches, tables exist
+                    run()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            H.check_cluster_errors(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                st["out"], st["summary"] = run()
+            st["graph"] = g
+        finally:
+            me.permutation_source = prev
+        return st
+
+    # ------------------------------------------------------------------------------- replay
+    def __call__(self, ex):
+        """-> (ForwardOutput, ReviewSummary) of this step; both are STATIC objects that the next call
+        overwrites.  Gradients are in the optimizer's flat bucket afterwards (call ``optimizer.step()``)."""
+        sig = self._signature(ex)
+        st = self._graphs.get(sig)
+        if st is None:
+            st = self._graphs[sig] = self._capture(ex)
+        for k in st["keys"]:
+            if ex[k].data_ptr() != st["static"][k].data_ptr():
+                st["static"][k].copy_(ex[k], non_blocking=True)
+        if "perm_dev" in st:
+            slot = self.replays % len(st["perm_pinned"])
+            ev = st["perm_events"][slot]
+            if ev is not None:
+                ev.synchronize()                                   # the copy that last read this buffer
+            st["perm_pinned"][slot].copy_(torch.from_numpy(
+                self.model.mask_estimator.draw_permutations(*st["perm_shape"])))
+            st["perm_dev"].copy_(st["perm_pinned"][slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["perm_events"][slot] = ev
+        st["graph"].replay()
+        self.replays += 1
+        return st["out"], st["summary"]

@@ -141,6 +141,24 @@ class MaskEstimator_v2(Configurable, torch.nn.Module):
     def extra_repr(self) -> str:
         return f"combination={self.combination!r},"
 
+    # hook for hipGraph replay (tssep_amd.train.graph.GraphedStep): a callable (B, K, device) ->
+    # (perm, iperm) device int32 [B, K] that replaces the host draw + H2D copy below
+    permutation_source = None
+
+    @staticmethod
+    def draw_permutations(B, K):
+        """One np.random.permutation(K) per batch entry, in batch order, from the GLOBAL numpy RNG
+        (net.py:824-826) -> int32 [2, B, K]: the permutations and their inverses (net.py:827-831)."""
+        perm = np.stack([np.random.permutation(K) for _ in range(B)])
+        return np.stack([perm, np.argsort(perm, axis=-1)]).astype(np.int32)
+
+    def _speaker_permutations(self, B, K, dev):
+        if self.permutation_source is not None:
+            return self.permutation_source(B, K, dev)
+        # kernels want: output index of the speaker at shuffled position s == perm[b][s]
+        both = torch.as_tensor(self.draw_permutations(B, K)).to(dev)              # one H2D copy
+        return both[0], both[1]
+
     # ----------------------------------------------------------------------------------
     def logits(self, xs, aux):
         """-> (logit [B,K,T,F], embedding [B,K,1,E]).  Batched input only."""
@@ -156,12 +174,7 @@ class MaskEstimator_v2(Configurable, torch.nn.Module):
         dev = xs.device
         perm_d = iperm_d = None
         if self.random_speaker_order:
-            # one np.random.permutation per batch entry, in batch order (net.py:824-826)
-            perm = np.stack([np.random.permutation(K) for _ in range(B)])
-            iperm = np.argsort(perm, axis=-1)
-            # kernels want: output index of the speaker at shuffled position s == perm[b][s]
-            both = torch.as_tensor(np.stack([perm, iperm]), dtype=torch.int32).to(dev)   # one H2D copy
-            perm_d, iperm_d = both[0], both[1]
+            perm_d, iperm_d = self._speaker_permutations(B, K, dev)
             # shuffled aux[b, s] = aux[b, perm[b, s]]: one gather for the whole batch
             aux = torch.gather(aux, 1, perm_d.long()[..., None].expand(-1, -1, aux.shape[-1]))
         aux = aux.to(torch.float32).contiguous()

@@ -34,6 +34,8 @@ class Adam(Configurable):
             p.data = self.flat_param[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.params = params
+        from .. import hip_ops
+        hip_ops.weights_changed()
         self.bucket = GradBucket(params)
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
@@ -57,6 +59,8 @@ class Adam(Configurable):
             p(self.grad_norm), p(self._ws),
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "adam_step")
+        from .. import hip_ops
+        hip_ops.weights_changed()            # derived weight layouts (packs, transposes) are stale now
         return self.grad_norm
 
     def state_dict(self):
