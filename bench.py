@@ -168,7 +168,7 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
         opt.bucket.sync()
         torch.cuda.synchronize()
         _, o = one_step(keep=True)
-        merr = float((out.mask.cpu() - o["mask"]).abs().max())
+        merr = float((out.mask.detach().cpu() - o["mask"]).abs().max())
         lrel = abs(float(loss) - float(o["loss"].sum())) / max(abs(float(o["loss"].sum())), 1e-12)
         gerrs = {k: float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max()
                           / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
@@ -334,7 +334,7 @@ def main():
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax), int(out.mask.shape[-2]), float(np.median(per_step))
+        return float(tmax), int(out.logit.shape[-2]), float(np.median(per_step))
 
     def rooflines(dt, gemm_name):
         """Live HIP-event timings of this run -> (dominant MFMA kernel, mask head)."""

@@ -78,6 +78,23 @@ int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int size, int shif
                     int fading, const float* wsyn, const float* tw,
                     float* dX, int64_t T, void* stream);
 
+/* Mask head fused with the inverse STFT and with its adjoint: the chain
+ *   mask = sigmoid(logit)                      tssep/train/net.py:983
+ *   stft_estimate = Observation * mask         tssep/train/enhancer.py:98-100
+ *   time_estimate = fe.istft(stft_estimate)    tssep/train/model.py:661-664
+ * without writing mask or stft_estimate (results identical to tssep_maskhead_fwd followed by
+ * tssep_istft_fwd; the unfused entry points remain for callers that want the intermediates).
+ *   logit [B, K, T, F] fp32, obs [B, T, F] complex64 (reference channel), y [B*K, N]
+ *   tgt / abs_partial: as tssep_istft_fwd (rows = B*K).
+ * Backward: dy [B*K, N] -> dlogit [B, K, T, F] = Re(conj(obs) dEst) m (1 - m), dEst = adjoint(dy)
+ * (identical to tssep_istft_bwd followed by tssep_maskhead_bwd with dmask = NULL). */
+int tssep_mask_istft_fwd(const float* logit, const float* obs, int64_t B, int64_t K, int64_t T,
+                         int size, int shift, int fading, const float* wsyn, const float* tw,
+                         float* y, int64_t N, const float* tgt, float* abs_partial, void* stream);
+int tssep_mask_istft_bwd(const float* dy, const float* logit, const float* obs, int64_t B,
+                         int64_t K, int64_t N, int size, int shift, int fading,
+                         const float* wsyn, const float* tw, float* dlogit, int64_t T, void* stream);
+
 /* --------------------------------------------------------------- features ----
  * ConcaternatedSTFTFeatures(TorchMFCC, Log1pMaxNormAbsSTFT).stft_to_feature
  * (tssep/train/feature_extractor.py:352-360, feature_extractor_torchaudio.py:93-106,

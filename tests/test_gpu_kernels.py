@@ -230,6 +230,42 @@ def test_stft_istft(rows, N):
     close(xr, x, rtol=1e-4, atol=2e-5, name="round trip")
 
 
+@pytest.mark.parametrize("B,K,N", [(1, 3, 2000), (2, 4, 64000), (3, 8, 9300)])
+def test_mask_istft_fused_against_oracle_and_unfused_chain(B, K, N):
+    """tssep_mask_istft_fwd / _bwd: sigmoid (net.py:983) -> Masking (enhancer.py:98-100) -> istft
+    (model.py:661-664) in one kernel each way, against (a) the CPU oracle with autograd and (b) the unfused
+    HIP chain maskhead -> istft and istft adjoint -> maskhead backward (same arithmetic, so near bit-equal),
+    including the |estimate - target| partial sums of LogMAE (loss.py:244-247)."""
+    torch.manual_seed(8)
+    h = H()
+    T = ostft.stft(torch.zeros(1, N)).shape[-2]
+    wsyn = torch.as_tensor(ostft.synthesis_window("hann", 1024, 256), dtype=torch.float32).cuda()
+    logit = (torch.randn(B, K, T, 513) * 2).requires_grad_()
+    obs = torch.randn(B, T, 513, dtype=torch.complex64)
+    tgt = torch.randn(B, K, N) * 0.1
+    dy = torch.randn(B, K, N)
+    # (a) oracle
+    est_ref = obs[:, None] * torch.sigmoid(logit)
+    y_ref = ostft.istft(est_ref, num_samples=N)
+    (y_ref * dy).sum().backward()
+    y, part = h.mask_istft_fwd(logit.detach().cuda(), obs.cuda(), wsyn, N, tgt=tgt.cuda())
+    close(y, y_ref, rtol=1e-4, atol=2e-5, name="fused fwd vs oracle")
+    close(part.view(B, K, -1).sum(-1), (y_ref - tgt).abs().sum(-1), rtol=1e-4, name="abs partials")
+    dlogit = h.mask_istft_bwd(dy.cuda(), logit.detach().cuda(), obs.cuda(), wsyn)
+    close(dlogit, logit.grad, rtol=1e-4, atol=1e-6 * float(logit.grad.abs().max()) * 10, name="fused bwd vs oracle")
+    # (b) unfused HIP chain
+    mask, est = h.maskhead_fwd(logit.detach().cuda(), obs.cuda())
+    y_u, part_u = h.istft_fwd(est.reshape(B * K, T, 513), wsyn, N, tgt=tgt.cuda().reshape(B * K, N))
+    close(y, y_u.view(B, K, N), rtol=1e-6, atol=1e-7, name="fused fwd vs unfused")
+    close(part, part_u, rtol=1e-5, name="partials vs unfused")
+    dX = h.istft_bwd(dy.cuda().reshape(B * K, N), wsyn, T)
+    dl_u = h.maskhead_bwd(dX.view(B, K, T, 513), None, mask, obs.cuda())
+    close(dlogit, dl_u, rtol=1e-5, atol=1e-7 * float(dl_u.abs().max()) * 10, name="fused bwd vs unfused")
+    # without a target there are no partial sums
+    y2, none = h.mask_istft_fwd(logit.detach().cuda(), obs.cuda(), wsyn, N)
+    assert none is None and torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("B,T,mfcc", [(2, 9, True), (3, 30, True), (2, 9, False)])
 def test_features(B, T, mfcc):
     torch.manual_seed(6)

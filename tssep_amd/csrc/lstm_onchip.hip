@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   for (int round = 0;; ++round) {
     const int64_t work = next_item<XCD>(xhead, mem, round, (int)(2 * ngroups), nclusters, s_mem);
     if (work >= 2 * ngroups) {
-      if (work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed
+      if (XCD && work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed (the static map of the cross-XCD mode simply runs past the end)
       break;
     }
     const int dir = (int)(work & 1);
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
   for (int round = 0;; ++round) {
     const int64_t work = next_item<XCD>(xhead, mem, round, (int)(2 * ngroups), nclusters, s_mem);
     if (work >= 2 * ngroups) {
-      if (work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed
+      if (XCD && work > 2 * ngroups && tid == 0) atomicExch(err, 5);      // leader never claimed (the static map of the cross-XCD mode simply runs past the end)
       break;
     }
     const int dir = (int)(work & 1);

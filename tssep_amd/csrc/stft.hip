@@ -90,10 +90,18 @@ __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* buf, const f
 // frames -> rfft.  Used as the STFT (window = analysis window, scales 1) and as the adjoint of
 // the inverse STFT (window = synthesis window, interior bins x 2/1024, DC/Nyquist x 1/1024).
 // tw: [512] exp(-2 pi i k/512) followed by [513] exp(-2 pi i k/1024).
+//
+// MASKED = true fuses the mask head's backward into the adjoint (tssep/train/net.py:983 sigmoid +
+// tssep/train/enhancer.py:98-100 Masking, backward): a frame's d(estimate) bin never leaves the wave;
+// the epilogue reads the logit (4 B) and the observation bin (8 B, shared by the K speakers of an
+// utterance: L2) and writes d(logit) = Re(conj(Obs) dEst) m (1 - m), m = sigmoid(logit) -- the chain
+// adjoint -> mask head moves 8 K F + 8 F bytes per frame instead of 24 K F + 8 F.
+template <bool MASKED>
 __global__ __launch_bounds__(256) void rfft_frames_kernel(
     const float* __restrict__ x, int64_t rows, int64_t N, int64_t T, int shift, int pad_left,
     const float* __restrict__ window, const float2* __restrict__ tw, float2* __restrict__ X,
-    float s_in, float s_edge, int iters) {
+    float s_in, float s_edge, int iters, const float* __restrict__ logit,
+    const float2* __restrict__ obs, float* __restrict__ dlogit, int64_t Kspk) {
   __shared__ float2 twl[NH];
   __shared__ float2 line[4][LINE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -129,7 +137,20 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
     float2* buf = line[wave];
     fft512_wave(v, buf, twl, lane);
     if (valid) {
-      float2* Xo = X + fidx * (NH + 1);
+      float2* Xo = MASKED ? nullptr : X + fidx * (NH + 1);
+      // MASKED: row = (utterance b, speaker); the observation frame is the utterance's
+      const float* Lr = MASKED ? logit + fidx * (NH + 1) : nullptr;
+      const float2* Or = MASKED ? obs + ((row / Kspk) * T + t) * (NH + 1) : nullptr;
+      float* Dr = MASKED ? dlogit + fidx * (NH + 1) : nullptr;
+      auto emit = [&](int k, float2 o) {
+        if (MASKED) {
+          const float m = sigmoidf_acc(Lr[k]);
+          const float2 ob = Or[k];
+          Dr[k] = (ob.x * o.x + ob.y * o.y) * m * (1.0f - m);
+        } else {
+          Xo[k] = o;
+        }
+      };
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
@@ -144,11 +165,11 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
         } else {
           o.x *= s_in; o.y *= s_in;
         }
-        Xo[k] = o;
+        emit(k, o);
       }
       if (lane == 0) {
         const float2 z0 = buf[0];
-        Xo[NH] = make_float2((z0.x - z0.y) * s_edge, 0.f);
+        emit(NH, make_float2((z0.x - z0.y) * s_edge, 0.f));
       }
     }
     WAVE_SYNC();          // the line is rewritten by this wave's next frame
@@ -161,10 +182,18 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
 constexpr int HC = 9;
 constexpr int NFR = HC + 3;
 
+//
+// MASKED = true fuses the mask head in front (net.py:983 + enhancer.py:98-100): a frame's spectrum is
+// formed in the wave's LDS line as sigmoid(logit) * Obs (logit 4 B per bin; the 8-B observation bin is
+// shared by the K speakers of an utterance: L2) -- neither the mask nor the masked STFT is written;
+// the chain mask head -> inverse STFT moves (4 K F + 8 F) HC'/HC + 4 K 256 bytes per frame instead of
+// 16 K F + 8 F + 8 K F HC'/HC + 4 K 256  (HC'/HC = 12/9: the frames a chunk re-transforms).
+template <bool MASKED>
 __global__ __launch_bounds__(256) void istft_kernel(
     const float2* __restrict__ X, int64_t T, int shift_, int64_t N,
     const float* __restrict__ wsyn, const float2* __restrict__ tw, float* __restrict__ y,
-    const float* __restrict__ tgt, float* __restrict__ abs_partial, int nchunks) {
+    const float* __restrict__ tgt, float* __restrict__ abs_partial, int nchunks,
+    const float* __restrict__ logit, const float2* __restrict__ obs, int64_t Kspk) {
   __shared__ float2 twl[NH];
   __shared__ float2 line[4][LINE];
   __shared__ __attribute__((aligned(16))) float fr[NFR][1024];
@@ -182,13 +211,32 @@ __global__ __launch_bounds__(256) void istft_kernel(
     const int64_t t = t_lo + lf;
     const bool valid = t < T;
     float2 v[8];
-    if (valid) {
-      const float2* Xr = X + (row * T + t) * (NH + 1);
+    float2* buf = line[wave];
+    float2 xnyq = make_float2(0.f, 0.f);              // MASKED: X[512], needed by lane 0 only
+    if (MASKED && valid) {
+      const float* Lr = logit + (row * T + t) * (NH + 1);
+      const float2* Or = obs + ((row / Kspk) * T + t) * (NH + 1);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
-        float2 xk = Xr[k];
-        float2 xm = Xr[NH - k];
+        const float m = sigmoidf_acc(Lr[k]);
+        const float2 ob = Or[k];
+        buf[PADI(k)] = make_float2(ob.x * m, ob.y * m);
+      }
+      if (lane == 0) {
+        const float m = sigmoidf_acc(Lr[NH]);
+        const float2 ob = Or[NH];
+        xnyq = make_float2(ob.x * m, ob.y * m);
+      }
+      WAVE_SYNC();
+    }
+    if (valid) {
+      const float2* Xr = MASKED ? nullptr : X + (row * T + t) * (NH + 1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r;
+        float2 xk = MASKED ? buf[PADI(k)] : Xr[k];
+        float2 xm = MASKED ? (k == 0 ? xnyq : buf[PADI(NH - k)]) : Xr[NH - k];
         xm.y = -xm.y;
         if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
         const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
@@ -202,7 +250,7 @@ __global__ __launch_bounds__(256) void istft_kernel(
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
     }
-    float2* buf = line[wave];
+    if (MASKED) WAVE_SYNC();        // every lane has read the spectrum before the FFT reuses the line
     fft512_wave(v, buf, twl, lane);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -286,9 +334,10 @@ extern "C" int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size,
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
-  hipLaunchKernelGGL(rfft_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rfft_frames_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      x, rows, N, T, shift, fading ? size - shift : 0, window, (const float2*)tw,
-                     (float2*)X, 1.0f, 1.0f, iters);
+                     (float2*)X, 1.0f, 1.0f, iters, (const float*)nullptr, (const float2*)nullptr,
+                     (float*)nullptr, (int64_t)1);
   return tssep_launch_status();
 }
 
@@ -302,9 +351,28 @@ extern "C" int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int siz
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
-  hipLaunchKernelGGL(rfft_frames_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rfft_frames_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      dy, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
-                     (float2*)dX, 2.0f / (float)size, 1.0f / (float)size, iters);
+                     (float2*)dX, 2.0f / (float)size, 1.0f / (float)size, iters, (const float*)nullptr,
+                     (const float2*)nullptr, (float*)nullptr, (int64_t)1);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_mask_istft_bwd(const float* dy, const float* logit, const float* obs, int64_t B,
+                                    int64_t K, int64_t N, int size, int shift, int fading,
+                                    const float* wsyn, const float* tw, float* dlogit, int64_t T,
+                                    void* stream) {
+  if (!dy || !logit || !obs || !wsyn || !tw || !dlogit) return TSSEP_E_NULL;
+  if (B <= 0 || K <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  const int iters = 4;
+  const int64_t rows = B * K, total = rows * T;
+  const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
+  hipLaunchKernelGGL(rfft_frames_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     dy, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
+                     (float2*)nullptr, 2.0f / (float)size, 1.0f / (float)size, iters, logit,
+                     (const float2*)obs, dlogit, K);
   return tssep_launch_status();
 }
 
@@ -320,8 +388,26 @@ extern "C" int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size
   if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
   if (rows > 65535) return TSSEP_E_SHAPE;
   const int nchunks = (int)tssep_istft_chunks(N);
-  hipLaunchKernelGGL(istft_kernel, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
+  hipLaunchKernelGGL(istft_kernel<false>, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)X, T, shift, N, wsyn, (const float2*)tw, y,
-                     tgt, abs_partial, nchunks);
+                     tgt, abs_partial, nchunks, (const float*)nullptr, (const float2*)nullptr, (int64_t)1);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_mask_istft_fwd(const float* logit, const float* obs, int64_t B, int64_t K,
+                                    int64_t T, int size, int shift, int fading, const float* wsyn,
+                                    const float* tw, float* y, int64_t N, const float* tgt,
+                                    float* abs_partial, void* stream) {
+  if (!logit || !obs || !wsyn || !tw || !y) return TSSEP_E_NULL;
+  if (B <= 0 || K <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if (!fading) return TSSEP_E_UNSUPPORTED;
+  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
+  const int64_t rows = B * K;
+  if (rows > 65535) return TSSEP_E_SHAPE;
+  const int nchunks = (int)tssep_istft_chunks(N);
+  hipLaunchKernelGGL(istft_kernel<true>, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, (const float2*)nullptr, T, shift, N, wsyn, (const float2*)tw, y,
+                     tgt, abs_partial, nchunks, logit, (const float2*)obs, K);
   return tssep_launch_status();
 }

@@ -404,41 +404,84 @@ def istft(X, wsyn, N, size=1024, shift=256, fading=True):
     return _ISTFT.apply(X, wsyn, N, size, shift, fading)
 
 
+class _MaskISTFT(torch.autograd.Function):
+    """sigmoid (net.py:983) -> Masking (enhancer.py:98-100) -> fe.istft (model.py:661-664) as ONE kernel
+    each way; with ``tgt`` the forward also leaves the per-chunk sums of |estimate - tgt| on the result
+    (``_tssep_absdiff``), which ``log_mae`` / ``mae`` consume instead of re-reading both signals."""
+
+    @staticmethod
+    def forward(ctx, logit, obs, wsyn, N, size, shift, fading, tgt):
+        y, part = H.mask_istft_fwd(logit, obs, wsyn, N, size, shift, fading, tgt)
+        ctx.save_for_backward(logit, obs, wsyn)
+        ctx.meta = (size, shift, fading)
+        ctx.mark_non_differentiable(*([part] if part is not None else []))
+        return (y, part) if part is not None else (y,)
+
+    @staticmethod
+    def backward(ctx, dy, *_):
+        logit, obs, wsyn = ctx.saved_tensors
+        size, shift, fading = ctx.meta
+        return (H.mask_istft_bwd(dy, logit, obs, wsyn, size, shift, fading), None, None, None, None,
+                None, None, None)
+
+
+def mask_istft(logit, obs, wsyn, N, size=1024, shift=256, fading=True, tgt=None):
+    """logit [B,K,T,F], obs complex [B,T,F] -> time_estimate [B,K,N] (differentiable w.r.t. logit)."""
+    if tgt is not None and tuple(tgt.shape) != (logit.shape[0], logit.shape[1], N):
+        tgt = None
+    out = _MaskISTFT.apply(logit, obs, wsyn, N, size, shift, fading, tgt)
+    y = out[0]
+    if len(out) > 1:
+        y._tssep_absdiff = (out[1], tgt.data_ptr(), tuple(tgt.shape))
+    return y
+
+
 # ------------------------------------------------------------------------------ losses
+def _fused_absdiff(est, tgt):
+    """Partial sums the fused mask-head + iSTFT forward left on `est` for exactly this target."""
+    info = getattr(est, "_tssep_absdiff", None)
+    if info is not None and info[1] == tgt.data_ptr() and info[2] == tuple(tgt.shape):
+        return info[0]
+    return None
+
+
 class _LogMAE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, est, tgt):
-        loss, sums = H.logmae_fwd(est, tgt)
+    def forward(ctx, est, tgt, part=None):
+        if part is not None:
+            loss, sums = H.logmae_finalize(part, *est.shape)
+        else:
+            loss, sums = H.logmae_fwd(est, tgt)
         ctx.save_for_backward(est, tgt, sums)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         est, tgt, sums = ctx.saved_tensors
-        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), sums, g), None
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), sums, g), None, None
 
 
 def log_mae(est, tgt):
-    return _LogMAE.apply(est, tgt)
+    return _LogMAE.apply(est, tgt, _fused_absdiff(est, tgt))
 
 
 class _MAE(torch.autograd.Function):
     """sum_k mean_n |e - t| (loss.py:214-216): the argument of LogMAE's logarithm."""
 
     @staticmethod
-    def forward(ctx, est, tgt):
-        _, sums = H.logmae_fwd(est, tgt)
+    def forward(ctx, est, tgt, part=None):
+        _, sums = H.logmae_finalize(part, *est.shape) if part is not None else H.logmae_fwd(est, tgt)
         ctx.save_for_backward(est, tgt)
         return sums
 
     @staticmethod
     def backward(ctx, g):
         est, tgt = ctx.saved_tensors
-        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), None, g), None
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), None, g), None, None
 
 
 def mae(est, tgt):
-    return _MAE.apply(est, tgt)
+    return _MAE.apply(est, tgt, _fused_absdiff(est, tgt))
 
 
 class _VadBCE(torch.autograd.Function):

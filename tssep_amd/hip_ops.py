@@ -173,6 +173,40 @@ def istft_bwd(dy, wsyn, T, size=1024, shift=256, fading=True):
     return torch.view_as_complex(dX)
 
 
+def mask_istft_fwd(logit, obs, wsyn, N, size=1024, shift=256, fading=True, tgt=None):
+    """logit [B,K,T,F], obs complex64 [B,T,F] -> y [B,K,N] = istft(sigmoid(logit) * obs), neither the mask
+    nor the masked STFT is materialised (+ per-chunk sums of |y - tgt| when tgt [B,K,N] is given)."""
+    L = _lib.lib()
+    B, K, T, F = logit.shape
+    logit = _f32(logit).contiguous()
+    obs_r = torch.view_as_real(obs.contiguous())
+    y = torch.empty(B, K, N, device=logit.device, dtype=torch.float32)
+    part = None
+    if tgt is not None:
+        part = torch.empty(B * K, int(L.tssep_istft_chunks(N)), device=logit.device, dtype=torch.float32)
+        tgt = _f32(tgt).contiguous()
+    # roofline bookkeeping: the UNFUSED mask head's algorithmic bytes (SURVEY 8d), whatever is moved
+    with _timed("maskhead_fwd", 0, B * T * (16 * K * F + 8 * F)):
+        check(L.tssep_mask_istft_fwd(_p(logit), _p(obs_r), B, K, T, size, shift, int(fading), _p(wsyn),
+                                     _p(fft_tables(size, logit.device)), _p(y), N, _p(tgt), _p(part),
+                                     _stream()), "mask_istft_fwd")
+    return y, part
+
+
+def mask_istft_bwd(dy, logit, obs, wsyn, size=1024, shift=256, fading=True):
+    """dy [B,K,N] -> dlogit [B,K,T,F] through the iSTFT adjoint and the mask head's backward."""
+    L = _lib.lib()
+    B, K, T, F = logit.shape
+    dy = _f32(dy).contiguous()
+    obs_r = torch.view_as_real(obs.contiguous())
+    dlogit = torch.empty_like(logit)
+    with _timed("maskhead_bwd", 0, B * T * (16 * K * F + 8 * F)):
+        check(L.tssep_mask_istft_bwd(_p(dy), _p(logit), _p(obs_r), B, K, dy.shape[-1], size, shift,
+                                     int(fading), _p(wsyn), _p(fft_tables(size, logit.device)), _p(dlogit),
+                                     T, _stream()), "mask_istft_bwd")
+    return dlogit
+
+
 # --------------------------------------------------------------------------- features
 def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
     """X complex64 [B,T,F] -> (view [B,T,n_mfcc+F], ld)."""
@@ -397,6 +431,9 @@ RECURRENCE = "auto"    # "auto" | "stream" (lstm.hip) | "cluster" (lstm_cluster.
 
 
 def _err_flag(device):
+    device = torch.device(device)
+    if device.index is None:      # "cuda" and "cuda:0" must name the SAME flag (a check on the wrong key sees nothing)
+        device = torch.device("cuda", torch.cuda.current_device())
     key = str(device)
     if key not in _ERR:
         # [0] error flag, [1] launch epoch of the W-stationary kernels (library-maintained), [2..3] spare
@@ -406,7 +443,7 @@ def _err_flag(device):
 
 def check_cluster_errors(device="cuda"):
     """Synchronising check of the cluster kernels' timeout flag (tests / end of a bench run)."""
-    f = _err_flag(torch.device(device) if not isinstance(device, torch.device) else device)
+    f = _err_flag(device)
     v = int(f[0].item())
     if v:
         f[0].zero_()

@@ -64,6 +64,18 @@ class STFT(Configurable):
         _, wsyn = self._windows(signal.device)
         return Fn.istft(signal, wsyn, N, self.size, self.shift, self.fading)
 
+    def masked_istft(self, logit, observation, num_samples=None, target=None):
+        """istft(sigmoid(logit) * observation) as one fused kernel each way (functional.mask_istft):
+        logit [B,K,T,F], observation complex [B,T,F] -> [B,K,N]; ``target`` [B,K,N] (optional) lets the
+        forward accumulate the |estimate - target| sums a LogMAE / MAE loss needs."""
+        T = logit.shape[-2]
+        full = (T - 1) * self.shift + self.size - (2 * (self.size - self.shift) if self.fading else 0)
+        N = full if num_samples is None else min(num_samples, full)
+        if not self.fading:
+            raise NotImplementedError("fading=False")
+        _, wsyn = self._windows(logit.device)
+        return Fn.mask_istft(logit, observation, wsyn, N, self.size, self.shift, self.fading, tgt=target)
+
     def stft_to_feature(self, stft_signals):
         raise NotImplementedError(type(self))
 

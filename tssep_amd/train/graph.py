@@ -104,8 +104,9 @@ class GraphedStep:
 
     # ------------------------------------------------------------------------------- replay
     def __call__(self, ex):
-        """-> (ForwardOutput, ReviewSummary) of this step; both are STATIC objects that the next call
-        overwrites.  Gradients are in the optimizer's flat bucket afterwards (call ``optimizer.step()``)."""
+        """-> (ForwardOutput, ReviewSummary) of this step; their tensors are STATIC buffers that the next
+        call overwrites (lazily computed fields -- mask, stft_estimate -- are evaluated from them on
+        access).  Gradients are in the optimizer's flat bucket afterwards (call ``optimizer.step()``)."""
         sig = self._signature(ex)
         st = self._graphs.get(sig)
         if st is None:
@@ -126,4 +127,5 @@ class GraphedStep:
             st["perm_events"][slot] = ev
         st["graph"].replay()
         self.replays += 1
-        return st["out"], st["summary"]
+        out = st["out"]
+        return (out.fresh() if hasattr(out, "fresh") else out), st["summary"]

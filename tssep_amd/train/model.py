@@ -180,15 +180,71 @@ class Model(Configurable, torch.nn.Module):
                                     batch_size=batch_size, prefetch=prefetch, reader=reader, sort=sort)
 
     # ------------------------------------------------------------------------ forward
-    @dataclasses.dataclass
-    class ForwardOutput:                                    # model.py:454-463
-        mask: torch.Tensor
-        logit: torch.Tensor
-        embedding: torch.Tensor = None
-        stft_estimate: torch.Tensor = None
-        time_estimate: torch.Tensor = None
-        vad_mask: torch.Tensor = None
-        vad_logit: torch.Tensor = None
+    class ForwardOutput:
+        """The fields of the reference's dataclass (model.py:454-463): mask, logit, embedding,
+        stft_estimate, time_estimate, vad_mask, vad_logit.  ``mask`` and ``stft_estimate`` are computed on
+        first access: the training step needs neither -- the loss path runs sigmoid, masking and the
+        inverse STFT as one fused kernel from ``logit`` (functional.mask_istft) -- so the two largest
+        tensors of the step ([B,K,T,F] fp32 and complex64) are only materialised for callers that look
+        at them (snapshots, evaluation, custom losses).  Accessing them gives exactly the tensors the
+        eager chain would have produced, connected to the same autograd graph."""
+
+        def __init__(self, mask=None, logit=None, embedding=None, stft_estimate=None, time_estimate=None,
+                     vad_mask=None, vad_logit=None, _lazy=None):
+            self._mask, self._stft_estimate, self._lazy, self._lazy0 = mask, stft_estimate, _lazy, _lazy
+            self.logit, self.embedding, self.time_estimate = logit, embedding, time_estimate
+            self.vad_mask, self.vad_logit = vad_mask, vad_logit
+
+        def _materialise(self):
+            if self._lazy is not None:
+                lazy, self._lazy = self._lazy, None
+                mask, est = lazy()
+                if self._mask is None:
+                    self._mask = mask
+                if self._stft_estimate is None:
+                    self._stft_estimate = est
+
+        @property
+        def mask(self):
+            if self._mask is None:
+                self._materialise()
+            return self._mask
+
+        @mask.setter
+        def mask(self, value):
+            self._mask = value
+
+        @property
+        def stft_estimate(self):
+            if self._stft_estimate is None:
+                self._materialise()
+            return self._stft_estimate
+
+        @stft_estimate.setter
+        def stft_estimate(self, value):
+            self._stft_estimate = value
+
+        @property
+        def materialised(self):
+            return self._lazy is None
+
+        def fresh(self):
+            """A new view of the same tensors with mask / stft_estimate un-materialised again (hipGraph
+            replay: the static logit holds new values after every replay)."""
+            import copy
+            other = copy.copy(self)
+            if other._lazy0 is not None:
+                other._mask = other._stft_estimate = None
+                other._lazy = other._lazy0
+            return other
+
+        def __repr__(self):
+            def sh(t):
+                return None if t is None else tuple(t.shape)
+            return (f"ForwardOutput(mask={'<lazy>' if self._mask is None and self._lazy else sh(self._mask)}, "
+                    f"logit={sh(self.logit)}, embedding={sh(self.embedding)}, "
+                    f"stft_estimate={'<lazy>' if self._stft_estimate is None and self._lazy else sh(self._stft_estimate)}, "
+                    f"time_estimate={sh(self.time_estimate)})")
 
     def forward(self, ex, feature_transform=None) -> "Model.ForwardOutput":
         ex["AuxInput"] = [a for a in ex["auxInput"]]
@@ -211,33 +267,51 @@ class Model(Configurable, torch.nn.Module):
         aux = ex["auxInput"] if isinstance(ex["auxInput"], torch.Tensor) else ex["AuxInput"]
         batched = ex["Input"].dim() == 3
         logit, emb = self.mask_estimator.logits(ex["Input"], aux)
-        if "Observation" in ex:
+        logit4 = logit if batched else logit[None]
+        out = self.ForwardOutput(logit=logit.unsqueeze(-3), embedding=emb)
+        if "Observation" in ex and isinstance(self.enhancer, _enh.Masking):
             obs = ex["Observation"][..., ref, :, :]
-            if isinstance(self.enhancer, _enh.Masking):
-                # sigmoid (net.py:983) + Masking (enhancer.py:98-100): one fused kernel
-                if batched:
-                    mask, est = Fn.mask_head(logit, obs.contiguous())
-                else:
-                    mask, est = Fn.mask_head(logit[None], obs[None].contiguous())
+            obs3 = (obs if batched else obs[None]).contiguous()
+            out._fusable = (logit4, obs3, batched)           # review() runs the fused chain from here
+
+            def lazy():                                     # sigmoid (net.py:983) + Masking (enhancer.py:98-100)
+                mask, est = Fn.mask_head(logit4, obs3)
+                if not batched:
                     mask, est = mask[0], est[0]
-            else:
-                mask = Fn.sigmoid(logit if batched else logit[None])
-                mask = mask if batched else mask[0]
-                est = self.enhancer(mask.unsqueeze(-3), ex, self)
+                return mask.unsqueeze(-3), est
+        elif "Observation" in ex:
+            def lazy():
+                mask = Fn.sigmoid(logit4)
+                mask = (mask if batched else mask[0]).unsqueeze(-3)
+                return mask, self.enhancer(mask, ex, self)
         else:
             assert isinstance(self.loss, _loss.VADSigmoidBCE), type(self.loss)
-            mask = Fn.sigmoid(logit if batched else logit[None])
-            mask = mask if batched else mask[0]
-            est = None
-        return self.ForwardOutput(mask=mask.unsqueeze(-3), logit=logit.unsqueeze(-3),
-                                  embedding=emb, stft_estimate=est)
+
+            def lazy():
+                mask = Fn.sigmoid(logit4)
+                return (mask if batched else mask[0]).unsqueeze(-3), None
+        out._lazy = out._lazy0 = lazy
+        return out
 
     # ------------------------------------------------------------------------- review
     def review(self, ex, out: "Model.ForwardOutput"):
         summary = ReviewSummary()
         if hasattr(self.fe, "istft") and "observation" in ex:          # model.py:661-664
-            out.time_estimate = self.fe.istft(out.stft_estimate,
-                                              num_samples=ex["observation"].shape[-1])
+            n = ex["observation"].shape[-1]
+            fus = getattr(out, "_fusable", None)
+            if fus is not None and not out.materialised and hasattr(self.fe, "masked_istft"):
+                # nobody looked at mask / stft_estimate: sigmoid -> masking -> istft in one kernel, with
+                # the |estimate - target| partial sums of a time-domain loss on the side
+                logit4, obs3, batched = fus
+                tgt = ex.get(getattr(self.loss, "target", None)) if isinstance(self.loss, _loss.TimeDomain) else None
+                if isinstance(tgt, torch.Tensor):
+                    tgt = tgt if batched else tgt[None]
+                else:
+                    tgt = None
+                te = self.fe.masked_istft(logit4, obs3, num_samples=n, target=tgt)
+                out.time_estimate = te if batched else te[0]
+            else:
+                out.time_estimate = self.fe.istft(out.stft_estimate, num_samples=n)
         loss_value = self.loss.from_ex_out(ex, out, self, summary)
         summary.add_to_loss(loss_value.sum())                            # model.py:669
         with torch.no_grad():
