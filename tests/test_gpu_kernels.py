@@ -113,6 +113,51 @@ def test_gemm_nt_bias_tanh(M, N, K, gemm_precision):
     close(C, C0 + ref - bias, rtol=tol, atol=1.5 * tol, name="nt accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47)])
+def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
+    """The 256 x 256 / 8-wave variant of the split-bf16 row x row GEMM (N >= 1024 whose padding to 256 stays
+    under 10 %) against fp64, and bit for bit against the 256 x 128 tile (same K order, same MFMA sequence per
+    output element); bias + tanh, accumulate and the speaker-combination store remap."""
+    import os
+    torch.manual_seed(2)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        outs = {}
+        for wide in ("1", "0"):
+            os.environ["TSSEP_GEMM_WIDE"] = wide
+            C = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
+            C2 = torch.ones(M, N, device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+            outs[wide] = (C, C2)
+        close(outs["1"][0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="wide nt+bias+tanh")
+        close(outs["1"][1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="wide accumulate")
+        assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+        # store remap (rows (b,k,t) -> [b, t, k*N + n]), as the projection in front of the combination layer
+        Kspk, T = 4, M // 8
+        R = 2 * Kspk * T
+        for wide in ("1", "0"):
+            os.environ["TSSEP_GEMM_WIDE"] = wide
+            Y = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], Y, 0, R, N, K, bias=bd,
+                   remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+            outs["r" + wide] = Y
+        want = ref[:R].view(2, Kspk, T, N).permute(0, 2, 1, 3).reshape(2 * T, Kspk * N)
+        close(outs["r1"], want, rtol=2e-4, atol=2e-4, name="wide remap")
+        assert torch.equal(outs["r1"], outs["r0"])
+    finally:
+        os.environ.pop("TSSEP_GEMM_WIDE", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn_and_tn(M, N, K, gemm_precision):
     tol = gemm_precision

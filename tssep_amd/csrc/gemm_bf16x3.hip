@@ -418,22 +418,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // stage of 61 KB and two barriers per tile (48 MFMAs between them, 246 VGPRs, no spills) measured 3-10 %
 // SLOWER on the N = 2400 shapes and equal on the rest (alternating A/B): the second barrier costs more than the
 // line traffic saves.
+// WN = 4 ("wide", round 2): the same wave tile in a 256 x 256 workgroup tile of 8 waves (one workgroup per
+// CU instead of two: the same 2 waves per SIMD).  The A panel -- the streamed activation matrix, of which
+// a K tile of 16 fp32 uses only half of every 128-byte line it pulls through the L1 -- is then fetched
+// once per 256 output columns instead of once per 128: a third less L2 -> L1 line traffic per MFMA
+// (A + B lines per 16-k step and 256 x 256 outputs: 64 KB against 96 KB), and a thread stages 16
+// instead of 24 raw values.  Used where the padding of N to a multiple of 256 costs < 10 %.
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
-constexpr int TARR_A = TBM * TPITCH, TARR_B = BN * TPITCH;
-constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;            // A hi, A lo, B hi, B lo = 36 864 B
+constexpr int TARR_A = TBM * TPITCH;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
+template <int WN>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
     int64_t N, int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act,
     int accumulate, StoreMap sm, TileMap tmap) {
+  constexpr int NT = 128 * WN, TBN = 64 * WN, TARR_B = TBN * TPITCH;
+  constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;        // A hi, A lo, B hi, B lo = 36 864 B (WN = 2) / 49 152 B
+  constexpr int NA = TBM * 4 / NT, NB = TBN * 4 / NT;    // 16-byte loads per thread and K tile: 4 + 2 / 2 + 2
+  constexpr int RSTEP = NT / 4;                          // rows covered by one load of all threads
   __shared__ __attribute__((aligned(16))) char lds0[TSTAGE];
   __shared__ __attribute__((aligned(16))) char lds1[TSTAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int mt, nt, zsplit;
   if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
-  const int64_t m0 = (int64_t)mt * TBM, n0 = (int64_t)nt * BN;
+  const int64_t m0 = (int64_t)mt * TBM, n0 = (int64_t)nt * TBN;
   const int64_t ktiles = (K + TBK - 1) / TBK, kt_full = K / TBK;
   f32x16 acc[4][2];
 #pragma unroll
@@ -451,56 +461,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
   const int lrow = ((tid >> 2) & ~7) | (((tid >> 2) & 3) << 1) | ((tid >> 4) & 1);
   const char* abase = reinterpret_cast<const char*>(A + m0 * lda);
   const char* bbase = reinterpret_cast<const char*>(B + n0 * ldb);
-  unsigned aoffs[4], boffs[2];
+  unsigned aoffs[NA], boffs[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t r = m0 + lrow + 64 * i;
+  for (int i = 0; i < NA; ++i) {
+    int64_t r = m0 + lrow + RSTEP * i;
     r = r > M - 1 ? M - 1 : r;
     aoffs[i] = (unsigned)(((r - m0) * lda + kq) * 4);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int64_t r = n0 + lrow + 64 * i;
+  for (int i = 0; i < NB; ++i) {
+    int64_t r = n0 + lrow + RSTEP * i;
     r = r > N - 1 ? N - 1 : r;
     boffs[i] = (unsigned)(((r - n0) * ldb + kq) * 4);
   }
-  f32x4 ra[4], rb[2];
+  f32x4 ra[NA], rb[NB];
   auto gload = [&](int64_t kt, bool tail) {
     const int64_t k0 = kt * TBK, k = k0 + kq;
     // (tail) a 16-byte load that starts at or beyond K would leave the row: read the row start
     const int64_t adj = (!tail || k < K) ? k0 : -(int64_t)kq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + adj * 4 + aoffs[i]);
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + adj * 4 + aoffs[i]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + adj * 4 + boffs[i]);
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + adj * 4 + boffs[i]);
     if (tail) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool ok = k + e < K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i][e] = ok ? ra[i][e] : 0.f;
+        for (int i = 0; i < NA; ++i) ra[i][e] = ok ? ra[i][e] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) rb[i][e] = ok ? rb[i][e] : 0.f;
+        for (int i = 0; i < NB; ++i) rb[i][e] = ok ? rb[i][e] : 0.f;
       }
     }
   };
   const int soff = lrow * TPITCH + ((tid & 3) << 3);
   auto sstore = [&](char* st) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       unsigned h0, l0, h1, l1;
       split2n(ra[i][0], ra[i][1], h0, l0);
       split2n(ra[i][2], ra[i][3], h1, l1);
-      *reinterpret_cast<u32x2*>(st + soff + i * 64 * TPITCH) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(st + TARR_A + soff + i * 64 * TPITCH) = u32x2{l0, l1};
+      *reinterpret_cast<u32x2*>(st + soff + i * RSTEP * TPITCH) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + TARR_A + soff + i * RSTEP * TPITCH) = u32x2{l0, l1};
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NB; ++i) {
       unsigned h0, l0, h1, l1;
       split2n(rb[i][0], rb[i][1], h0, l0);
       split2n(rb[i][2], rb[i][3], h1, l1);
-      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + soff + i * 64 * TPITCH) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + TARR_B + soff + i * 64 * TPITCH) = u32x2{l0, l1};
+      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + soff + i * RSTEP * TPITCH) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + 2 * TARR_A + TARR_B + soff + i * RSTEP * TPITCH) = u32x2{l0, l1};
     }
   };
   const int foff = (lane & 31) * TPITCH + (lane >> 5) * 16;
@@ -540,9 +550,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
     sstore(nxt);                                                                                \
     gload((kt_) + 2, false);                                                                    \
     SGB(0x100, 6);                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
-    _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x200, 1); }              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x020, 1); }                              \
+    if (WN == 2) {                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
+      _Pragma("unroll") for (int i_ = 0; i_ < 10; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x200, 1); }              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x020, 1); }                              \
+    } else {      /* 8 ds_writes, 4 global loads, two thirds of the split VALU per thread */   \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
+      _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { SGB(0x008, 1); SGB(0x002, 4); SGB(0x200, 1); }               \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) { SGB(0x008, 1); SGB(0x002, 3); }                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { SGB(0x008, 1); SGB(0x020, 1); }                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { SGB(0x008, 1); }                                             \
+    }                                                                                           \
     __syncthreads();                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
@@ -566,9 +584,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
     __syncthreads();
   }
 #undef TPIPE
-  if (!sm.remap) {
-    static_assert(2 * 64 * EPITCH * 4 <= TSTAGE, "epilogue scratch must fit in one stage");
-    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+  // epilogue: every wave transposes its 64 x 64 blocks through a private LDS scratch (17 KB); a stage
+  // array holds two of them, so the 8 waves of the wide tile take turns in two phases of 4
+  static_assert(2 * 64 * EPITCH * 4 <= TSTAGE, "epilogue scratch must fit in one stage");
+  float* stage = reinterpret_cast<float*>((wave & 2) ? lds1 : lds0) + (wave & 1) * 64 * EPITCH;
+#pragma unroll 1
+  for (int phase = 0; phase < WN / 2; ++phase) {
+    if (WN > 2 && phase) __syncthreads();
+    if ((wave >> 2) != phase) continue;
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {
       f32x16 a2[2][2];
@@ -576,22 +599,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tall_kernel(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
-      gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
-                         bias, act, accumulate, sm.ldc, true);
-    }
-    return;
-  }
-  {
-    float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      f32x16 a2[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
-      gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
-                               lane, bias, act, accumulate, sm);
+      if (!sm.remap)
+        gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
+                           bias, act, accumulate, sm.ldc, true);
+      else
+        gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                                 lane, bias, act, accumulate, sm);
     }
   }
 }
@@ -849,8 +862,20 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   if (g->b_ones_col && (!g->b_kmajor || shift || g->N < 2)) return TSSEP_E_UNSUPPORTED;
   static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
   if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+    // wide (256 x 256) tile where rounding N up to 256 wastes < 10 % of the columns (N = 2400, 1280 of the
+    // step; not 513 / 320 / 600 / 2052)
+    const char* wide_env = getenv("TSSEP_GEMM_WIDE");          // read per call: A/B runs toggle it in-process
+    const int wide = wide_env ? atoi(wide_env) : 1;
+    const int64_t n256 = (g->N + 255) / 256 * 256;
+    if (wide && g->N >= 1024 && n256 * 10 <= g->N * 11) {
+      const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
+      hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<4>, dim3((unsigned)tile_map_blocks(tm4)), dim3(512), 0, s,
+                         g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
+                         g->accumulate, sm, tm4);
+      return tssep_launch_status();
+    }
     const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
-    hipLaunchKernelGGL(gemm_bf16x3_tall_kernel, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
+    hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<2>, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
                        g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
                        g->accumulate, sm, tm2);
     return tssep_launch_status();
