@@ -383,8 +383,15 @@ def main():
                              frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
                              traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
                              avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l,
-                             note="bytes = (16 K F + 8 F) per frame and direction: the UNFUSED chain of "
-                                  "net.py:983 + enhancer.py:98-100, whatever the kernels actually move")
+                             note="bytes = (16 K F + 8 F) per frame and direction: the UNFUSED mask head of "
+                                  "net.py:983 + enhancer.py:98-100; the time is that of the FUSED kernels (mask "
+                                  "head + inverse STFT, iSTFT adjoint + mask-head backward), which also run the "
+                                  "FFTs: `chain` prices the same time against the unfused chain's bytes")
+            chain = by + n_l * B * T * 8 * K * FBINS + n_l * 4 * B * K * N_s      # + estimate (8 K F) + samples
+            cg = chain / (ms * 1e-3) / 1e9
+            mask_head["chain"] = dict(kernel="maskhead+istft fwd, istft adjoint+maskhead bwd (fused)",
+                                      algorithmic_bytes_per_launch=chain // n_l, achieved=round(cg, 1),
+                                      frac=round(cg / PEAK_HBM_GBPS, 4))
         return roofline, mask_head
 
     def arithmetic(gemm_name):

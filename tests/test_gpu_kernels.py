@@ -301,11 +301,11 @@ def test_mask_istft_fused_against_oracle_and_unfused_chain(B, K, N):
     # (b) unfused HIP chain
     mask, est = h.maskhead_fwd(logit.detach().cuda(), obs.cuda())
     y_u, part_u = h.istft_fwd(est.reshape(B * K, T, 513), wsyn, N, tgt=tgt.cuda().reshape(B * K, N))
-    close(y, y_u.view(B, K, N), rtol=1e-6, atol=1e-7, name="fused fwd vs unfused")
+    close(y, y_u.view(B, K, N), rtol=1e-5, atol=2e-6, name="fused fwd vs unfused")
     close(part, part_u, rtol=1e-5, name="partials vs unfused")
     dX = h.istft_bwd(dy.cuda().reshape(B * K, N), wsyn, T)
     dl_u = h.maskhead_bwd(dX.view(B, K, T, 513), None, mask, obs.cuda())
-    close(dlogit, dl_u, rtol=1e-5, atol=1e-7 * float(dl_u.abs().max()) * 10, name="fused bwd vs unfused")
+    close(dlogit, dl_u, rtol=2e-5, atol=2e-6 * float(dl_u.abs().max()), name="fused bwd vs unfused")
     # without a target there are no partial sums
     y2, none = h.mask_istft_fwd(logit.detach().cuda(), obs.cuda(), wsyn, N)
     assert none is None and torch.equal(y2, y)

@@ -752,8 +752,8 @@ def test_fused_tail_equals_materialised_chain():
                          [p.grad.clone() for p in m.parameters()], out.mask.detach().clone(),
                          out.stft_estimate.detach().clone())
         a, b = res["fused"], res["materialised"]
-        assert a[0] == pytest.approx(b[0], rel=1e-6)
-        close(a[1], b[1], rtol=1e-6, atol=1e-7, name="time estimate")
+        assert a[0] == pytest.approx(b[0], rel=1e-5)
+        close(a[1], b[1], rtol=1e-5, atol=2e-6, name="time estimate")
         for ga, gb in zip(a[2], b[2]):
             close(ga, gb, rtol=1e-4, atol=1e-6 * float(gb.abs().max()) + 1e-12, name="gradient")
         close(a[3], b[3], rtol=0, atol=0, name="lazy mask")

@@ -176,27 +176,37 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
   }
 }
 
-// inverse STFT: per workgroup HC output hops of one row; (HC + 3) frames are inverse
-// transformed (4 waves, strided), windowed and parked in LDS, then every output sample
-// sums its <= 4 frame contributions in a fixed order (deterministic overlap-add).
-constexpr int HC = 9;
-constexpr int NFR = HC + 3;
+// inverse STFT: a workgroup walks `hcb` consecutive output hops of one row.  Its 4 waves inverse-transform
+// 4 consecutive frames per iteration into a RING of 7 windowed frames in LDS (4 being written + the 3
+// older ones the pending hops still need); after each iteration the hops whose 4 contributing frames are
+// complete are emitted: every output sample sums its <= 4 frame contributions in a fixed order
+// (deterministic overlap-add).  Only the first 3 frames of a chunk are transformed twice (by the
+// neighbouring chunk as well): 66 transforms per 63 hops.  Round 1 parked HC + 3 = 12 frames per 9 hops
+// (a third of all transforms redundant, 48 KB of LDS, two workgroups per CU); the ring needs 28 KB and
+// three workgroups fit.
+constexpr int RING = 7;
+constexpr int HCB_MAX = 64;              // hops per workgroup (upper bound; the launcher balances the chunks)
 
 //
 // MASKED = true fuses the mask head in front (net.py:983 + enhancer.py:98-100): a frame's spectrum is
 // formed in the wave's LDS line as sigmoid(logit) * Obs (logit 4 B per bin; the 8-B observation bin is
 // shared by the K speakers of an utterance: L2) -- neither the mask nor the masked STFT is written;
-// the chain mask head -> inverse STFT moves (4 K F + 8 F) HC'/HC + 4 K 256 bytes per frame instead of
-// 16 K F + 8 F + 8 K F HC'/HC + 4 K 256  (HC'/HC = 12/9: the frames a chunk re-transforms).
+// the chain mask head -> inverse STFT moves (4 K F + 8 F) + 4 K 256 bytes per frame instead of
+// 16 K F + 8 F + 8 K F + 4 K 256.  (Measured, batch 768: 2.07 ms against 1.44 + 1.98 ms; the kernel is bound
+// by the per-wave FFT chain, not by bytes: the hardware exp / rcp sigmoid instead of the accurate one changed
+// nothing, three resident workgroups instead of two gained 20 %.)
+#ifndef TSSEP_ISTFT_OCC
+#define TSSEP_ISTFT_OCC 3            // waves per SIMD the register allocation aims at (A/B: build with -D...=2)
+#endif
 template <bool MASKED>
-__global__ __launch_bounds__(256) void istft_kernel(
+__global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
     const float2* __restrict__ X, int64_t T, int shift_, int64_t N,
     const float* __restrict__ wsyn, const float2* __restrict__ tw, float* __restrict__ y,
-    const float* __restrict__ tgt, float* __restrict__ abs_partial, int nchunks,
+    const float* __restrict__ tgt, float* __restrict__ abs_partial, int nchunks, int hcb,
     const float* __restrict__ logit, const float2* __restrict__ obs, int64_t Kspk) {
   __shared__ float2 twl[NH];
   __shared__ float2 line[4][LINE];
-  __shared__ __attribute__((aligned(16))) float fr[NFR][1024];
+  __shared__ __attribute__((aligned(16))) float fr[RING][1024];
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row = blockIdx.y;
@@ -204,33 +214,41 @@ __global__ __launch_bounds__(256) void istft_kernel(
   for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
   __syncthreads();
   const float2* tw2 = tw + NH;
-  const int64_t t_lo = (int64_t)c * HC;  // = h0 - 3 with h0 = 3 + c*HC
+  const int64_t t_lo = (int64_t)c * hcb;   // hop h of this chunk sums frames t_lo + h .. t_lo + h + 3
+  const int64_t n0 = t_lo * 256;
+  const int64_t total_hops = (N + 255) / 256;
+  const int hops = (int)(total_hops - t_lo < hcb ? total_hops - t_lo : hcb);
+  const int iters = (hops + 3 + 3) / 4;    // frames 0 .. hops + 2
   const float inv = 1.0f / 512.0f;
-  for (int it = 0; it < NFR / 4; ++it) {
+  float* yr = y + row * N;
+  const float* tr = tgt ? tgt + row * N : nullptr;
+  float asum = 0.f;
+  float2* buf = line[wave];
+  for (int it = 0; it < iters; ++it) {
     const int lf = it * 4 + wave;
     const int64_t t = t_lo + lf;
-    const bool valid = t < T;
-    float2 v[8];
-    float2* buf = line[wave];
-    float2 xnyq = make_float2(0.f, 0.f);              // MASKED: X[512], needed by lane 0 only
-    if (MASKED && valid) {
-      const float* Lr = logit + (row * T + t) * (NH + 1);
-      const float2* Or = obs + ((row / Kspk) * T + t) * (NH + 1);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int k = lane + 64 * r;
-        const float m = sigmoidf_acc(Lr[k]);
-        const float2 ob = Or[k];
-        buf[PADI(k)] = make_float2(ob.x * m, ob.y * m);
-      }
-      if (lane == 0) {
-        const float m = sigmoidf_acc(Lr[NH]);
-        const float2 ob = Or[NH];
-        xnyq = make_float2(ob.x * m, ob.y * m);
-      }
-      WAVE_SYNC();
-    }
+    const bool valid = t < T && lf < hops + 3;
+    float* slot = fr[lf % RING];
     if (valid) {
+      float2 v[8];
+      float2 xnyq = make_float2(0.f, 0.f);              // MASKED: X[512], needed by lane 0 only
+      if (MASKED) {
+        const float* Lr = logit + (row * T + t) * (NH + 1);
+        const float2* Or = obs + ((row / Kspk) * T + t) * (NH + 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int k = lane + 64 * r;
+          const float m = sigmoidf_acc(Lr[k]);
+          const float2 ob = Or[k];
+          buf[PADI(k)] = make_float2(ob.x * m, ob.y * m);
+        }
+        if (lane == 0) {
+          const float m = sigmoidf_acc(Lr[NH]);
+          const float2 ob = Or[NH];
+          xnyq = make_float2(ob.x * m, ob.y * m);
+        }
+        WAVE_SYNC();
+      }
       const float2* Xr = MASKED ? nullptr : X + (row * T + t) * (NH + 1);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -246,38 +264,38 @@ __global__ __launch_bounds__(256) void istft_kernel(
         // Zi = E + i O ; feed conj(Zi) to the forward FFT
         v[r] = make_float2(e.x - o.y, -(e.y + o.x));
       }
+      if (MASKED) WAVE_SYNC();        // every lane has read the spectrum before the FFT reuses the line
+      fft512_wave(v, buf, twl, lane);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int n = lane + 64 * r;
+        const float2 z = buf[PADI(n)];
+        const float2 w = *reinterpret_cast<const float2*>(wsyn + 2 * n);
+        *reinterpret_cast<float2*>(&slot[2 * n]) = make_float2(z.x * inv * w.x, -z.y * inv * w.y);
+      }
+      WAVE_SYNC();          // the wave's line is reused by its next frame; ring slots are disjoint
     } else {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+      for (int r = 0; r < 8; ++r)
+        *reinterpret_cast<float2*>(&slot[2 * (lane + 64 * r)]) = make_float2(0.f, 0.f);
     }
-    if (MASKED) WAVE_SYNC();        // every lane has read the spectrum before the FFT reuses the line
-    fft512_wave(v, buf, twl, lane);
+    __syncthreads();        // frames <= 4 it + 3 are in the ring
+    // emit the hops completed by this iteration: h in [4 it - 3, 4 it] (4 x 256 samples, 4 per thread)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n = lane + 64 * r;
-      const float2 z = buf[PADI(n)];
-      const float2 w = *reinterpret_cast<const float2*>(wsyn + 2 * n);
-      *reinterpret_cast<float2*>(&fr[lf][2 * n]) = make_float2(z.x * inv * w.x, -z.y * inv * w.y);
+    for (int q = 0; q < 4; ++q) {
+      const int h = 4 * it - 3 + q;
+      if (h < 0 || h >= hops) continue;                 // (uniform)
+      const int64_t n = n0 + (int64_t)h * 256 + tid;
+      if (n < N) {
+        float s = fr[h % RING][tid + 768];
+        s += fr[(h + 1) % RING][tid + 512];
+        s += fr[(h + 2) % RING][tid + 256];
+        s += fr[(h + 3) % RING][tid];
+        yr[n] = s;
+        if (tr) asum += fabsf(s - tr[n]);
+      }
     }
-    WAVE_SYNC();          // the wave's line is reused by its next frame; fr rows are disjoint
-  }
-  __syncthreads();        // all NFR windowed frames parked
-  // overlap-add + un-fade + truncate
-  const int64_t n0 = (int64_t)c * HC * 256;
-  float* yr = y + row * N;
-  const float* tr = tgt ? tgt + row * N : nullptr;
-  float asum = 0.f;
-  for (int i = tid; i < HC * 256; i += 256) {
-    const int64_t n = n0 + i;
-    if (n < N) {
-      const int hop = i >> 8, off = i & 255;
-      float s = fr[hop][off + 768];
-      s += fr[hop + 1][off + 512];
-      s += fr[hop + 2][off + 256];
-      s += fr[hop + 3][off];
-      yr[n] = s;
-      if (tr) asum += fabsf(s - tr[n]);
-    }
+    __syncthreads();        // the next iteration overwrites the slots of frames <= 4 it
   }
   if (abs_partial) {
     asum = wave_sum(asum);
@@ -376,7 +394,15 @@ extern "C" int tssep_mask_istft_bwd(const float* dy, const float* logit, const f
   return tssep_launch_status();
 }
 
-extern "C" int64_t tssep_istft_chunks(int64_t N) { return (N + HC * 256 - 1) / (HC * 256); }
+// chunks per row: balanced, at most HCB_MAX hops each
+extern "C" int64_t tssep_istft_chunks(int64_t N) {
+  const int64_t hops = (N + 255) / 256;
+  return (hops + HCB_MAX - 1) / HCB_MAX;
+}
+static int istft_hops_per_chunk(int64_t N, int nchunks) {
+  const int64_t hops = (N + 255) / 256;
+  return (int)((hops + nchunks - 1) / nchunks);
+}
 
 extern "C" int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size, int shift,
                                int fading, const float* wsyn, const float* tw, float* y, int64_t N,
@@ -390,7 +416,8 @@ extern "C" int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size
   const int nchunks = (int)tssep_istft_chunks(N);
   hipLaunchKernelGGL(istft_kernel<false>, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)X, T, shift, N, wsyn, (const float2*)tw, y,
-                     tgt, abs_partial, nchunks, (const float*)nullptr, (const float2*)nullptr, (int64_t)1);
+                     tgt, abs_partial, nchunks, istft_hops_per_chunk(N, nchunks), (const float*)nullptr,
+                     (const float2*)nullptr, (int64_t)1);
   return tssep_launch_status();
 }
 
@@ -408,6 +435,6 @@ extern "C" int tssep_mask_istft_fwd(const float* logit, const float* obs, int64_
   const int nchunks = (int)tssep_istft_chunks(N);
   hipLaunchKernelGGL(istft_kernel<true>, dim3((unsigned)nchunks, (unsigned)rows), dim3(256), 0,
                      (hipStream_t)stream, (const float2*)nullptr, T, shift, N, wsyn, (const float2*)tw, y,
-                     tgt, abs_partial, nchunks, logit, (const float2*)obs, K);
+                     tgt, abs_partial, nchunks, istft_hops_per_chunk(N, nchunks), logit, (const float2*)obs, K);
   return tssep_launch_status();
 }
