@@ -15,8 +15,9 @@ def test_recurrence_policy():
         H.RECURRENCE = "auto"
         assert H.recurrence_kernel(8, 300, False) == "onchip"
         assert H.recurrence_kernel(1536, 300, False) == "onchip"
-        assert H.recurrence_kernel(8, 300, True) == "cluster"
-        assert H.recurrence_kernel(32, 300, True) == "cluster"
+        assert H.recurrence_kernel(8, 300, True) == "onchip"
+        assert H.recurrence_kernel(32, 300, True) == "onchip"
+        assert H.recurrence_kernel(32, 300, True, T=1878) == "onchip" and H.recurrence_kernel(32, 300, True, T=4000) == "stream"
         assert H.recurrence_kernel(33, 300, True) == "onchip"
         assert H.recurrence_kernel(768, 300, True) == "onchip"
         # small or unsupported hidden sizes fall back to the streaming kernels

@@ -1,31 +1,38 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): every measurement DESIGN.md cites, into gpurun_out/final/.
-# usage: bash tools/collect_profiles.sh [tag]
+# Runs on the GPU box (gpurun): every measurement DESIGN.md cites for this round, into gpurun_out/final/.
+# usage: bash tools/collect_profiles.sh
 set -u
 O=gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python tools/bench_recurrence.py 8 32 64 128 192 256 512 768 800 1024 1536 2048 > $O/recurrence_microbench.jsonl 2>/dev/null
-TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
-TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 192 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
-python tools/bench_maskhead.py > $O/maskhead_microbench.txt 2>/dev/null
-for b in 8 32 64 128 160 192 256 384 512 768 1152 1536; do
-  python bench.py --batch $b --steps 20 --warmup 4 --no-cpu-baseline --no-exact-f32 2>/dev/null | tail -1
+B="--no-cpu-baseline --no-exact-f32"
+python tools/bench_recurrence.py 8 32 64 128 256 512 768 1024 1536 2048 3072 > $O/recurrence_microbench.jsonl 2>/dev/null
+python tools/stress_recurrence.py 400 2>/dev/null | tail -1 > $O/recurrence_stress.json
+TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
+TSSEP_GEMM_WIDE=0 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_bf16x3_wide0.jsonl
+TSSEP_WGRAD_PRODUCTS=2 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/dev/null | grep wgrad > $O/gemm_microbench_bf16x3_wgrad2.jsonl
+TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
+python tools/bench_tail.py > $O/tail_microbench.jsonl 2>/dev/null
+python tools/grad_parity.py 2 > $O/parity_full_size.jsonl 2>/dev/null
+for b in 8 32 64 128 192 256 384 512 768 1152 1536; do
+  python bench.py --batch $b --steps 20 --warmup 4 $B 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
-python bench.py > $O/bench_default.json 2>$O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32 > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_write.log 2>&1
-find $O -name "*.csv" | head -20
-ls -la $O
+# alternating A/B inside one job: wide GEMM tile, two-product weight gradients
+for w in 0 1 0 1; do TSSEP_GEMM_WIDE=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(gemm_wide=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], gemm_tflops=d['roofline']['achieved'])))"; done > $O/ab_gemm_wide.jsonl
+for w in 3 2 3 2; do TSSEP_WGRAD_PRODUCTS=$w python bench.py --steps 15 --warmup 3 --no-exact-f32 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); p=d['cpu_baseline']['parity_vs_hip']; print(json.dumps(dict(wgrad_products=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], max_rel_grad_err=p['max_rel_grad_err'], median_rel_grad_err=p['median_rel_grad_err'], worst=p['worst_gradient'])))"; done > $O/ab_wgrad_products.jsonl
+python bench.py --workload cfg4 --steps 40 --warmup 5 > $O/bench_cfg4.json 2>$O/bench_cfg4.err
+python bench.py --workload cfg4 --steps 40 --warmup 5 --graph off --no-cpu-baseline > $O/bench_cfg4_nograph.json 2>/dev/null
+python bench.py --workload cfg5 --steps 5 --warmup 2 > $O/bench_cfg5.json 2>$O/bench_cfg5.err
+python bench.py --gemm f32 > $O/bench_f32.json 2>$O/bench_f32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python3 bench.py --steps 6 --warmup 2 $B > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32 -o s -- python3 bench.py --gemm f32 --steps 6 --warmup 2 $B > $O/stats_f32.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o s -- python3 bench.py --workload cfg4 --graph off --steps 10 --warmup 3 $B > $O/stats_cfg4.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg5 -o s -- python3 bench.py --workload cfg5 --steps 3 --warmup 1 $B > $O/stats_cfg5.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 2 --warmup 1 $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 2 --warmup 1 $B > $O/pmc_write.log 2>&1
 # MFMA pipe and wave-state counters of the same command (own pass: SQ counters only)
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -o q -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 > $O/pmc_sq.log 2>&1
-# eval-time MVDR beamformer (TorchBF): microbench with the CPU oracle beside it + kernel stats
-python tools/bench_mvdr.py > $O/mvdr_microbench.jsonl 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/mvdr_stats -o m -- python3 tools/bench_mvdr.py --no-cpu --iters 10 > $O/mvdr_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pmc_sq -o q -- python3 bench.py --steps 2 --warmup 1 $B > $O/pmc_sq.log 2>&1
 python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null
-python tools/bench_input_pipeline.py 768 > $O/input_pipeline.jsonl 2>/dev/null; python tools/bench_input_pipeline.py 384 >> $O/input_pipeline.jsonl 2>/dev/null
 python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
-# experimental GEMM probes (pre-split planes + asynchronous copies) and their ablations
-python tools/probe_presplit.py > $O/gemm_presplit_probe.jsonl 2>/dev/null
-python tools/probe_presplit_ablation.py > $O/gemm_presplit_ablation.jsonl 2>/dev/null
-python tools/probe_presplit_tn.py > $O/gemm_presplit_tn_probe.jsonl 2>/dev/null
+ls -la $O | head -60

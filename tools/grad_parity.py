@@ -19,9 +19,11 @@ o = omodel.forward_loss(p, *x, cfg=dict(odim=513, combination="mul", ts_vad=4, o
 o["loss"].sum().backward()
 ex = dict(observation=x[0].cuda(), auxInput=x[1].cuda(), speaker_reverberation_early_ch0=x[2].cuda(),
           reference_channel=0, dataset=["p"] * B)
-for gemm in ("f32", "bf16x3"):
-    for rec in ("stream", "cluster", "onchip"):
+for gemm, rec, products in [(g, r, "3") for g in ("f32", "bf16x3") for r in ("stream", "cluster", "onchip")] + \
+        [("bf16x3", "onchip", "2")]:
+    if True:
         H.GEMM_PRECISION, H.RECURRENCE = gemm, rec
+        os.environ["TSSEP_WGRAD_PRODUCTS"] = products
         model.zero_grad(set_to_none=True)
         np.random.seed(5)
         out = model(ex)
@@ -31,6 +33,8 @@ for gemm in ("f32", "bf16x3"):
                          / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
                 for k, v in model.mask_estimator.named_parameters()}
         worst = max(errs, key=errs.get)
-        print(json.dumps(dict(gemm=gemm, recurrence=rec, batch=B,
-                              max_abs_mask_err=float((out.mask.cpu() - o["mask"]).abs().max()),
+        gs = sorted(errs.values())
+        print(json.dumps(dict(gemm=gemm, recurrence=rec, wgrad_products=int(products), batch=B,
+                              max_abs_mask_err=float((out.mask.detach().cpu() - o["mask"]).abs().max()),
+                              median_rel_grad_err=gs[len(gs) // 2],
                               max_rel_grad_err=errs[worst], worst_param=worst)), flush=True)

@@ -1,39 +1,38 @@
 #!/bin/bash
-# Copies what tools/collect_profiles.sh wrote under gpurun_out/final/ into profiles/ (tracked).
-# usage: bash tools/install_profiles.sh <batch> <gemm>
+# Copies what tools/collect_profiles.sh wrote under gpurun_out/final/ into profiles/ (tracked), names r<round>_*.
+# usage: bash tools/install_profiles.sh [round] [batch] [gemm]      then re-run `python bench.py` on the GPU box
+# for the default line with the PMC fields filled (profiles/r<round>_bench_default.json).
 set -e
-F=gpurun_out/final; B=${1:-768}; G=${2:-bf16x3}
-python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G > profiles/r1_traffic_pmc.json
-python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G > profiles/r1_mfma_pmc.json
-cp $F/recurrence_microbench.jsonl profiles/r1_recurrence_microbench.jsonl
-cp $F/gemm_microbench_bf16x3.jsonl profiles/r1_gemm_microbench_bf16x3.jsonl
-cp $F/gemm_microbench_f32.jsonl profiles/r1_gemm_microbench_f32.jsonl
-cp $F/maskhead_microbench.txt profiles/r1_maskhead_microbench.jsonl
-cp $F/batch_sweep.jsonl profiles/r1_batch_sweep_final.jsonl
-cp $F/bench_default.json profiles/r1_bench_default.json
-[ -f $F/gemm_in_step_b$B.jsonl ] && cp $F/gemm_in_step_b$B.jsonl profiles/r1_gemm_in_step_b$B.jsonl
-[ -f $F/mvdr_microbench.jsonl ] && cp $F/mvdr_microbench.jsonl profiles/r1_mvdr_microbench.jsonl
-for f in input_pipeline.jsonl gemm_presplit_probe.jsonl gemm_presplit_ablation.jsonl gemm_presplit_tn_probe.jsonl; do [ -s $F/$f ] && cp $F/$f profiles/r1_$f; done
-[ -s $F/step_clock.json ] && cp $F/step_clock.json profiles/r1_step_clock.json
+R=${1:-2}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
+python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G cfg3 > ${P}_traffic_pmc.json
+python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G cfg3 > ${P}_mfma_pmc.json
+for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16x3.jsonl gemm_microbench_bf16x3_wide0.jsonl \
+         gemm_microbench_bf16x3_wgrad2.jsonl gemm_microbench_f32.jsonl tail_microbench.jsonl parity_full_size.jsonl \
+         batch_sweep.jsonl ab_gemm_wide.jsonl ab_wgrad_products.jsonl bench_cfg4.json bench_cfg4_nograph.json bench_cfg5.json \
+         bench_f32.json gemm_in_step_b768.jsonl step_clock.json; do
+  [ -s $F/$f ] && cp $F/$f ${P}_$f
+done
 python - <<PY
 import csv, os
-if os.path.exists('$F/mvdr_stats/m_kernel_stats.csv'):
-    rows = list(csv.DictReader(open('$F/mvdr_stats/m_kernel_stats.csv')))
-    with open('profiles/r1_kernel_stats_mvdr.txt', 'w') as f:
-        f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 tools/bench_mvdr.py --no-cpu --iters 10   (4 configurations, see profiles/r1_mvdr_microbench.jsonl)\n")
-        f.write(f"{'Name':72s} {'Calls':>6s} {'TotalNs':>12s} {'AvgNs':>11s} {'Pct':>6s} {'MinNs':>9s} {'MaxNs':>9s}\n")
+def table(src, dst, header):
+    if not os.path.exists(src):
+        return None
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, 'w') as f:
+        f.write("# " + header + "\n")
+        f.write(f"{'Name':78s} {'Calls':>6s} {'TotalNs':>12s} {'AvgNs':>11s} {'Pct':>6s} {'MinNs':>9s} {'MaxNs':>9s}\n")
         for r in rows:
             n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
-            f.write(f"{n[:72]:72s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
-rows = list(csv.DictReader(open('$F/stats/s_kernel_stats.csv')))
-with open('profiles/r1_kernel_stats_default_b${B}_${G}.txt', 'w') as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-f32   (default config: batch $B, $G; 8 steps in total)\n")
-    f.write(f"{'Name':72s} {'Calls':>6s} {'TotalNs':>12s} {'AvgNs':>11s} {'Pct':>6s} {'MinNs':>9s} {'MaxNs':>9s}\n")
-    for r in rows:
-        n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
-        f.write(f"{n[:72]:72s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
+            f.write(f"{n[:78]:78s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
+    return rows
+cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --no-cpu-baseline --no-exact-f32"
+rows = table('$F/stats/s_kernel_stats.csv', '${P}_kernel_stats_default_b${B}_${G}.txt', cmd % "--steps 6 --warmup 2" + "   (default config: batch $B, $G; 8 steps in total)")
+table('$F/stats_f32/s_kernel_stats.csv', '${P}_kernel_stats_b${B}_f32.txt', cmd % "--gemm f32 --steps 6 --warmup 2" + "   (fp32 GEMMs; 8 steps in total)")
+table('$F/stats_cfg4/s_kernel_stats.csv', '${P}_kernel_stats_cfg4_b8.txt', cmd % "--workload cfg4 --graph off --steps 10 --warmup 3" + "   (8 utterances per GPU: the configs[3] shard; 13 steps in total)")
+table('$F/stats_cfg5/s_kernel_stats.csv', '${P}_kernel_stats_cfg5_b96.txt', cmd % "--workload cfg5 --steps 3 --warmup 1" + "   (8 speakers x 30 s, batch 96; 4 steps in total)")
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 g = sum(int(r['TotalDurationNs']) for r in rows if 'gemm' in r['Name'])
 rec = sum(int(r['TotalDurationNs']) for r in rows if 'blstm' in r['Name'])
 print("busy ms/step", round(tot / 8 / 1e6, 2), "gemm %", round(100 * g / tot, 1), "recurrence %", round(100 * rec / tot, 1))
 PY
+ls profiles | grep "^r${R}_" | head -40

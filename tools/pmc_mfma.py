@@ -7,6 +7,7 @@ import re
 import sys
 
 path, batch, gemm = sys.argv[1:4]
+workload = sys.argv[4] if len(sys.argv) > 4 else "cfg3"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(path)):
     name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
@@ -15,7 +16,7 @@ N_SIMD, N_CU = 1024, 256
 out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                   "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT --output-format csv "
                   "-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32",
-       "config": {"batch_per_gpu": int(batch), "gemm": gemm},
+       "config": {"batch_per_gpu": int(batch), "gemm": gemm, "workload": workload},
        "definitions": "per launch averages, summed over the chip by the profiler.  mfma_busy_frac = "
                       "(SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (SQ_BUSY_CU_CYCLES / 256 CUs): the share of the "
                       "kernel's CU-busy time during which a SIMD's matrix pipe is executing (32 cycles per "

@@ -7,12 +7,13 @@ import re
 import sys
 
 fetch_csv, write_csv, batch, gemm = sys.argv[1:5]
+workload = sys.argv[5] if len(sys.argv) > 5 else "cfg3"
 
 
 def per_kernel(path):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        name = re.sub(r"[<(].*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
+        name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))
         acc[name].append(float(r["Counter_Value"]))
     return acc
 
@@ -37,13 +38,16 @@ def avg(d, names):
 gem = [k for k in kernels if k.startswith("gemm_bf16x3")]
 gf, n = avg(F, gem)
 gw, _ = avg(W, gem)
-mf, nm = avg(F, ["maskhead_fwd_kernel", "maskhead_bwd_kernel"])
-mw, _ = avg(W, ["maskhead_fwd_kernel", "maskhead_bwd_kernel"])
+tail = ["istft_kernel<true>", "rfft_frames_kernel<true>"]     # mask head + iSTFT, iSTFT adjoint + mask-head backward
+mf, nm = avg(F, tail)
+mw, _ = avg(W, tail)
+rec = {k: dict(fetch_kb=round(avg(F, [k])[0], 1), write_kb=round(avg(W, [k])[0], 1), launches=avg(W, [k])[1])
+       for k in kernels if k.startswith("blstm_onchip")}
 B = int(batch)
 out = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --output-format csv "
                "-- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32",
-    "config": {"batch_per_gpu": B, "gemm": gemm},
+    "config": {"batch_per_gpu": B, "gemm": gemm, "workload": workload},
     "units": "KB per launch as reported (x1024 = bytes). gfx950 caveat (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
              "under-reports wide (16 B/lane) streaming loads by 2x; 8 B/lane accesses are uncalibrated. Raw "
              "values are stored; 'bytes_raw' = (FETCH+WRITE)*1024, 'bytes_fetch_x2' applies the 2x correction "
@@ -53,8 +57,11 @@ out = {
                         "bytes_raw": int((gf + gw) * 1024), "bytes_fetch_x2": int((2 * gf + gw) * 1024)},
         "maskhead_fwd+bwd": {"launches": nm, "bytes_raw": int((mf + mw) * 1024),
                              "bytes_fetch_x2": int((2 * mf + mw) * 1024),
-                             "algorithmic_bytes": B * 253 * (16 * 4 * 513 + 8 * 513)},
+                             "algorithmic_bytes": B * 253 * (16 * 4 * 513 + 8 * 513),
+                             "note": "the FUSED tail kernels (mask head + iSTFT; iSTFT adjoint + mask-head backward), "
+                                     "per launch; algorithmic_bytes = the unfused mask head's (SURVEY 8d)"},
     },
+    "recurrence": rec,
     "kernels": kernels,
 }
 print(json.dumps(out, indent=1))

@@ -458,14 +458,17 @@ ONCHIP_MAX_T = 2046       # the on-chip kernels' 16-bit granule tag holds the st
 
 
 def recurrence_kernel(N, H, backward, T=0):
-    """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch measured on
-    MI355X at H=300, T=253, profiles/r1_recurrence_microbench.jsonl):
-      forward : on-chip bf16x3 1.4 (8 sequences) .. 1.8 (192) .. 2.25 (768 = one resident round of
-                48 XCD-local clusters x 32), 4.5 at 1536; fp32 cluster 1.5-1.9 up to 128 (never
-                ahead); streaming 4.8 (<= 512) .. 11.4 (2048)
-      backward: fp32 cluster 1.35-1.55 up to 32 sequences (2.9 at 96); on-chip bf16x3 1.7-2.9 up to
-                768, 5.4 at 1024, 8.2 at 2048; streaming 6.0 .. 12.5
-    The streaming kernels remain the path for H the W-stationary kernels do not support."""
+    """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch on MI355X at H=300,
+    T=253, profiles/r2_recurrence_microbench.jsonl, forward / backward):
+      on-chip bf16x3 (compact granules)  1.34 / 1.32 (8 sequences), 1.58 / 1.53 (32), 1.85 / 1.74 (256),
+                                         2.26 / 2.14 (768 = one resident round of 48 XCD-local clusters x
+                                         32 sequences x 1 direction), 4.3 / 4.1 (1536), 8.4 / 8.1 (3072)
+      fp32 cluster                       1.50 / 1.34 (8), 1.50 / 1.57 (32), 7.8 / 21.5 (768)
+      streaming fp32                     4.75 / 6.0 (<= 512), 5.3 / 6.2 (768), 17.0 / 18.7 (3072)
+    Policy: the on-chip kernels for every N where they exist (H >= 128, T <= 2046); round 1 sent backward
+    launches of <= 32 sequences to the fp32 cluster kernel, which the compact granules overtook.  The fp32
+    W-stationary (cluster) and streaming kernels remain selectable (RECURRENCE) as the exact-fp32
+    recurrences, and streaming is the path for H the W-stationary kernels do not support."""
     L = _lib.lib()
     onchip_ok = bool(L.tssep_lstm_onchip_supported(H)) and T <= ONCHIP_MAX_T
     if RECURRENCE in ("stream", "cluster", "onchip"):
@@ -473,8 +476,6 @@ def recurrence_kernel(N, H, backward, T=0):
         return RECURRENCE if ok else "stream"
     if H < 128:
         return "stream"
-    if backward and L.tssep_lstm_cluster_supported(H) and N <= 32:
-        return "cluster"
     if onchip_ok:
         return "onchip"
     return "stream"
