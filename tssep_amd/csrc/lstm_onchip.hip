@@ -340,16 +340,44 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
     // below 160 sequences (a few clusters, pure latency) the hint costs 10 % and is off.  The backward's
     // accesses are 16-B pieces at a 64-B stride (four instructions per line): there the same hint makes
     // partial-line HBM transactions, 1.2-1.6x slower.
+    // Addressing of the io arm: ONE uniform 64-bit base per tensor and step (SGPRs) + a 32-bit per-lane
+    // byte offset fixed for the whole work item (+ an immediate for the unit block q).  The first version
+    // rebuilt a 64-bit per-lane address for each of the 8 copies and 12 stores of a step; at the kernel's
+    // 256-VGPR ceiling the compiler then spilled a few of those values to scratch, and a scratch reload
+    // is a VMEM load: its `s_waitcnt vmcnt(0)` also waits -- the counter retires in order -- for the
+    // asynchronous copies and stores issued just before it.  The ISA of round 1 had six such reloads
+    // inside the io path of every step: six serialised memory round trips per step.
+    // ROW(seq0 + s, t) = ROW(seq0, 0) + s * SN + t * ST in both row layouts (seq0 is a multiple of 32).
+    const int64_t SN = layout ? 1 : T, ST = layout ? 32 : 1;
+    const int64_t row0 = ROW(seq0, 0);
+    unsigned goff[2], coff[2], hoff[2];
+    bool rok[2], uok[4], uval[4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const unsigned lr = (unsigned)((s2 + 16 * hf) * SN);              // row distance from row0
+      rok[hf] = seq0 + s2 + 16 * hf < N;
+      goff[hf] = (lr * 2u * (unsigned)H + (unsigned)usw) * 16u;         // gates: 16 B per unit
+      coff[hf] = (lr * 2u * (unsigned)H + 4u * (unsigned)uq) * 4u;      // cell
+      hoff[hf] = (lr * (unsigned)ldo + 4u * (unsigned)uq) * 4u;         // hout
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uok[q] = 64 * g + 16 * q + usw < H;
+      uval[q] = 64 * g + 4 * uq + q < H;
+    }
+    const bool full4 = vec_ok && 64 * g + 4 * uq + 4 <= H;
+    auto gates_base = [&](int64_t t_) {
+      return reinterpret_cast<char*>(gates) + (((row0 + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16;
+    };
     auto io_dma = [&](int64_t step_, int b_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
+      const char* gb = gates_base(t_);
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const int64_t ns = seq0 + s2 + 16 * hf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int u = 64 * g + 16 * q + usw;
-          if (ns < N && u < H) {
-            const auto* src = (const __attribute__((address_space(1))) void*)(gates + ((ROW(ns, t_) * 2 + dir) * (int64_t)H + u) * 4);
+          if (rok[hf] && uok[q]) {
+            const auto* src = (const __attribute__((address_space(1))) void*)(gb + goff[hf] + q * 256);
             auto* dst = (__attribute__((address_space(3))) void*)&xg[b_][((hf * 4 + q) * 4 + iow) * 64];
             if (stream_nt) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);      // aux 2 = nt
             else __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
@@ -357,42 +385,51 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         }
       }
     };
-    auto io_flush = [&](int64_t step_, int b_) {
+    // flush of step_: cell state + h first (their addresses may be reloaded from scratch: harmless while
+    // nothing younger is in flight), then -- after the copies of step_ + 2 have been issued -- the gates
+    auto io_flush_ch = [&](int64_t step_) {
       const int64_t t_ = dir ? T - 1 - step_ : step_;
+      char* cb = reinterpret_cast<char*>(cell) + (((row0 + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4;
+      char* hb = reinterpret_cast<char*>(hout) + ((row0 + t_ * ST) * ldo + dir * dstride + 64 * g) * 4;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
+        if (!rok[hf]) continue;
         const int s = s2 + 16 * hf;
-        const int64_t ns = seq0 + s;
-        if (ns >= N) continue;
-        const int64_t rowg = (ROW(ns, t_) * 2 + dir) * (int64_t)H;
-        const int64_t rowh = ROW(ns, t_) * ldo + dir * dstride;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int u = 64 * g + 16 * q + usw;
-          if (u < H) {
-            const f32x4 v = xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane];
-            f32x4* dst = reinterpret_cast<f32x4*>(gates + (rowg + u) * 4);
-            if (stream_nt) __builtin_nontemporal_store(v, dst); else *dst = v;
-          }
-        }
-        const int u4 = 64 * g + 4 * uq;
         const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s * PUBPITCH + 4 * uq);
         const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s * PUBPITCH + 4 * uq);
-        if (vec_ok && u4 + 4 <= H) {
+        float* cdst = reinterpret_cast<float*>(cb + coff[hf]);
+        float* hdst = reinterpret_cast<float*>(hb + hoff[hf]);
+        if (full4) {
           if (stream_nt) {
-            __builtin_nontemporal_store(cq, reinterpret_cast<f32x4*>(cell + rowg + u4));
-            __builtin_nontemporal_store(hq, reinterpret_cast<f32x4*>(hout + rowh + u4));
+            __builtin_nontemporal_store(cq, reinterpret_cast<f32x4*>(cdst));
+            __builtin_nontemporal_store(hq, reinterpret_cast<f32x4*>(hdst));
           } else {
-            *reinterpret_cast<f32x4*>(cell + rowg + u4) = cq;
-            *reinterpret_cast<f32x4*>(hout + rowh + u4) = hq;
+            *reinterpret_cast<f32x4*>(cdst) = cq;
+            *reinterpret_cast<f32x4*>(hdst) = hq;
           }
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (u4 + q < H) {
-              cell[rowg + u4 + q] = cq[q];
-              hout[rowh + u4 + q] = hq[q];
+            if (uval[q]) {
+              cdst[q] = cq[q];
+              hdst[q] = hq[q];
             }
+        }
+      }
+    };
+    auto io_flush_g = [&](int64_t step_, int b_) {
+      const int64_t t_ = dir ? T - 1 - step_ : step_;
+      char* gb = gates_base(t_);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        if (!rok[hf]) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (uok[q]) {
+            const f32x4 v = xg[b_][((hf * 4 + q) * 4 + iow) * 64 + lane];
+            f32x4* dst = reinterpret_cast<f32x4*>(gb + goff[hf] + q * 256);
+            if (stream_nt) __builtin_nontemporal_store(v, dst); else *dst = v;
+          }
         }
       }
     };
@@ -517,8 +554,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         // in order, so loads issued after the stores would also wait for their acknowledgements
         int b2 = buf + 2;
         if (b2 >= 3) b2 -= 3;
+        io_flush_ch(step);
         if (step + 2 < T) io_dma(step + 2, b2);
-        io_flush(step, buf);
+        io_flush_g(step, buf);
       }
       buf = buf == 2 ? 0 : buf + 1;
     }
@@ -550,6 +588,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float red[8 * 64 * 16];          // tiles 8/9 partials
   __shared__ __attribute__((aligned(16))) float psum[SEQS * PPITCH];       // [seq][unit] partial dh
   __shared__ u32x4 wl_sh[4 * 512];        // lo words of the shared-tile fragments (register relief)
+  // the per-thread carries of the cell backward (dc chain, c_{t-1} prefetched a step ahead) rest in LDS
+  // across the MFMA phase -- the high-pressure zone, where the compiler otherwise spilled a W fragment to
+  // scratch and reloaded it right behind the d(gates) stores: `s_waitcnt vmcnt(0)` for the reload then
+  // waited for the store acknowledgements of every step
+  __shared__ f32x4 carry[2 * 512];
   __shared__ int s_fail, s_mem[4];
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -576,6 +619,17 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
     const int64_t seq0 = (work >> 1) * SEQS;
     const int64_t n = seq0 + s;
     const bool nvalid = n < N;
+    // addressing as in the forward: one uniform base per tensor and step + 32-bit per-lane byte offsets
+    // (ROW(seq0 + s, t) = ROW(seq0, 0) + s * SN + t * ST in both row layouts), instead of 64-bit per-lane
+    // addresses rebuilt for every access: fewer live registers, fewer scratch reloads -- each of which
+    // drains the in-order memory counter, i.e. waits for the d(gates) stores issued just before it
+    const int64_t SN = layout ? 1 : T, ST = layout ? 32 : 1;
+    const int64_t row0 = ROW(seq0, 0);
+    const unsigned lr = (unsigned)(s * SN);
+    const unsigned goffb = (lr * 2u * (unsigned)H + 4u * (unsigned)uq) * 16u;       // gates (16 B per unit)
+    const unsigned coffb = (lr * 2u * (unsigned)H + 4u * (unsigned)uq) * 4u;        // cell
+    const unsigned hoffb = (lr * (unsigned)ldo + 4u * (unsigned)uq) * 4u;           // dhout
+    const bool full = nvalid && unit0 + 4 <= H && vec_ok;
     // stationary W_hh^T fragments: own tile (16 k-steps) + k-steps {2w, 2w+1} of tiles 8 and 9
     u32x4 wh[20], wl[16];
     {
@@ -592,8 +646,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         wl_sh[x * 512 + tid] = wbase[(((int64_t)tile * 16 + ks) * 2 + 1) * 64];
       }
     }
-    float dcc[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cnext = {0.f, 0.f, 0.f, 0.f};
+    carry[tid] = f32x4{0.f, 0.f, 0.f, 0.f};            // dcc
+    carry[512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};      // c_{t-1} loaded by the previous step
     float* pl = xpayload + work * 2 * G * SEQS * Hp;            // 8-byte granules of 2 values: 4 B per value
     const __amdgpu_buffer_rsrc_t prs =
         __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 4, 0x00020000);
@@ -605,30 +659,34 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       const int64_t tp = dir ? t + 1 : t - 1;
       // ---- (1) this thread's saved activations (issued before waiting on the exchange)
       // (the cell state of this step is the "previous cell state" the last step loaded)
-      f32x4 g4[4], ct = cnext, cp = {0.f, 0.f, 0.f, 0.f}, dh = cp;
+      f32x4 g4[4], ct = carry[512 + tid], cp = {0.f, 0.f, 0.f, 0.f}, dh = cp;
+      f32x4 dcc = carry[tid];
 #pragma unroll
       for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int64_t cell0 = (ROW(n, t) * 2 + dir) * (int64_t)H + unit0;
-      const bool full = nvalid && unit0 + 4 <= H && vec_ok;
+      char* gb = reinterpret_cast<char*>(gates) + (((row0 + t * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16 + goffb;
+      const char* cb = reinterpret_cast<const char*>(cell) + (((row0 + t * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
+      const char* cpb = reinterpret_cast<const char*>(cell) + (((row0 + tp * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
+      const char* hb = reinterpret_cast<const char*>(dhout) + ((row0 + t * ST) * ldo + dir * dstride + 64 * g) * 4 + hoffb;
       if (full) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
-        if (step == 0) ct = *reinterpret_cast<const f32x4*>(cell + cell0);
-        if (has_prev)
-          cp = *reinterpret_cast<const f32x4*>(cell + (ROW(n, tp) * 2 + dir) * (int64_t)H + unit0);
-        dh = *reinterpret_cast<const f32x4*>(dhout + ROW(n, t) * ldo + dir * dstride + unit0);
+        for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gb + 16 * q);
+        if (step == 0) ct = *reinterpret_cast<const f32x4*>(cb);
+        if (has_prev) cp = *reinterpret_cast<const f32x4*>(cpb);
+        dh = *reinterpret_cast<const f32x4*>(hb);
       } else if (nvalid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (unit0 + q < H) {
-            g4[q] = *reinterpret_cast<const f32x4*>(gates + (cell0 + q) * 4);
-            if (step == 0) ct[q] = cell[cell0 + q];
-            if (has_prev) cp[q] = cell[(ROW(n, tp) * 2 + dir) * (int64_t)H + unit0 + q];
-            dh[q] = dhout[ROW(n, t) * ldo + dir * dstride + unit0 + q];
+            g4[q] = *reinterpret_cast<const f32x4*>(gb + 16 * q);
+            if (step == 0) ct[q] = reinterpret_cast<const float*>(cb)[q];
+            if (has_prev) cp[q] = reinterpret_cast<const float*>(cpb)[q];
+            dh[q] = reinterpret_cast<const float*>(hb)[q];
           }
       }
-      cnext = cp;
       // ---- (2) reduce-scatter: add the G partial dh published with tag = step (fixed order)
+      // (issuing the gather BEFORE the activation loads -- so that it does not retire behind their HBM
+      // latency -- was tried: the compiler then waits for everything at the first tag check anyway and
+      // spills 16 registers)
       if (step > 0) {
         const int slot = (int)((step - 1) & 1);
         const unsigned want = tagbase | (unsigned)step;
@@ -684,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           d[1] = dc * cp[q] * g4[q][1] * (1.f - g4[q][1]);
           d[2] = dc * g4[q][0] * (1.f - g4[q][2] * g4[q][2]);
           d[3] = d_o * g4[q][3] * (1.f - g4[q][3]);
-          *reinterpret_cast<f32x4*>(gates + (cell0 + q) * 4) = d;
+          *reinterpret_cast<f32x4*>(gb + 16 * q) = d;
         }
         split2(d[0], d[1], hi[2 * q], lo[2 * q]);
         split2(d[2], d[3], hi[2 * q + 1], lo[2 * q + 1]);
@@ -696,6 +754,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         *reinterpret_cast<u32x4*>(dg_lo + o) = u32x4{lo[0], lo[1], lo[2], lo[3]};
         *reinterpret_cast<u32x4*>(dg_lo + o + 16) = u32x4{lo[4], lo[5], lo[6], lo[7]};
       }
+      carry[tid] = dcc;                 // same thread reads them back at the next step
+      carry[512 + tid] = cp;
       __syncthreads();
       if (s_fail) {
         if (tid == 0) atomicExch(err, 4);
