@@ -424,6 +424,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
 // once per 256 output columns instead of once per 128: a third less L2 -> L1 line traffic per MFMA
 // (A + B lines per 16-k step and 256 x 256 outputs: 64 KB against 96 KB), and a thread stages 16
 // instead of 24 raw values.  Used where the padding of N to a multiple of 256 costs < 10 %.
+// (A second raw-tile register set in this variant -- loads of tile t + 3 issued during stage t, two stages of
+// latency budget, 246 VGPRs, no spills -- measured 0..8 % SLOWER per shape and 0.4 % slower per step in an
+// alternating A/B: the loop is not load-latency bound, as round 1 found for the 128 x 128 kernel.)
 constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH;
 
