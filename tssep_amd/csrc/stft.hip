@@ -53,6 +53,17 @@ __device__ __forceinline__ void fft8(float2 (&v)[8]) {
   v[3] = cadd(b6, b7); v[7] = csub(b6, b7);
 }
 
+// tw2[lane + 64 r] = exp(-2 pi i (lane + 64 r) / 1024) = tw2[lane] * exp(-2 pi i r / 16): one per-lane value
+// loaded once per kernel and eight compile-time constants, instead of eight table loads from global memory
+// in every frame's dependent chain
+__device__ __forceinline__ float2 tw16(int r) {
+  constexpr float c[8] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                          0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f};
+  constexpr float sn[8] = {0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
+                           -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+  return make_float2(c[r], sn[r]);
+}
+
 // 512-point forward FFT by one wave.  In: v[r] = z[lane + 64 r].  Out: buf[PADI(k)] = Z[k].
 // twl[k] = exp(-2 pi i k / 512) (LDS copy).  The line is private to the wave: LDS operations of one
 // wave execute in order, so the hand-offs between lanes need only a wave-level fence (the compiler
@@ -96,8 +107,11 @@ __device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* buf, const f
 // the epilogue reads the logit (4 B) and the observation bin (8 B, shared by the K speakers of an
 // utterance: L2) and writes d(logit) = Re(conj(Obs) dEst) m (1 - m), m = sigmoid(logit) -- the chain
 // adjoint -> mask head moves 8 K F + 8 F bytes per frame instead of 24 K F + 8 F.
+#ifndef TSSEP_RFFT_OCC
+#define TSSEP_RFFT_OCC 3
+#endif
 template <bool MASKED>
-__global__ __launch_bounds__(256) void rfft_frames_kernel(
+__global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
     const float* __restrict__ x, int64_t rows, int64_t N, int64_t T, int shift, int pad_left,
     const float* __restrict__ window, const float2* __restrict__ tw, float2* __restrict__ X,
     float s_in, float s_edge, int iters, const float* __restrict__ logit,
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
   __syncthreads();
-  const float2* tw2 = tw + NH;
+  const float2 tw2_lane = tw[NH + lane];
   const int64_t total = rows * T;
   for (int it = 0; it < iters; ++it) {
     const int64_t fidx = ((int64_t)blockIdx.x * iters + it) * 4 + wave;
@@ -116,23 +130,44 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
     const int64_t t = valid ? fidx - row * T : 0;
     const int64_t base = t * shift - pad_left;
     const float* xr = x + row * N;
-    // (row * N + base) even and x 8-byte aligned -> the sample pair is one aligned float2
-    const bool pair_ok = (((row * N + base) & 1) == 0) && ((((uintptr_t)x) & 7u) == 0);
+    // Sample loads, branch-free per lane: the eight loads of a frame go out back to back and are waited for
+    // once.  (With per-lane branches around them the compiler waited for each load before issuing the
+    // next: eight serialised round trips per frame.)  Wave-uniform fast path: N even, x 8-byte aligned and
+    // the frame start even -> every sample pair is one aligned float2 that lies inside the row or outside
+    // it as a whole; otherwise two clamped 4-byte loads per pair.
+    const bool fast = ((N & 1) == 0) && ((base & 1) == 0) && ((((uintptr_t)x) & 7u) == 0);
     float2 v[8];
+    if (!valid) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int n2 = 2 * (lane + 64 * r);
-      const int64_t i0 = base + n2;
-      float a = 0.f, b = 0.f;
-      if (valid && pair_ok && i0 >= 0 && i0 + 1 < N) {            // both samples inside: one 8-byte load
-        const float2 xv = *reinterpret_cast<const float2*>(xr + i0);
-        a = xv.x; b = xv.y;
-      } else if (valid) {
-        if (i0 >= 0 && i0 < N) a = xr[i0];
-        if (i0 + 1 >= 0 && i0 + 1 < N) b = xr[i0 + 1];
+      for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
+    } else if (fast) {
+      float2 xv[8];
+      bool in[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t i0 = base + 2 * (lane + 64 * r);
+        in[r] = i0 >= 0 && i0 + 1 < N;
+        xv[r] = *reinterpret_cast<const float2*>(xr + (in[r] ? i0 : 0));
       }
-      const float2 wv = *reinterpret_cast<const float2*>(window + n2);
-      v[r] = make_float2(a * wv.x, b * wv.y);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
+        v[r] = make_float2(in[r] ? xv[r].x * wv.x : 0.f, in[r] ? xv[r].y * wv.y : 0.f);
+      }
+    } else {
+      float xa[8], xb[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t i0 = base + 2 * (lane + 64 * r), i1 = i0 + 1;
+        xa[r] = xr[i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0)];
+        xb[r] = xr[i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int64_t i0 = base + 2 * (lane + 64 * r), i1 = i0 + 1;
+        const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
+        v[r] = make_float2((i0 >= 0 && i0 < N) ? xa[r] * wv.x : 0.f, (i1 >= 0 && i1 < N) ? xb[r] * wv.y : 0.f);
+      }
     }
     float2* buf = line[wave];
     fft512_wave(v, buf, twl, lane);
@@ -158,7 +193,7 @@ __global__ __launch_bounds__(256) void rfft_frames_kernel(
         const int km = (NH - k) & (NH - 1);
         float2 zm = buf[PADI(km)];
         zm.y = -zm.y;
-        const float2 u = cmul(tw2[k], csub(zk, zm));
+        const float2 u = cmul(cmul(tw2_lane, tw16(r)), csub(zk, zm));
         float2 o = make_float2(0.5f * (zk.x + zm.x + u.y), 0.5f * (zk.y + zm.y - u.x));
         if (k == 0) {
           o.x *= s_edge; o.y = 0.f;
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
   const int c = blockIdx.x;
   for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
   __syncthreads();
-  const float2* tw2 = tw + NH;
+  const float2 tw2_lane = tw[NH + lane];
   const int64_t t_lo = (int64_t)c * hcb;   // hop h of this chunk sums frames t_lo + h .. t_lo + h + 3
   const int64_t n0 = t_lo * 256;
   const int64_t total_hops = (N + 255) / 256;
@@ -258,7 +293,7 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
         xm.y = -xm.y;
         if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
         const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
-        float2 w = tw2[k];
+        float2 w = cmul(tw2_lane, tw16(r));
         w.y = -w.y;
         const float2 o = cmul(make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y)), w);
         // Zi = E + i O ; feed conj(Zi) to the forward FFT
@@ -280,19 +315,36 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
         *reinterpret_cast<float2*>(&slot[2 * (lane + 64 * r)]) = make_float2(0.f, 0.f);
     }
     __syncthreads();        // frames <= 4 it + 3 are in the ring
-    // emit the hops completed by this iteration: h in [4 it - 3, 4 it] (4 x 256 samples, 4 per thread)
+    // emit the hops completed by this iteration: h in [4 it - 3, 4 it] (4 x 256 samples, 4 per thread).
+    // The target samples are requested for all four hops first: interleaved with the stores of y the
+    // compiler kept each load behind the previous store and waited for it (four serialised round trips
+    // per iteration, a third of a workgroup's time).
+    {
+      float tv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4];
+      bool em[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int h = 4 * it - 3 + q;
-      if (h < 0 || h >= hops) continue;                 // (uniform)
-      const int64_t n = n0 + (int64_t)h * 256 + tid;
-      if (n < N) {
+      for (int q = 0; q < 4; ++q) {
+        const int h = 4 * it - 3 + q;
+        const int64_t n = n0 + (int64_t)h * 256 + tid;
+        em[q] = h >= 0 && h < hops && n < N;
+        if (em[q] && tr) tv[q] = tr[n];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = 4 * it - 3 + q;
+        if (!em[q]) continue;
         float s = fr[h % RING][tid + 768];
         s += fr[(h + 1) % RING][tid + 512];
         s += fr[(h + 2) % RING][tid + 256];
         s += fr[(h + 3) % RING][tid];
-        yr[n] = s;
-        if (tr) asum += fabsf(s - tr[n]);
+        sv[q] = s;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!em[q]) continue;
+        const int h = 4 * it - 3 + q;
+        yr[n0 + (int64_t)h * 256 + tid] = sv[q];
+        if (tr) asum += fabsf(sv[q] - tv[q]);
       }
     }
     __syncthreads();        // the next iteration overwrites the slots of frames <= 4 it
