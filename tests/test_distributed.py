@@ -155,6 +155,24 @@ def test_model_level_data_parallel_equivalence():
     torch.testing.assert_close(torch.tensor(sum(r[2] for r in res)), torch.tensor(float(loss.detach())), rtol=1e-5, atol=1e-6)
 
 
+def _replica_worker(rank, world, port, q):
+    from tssep_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    assert D.init_from_env() == (rank, world, rank) and D.get_rank() == rank and D.world_size() == world
+    t = torch.arange(5.0) + 10 * rank
+    same_before = D.replicas_agree(t)
+    D.broadcast_(t, src=0)
+    q.put((rank, same_before, D.replicas_agree(t), t.tolist()))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_replica_check_world2():
+    res = _spawn(_replica_worker, 2)
+    for rank, before, after, values in res:
+        assert before is False and after is True and values == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
 def test_bucket_grads_are_views():
     lin = torch.nn.Linear(4, 2)
     b = GradBucket(lin.parameters())

@@ -82,14 +82,50 @@ def init_from_env(backend=None):
     rank, world, local_rank = env_rank()
     on_gpu = torch.cuda.is_available()
     if on_gpu:
+        if os.environ.get("TSSEP_DIST_BACKEND") == "gloo":       # several ranks may share a GPU there
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if on_gpu else "gloo")
+        # TSSEP_DIST_BACKEND=gloo: several ranks on ONE GPU (tests, debugging; RCCL refuses that)
+        backend = backend or os.environ.get("TSSEP_DIST_BACKEND") or ("nccl" if on_gpu else "gloo")
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
+
+
+def _staged(tensor):
+    """gloo moves host memory: device tensors are staged through the host there (RCCL works in place)."""
+    return tensor.is_cuda and dist.get_backend() == "gloo"
+
+
+def broadcast_(tensor, src=0):
+    """In-place broadcast of `tensor` from rank `src` (no-op without a process group)."""
+    if world_size() == 1:
+        return tensor
+    if _staged(tensor):
+        host = tensor.cpu()
+        dist.broadcast(host, src=src)
+        tensor.copy_(host)
+    else:
+        dist.broadcast(tensor, src=src)
+    return tensor
+
+
+def replicas_agree(tensor):
+    """True when `tensor` holds the same values on every rank (two scalar all-reduces of its fp64 sum and
+    its fp64 sum of squares: MIN and MAX must coincide)."""
+    if world_size() == 1:
+        return True
+    t = tensor.detach().double()
+    stat = torch.stack([t.sum(), (t * t).sum()])
+    if _staged(stat):
+        stat = stat.cpu()
+    lo, hi = stat.clone(), stat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo.cpu(), hi.cpu()))
 
 
 def world_size():

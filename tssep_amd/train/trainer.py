@@ -116,7 +116,7 @@ class Trainer(Configurable):
             # permutation / shuffle stream of its own per rank, derived from the current state so that a
             # seeded run stays reproducible
             for t in (self.optimizer.flat_param, self.optimizer.exp_avg, self.optimizer.exp_avg_sq):
-                torch.distributed.broadcast(t, src=0)
+                _dist.broadcast_(t, src=0)
             np.random.seed((int(np.random.get_state()[1][0]) + 7919 * rank) & 0x7FFFFFFF)
         chief = rank == 0
         stop_n, stop_unit = self.stop_trigger
@@ -147,5 +147,9 @@ class Trainer(Configurable):
             (self.storage_dir / "log" / "history.json").write_text(json.dumps(
                 dict(iteration=self.iteration, epoch=self.epoch, loss=self.history)))
         if world > 1:
+            # identical replicas fed with summed gradients must still be identical: anything else is a
+            # lost or doubled all-reduce
+            if not _dist.replicas_agree(self.optimizer.flat_param):
+                raise RuntimeError(f"rank {rank}: the parameter replicas diverged during data-parallel training")
             torch.distributed.barrier()              # nobody leaves before rank 0 has written its files
         return self.history
