@@ -247,7 +247,10 @@ def test_gemm_store_remaps(gemm_precision):
     close(C, ref, rtol=tol, atol=tol, name="logit remap")
 
 
-@pytest.mark.parametrize("rows,N", [(3, 4000), (2, 64000), (1, 1023)])
+# odd lengths take the clamped 4-byte load path of the frame loader, N < one hop / one window and N just past a
+# chunk boundary of the rolling overlap-add (64 hops = 16 384 samples) exercise the ring's edges
+@pytest.mark.parametrize("rows,N", [(3, 4000), (2, 64000), (1, 1023), (2, 255), (1, 257), (3, 16385), (2, 16640),
+                                    (1, 33333)])
 def test_stft_istft(rows, N):
     torch.manual_seed(5)
     h = H()
@@ -275,7 +278,7 @@ def test_stft_istft(rows, N):
     close(xr, x, rtol=1e-4, atol=2e-5, name="round trip")
 
 
-@pytest.mark.parametrize("B,K,N", [(1, 3, 2000), (2, 4, 64000), (3, 8, 9300)])
+@pytest.mark.parametrize("B,K,N", [(1, 3, 2000), (2, 4, 64000), (3, 8, 9300), (1, 1, 300), (2, 2, 16385), (1, 5, 7777)])
 def test_mask_istft_fused_against_oracle_and_unfused_chain(B, K, N):
     """tssep_mask_istft_fwd / _bwd: sigmoid (net.py:983) -> Masking (enhancer.py:98-100) -> istft
     (model.py:661-664) in one kernel each way, against (a) the CPU oracle with autograd and (b) the unfused
