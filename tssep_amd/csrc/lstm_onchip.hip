@@ -656,36 +656,49 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         __builtin_amdgcn_make_buffer_rsrc(pl, 0, 2 * G * SEQS * Hp * 4, 0x00020000);
     __syncthreads();
 
-    for (int64_t step = 0; step < T; ++step) {
-      const int64_t t = dir ? step : T - 1 - step;
-      const bool has_prev = step + 1 < T;
-      const int64_t tp = dir ? t + 1 : t - 1;
-      // ---- (1) this thread's saved activations (issued before waiting on the exchange)
-      // (the cell state of this step is the "previous cell state" the last step loaded)
-      f32x4 g4[4], ct = carry[512 + tid], cp = {0.f, 0.f, 0.f, 0.f}, dh = cp;
-      f32x4 dcc = carry[tid];
+    // ---- (1) this thread's saved activations, software-pipelined: the loads of step t + 1 are issued at
+    // the END of step t (behind its publish), not at the start of step t + 1 in front of the gather -- a
+    // wave's memory counter retires in order, so a gather issued behind HBM loads returns no earlier than
+    // they do, even when its granules have long been sitting in the L2.  The values are not live across
+    // the MFMA phase (same register pressure as before).
+    f32x4 g4[4], ct0 = {0.f, 0.f, 0.f, 0.f}, cp = ct0, dh = ct0;
+    char* gb = nullptr;
+    auto load_act = [&](int64_t step_) {
+      const int64_t t_ = dir ? step_ : T - 1 - step_;
+      const int64_t tp_ = dir ? t_ + 1 : t_ - 1;
+      const bool prev_ = step_ + 1 < T;
+      cp = f32x4{0.f, 0.f, 0.f, 0.f};
+      dh = cp;
 #pragma unroll
       for (int q = 0; q < 4; ++q) g4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-      char* gb = reinterpret_cast<char*>(gates) + (((row0 + t * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16 + goffb;
-      const char* cb = reinterpret_cast<const char*>(cell) + (((row0 + t * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
-      const char* cpb = reinterpret_cast<const char*>(cell) + (((row0 + tp * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
-      const char* hb = reinterpret_cast<const char*>(dhout) + ((row0 + t * ST) * ldo + dir * dstride + 64 * g) * 4 + hoffb;
+      gb = reinterpret_cast<char*>(gates) + (((row0 + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16 + goffb;
+      const char* cb = reinterpret_cast<const char*>(cell) + (((row0 + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
+      const char* cpb = reinterpret_cast<const char*>(cell) + (((row0 + tp_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 4 + coffb;
+      const char* hb = reinterpret_cast<const char*>(dhout) + ((row0 + t_ * ST) * ldo + dir * dstride + 64 * g) * 4 + hoffb;
       if (full) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) g4[q] = *reinterpret_cast<const f32x4*>(gb + 16 * q);
-        if (step == 0) ct = *reinterpret_cast<const f32x4*>(cb);
-        if (has_prev) cp = *reinterpret_cast<const f32x4*>(cpb);
+        if (step_ == 0) ct0 = *reinterpret_cast<const f32x4*>(cb);
+        if (prev_) cp = *reinterpret_cast<const f32x4*>(cpb);
         dh = *reinterpret_cast<const f32x4*>(hb);
       } else if (nvalid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (unit0 + q < H) {
             g4[q] = *reinterpret_cast<const f32x4*>(gb + 16 * q);
-            if (step == 0) ct[q] = reinterpret_cast<const float*>(cb)[q];
-            if (has_prev) cp[q] = reinterpret_cast<const float*>(cpb)[q];
+            if (step_ == 0) ct0[q] = reinterpret_cast<const float*>(cb)[q];
+            if (prev_) cp[q] = reinterpret_cast<const float*>(cpb)[q];
             dh[q] = reinterpret_cast<const float*>(hb)[q];
           }
       }
+    };
+    load_act(0);
+    carry[512 + tid] = ct0;                 // the cell state of step 0 (later steps: what the previous one loaded)
+
+    for (int64_t step = 0; step < T; ++step) {
+      const bool has_prev = step + 1 < T;
+      const f32x4 ct = carry[512 + tid];
+      f32x4 dcc = carry[tid];
       // ---- (2) reduce-scatter: add the G partial dh published with tag = step (fixed order)
       // (issuing the gather BEFORE the activation loads -- so that it does not retire behind their HBM
       // latency -- was tried: the compiler then waits for everything at the first tag check anyway and
@@ -838,6 +851,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
           }
         }
       }
+      if (has_prev) load_act(step + 1);     // prefetch: in flight while the peers finish their step
       // no barrier here: dg_* is rewritten after the next step's gather, psum/red after its barrier
     }
   }
