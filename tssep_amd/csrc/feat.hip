@@ -69,54 +69,114 @@ __global__ __launch_bounds__(64) void feat_init_kernel(void* ws, int64_t B, cons
   }
 }
 
+// pass 1.  A block prepares the mel filterbank ONCE in LDS -- the filters' supports [lo, hi) and their
+// weights packed back to back (triangular htk filters overlap pairwise: < 2 F weights in total) -- and
+// then walks FPW frames per wave.  (Round 1 read range and weights of each of the 40 filters from global
+// memory inside every frame's loop: 80 dependent load round trips per frame, 0.7 TB/s.)  The sums keep
+// their order (lane-strided partial sums, butterfly): results are bit-identical to round 1.
+constexpr int FPW = 4;            // frames per wave and block
+constexpr int CWMAX = 2 * MAXF;   // packed filter weights
+constexpr int LMELS = 128;        // filters whose table fits in LDS (40 in every shipped config)
+
 __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restrict__ X, int64_t B,
                                                          int64_t T, int F,
                                                          const float* __restrict__ fb, int n_mels,
                                                          int n_mfcc, void* ws) {
   __shared__ float pw[4][MAXF];
+  __shared__ float cw[CWMAX];
+  __shared__ int clo[LMELS], chi[LMELS], coff[LMELS + 1];
+  __shared__ int s_packed;
   FeatWs w = feat_ws(ws, B, n_mels);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t frame = (int64_t)blockIdx.x * 4 + wave;
-  const bool valid = frame < B * T;
-  float amax = 0.f;
-  if (valid) {
-    const float2* x = X + frame * F;
-    for (int f = lane; f < F; f += 64) {
-      const float2 v = x[f];
-      const float p = v.x * v.x + v.y * v.y;
-      pw[wave][f] = p;
-      amax = fmaxf(amax, sqrtf(p));
-    }
-  }
-  __syncthreads();
-  if (!valid) return;
-  amax = wave_max(amax);
-  if (lane == 0) atomicMax(w.umax + frame / T, ord(amax));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- filterbank -> LDS
   if (n_mfcc > 0) {
-    // all 64 lanes share every filter's band (fixed-order butterfly sum: deterministic); lane
-    // m % 64 keeps the result.  A lane per filter walked the widest band (~100 bins) serially
-    // through dependent, strided global loads of the filterbank.
-    float dbmax = -INFINITY;
-    for (int m0 = 0; m0 < n_mels; m0 += 64) {
-      float mine = 0.f;
-      const int mm = n_mels - m0 < 64 ? n_mels - m0 : 64;
-      for (int j = 0; j < mm; ++j) {
-        const int m = m0 + j;
-        const int lo = w.range[2 * m], hi = w.range[2 * m + 1];
-        const float* frow = w.fbT + (int64_t)m * MAXF;
-        float s = 0.f;
-        for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
-        s = wave_sum(s);
-        if (lane == j) mine = s;
+    if (tid < n_mels && tid < LMELS) {
+      clo[tid] = w.range[2 * tid];
+      chi[tid] = w.range[2 * tid + 1];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      const int nm = n_mels < LMELS ? n_mels : LMELS;
+      for (int m = 0; m < nm; ++m) {
+        coff[m] = tot;
+        const int wd = chi[m] - clo[m];
+        tot += wd > 0 ? wd : 0;
       }
-      if (lane < mm) {
-        const float db = 10.0f * log10f(fmaxf(mine, 1e-10f));
-        w.db[frame * n_mels + m0 + lane] = db;
-        dbmax = fmaxf(dbmax, db);
+      coff[nm] = tot;
+      s_packed = (n_mels <= LMELS && tot <= CWMAX) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_packed)
+      for (int m = wave; m < n_mels; m += 4)
+        for (int f = clo[m] + lane; f < chi[m]; f += 64) cw[coff[m] + f - clo[m]] = w.fbT[(int64_t)m * MAXF + f];
+    __syncthreads();
+  }
+  const bool packed = n_mfcc > 0 && s_packed;
+  float dbmax = -INFINITY;
+  for (int it = 0; it < FPW; ++it) {
+    const int64_t frame = ((int64_t)blockIdx.x * FPW + it) * 4 + wave;
+    if (frame >= B * T) break;                          // (wave-uniform; pw rows are private to a wave)
+    const float2* x = X + frame * F;
+    float amax = 0.f;
+    // all loads of the frame first (F <= 1025: at most 17 per lane), then the arithmetic
+    float2 xv[17];
+#pragma unroll
+    for (int r = 0; r < 17; ++r) {
+      const int f = lane + 64 * r;
+      xv[r] = f < F ? x[f] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 17; ++r) {
+      const int f = lane + 64 * r;
+      if (f < F) {
+        const float p = xv[r].x * xv[r].x + xv[r].y * xv[r].y;
+        pw[wave][f] = p;
+        amax = fmaxf(amax, sqrtf(p));
       }
     }
+    // pw[wave] is private to the wave: LDS operations of one wave execute in order, a wave-level fence
+    // keeps the compiler from reordering the row's writes and the band reads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    amax = wave_max(amax);
+    if (lane == 0) atomicMax(w.umax + frame / T, ord(amax));
+    if (n_mfcc > 0) {
+      // all 64 lanes share every filter's band (fixed-order butterfly sum: deterministic); lane
+      // m % 64 keeps the result
+      for (int m0 = 0; m0 < n_mels; m0 += 64) {
+        float mine = 0.f;
+        const int mm = n_mels - m0 < 64 ? n_mels - m0 : 64;
+        for (int j = 0; j < mm; ++j) {
+          const int m = m0 + j;
+          float s = 0.f;
+          if (packed) {
+            const int lo = clo[m], hi = chi[m];
+            const float* frow = cw + coff[m] - lo;
+            for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
+          } else {
+            const int lo = w.range[2 * m], hi = w.range[2 * m + 1];
+            const float* frow = w.fbT + (int64_t)m * MAXF;
+            for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
+          }
+          s = wave_sum(s);
+          if (lane == j) mine = s;
+        }
+        if (lane < mm) {
+          const float db = 10.0f * log10f(fmaxf(mine, 1e-10f));
+          w.db[frame * n_mels + m0 + lane] = db;
+          dbmax = fmaxf(dbmax, db);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // band reads done before the next frame's row
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  if (n_mfcc > 0) {
     dbmax = wave_max(dbmax);
-    if (lane == 0) atomicMax(w.gmax + (blockIdx.x & (GSLOTS - 1)), ord(dbmax));
+    if (lane == 0 && dbmax > -INFINITY) atomicMax(w.gmax + (blockIdx.x & (GSLOTS - 1)), ord(dbmax));
   }
 }
 
@@ -153,9 +213,16 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
   const float norm = unord(w.umax[frame / T]);
   const float scale = (float)(M_E - 1.0) / norm;
   const float2* x = X + frame * F;
-  for (int f = lane; f < F; f += 64) {
-    const float2 v = x[f];
-    o[n_mfcc + f] = log1pf(sqrtf(v.x * v.x + v.y * v.y) * scale);
+  float2 xv[17];                      // all loads of the frame first (F <= 1025), then the arithmetic
+#pragma unroll
+  for (int r = 0; r < 17; ++r) {
+    const int f = lane + 64 * r;
+    xv[r] = f < F ? x[f] : make_float2(0.f, 0.f);
+  }
+#pragma unroll
+  for (int r = 0; r < 17; ++r) {
+    const int f = lane + 64 * r;
+    if (f < F) o[n_mfcc + f] = log1pf(sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y) * scale);
   }
 }
 
@@ -179,7 +246,8 @@ extern "C" int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F, const
   const int nm = n_mels > 0 ? n_mels : 1;
   hipLaunchKernelGGL(feat_init_kernel, dim3((unsigned)nm), dim3(64), 0, s, ws, B, fb, F, n_mels);
   const unsigned blocks = (unsigned)((B * T + 3) / 4);
-  hipLaunchKernelGGL(feat_pass1_kernel, dim3(blocks), dim3(256), 0, s, (const float2*)X, B, T, F,
+  const unsigned blocks1 = (unsigned)((B * T + 4 * FPW - 1) / (4 * FPW));
+  hipLaunchKernelGGL(feat_pass1_kernel, dim3(blocks1), dim3(256), 0, s, (const float2*)X, B, T, F,
                      fb, n_mels, n_mfcc, ws);
   hipLaunchKernelGGL(feat_pass2_kernel, dim3(blocks), dim3(256), 0, s, (const float2*)X, B, T, F,
                      dct, n_mels, n_mfcc, top_db, out, ld_out, ws);
