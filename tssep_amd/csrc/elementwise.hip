@@ -33,13 +33,62 @@ __global__ __launch_bounds__(256) void cond_mul_fwd_kernel(
     float* __restrict__ xs, int64_t ld_xs, int64_t B, int64_t K, int64_t T, int F, int trials) {
   const int lane = threadIdx.x & 63;
   const int64_t rows = B * trials * K * T;
+  const bool vec = F <= 1024 && ((ld_pre | ld_aux | ld_xs) & 3) == 0 && ld_pre >= ((F + 3) & ~3) &&
+                   ld_aux >= ((F + 3) & ~3) && ld_xs >= ((F + 3) & ~3) &&
+                   ((((uintptr_t)pre) | ((uintptr_t)aux) | ((uintptr_t)xs)) & 15) == 0;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
     int64_t b, t, spk;
     cond_row(row, K, T, trials, b, t, spk);
     const float* p = pre + (b * T + t) * ld_pre;
     const float* a = aux + (b * K + spk) * ld_aux;
     float* o = xs + row * ld_xs;
-    for (int f = lane; f < F; f += 64) o[f] = p[f] * a[f];
+    if (vec) {
+      // 16-byte accesses, all loads of the row first (F <= 1024: at most 4 quads per lane); the pad
+      // columns of a row (ld rounded to 4) are written too: they are zero in both inputs
+      const int nq = (F + 3) >> 2;
+      f32x4 pv[4], av[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = lane + 64 * r;
+        if (q < nq) {
+          pv[r] = *reinterpret_cast<const f32x4*>(p + 4 * q);
+          av[r] = *reinterpret_cast<const f32x4*>(a + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = lane + 64 * r;
+        if (q < nq) __builtin_nontemporal_store(pv[r] * av[r], reinterpret_cast<f32x4*>(o + 4 * q));
+      }
+    } else {
+      for (int f = lane; f < F; f += 64) o[f] = p[f] * a[f];
+    }
+  }
+}
+// 16-byte variant: a thread owns 4 consecutive features of one (b, t) row and sums over (trial, speaker);
+// the K * trials loads are independent of each other (no per-element index arithmetic, 4x fewer requests)
+__global__ void cond_mul_bwd_v4_kernel(const float* __restrict__ dxs, int64_t ld_dxs,
+                                       const float* __restrict__ aux, int64_t ld_aux,
+                                       float* __restrict__ dpre, int64_t ld_dpre, int64_t B, int64_t K,
+                                       int64_t T, int F, int trials) {
+  const int nq = (F + 3) >> 2;
+  const int64_t total = B * T * nq;
+  GRID_STRIDE(e, total) {
+    const int64_t row = e / nq;
+    const int q = (int)(e - row * nq);
+    const int64_t t = row % T, b = row / T;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int tr = 0; tr < trials; ++tr) {
+#pragma unroll 4
+      for (int64_t k = 0; k < K; ++k) {
+        int64_t spk = k + tr;
+        if (spk >= K) spk -= K;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dxs + (((b * trials + tr) * K + k) * T + t) * ld_dxs + 4 * q);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(aux + (b * K + spk) * ld_aux + 4 * q);
+        s[0] += d[0] * a[0]; s[1] += d[1] * a[1]; s[2] += d[2] * a[2]; s[3] += d[3] * a[3];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dpre + row * ld_dpre + 4 * q) = s;
   }
 }
 __global__ void cond_mul_bwd_kernel(const float* __restrict__ dxs, int64_t ld_dxs,
@@ -358,6 +407,14 @@ extern "C" int tssep_cond_mul_bwd(const float* dxs, int64_t ld_dxs, const float*
                                   int64_t K, int64_t T, int F, int trials, void* stream) {
   if (!dxs || !aux || !dpre) return TSSEP_E_NULL;
   if (B <= 0 || K <= 0 || T <= 0 || F <= 0 || trials <= 0 || trials > K) return TSSEP_E_SHAPE;
+  const int64_t fp = (F + 3) & ~3;
+  if (((ld_dxs | ld_aux | ld_dpre) & 3) == 0 && ld_dxs >= fp && ld_aux >= fp && ld_dpre >= fp &&
+      ((((uintptr_t)dxs) | ((uintptr_t)aux) | ((uintptr_t)dpre)) & 15) == 0) {
+    // (the pad columns of a row are summed too: products of the inputs' pad columns, zero in the step)
+    hipLaunchKernelGGL(cond_mul_bwd_v4_kernel, dim3(grid_for(B * T * (fp / 4))), dim3(256), 0, S_, dxs, ld_dxs,
+                       aux, ld_aux, dpre, ld_dpre, B, K, T, F, trials);
+    return tssep_launch_status();
+  }
   hipLaunchKernelGGL(cond_mul_bwd_kernel, dim3(grid_for(B * T * F)), dim3(256), 0, S_, dxs, ld_dxs,
                      aux, ld_aux, dpre, ld_dpre, B, K, T, F, trials);
   return tssep_launch_status();
