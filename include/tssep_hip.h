@@ -409,6 +409,12 @@ int tssep_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float
 /* split-K / slab reduction: dst[i] (+)= sum_{s<nsplit} src[s*stride + i] */
 int tssep_reduce_splits(const float* src, int nsplit, int64_t stride, int64_t count, float* dst,
                         int accumulate, void* stream);
+/* the same for the partials [nsplit][M][ldp] of a weight-gradient GEMM with b_ones_col (tssep_gemm_f32):
+ * columns [0,N) -> dw [M, ld_w], column N (the column sums of dY = the bias gradient of an nn.Linear,
+ * tssep/train/rnnp.py:96,161, net.py:663-666) -> db [M] */
+int tssep_reduce_splits_bias(const float* src, int nsplit, int64_t stride, int64_t M, int64_t N,
+                             int64_t ldp, float* dw, int64_t ld_w, float* db, int accumulate,
+                             void* stream);
 
 #ifdef __cplusplus
 }

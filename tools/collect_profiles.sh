@@ -12,7 +12,7 @@ TSSEP_GEMM_WIDE=0 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/
 TSSEP_WGRAD_PRODUCTS=2 TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/dev/null | grep wgrad > $O/gemm_microbench_bf16x3_wgrad2.jsonl
 TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_tail.py > $O/tail_microbench.jsonl 2>/dev/null
-python tools/grad_parity.py 2 > $O/parity_full_size.jsonl 2>/dev/null
+python tools/grad_parity.py 4 > $O/parity_full_size.jsonl 2>/dev/null
 for b in 8 32 64 128 192 256 384 512 768 1152 1536; do
   python bench.py --batch $b --steps 20 --warmup 4 $B 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl

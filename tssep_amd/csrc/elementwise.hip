@@ -219,6 +219,21 @@ __global__ void reduce_splits_kernel(const float* __restrict__ src, int nsplit, 
   }
 }
 
+// split-K partials [nsplit][M][ldp] of a weight-gradient GEMM whose B operand carried a virtual ones column:
+// columns [0, N) -> dW [M, ld_w] (dense), column N -> the bias gradient db [M] (the column sums of dY).
+__global__ void reduce_splits_bias_kernel(const float* __restrict__ src, int nsplit, int64_t stride,
+                                          int64_t M, int64_t N, int64_t ldp, float* __restrict__ dw,
+                                          int64_t ld_w, float* __restrict__ db, int accumulate) {
+  const int64_t total = M * (N + 1);
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / (N + 1), n = i - m * (N + 1);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += src[k * stride + m * ldp + n];
+    float* d = n < N ? dw + m * ld_w + n : db + m;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
 // ---- LogMAE -------------------------------------------------------------------------------
 constexpr int LM_CHUNK = 4096;
 __global__ __launch_bounds__(256) void absdiff_partial_kernel(const float* __restrict__ est,
@@ -470,6 +485,16 @@ extern "C" int tssep_reduce_splits(const float* src, int nsplit, int64_t stride,
   if (nsplit <= 0 || count <= 0) return TSSEP_E_SHAPE;
   hipLaunchKernelGGL(reduce_splits_kernel, dim3(grid_for(count)), dim3(256), 0, S_, src, nsplit,
                      stride, count, dst, accumulate);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_reduce_splits_bias(const float* src, int nsplit, int64_t stride, int64_t M, int64_t N,
+                                        int64_t ldp, float* dw, int64_t ld_w, float* db, int accumulate,
+                                        void* stream) {
+  if (!src || !dw || !db) return TSSEP_E_NULL;
+  if (nsplit <= 0 || M <= 0 || N <= 0 || ldp < N + 1 || ld_w < N) return TSSEP_E_SHAPE;
+  hipLaunchKernelGGL(reduce_splits_bias_kernel, dim3(grid_for(M * (N + 1))), dim3(256), 0, S_, src, nsplit,
+                     stride, M, N, ldp, dw, ld_w, db, accumulate);
   return tssep_launch_status();
 }
 

@@ -99,6 +99,13 @@ class _RNNP(torch.autograd.Function):
 
         # ---- projection weight / bias gradients (side stream when direct)
         def proj_wgrads():
+            if direct and Hp == Hh and H.fused_colsum():
+                # the bias gradient (column sums of dz) rides on the weight-gradient GEMM as a virtual ones
+                # column of hout: one pass over dz instead of two, and N = 600 -> 601 costs no extra tile
+                part, S = H.wgrad(dz, ld_dz, hout, 2 * Hp, hdim, 2 * Hp, R, with_colsum=True)
+                H.reduce_splits_bias(part, S, hdim, 2 * Hp, H.round_up(2 * Hp + 1, 4), sinks[8], sinks[9],
+                                     accumulate=True)
+                return None, None
             part, S = H.wgrad(dz, ld_dz, hout, 2 * Hp, hdim, 2 * Hp, R)
             if direct and Hp == Hh:
                 H.reduce_splits(part, S, hdim * 2 * Hp, sinks[8], accumulate=True)
@@ -294,9 +301,13 @@ class _Head(torch.autograd.Function):
             for t_ in (dv, xv):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
-                part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
-                H.reduce_splits(part, S, Nout * P, sw, accumulate=True)
-                H.colsum(dv, ld_d, R, Nout, out=sb, accumulate=True)
+                if H.fused_colsum():
+                    part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R, with_colsum=True)
+                    H.reduce_splits_bias(part, S, Nout, P, H.round_up(P + 1, 4), sw, sb, accumulate=True)
+                else:
+                    part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
+                    H.reduce_splits(part, S, Nout * P, sw, accumulate=True)
+                    H.colsum(dv, ld_d, R, Nout, out=sb, accumulate=True)
             dw = db = None
         else:
             part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)

@@ -341,6 +341,12 @@ def reduce_splits(part, S, count, dst, accumulate=False):
                                          _stream()), "reduce_splits")
 
 
+def reduce_splits_bias(part, S, M, N, ldp, dw, db, accumulate=False):
+    """partials [S, M, ldp] of wgrad(..., with_colsum=True) -> dw [M, N] (dense) and db [M] (column N)."""
+    check(_lib.lib().tssep_reduce_splits_bias(_p(part), S, M * ldp, M, N, ldp, _p(dw), N, _p(db), int(accumulate),
+                                              _stream()), "reduce_splits_bias")
+
+
 def colsum(A, lda, M, N, out=None, accumulate=False):
     L = _lib.lib()
     dev = A[0].device if isinstance(A, tuple) else A.device
