@@ -221,6 +221,49 @@ def test_gemm_wgrad_with_fused_column_sums():
         h.GEMM_PRECISION = old
 
 
+def test_gemm_extra_column_instead_of_an_edge_tile():
+    """N = 256 q + 1 (the 513 frequency bins: pre-net projection, d(input) of the first speaker BLSTM): the
+    split-bf16 row x row kernel covers N - 1 columns with 256-wide tiles and computes the last column on the VALU
+    from the A values it stages anyway, instead of a fifth 128-wide tile column.  Against fp64; the MFMA columns
+    bit for bit against the run with the extra tile column (TSSEP_GEMM_XCOL=0); the VALU column is exact fp32, so
+    tighter than the split-bf16 ones.  bias + tanh, accumulate, store remap, K tail."""
+    import os
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        torch.manual_seed(11)
+        for M, N, K in ((1100, 513, 600), (2051, 257, 64), (1024, 129, 2400), (1500, 513, 36), (4096, 769, 2400)):
+            A = torch.randn(M, K); W = torch.randn(N, K) / K ** 0.5; bias = torch.randn(N)
+            Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+            ref = (A.double() @ W.double().t() + bias.double()).float()
+            Kspk, T = 2, M // 4
+            R = 2 * Kspk * T
+            want_r = ref[:R].view(2, Kspk, T, N).permute(0, 2, 1, 3).reshape(2 * T, Kspk * N)
+            outs = {}
+            for x in ("1", "0"):
+                os.environ["TSSEP_GEMM_XCOL"] = x
+                C = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C, N, M, N, K, bias=bd, act=1)
+                C2 = torch.ones(M, N, device="cuda")
+                h.gemm(Ad, K, Wd, K, C2, N, M, N, K, accumulate=True)
+                Y = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, Y, 0, R, N, K, bias=bd, remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+                outs[x] = (C, C2, Y)
+            close(outs["1"][0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name=f"xcol nt+bias+tanh {M, N, K}")
+            close(outs["1"][1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="xcol accumulate")
+            close(outs["1"][2], want_r, rtol=2e-4, atol=2e-4, name="xcol remap")
+            if N % 256 == 1:          # (129 takes the ordinary tiles)
+                close(outs["1"][1][:, N - 1], (1 + ref - bias)[:, N - 1], rtol=1e-5, atol=1e-5, name="exact-fp32 column")
+            for a, b in zip(outs["1"][:2], outs["0"][:2]):
+                assert torch.equal(a[:, :N - 1], b[:, :N - 1])
+            y1, y0 = outs["1"][2].view(2 * T, Kspk, N), outs["0"][2].view(2 * T, Kspk, N)
+            assert torch.equal(y1[..., :N - 1], y0[..., :N - 1])
+    finally:
+        os.environ.pop("TSSEP_GEMM_XCOL", None)
+        h.GEMM_PRECISION = old
+
+
 def test_gemm_store_remaps(gemm_precision):
     tol = gemm_precision
     torch.manual_seed(4)

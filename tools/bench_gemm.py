@@ -47,6 +47,7 @@ run("proj 600->320", R4, 320, 600, "nt")
 run("proj 600->513", R1, 513, 600, "nt")
 run("linear2", R1, 2052, 320, "nt")
 run("dgrad birnn0 dx", R4, 513, 2400, "nn")
+run("dgrad birnn0 dx (W^T, as on the step)", R4, 513, 2400, "nt")
 run("dgrad proj dh", R4, 600, 320, "nn")
 run("dgrad birnn2 dx", R1, 1280, 2400, "nn")
 run("wgrad W_ih birnn0", 2400, 513, R4, "tn")

@@ -44,6 +44,22 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// Buffer loads for the steady-state operand streams: one buffer resource (4 SGPRs: base + range) per operand,
+// ONE 32-bit VGPR byte offset per lane and operand, the per-load part of the address (row group, K tile) in an
+// SGPR.  With plain pointers the compiler kept a 64-bit VGPR address per load (8 in the weight-gradient kernel,
+// 6 in the tall one) and re-derived them with v_lshl_add_u64 / v_mov_b64 every K tile: 12-16 VGPRs and ~20 VALU
+// instructions per tile.  The range only has to cover one tile's rows (offsets stay far below 2 GB).
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(srd_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float bload1(srd_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Software pipeline: two LDS stages in SEPARATE arrays (so the compiler knows that the fragment
 // reads of stage t and the staging writes of stage t+1 never alias), one barrier per K tile, and
@@ -431,11 +447,19 @@ constexpr int TBM = 256, TBK = 16, TPITCH = 48;
 constexpr int TARR_A = TBM * TPITCH;
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, SID)
-template <int WN>
+// XCOL (wide tile only, N = 256 q + 1: the 513 frequency bins of `dgrad birnn0 dx` and of the pre-net
+// projection): the MFMA tiles cover the first N - 1 columns -- two 256-wide tiles instead of five 128-wide ones
+// of which the fifth staged the whole A panel once more for ONE column -- and column N - 1 is computed on the
+// VALU from the raw fp32 A values every workgroup stages anyway (8 FMAs per thread and K tile against row
+// N - 1 of B, exact fp32; every workgroup computes it -- no branch inside the loop body the scheduler
+// interleaves, a uniform branch there measured 10 % slower -- and those of the last column tile store it).
+// The 256 x 128 variant has no registers left for this (248 VGPRs: it spilled inside the loop).
+template <int WN, bool XCOL = false>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
-    int64_t N, int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act,
+    int64_t Nfull, int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act,
     int accumulate, StoreMap sm, TileMap tmap) {
+  const int64_t N = XCOL ? Nfull - 1 : Nfull;          // columns of the MFMA tiles
   constexpr int NT = 128 * WN, TBN = 64 * WN, TARR_B = TBN * TPITCH;
   constexpr int TSTAGE = 2 * TARR_A + 2 * TARR_B;        // A hi, A lo, B hi, B lo = 36 864 B (WN = 2) / 49 152 B
   constexpr int NA = TBM * 4 / NT, NB = TBN * 4 / NT;    // 16-byte loads per thread and K tile: 4 + 2 / 2 + 2
@@ -478,14 +502,22 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     boffs[i] = (unsigned)(((r - n0) * ldb + kq) * 4);
   }
   f32x4 ra[NA], rb[NB];
-  auto gload = [&](int64_t kt, bool tail) {
+  const bool xwg = XCOL && nt == tmap.NT - 1;           // workgroup-uniform
+  const srd_t asrd = make_srd(abase), bsrd = make_srd(bbase), xsrd = make_srd(B + N * ldb);
+  f32x4 rx = {0.f, 0.f, 0.f, 0.f};
+  float xacc[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) xacc[i] = 0.f;
+  auto gload = [&](int64_t kt, bool tail, auto xtag) {
     const int64_t k0 = kt * TBK, k = k0 + kq;
     // (tail) a 16-byte load that starts at or beyond K would leave the row: read the row start
-    const int64_t adj = (!tail || k < K) ? k0 : -(int64_t)kq;
+    const unsigned fix = (!tail || k < K) ? 0u : (unsigned)(-(k0 + kq) * 4);     // per lane, wraps with the offsets
+    const int so = (int)(k0 * 4);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(abase + adj * 4 + aoffs[i]);
+    for (int i = 0; i < NA; ++i) ra[i] = bload4(asrd, aoffs[i] + fix, so);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bbase + adj * 4 + boffs[i]);
+    for (int i = 0; i < NB; ++i) rb[i] = bload4(bsrd, boffs[i] + fix, so);
+    if constexpr (decltype(xtag)::value) rx = bload4(xsrd, (unsigned)(kq * 4) + fix, so);   // (ra is zeroed in the tail)
     if (tail) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -498,7 +530,12 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     }
   };
   const int soff = lrow * TPITCH + ((tid & 3) << 3);
-  auto sstore = [&](char* st) {
+  auto sstore = [&](char* st, auto xtag) {
+    if constexpr (decltype(xtag)::value) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        xacc[i] = fmaf(ra[i][3], rx[3], fmaf(ra[i][2], rx[2], fmaf(ra[i][1], rx[1], fmaf(ra[i][0], rx[0], xacc[i]))));
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       unsigned h0, l0, h1, l1;
@@ -550,8 +587,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
   do {                                                                                          \
     constexpr int SID = SID_;                                                                   \
     compute(cur);                                                                               \
-    sstore(nxt);                                                                                \
-    gload((kt_) + 2, false);                                                                    \
+    sstore(nxt, xtag);                                                                          \
+    gload((kt_) + 2, false, xtag);                                                              \
     SGB(0x100, 6);                                                                              \
     if (WN == 2) {                                                                              \
       _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) { SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x200, 1); } \
@@ -568,9 +605,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
 
-  gload(0, 0 >= kt_full);
-  sstore(lds0);
-  if (1 < ktiles) gload(1, 1 >= kt_full);
+  const std::integral_constant<bool, XCOL> xtag{};
+  gload(0, 0 >= kt_full, xtag);
+  sstore(lds0, xtag);
+  if (1 < ktiles) gload(1, 1 >= kt_full, xtag);
   __syncthreads();
   int64_t kt = 0;
   const int64_t lim = kt_full - 3;
@@ -582,9 +620,37 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     const char* cur = par ? lds1 : lds0;
     char* nxt = par ? lds0 : lds1;
     compute(cur);
-    if (kt + 1 < ktiles) sstore(nxt);
-    if (kt + 2 < ktiles) gload(kt + 2, kt + 2 >= kt_full);
+    if (kt + 1 < ktiles) sstore(nxt, xtag);
+    if (kt + 2 < ktiles) gload(kt + 2, kt + 2 >= kt_full, xtag);
     __syncthreads();
+  }
+  if (XCOL && xwg) {
+    // column N of the full matrix: the 4 lanes of a row hold its four k quarters
+    const int64_t n = N;
+    const float bv = bias ? bias[n] : 0.f;
+    const int64_t cq = sm.remap ? n / sm.cm : 0, cr = sm.remap ? n - cq * sm.cm : n;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float v = xacc[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      const int64_t m = m0 + lrow + RSTEP * i;
+      if ((tid & 3) == 0 && m < M) {
+        int64_t a;
+        if (sm.remap) {
+          const int64_t t = m % sm.T, q = m / sm.T;
+          const int64_t k = q % sm.K, b = q / sm.K;
+          const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq] : cq;
+          a = b * sm.sb + k * sm.sk + t * sm.st + cqq * sm.co + cr;
+        } else {
+          a = m * sm.ldc + n;
+        }
+        v += bv;
+        if (act == 1) v = tanhf(v);
+        if (accumulate) v += C[a];
+        C[a] = v;
+      }
+    }
   }
 #undef TPIPE
   // epilogue: every wave transposes its 64 x 64 blocks through a private LDS scratch (17 KB); a stage
@@ -881,6 +947,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<4>, dim3((unsigned)tile_map_blocks(tm4)), dim3(512), 0, s,
                          g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
                          g->accumulate, sm, tm4);
+      return tssep_launch_status();
+    }
+    const char* xc_env = getenv("TSSEP_GEMM_XCOL");            // read per call (alternating A/B)
+    if ((!xc_env || xc_env[0] != '0') && g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0) {
+      const TileMap tmx = make_tile_map((g->M + TBM - 1) / TBM, (g->N - 1) / 256, 1);
+      hipLaunchKernelGGL((gemm_bf16x3_tall_kernel<4, true>), dim3((unsigned)tile_map_blocks(tmx)), dim3(512), 0, s,
+                         g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
+                         g->accumulate, sm, tmx);
       return tssep_launch_status();
     }
     const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);

@@ -309,6 +309,10 @@ def transposed(w, rows, cols):
 
 
 def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
+    # (tools/sweep_splitk.py, profiles/r2_splitk_sweep.jsonl: a model that prices whole rounds of 512 resident
+    # workgroups predicts up to 20 % from other factors; measured, the large-K shapes get SLOWER with more splits
+    # -- the tiles of a K slab share it through one L2 only while they run together -- and this rule is within
+    # 0..5 % of the best S on every shape of the step)
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
     s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
@@ -317,13 +321,13 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     return min(s, 64)
 
 
-def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False):
+def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False, splitk=None):
     """dW[M,N] = dY[R,M]^T X[R,N] by split-K partials -> (partials [S, M*N], S).
     with_colsum (split-bf16 GEMM only): partials are [S, M, round_up(N+1, 4)] and column N holds
     the column sums of dY (the bias gradient), from a virtual all-ones column of X."""
     Nc = N + 1 if with_colsum else N
     ldp = round_up(Nc, 4) if with_colsum else N      # 16-byte rows keep the vector epilogue
-    S = pick_splitk(M, Nc, R)
+    S = splitk or pick_splitk(M, Nc, R)
     dev = dY[0].device if isinstance(dY, tuple) else dY.device
     part = torch.empty(S, M * ldp, device=dev, dtype=torch.float32)
     gemm(dY, ld_dy, X, ld_x, part, ldp, M, Nc, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
