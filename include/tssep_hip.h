@@ -131,7 +131,9 @@ typedef struct tssep_gemm_args {
   int64_t b_kshift, kperiod;
   /* epilogue */
   const float* bias;              /* [N] added to every row; NULL = off */
-  int32_t act;                    /* 0 none, 1 tanh (Tanh between post-net layers, net.py:623-625) */
+  int32_t act;                    /* 0 none, 1 tanh (Tanh between post-net layers, net.py:623-625),
+                                   * 2 multiply by 1 - aux^2: the BACKWARD of that Tanh folded into the store of
+                                   * the d(input) GEMM of the layer that consumed its output (aux = that input) */
   int32_t accumulate;             /* C += result */
   /* output remap (c_remap != 0): row m = (b*c_K + k)*c_T + t and column n = q*c_cm + r are
    * stored at C[b*c_sb + k*c_sk + t*c_st + q'*c_co + r], q' = c_perm ? c_perm[b*c_perm_ld+q] : q.
@@ -153,6 +155,8 @@ typedef struct tssep_gemm_args {
    * k, so column N-1 of C holds the column sums of A -- the bias gradient comes out of the
    * weight-gradient GEMM that streams d(gates) anyway (B then has N-1 real columns). */
   int32_t b_ones_col;
+  /* act == 2 only: aux[m*ldaux + n], indexed like the UNREMAPPED C (row m, column n) */
+  const float* aux; int64_t ldaux;
 } tssep_gemm_args;
 int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 

@@ -111,6 +111,12 @@ def test_gemm_nt_bias_tanh(M, N, K, gemm_precision):
     C = C0.cuda()
     h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, accumulate=True)
     close(C, C0 + ref - bias, rtol=tol, atol=1.5 * tol, name="nt accumulate")
+    # act = 2: the Tanh backward of the consumer's input folded into the store, C = (A W^T) (1 - y^2)
+    ldy = ru(N, 4)
+    Y = torch.zeros(M, ldy); Y[:, :N] = torch.tanh(torch.randn(M, N))
+    C = torch.full((M, N), float("nan"), device="cuda")
+    h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, act=2, aux=(Y.cuda(), ldy))
+    close(C, (ref - bias) * (1 - Y[:, :N] ** 2), rtol=tol, atol=tol, name="nt (1 - y^2)")
 
 
 @pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47)])
@@ -282,6 +288,27 @@ def test_gemm_store_remaps(gemm_precision):
     C = torch.full((B, K, T, F), float("nan"), device="cuda")
     h.gemm(A.cuda(), 12, W.cuda(), 12, C, 0, B * T, K * F, 12, bias=bias.cuda(),
            remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm.cuda(), perm_ld=K))
+    # (3) rows (b,t) x (k, P) -> rows (b,k,t) x P with the Tanh backward folded in (functional.rnnp_layer)
+    A3 = torch.randn(B * T, 12); W3 = torch.randn(K * P, 12); Y3 = torch.tanh(torch.randn(B * T, K * P))
+    C3 = torch.full((B * K * T, P), float("nan"), device="cuda")
+    h.gemm(A3.cuda(), 12, W3.cuda(), 12, C3, 0, B * T, K * P, 12, act=2, aux=(Y3.cuda(), K * P),
+           remap=dict(T=T, K=1, sb=K * T * P, sk=0, st=P, cm=P, co=T * P))
+    ref3 = ((A3 @ W3.t()) * (1 - Y3 ** 2)).view(B, T, K, P).permute(0, 2, 1, 3).reshape(B * K * T, P)
+    close(C3, ref3, rtol=tol, atol=tol, name="un-combine + tanh backward")
+    # (4) the same two remaps with T >= 64 and 4-float granularity: the 16-byte remapped store
+    T4, P4 = 70, 72
+    A4 = torch.randn(B * K * T4, 12); W4 = torch.randn(P4, 12); b4 = torch.randn(P4)
+    C4 = torch.full((B, T4, K * P4), float("nan"), device="cuda")
+    h.gemm(A4.cuda(), 12, W4.cuda(), 12, C4, 0, B * K * T4, P4, 12, bias=b4.cuda(), act=1,
+           remap=dict(T=T4, K=K, sb=T4 * K * P4, sk=P4, st=K * P4))
+    close(C4, torch.tanh(A4 @ W4.t() + b4).view(B, K, T4, P4).permute(0, 2, 1, 3).reshape(B, T4, K * P4),
+          rtol=tol, atol=tol, name="combine, vector store")
+    A5 = torch.randn(B * T4, 12); W5 = torch.randn(K * P4, 12); Y5 = torch.tanh(torch.randn(B * T4, K * P4))
+    C5 = torch.full((B * K * T4, P4), float("nan"), device="cuda")
+    h.gemm(A5.cuda(), 12, W5.cuda(), 12, C5, 0, B * T4, K * P4, 12, act=2, aux=(Y5.cuda(), K * P4),
+           remap=dict(T=T4, K=1, sb=K * T4 * P4, sk=0, st=P4, cm=P4, co=T4 * P4))
+    close(C5, ((A5 @ W5.t()) * (1 - Y5 ** 2)).view(B, T4, K, P4).permute(0, 2, 1, 3).reshape(B * K * T4, P4),
+          rtol=tol, atol=tol, name="un-combine + tanh backward, vector store")
     raw = (A @ W.t() + bias).view(B, T, K, F).permute(0, 2, 1, 3)       # [B,K,T,F] by position
     ref = torch.empty(B, K, T, F)
     for b in range(B):

@@ -31,6 +31,7 @@ class GemmArgs(ctypes.Structure):
         ("splitk", ctypes.c_int32), ("c_split_stride", ctypes.c_int64),
         ("precision", ctypes.c_int32),
         ("b_ones_col", ctypes.c_int32),
+        ("aux", ctypes.c_void_p), ("ldaux", ctypes.c_int64),
     ]
 
 

@@ -251,6 +251,7 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (!aligned16(g->A) || !aligned16(g->B) || (g->lda & 3) || (g->ldb & 3)) return TSSEP_E_ALIGN;
   const int splitk = g->splitk > 1 ? g->splitk : 1;
   if (splitk > 1 && (g->bias || g->act || g->c_remap)) return TSSEP_E_UNSUPPORTED;
+  if (g->act < 0 || g->act > 2 || (g->act == 2 && !g->aux)) return TSSEP_E_SHAPE;
   if (g->a_kmajor && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
   if (g->kperiod > 0 && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
   const StoreMap sm = make_store_map(g);

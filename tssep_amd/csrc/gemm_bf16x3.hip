@@ -398,11 +398,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
     static_assert(2 * 64 * EPITCH * 4 <= 4 * ARR, "epilogue scratch must fit in one stage");
     float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
     gemm_epilogue_rows(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias,
-                       act, accumulate, sm.ldc, splitk == 1);
+                       act, accumulate, sm.ldc, splitk == 1, sm.aux, sm.ldaux);
     return;
   }
   {
     float* stage = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+    if (remap_vec_ok(sm, Cz))
+      gemm_epilogue_rows_remap_vec(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias,
+                                   act, accumulate, sm);
+    else
     gemm_epilogue_rows_remap(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane,
                              splitk == 1 ? bias : nullptr, splitk == 1 ? act : 0, accumulate, sm);
   }
@@ -670,7 +674,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
         for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
       if (!sm.remap)
         gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
-                           bias, act, accumulate, sm.ldc, true);
+                           bias, act, accumulate, sm.ldc, true, sm.aux, sm.ldaux);
+      else if (remap_vec_ok(sm, C))
+        gemm_epilogue_rows_remap_vec(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                                     lane, bias, act, accumulate, sm);
       else
         gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
                                  lane, bias, act, accumulate, sm);

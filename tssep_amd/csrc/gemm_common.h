@@ -56,6 +56,7 @@ struct StoreMap {
   int32_t remap;
   int64_t T, K, sb, sk, st, cm, co;
   const int32_t* perm; int64_t perm_ld;
+  const float* aux; int64_t ldaux;      // act == 2: C = acc * (1 - aux[m, n]^2)
 };
 
 inline StoreMap make_store_map(const tssep_gemm_args* g) {
@@ -65,6 +66,7 @@ inline StoreMap make_store_map(const tssep_gemm_args* g) {
   sm.sb = g->c_sb; sm.sk = g->c_sk; sm.st = g->c_st;
   sm.cm = g->c_cm > 0 ? g->c_cm : (g->N > 0 ? g->N : 1); sm.co = g->c_co;
   sm.perm = g->c_perm; sm.perm_ld = g->c_perm_ld;
+  sm.aux = g->aux; sm.ldaux = g->ldaux;
   return sm;
 }
 
@@ -123,6 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[TM][TN], float
             if (ii == i && ee == e) v = acc[ii][j][ee];
         v += bv[j];
         if (final_pass && act == 1) v = tanhf(v);
+        if (final_pass && act == 2) { const float y = sm.aux[m * sm.ldaux + ncol[j]]; v *= 1.f - y * y; }
         if (accumulate) v += Cz[a];
         Cz[a] = v;
       }
@@ -140,7 +143,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], fl
                                                    float* __restrict__ Cz, int64_t M, int64_t N,
                                                    int64_t mrow0, int64_t ncol0, int lane,
                                                    const float* __restrict__ bias, int act,
-                                                   int accumulate, int64_t ldc, bool final_pass) {
+                                                   int accumulate, int64_t ldc, bool final_pass,
+                                                   const float* __restrict__ aux = nullptr, int64_t ldaux = 0) {
   const int col = lane & 31, half = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -168,6 +172,17 @@ __device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], fl
     if (final_pass && act == 1) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+    }
+    if (final_pass && act == 2) {
+      const float* ya = aux + m * ldaux + n;
+      if (vec && ((ldaux & 3) == 0) && ((((uintptr_t)aux) & 15) == 0)) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(ya);
+        v *= 1.f - y * y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < N) v[q] *= 1.f - ya[q] * ya[q];
+      }
     }
     float* dst = Cz + m * ldc + n;
     if (vec) {
@@ -217,9 +232,88 @@ __device__ __forceinline__ void gemm_epilogue_rows_remap(const f32x16 (&acc)[2][
     }
     float v = stage[row * EPITCH + lane] + bv;
     if (act == 1) v = tanhf(v);
+    if (act == 2) { const float y = sm.aux[m * sm.ldaux + n]; v *= 1.f - y * y; }
     float* dst = Cz + b * sm.sb + k * sm.sk + t * sm.st + coff;
     if (accumulate) v += *dst;
     *dst = v;
+  }
+}
+
+
+// Vector variant of the remapped store for the speaker (un-)combination (net.py:608-611 and its inverse):
+// no permutation table, cm and every stride a multiple of 4 floats, T >= 64.  Same 16-byte lanes as
+// gemm_epilogue_rows -- the remap only changes each row's base and each lane's column offset: a lane's four
+// consecutive columns lie in one column group (cm % 4 == 0), and the (b, k, t) of a row follow from the wave's
+// first row by at most one carry per level (64 rows < T), so no per-row division.  The scalar variant above
+// stores 4 bytes per lane and ran the combined projection / the un-combining d(input) GEMM ~10 % slower.
+__device__ __forceinline__ bool remap_vec_ok(const StoreMap& sm, const float* C) {
+  return sm.remap && !sm.perm && sm.T >= 64 && ((sm.cm | sm.co | sm.sb | sm.sk | sm.st) & 3) == 0 &&
+         ((((uintptr_t)C) & 15) == 0);
+}
+__device__ __forceinline__ void gemm_epilogue_rows_remap_vec(const f32x16 (&acc)[2][2], float* __restrict__ stage,
+                                                             float* __restrict__ Cz, int64_t M, int64_t N,
+                                                             int64_t mrow0, int64_t ncol0, int lane,
+                                                             const float* __restrict__ bias, int act,
+                                                             int accumulate, const StoreMap& sm) {
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPITCH + j * 32 + col] = acc[i][j][e];
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const int64_t n = ncol0 + c4;
+  if (n >= N) return;
+  const bool full = n + 3 < N;
+  const int64_t cq = n / sm.cm, coff = cq * sm.co + (n - cq * sm.cm);
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bv[q] = n + q < N ? bias[n + q] : 0.f;
+  }
+  const bool auxvec = ((sm.ldaux & 3) == 0) && ((((uintptr_t)sm.aux) & 15) == 0);
+  // wave-uniform decomposition of the block's first row
+  const int64_t q0 = mrow0 / sm.T;
+  const int t0 = (int)(mrow0 - q0 * sm.T);
+  const int64_t b0 = q0 / sm.K;
+  const int k0 = (int)(q0 - b0 * sm.K);
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int row = r * 4 + r0;
+    const int64_t m = mrow0 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * EPITCH + c4);
+    if (m >= M) continue;
+    int t = t0 + row, k = k0;
+    int64_t b = b0;
+    if (t >= sm.T) { t -= (int)sm.T; ++k; }
+    if (k >= sm.K) { k -= (int)sm.K; ++b; }
+    v += bv;
+    if (act == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+    }
+    if (act == 2) {
+      const float* ya = sm.aux + m * sm.ldaux + n;
+      if (full && auxvec) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(ya);
+        v *= 1.f - y * y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < N) v[q] *= 1.f - ya[q] * ya[q];
+      }
+    }
+    float* dst = Cz + b * sm.sb + k * sm.sk + t * sm.st + coff;
+    if (full) {
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (n + q < N) dst[q] = accumulate ? dst[q] + v[q] : v[q];
+    }
   }
 }
 

@@ -189,7 +189,10 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_presplit_kerne
       for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
     if (!sm.remap)
       gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
-                         bias, act, accumulate, sm.ldc, true);
+                         bias, act, accumulate, sm.ldc, true, sm.aux, sm.ldaux);
+    else if (remap_vec_ok(sm, C))
+      gemm_epilogue_rows_remap_vec(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                                   lane, bias, act, accumulate, sm);
     else
       gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
                                lane, bias, act, accumulate, sm);

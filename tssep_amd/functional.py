@@ -23,7 +23,7 @@ class _RNNP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj,
-                N, T, act, combine):
+                N, T, act, combine, in_tanh=0, dz_given=False):
         dev = x.device
         Hh = w_hh.shape[1]
         I = w_ih.shape[1]
@@ -68,6 +68,8 @@ class _RNNP(torch.autograd.Function):
         ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj)
         ctx.pk = pk
         ctx.meta = (N, T, I, Hh, Hp, hdim, ld_x, ld_y, act, combine)
+        ctx.fold = (int(in_tanh), bool(dz_given))
+        assert not dz_given or act == 1, "dz_given: only behind the fused Tanh"
         ctx.x_shape = x.shape
         return y if combine else y[:, :hdim]
 
@@ -80,7 +82,10 @@ class _RNNP(torch.autograd.Function):
         R = N * T
         K = combine if combine else 1
         # d(pre-activation) of the projection, rows (n,t) x hdim, contiguous
-        if act:
+        in_tanh, dz_given = ctx.fold
+        if dz_given:      # the consumer's d(input) GEMM already applied 1 - y^2 and wrote dense rows (n,t) x hdim
+            dz = dy.contiguous().view(R, hdim)
+        elif act:
             dyc = dy.contiguous() if combine else _dense_rows(dy, hdim)
             yc = y if combine else _dense_rows(y[:, :hdim], hdim)
             dz = H.tanh_bwd(dyc, yc, R, hdim, K, T, bool(combine))
@@ -181,14 +186,25 @@ class _RNNP(torch.autograd.Function):
             lstm_grads = lstm_wgrads()
         dx = None
         if ctx.needs_input_grad[0]:
-            dxb, ld_dx = H.padded(R, I, dev, zero=True)
             wihT, ld_t = H.derived("wih_T", [params[0], params[4]],
                                    lambda: H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I))
-            H.gemm(gates, G, wihT, ld_t, dxb, ld_dx, R, I, G)
-            dx = dxb[:, :I]
-            if tuple(ctx.x_shape) != tuple(dx.shape):
-                dx = dx.reshape(ctx.x_shape)
-        return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None)
+            if in_tanh:       # my input is a Tanh output: its backward rides on this GEMM's store
+                Kc = in_tanh
+                assert I % 4 == 0 and I % Kc == 0 and ld_x == I, (I, Kc, ld_x)
+                dxb = torch.empty(R, I, device=dev, dtype=torch.float32)
+                remap = None
+                if Kc > 1:    # rows (b,t) x (k, hdim) -> rows (b,k,t) x hdim (inverse of net.py:608-611)
+                    hd = I // Kc
+                    remap = dict(T=T, K=1, sb=Kc * T * hd, sk=0, st=hd, cm=hd, co=T * hd)
+                H.gemm(gates, G, wihT, ld_t, dxb, 0 if remap else I, R, I, G, act=2, aux=(xv, ld_x), remap=remap)
+                dx = dxb.view(ctx.x_shape)
+            else:
+                dxb, ld_dx = H.padded(R, I, dev, zero=True)
+                H.gemm(gates, G, wihT, ld_t, dxb, ld_dx, R, I, G)
+                dx = dxb[:, :I]
+                if tuple(ctx.x_shape) != tuple(dx.shape):
+                    dx = dx.reshape(ctx.x_shape)
+        return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None, None, None)
 
 
 def _grad_sink(p):
@@ -221,12 +237,17 @@ def _proj_unlayout(dwp, Hh, Hp):
     return torch.cat([dwp[:, :Hh], dwp[:, Hp:Hp + Hh]], dim=1).contiguous()
 
 
-def rnnp_layer(x, lstm, linear, N, T, act=0, combine=0):
-    """x rows (n,t); lstm = torch.nn.LSTM parameter container, linear = nn.Linear container."""
+def rnnp_layer(x, lstm, linear, N, T, act=0, combine=0, in_tanh=0, dz_given=False):
+    """x rows (n,t); lstm = torch.nn.LSTM parameter container, linear = nn.Linear container.
+    The Tanh between two layers (net.py:623-625) runs forward in the producer's projection epilogue (act = 1);
+    its BACKWARD runs in the store of the consumer's d(input) GEMM: the consumer is called with in_tanh
+    (1: same row layout; K > 1: its input is the producer's speaker-combined tensor [B T, K hdim] and the
+    gradient is stored back as rows (b,k,t) x hdim) and the producer with dz_given -- what reaches it is already
+    d(pre-activation) in dense rows, shaped like its output only for autograd's shape check."""
     return _RNNP.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                        lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,
                        lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse,
-                       linear.weight, linear.bias, N, T, act, combine)
+                       linear.weight, linear.bias, N, T, act, combine, in_tanh, dz_given)
 
 
 # ---------------------------------------------------------------------- conditioning

@@ -239,7 +239,7 @@ _PREC = {"f32": 0, "bf16x3": 1}
 
 def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
                accumulate=False, b_kshift=0, kperiod=0, remap=None, splitk=1, split_stride=0,
-               b_ones_col=False):
+               b_ones_col=False, aux=None):
     def ptr(x):
         if isinstance(x, tuple):
             return x[0].data_ptr() + 4 * x[1]
@@ -263,13 +263,16 @@ def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, 
     g.splitk, g.c_split_stride = splitk, split_stride
     g.precision = _PREC[GEMM_PRECISION]
     g.b_ones_col = int(b_ones_col)
+    if act == 2:        # tanh backward folded into the store: aux = (tensor, ld) of the tanh OUTPUT, indexed like C
+        assert aux is not None and splitk <= 1
+        g.aux, g.ldaux = ptr(aux[0]), aux[1]
     return g
 
 
 def gemm(A, lda, B, ldb, C, ldc, M, N, K, **kw):
     """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
     float_offset) tuples) whose data pointers are used as given.  Keywords: a_kmajor, b_kmajor, bias, act,
-    accumulate, b_kshift, kperiod, remap, splitk, split_stride, b_ones_col."""
+    accumulate, b_kshift, kperiod, remap, splitk, split_stride, b_ones_col, aux."""
     g = _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, **kw)
     with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K):
         check(_lib.lib().tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
@@ -567,6 +570,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 # second HIP stream, overlapping the T-sequential recurrences of the layers still to come.
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
+FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 
 
 SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"

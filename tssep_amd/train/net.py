@@ -185,14 +185,19 @@ class MaskEstimator_v2(Configurable, torch.nn.Module):
         pre = self.pre_net.forward_rows(xs.reshape(B * T, xs.shape[-1]), B, T)       # [B*T, odim]
         h = Fn.condition(pre, aux, B, K, T, trials, self.combination)               # rows (b,tr,k,t)
         nb = len(self._birnns)
+        # the Tanh between two post-net modules runs forward in the producer's projection store and backward in
+        # the consumer's d(input) GEMM store (functional.rnnp_layer): `fold` = both ends agree on it
+        prev_tanh = 0
         for l, birnn in enumerate(self._birnns):
             last = l == nb - 1
+            fold = (not last) and birnn.hdim % 4 == 0 and Fn.H.FOLD_TANH
             if last and self.ts_vad is not False:
-                h = birnn.forward_rows(h, B * trials, T)                           # combined input
+                h = birnn.forward_rows(h, B * trials, T, in_tanh=prev_tanh)        # combined input
             else:
                 nxt_combined = (l == nb - 2) and self.ts_vad is not False
                 h = birnn.forward_rows(h, B * trials * K, T, final_act=0 if last else 1,
-                                       combine=K if nxt_combined else 0)
+                                       combine=K if nxt_combined else 0, in_tanh=prev_tanh, next_folds=fold)
+                prev_tanh = (K if nxt_combined else 1) if fold else 0
         Fr = F if self.output_resolution == "tf" else 1
         logit = Fn.head(h, self._linear, perm_d, iperm_d, B, K, T, F, trials, Fr,
                         spk_rows=self.ts_vad is False)

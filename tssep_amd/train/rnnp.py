@@ -33,15 +33,21 @@ class RNNP_packed(torch.nn.Module):
         self.dropout, self.return_states = dropout, return_states
         self.hdim = hdim
 
-    def forward_rows(self, rows, N, T, final_act=0, combine=0):
+    def forward_rows(self, rows, N, T, final_act=0, combine=0, in_tanh=0, next_folds=False):
         """rows: [N*T, I] (rows (n,t)) -> [N*T, hdim]; ``final_act``/``combine`` fuse the Tanh
-        that follows this module in the post-net and the speaker-combination rearrange."""
+        that follows this module in the post-net and the speaker-combination rearrange.  ``in_tanh``: the
+        rows are the output of such a fused Tanh of the module in front (K > 1: in its speaker-combined
+        layout) -- its backward is folded into this module's first d(input) GEMM; ``next_folds``: the module
+        behind does the same for this module's final Tanh (functional.rnnp_layer)."""
         h = rows
         for i in range(self.elayers):
             lstm, lin = self.net[4 * i], self.net[4 * i + 1]
             last = i == self.elayers - 1
+            fold_ok = self.hdim % 4 == 0 and Fn.H.FOLD_TANH
             h = Fn.rnnp_layer(h, lstm, lin, N, T, act=(final_act if last else 1),
-                              combine=(combine if last else 0))
+                              combine=(combine if last else 0),
+                              in_tanh=(in_tanh if i == 0 else (1 if fold_ok else 0)),
+                              dz_given=((next_folds and final_act == 1) if last else fold_ok))
         return h
 
     def forward(self, xs_pack, prev_state=None):
