@@ -388,8 +388,17 @@ def main():
                                   "head + inverse STFT, iSTFT adjoint + mask-head backward), which also run the "
                                   "FFTs: `chain` prices the same time against the unfused chain's bytes")
             chain = by + n_l * B * T * 8 * K * FBINS + n_l * 4 * B * K * N_s      # + estimate (8 K F) + samples
+            folded = ""
+            if H.FOLD_TAIL and "maskhead_bwd" in ktimes:      # what else the backward kernel now does per launch
+                n_b = ktimes["maskhead_bwd"][0]
+                if H.FOLD_TAIL in (1, 2):   # tssep_logmae_bwd: read est + tgt, write the gradient it no longer reads
+                    chain += n_b * 8 * B * K * N_s
+                    folded += " + LogMAE backward"
+                if H.FOLD_TAIL in (1, 3):   # tssep_logit_map_bwd: read + write d(logit)
+                    chain += n_b * B * T * 8 * K * FBINS
+                    folded += " + logit un-map"
             cg = chain / (ms * 1e-3) / 1e9
-            mask_head["chain"] = dict(kernel="maskhead+istft fwd, istft adjoint+maskhead bwd (fused)",
+            mask_head["chain"] = dict(kernel="maskhead+istft fwd, istft adjoint+maskhead bwd (fused)" + folded,
                                       algorithmic_bytes_per_launch=chain // n_l, achieved=round(cg, 1),
                                       frac=round(cg / PEAK_HBM_GBPS, 4))
         return roofline, mask_head

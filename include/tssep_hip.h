@@ -94,6 +94,19 @@ int tssep_mask_istft_fwd(const float* logit, const float* obs, int64_t B, int64_
 int tssep_mask_istft_bwd(const float* dy, const float* logit, const float* obs, int64_t B,
                          int64_t K, int64_t N, int size, int shift, int fading,
                          const float* wsyn, const float* tw, float* dlogit, int64_t T, void* stream);
+/* The same backward with the time-domain loss in front and the final Linear behind it folded in:
+ *   input : est, tgt [B*K, N] and the loss's own backward arguments instead of dy -- the frame samples are
+ *           d LogMAE / d est = gout[b] sign(est - tgt) / (N ln10 sums[b])  (tssep/train/loss.py:244-247;
+ *           sums == NULL: MAE, gout[b] sign(est - tgt) / N, loss.py:214-216), i.e. what tssep_logmae_bwd
+ *           would have written to a [B, K, N] buffer first (tgt == NULL: `est` IS dy, as above);
+ *   output: bt_major = 0: dlogit [B, K, T, F] as above; bt_major = 1: rows (b, t) x (speaker position
+ *           iperm[b*K + k] (NULL: k), f) -- the layout the final Linear's backward GEMMs read, i.e. what
+ *           tssep_logit_map_bwd (trials = 1, 'tf' resolution) would have produced from dlogit
+ *           (tssep/train/net.py:637-641, 957-967 backwards). */
+int tssep_mask_istft_bwd_loss(const float* est, const float* tgt, const float* sums, const float* gout,
+                              const float* logit, const float* obs, int64_t B, int64_t K, int64_t N,
+                              int size, int shift, int fading, const float* wsyn, const float* tw,
+                              const int32_t* iperm, int bt_major, float* dlogit, int64_t T, void* stream);
 
 /* --------------------------------------------------------------- features ----
  * ConcaternatedSTFTFeatures(TorchMFCC, Log1pMaxNormAbsSTFT).stft_to_feature

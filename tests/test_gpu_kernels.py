@@ -379,6 +379,24 @@ def test_mask_istft_fused_against_oracle_and_unfused_chain(B, K, N):
     dX = h.istft_bwd(dy.cuda().reshape(B * K, N), wsyn, T)
     dl_u = h.maskhead_bwd(dX.view(B, K, T, 513), None, mask, obs.cuda())
     close(dlogit, dl_u, rtol=2e-5, atol=2e-6 * float(dl_u.abs().max()), name="fused bwd vs unfused")
+    # (c) the loss in front and the final Linear's layout behind, folded into the same kernel
+    # (tssep_mask_istft_bwd_loss): bit for bit what logmae_bwd -> mask_istft_bwd -> logit_map_bwd produce
+    lg = logit.detach().cuda()
+    _, sums = h.logmae_finalize(part, B, K, N)
+    g = torch.rand(B, device="cuda") + 0.5
+    iperm = torch.stack([torch.randperm(K) for _ in range(B)]).int()
+    perm = torch.argsort(iperm.long(), dim=1).int()
+    for sm in (sums, None):                       # LogMAE / MAE
+        dy_l = h.logmae_bwd(y, tgt.cuda(), sm, g)
+        want = h.mask_istft_bwd(dy_l, lg, obs.cuda(), wsyn)
+        got = h.mask_istft_bwd(None, lg, obs.cuda(), wsyn, loss=(y, tgt.cuda(), sm, g))
+        assert torch.equal(got, want)
+        got_bt = h.mask_istft_bwd(None, lg, obs.cuda(), wsyn, loss=(y, tgt.cuda(), sm, g), iperm=iperm.cuda(),
+                                  bt_major=True)
+        want_bt = h.logit_map_bwd(want, perm.cuda(), iperm.cuda(), B, 1, K, T, 513, 513, False).view(B * T, K * 513)
+        assert torch.equal(got_bt, want_bt)
+        got_bt0 = h.mask_istft_bwd(None, lg, obs.cuda(), wsyn, loss=(y, tgt.cuda(), sm, g), bt_major=True)
+        assert torch.equal(got_bt0.view(B, T, K, 513), want.permute(0, 2, 1, 3))
     # without a target there are no partial sums
     y2, none = h.mask_istft_fwd(logit.detach().cuda(), obs.cuda(), wsyn, N)
     assert none is None and torch.equal(y2, y)

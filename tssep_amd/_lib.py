@@ -107,6 +107,14 @@ _ERR = {-1: "invalid shape", -2: "misaligned pointer / leading dimension",
         -3: "unsupported configuration", -4: "kernel launch failed", -5: "NULL pointer"}
 
 
+_SYNC_CHECK = os.environ.get("TSSEP_SYNC_CHECK") == "1"      # debugging: name the launch a device fault belongs to
+
+
 def check(status, what):
+    if _SYNC_CHECK:
+        import sys
+        import torch
+        sys.stderr.write(f"[tssep] {what}\n"); sys.stderr.flush()
+        torch.cuda.synchronize()
     if status != 0:
         raise RuntimeError(f"{what} failed: {_ERR.get(status, status)} (status {status})")

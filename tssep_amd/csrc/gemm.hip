@@ -72,7 +72,11 @@ __device__ __forceinline__ ColLoad make_col_load(const float* P, int64_t ld, int
     for (int e = 0; e < 4; ++e) m |= (c + e < C) ? (1 << e) : 0;
     d.cmask[i] = m;
     d.krow[i] = q / CQ;
-    const int64_t cc = (c + 4 <= ld) ? c : 0;          // keep the 16-byte load inside the row
+    // keep the 16-byte load inside the operand's OWN columns: P may be a column-offset view of a wider
+    // buffer ((hout, d*Hp), (gates, d*4H)), so `ld` says nothing about where the row ends -- a quad that
+    // starts at or beyond C (fully masked) would read up to 4H floats past the row, i.e. past the END of the
+    // buffer on its last row (found as a device fault that depended on where the allocator put the tensor)
+    const int64_t cc = (c < C && c + 4 <= ld) ? c : 0;
     d.p[i] = P + cc + (int64_t)d.krow[i] * ld;
   }
   return d;

@@ -115,7 +115,15 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
     const float* __restrict__ x, int64_t rows, int64_t N, int64_t T, int shift, int pad_left,
     const float* __restrict__ window, const float2* __restrict__ tw, float2* __restrict__ X,
     float s_in, float s_edge, int iters, const float* __restrict__ logit,
-    const float2* __restrict__ obs, float* __restrict__ dlogit, int64_t Kspk) {
+    const float2* __restrict__ obs, float* __restrict__ dlogit, int64_t Kspk,
+    const float* __restrict__ tgt, const float* __restrict__ sums, const float* __restrict__ gout,
+    const int32_t* __restrict__ iperm, int bt_major) {
+  // MASKED with tgt != NULL: x is the time-domain ESTIMATE and the frame's samples are the loss gradient
+  // d LogMAE / d est = gout[b] sign(est - tgt) / (N ln10 sums[b])  (sums == NULL: MAE, gout[b] sign / N;
+  // tssep/train/loss.py:214-216, 244-247) formed while they are loaded -- tssep_logmae_bwd and its [B,K,N]
+  // gradient leave the step.  bt_major: d(logit) is stored where the final Linear's backward reads it, rows
+  // (b,t) x (speaker position iperm[b,k], f) -- the inverse of the store remap of the forward
+  // (net.py:637-641, 957-967) -- instead of [B,K,T,F] + tssep_logit_map_bwd.
   __shared__ float2 twl[NH];
   __shared__ float2 line[4][LINE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,7 +143,16 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
     // next: eight serialised round trips per frame.)  Wave-uniform fast path: N even, x 8-byte aligned and
     // the frame start even -> every sample pair is one aligned float2 that lies inside the row or outside
     // it as a whole; otherwise two clamped 4-byte loads per pair.
-    const bool fast = ((N & 1) == 0) && ((base & 1) == 0) && ((((uintptr_t)x) & 7u) == 0);
+    const bool lossgrad = MASKED && tgt != nullptr;          // kernel-uniform
+    const float* tr_ = lossgrad ? tgt + row * N : xr;
+    float coef = 0.f;
+    if (lossgrad) {
+      const int64_t b = row / Kspk;
+      coef = sums ? gout[b] / ((float)N * 2.30258509299404568402f * sums[b]) : gout[b] / (float)N;
+    }
+    auto lg = [&](float e, float t_) { const float d = e - t_; return d > 0.f ? coef : (d < 0.f ? -coef : 0.f); };
+    const bool fast = ((N & 1) == 0) && ((base & 1) == 0) && ((((uintptr_t)x) & 7u) == 0) &&
+                      (!lossgrad || (((uintptr_t)tgt) & 7u) == 0);
     float2 v[8];
     if (!valid) {
 #pragma unroll
@@ -149,6 +166,16 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
         in[r] = i0 >= 0 && i0 + 1 < N;
         xv[r] = *reinterpret_cast<const float2*>(xr + (in[r] ? i0 : 0));
       }
+      if (lossgrad) {
+        float2 tv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int64_t i0 = base + 2 * (lane + 64 * r);
+          tv[r] = *reinterpret_cast<const float2*>(tr_ + (in[r] ? i0 : 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xv[r] = make_float2(lg(xv[r].x, tv[r].x), lg(xv[r].y, tv[r].y));
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
@@ -159,8 +186,10 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int64_t i0 = base + 2 * (lane + 64 * r), i1 = i0 + 1;
-        xa[r] = xr[i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0)];
-        xb[r] = xr[i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1)];
+        const int64_t c0 = i0 < 0 ? 0 : (i0 >= N ? N - 1 : i0), c1 = i1 < 0 ? 0 : (i1 >= N ? N - 1 : i1);
+        xa[r] = xr[c0];
+        xb[r] = xr[c1];
+        if (lossgrad) { xa[r] = lg(xa[r], tr_[c0]); xb[r] = lg(xb[r], tr_[c1]); }
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -177,6 +206,11 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
       const float* Lr = MASKED ? logit + fidx * (NH + 1) : nullptr;
       const float2* Or = MASKED ? obs + ((row / Kspk) * T + t) * (NH + 1) : nullptr;
       float* Dr = MASKED ? dlogit + fidx * (NH + 1) : nullptr;
+      if (MASKED && bt_major) {
+        const int64_t b = row / Kspk, j = row - b * Kspk;
+        const int64_t kpos = iperm ? (int64_t)iperm[b * Kspk + j] : j;
+        Dr = dlogit + ((b * T + t) * Kspk + kpos) * (NH + 1);
+      }
       auto emit = [&](int k, float2 o) {
         if (MASKED) {
           const float m = sigmoidf_acc(Lr[k]);
@@ -407,7 +441,8 @@ extern "C" int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size,
   hipLaunchKernelGGL(rfft_frames_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      x, rows, N, T, shift, fading ? size - shift : 0, window, (const float2*)tw,
                      (float2*)X, 1.0f, 1.0f, iters, (const float*)nullptr, (const float2*)nullptr,
-                     (float*)nullptr, (int64_t)1);
+                     (float*)nullptr, (int64_t)1, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const int32_t*)nullptr, 0);
   return tssep_launch_status();
 }
 
@@ -424,7 +459,8 @@ extern "C" int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int siz
   hipLaunchKernelGGL(rfft_frames_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      dy, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
                      (float2*)dX, 2.0f / (float)size, 1.0f / (float)size, iters, (const float*)nullptr,
-                     (const float2*)nullptr, (float*)nullptr, (int64_t)1);
+                     (const float2*)nullptr, (float*)nullptr, (int64_t)1, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const int32_t*)nullptr, 0);
   return tssep_launch_status();
 }
 
@@ -442,7 +478,28 @@ extern "C" int tssep_mask_istft_bwd(const float* dy, const float* logit, const f
   hipLaunchKernelGGL(rfft_frames_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      dy, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
                      (float2*)nullptr, 2.0f / (float)size, 1.0f / (float)size, iters, logit,
-                     (const float2*)obs, dlogit, K);
+                     (const float2*)obs, dlogit, K, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const int32_t*)nullptr, 0);
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_mask_istft_bwd_loss(const float* est, const float* tgt, const float* sums, const float* gout,
+                                         const float* logit, const float* obs, int64_t B, int64_t K, int64_t N,
+                                         int size, int shift, int fading, const float* wsyn, const float* tw,
+                                         const int32_t* iperm, int bt_major, float* dlogit, int64_t T,
+                                         void* stream) {
+  // tgt == NULL: `est` is dy itself (only the output layout is folded); sums == NULL: MAE
+  if (!est || (tgt && !gout) || !logit || !obs || !wsyn || !tw || !dlogit) return TSSEP_E_NULL;
+  if (B <= 0 || K <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (int e = check_plan(size, shift)) return e;
+  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  const int iters = 4;
+  const int64_t rows = B * K, total = rows * T;
+  const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
+  hipLaunchKernelGGL(rfft_frames_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     est, rows, N, T, shift, fading ? size - shift : 0, wsyn, (const float2*)tw,
+                     (float2*)nullptr, 2.0f / (float)size, 1.0f / (float)size, iters, logit,
+                     (const float2*)obs, dlogit, K, tgt, sums, gout, iperm, bt_major);
   return tssep_launch_status();
 }
 

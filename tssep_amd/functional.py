@@ -13,6 +13,41 @@ def _pad4(n):
     return H.round_up(n, 4)
 
 
+# ---- hand-offs between neighbouring Functions of the tail --------------------------------------------------
+# head (final Linear) -> fused mask / iSTFT -> LogMAE are three autograd Functions (three reference modules:
+# net.py:629-666, enhancer.py:98-100 + model.py:661-664, loss.py:244-247), but on the training step the
+# backward of the middle one can take the loss's arguments instead of a [B,K,N] gradient and write d(logit)
+# where the Linear's backward reads it.  A producer that folds its work into its neighbour returns _dummy_grad
+# (zeros without memory) and leaves the real arguments on a link object both Functions hold; a consumer that
+# receives anything but that pristine dummy (another loss used the same tensor, autograd summed gradients)
+# falls back to the unfused kernels for the linked part and adds it -- correct either way.
+_ZERO = {}
+
+
+def _dummy_grad(like):
+    z = _ZERO.get(like.device)
+    if z is None:
+        z = _ZERO[like.device] = torch.zeros(1, device=like.device, dtype=torch.float32)
+    return z.expand(like.shape)
+
+
+def _is_dummy(g):
+    z = _ZERO.get(g.device)
+    return z is not None and g.data_ptr() == z.data_ptr() and all(st == 0 for st in g.stride())
+
+
+class _Link:
+    """payload: set by the producer's backward, taken (and cleared) by the consumer's."""
+
+    def __init__(self, **kw):
+        self.payload = None
+        self.__dict__.update(kw)
+
+    def take(self):
+        p, self.payload = self.payload, None
+        return p
+
+
 # ------------------------------------------------------------------------------ RNNP
 class _RNNP(torch.autograd.Function):
     """One RNNP_packed layer (tssep/train/rnnp.py:88-96,146-168): BLSTM + Linear (+ tanh).
@@ -282,8 +317,9 @@ class _Head(torch.autograd.Function):
     (tssep/train/net.py:629-666, 928-967): x rows -> logit [B,K,T,F]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, perm, iperm, B, K, T, F, trials, Fr, spk_rows):
+    def forward(ctx, x, weight, bias, perm, iperm, B, K, T, F, trials, Fr, spk_rows, link=None):
         dev = x.device
+        ctx.link = link
         xv, ld_x = H.rows_view(x)
         P = weight.shape[1]
         wv, ld_w = H.rows_view(weight.detach())
@@ -312,7 +348,11 @@ class _Head(torch.autograd.Function):
         perm, iperm = ctx.aux
         B, K, T, F, trials, Fr, spk_rows, ld_x, ld_w, P, R, Nout = ctx.meta
         dev = dout.device
-        draw = H.logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows).view(R, Nout)
+        draw = ctx.link.take() if ctx.link is not None else None
+        if draw is None:
+            draw = H.logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows).view(R, Nout)
+        elif not _is_dummy(dout):      # the fused tail wrote its part already laid out; someone else used logit too
+            draw = draw + H.logit_map_bwd(dout, perm, iperm, B, trials, K, T, F, Fr, spk_rows).view(R, Nout)
         dv, ld_d = H.rows_view(draw)
         sw, sb = _grad_sink(ctx.params[0]), _grad_sink(ctx.params[1])
         direct = sw is not None and sb is not None and H.OVERLAP_WGRAD
@@ -341,12 +381,17 @@ class _Head(torch.autograd.Function):
         dx = dxb[:, :P]
         if tuple(ctx.x_shape) != tuple(dx.shape):
             dx = dx.reshape(ctx.x_shape)
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 def head(x, linear, perm, iperm, B, K, T, F, trials, Fr, spk_rows):
-    return _Head.apply(x, linear.weight, linear.bias, perm, iperm, B, K, T, F, trials, Fr,
-                       spk_rows)
+    link = None
+    if H.FOLD_TAIL and (not spk_rows) and trials == 1 and Fr == F and x.requires_grad:
+        link = _Link(iperm=iperm, shape=(B, K, T, F))       # the layout the fused tail may write d(logit) in
+    out = _Head.apply(x, linear.weight, linear.bias, perm, iperm, B, K, T, F, trials, Fr, spk_rows, link)
+    if link is not None:
+        out._tssep_head_link = link
+    return out
 
 
 # --------------------------------------------------------------------------- mask head
@@ -442,10 +487,11 @@ class _MaskISTFT(torch.autograd.Function):
     (``_tssep_absdiff``), which ``log_mae`` / ``mae`` consume instead of re-reading both signals."""
 
     @staticmethod
-    def forward(ctx, logit, obs, wsyn, N, size, shift, fading, tgt):
+    def forward(ctx, logit, obs, wsyn, N, size, shift, fading, tgt, head_link=None, loss_link=None):
         y, part = H.mask_istft_fwd(logit, obs, wsyn, N, size, shift, fading, tgt)
         ctx.save_for_backward(logit, obs, wsyn)
         ctx.meta = (size, shift, fading)
+        ctx.links = (head_link, loss_link)
         ctx.mark_non_differentiable(*([part] if part is not None else []))
         return (y, part) if part is not None else (y,)
 
@@ -453,18 +499,35 @@ class _MaskISTFT(torch.autograd.Function):
     def backward(ctx, dy, *_):
         logit, obs, wsyn = ctx.saved_tensors
         size, shift, fading = ctx.meta
-        return (H.mask_istft_bwd(dy, logit, obs, wsyn, size, shift, fading), None, None, None, None,
-                None, None, None)
+        head_link, loss_link = ctx.links
+        loss = loss_link.take() if loss_link is not None else None      # (est, tgt, sums, gout) of LogMAE / MAE
+        if loss is not None and not _is_dummy(dy):
+            dy = dy + H.logmae_bwd(loss[0].contiguous(), loss[1].contiguous(), loss[2], loss[3])
+            loss = None
+        if head_link is not None and tuple(head_link.shape) == tuple(logit.shape):
+            d = H.mask_istft_bwd(dy, logit, obs, wsyn, size, shift, fading, loss=loss, iperm=head_link.iperm,
+                                 bt_major=True)
+            head_link.payload = d if head_link.payload is None else head_link.payload + d
+            dl = _dummy_grad(logit)
+        elif loss is not None:
+            dl = H.mask_istft_bwd(None, logit, obs, wsyn, size, shift, fading, loss=loss)
+        else:
+            dl = H.mask_istft_bwd(dy, logit, obs, wsyn, size, shift, fading)
+        return (dl, None, None, None, None, None, None, None, None, None)
 
 
 def mask_istft(logit, obs, wsyn, N, size=1024, shift=256, fading=True, tgt=None):
     """logit [B,K,T,F], obs complex [B,T,F] -> time_estimate [B,K,N] (differentiable w.r.t. logit)."""
     if tgt is not None and tuple(tgt.shape) != (logit.shape[0], logit.shape[1], N):
         tgt = None
-    out = _MaskISTFT.apply(logit, obs, wsyn, N, size, shift, fading, tgt)
+    fold = H.FOLD_TAIL and logit.requires_grad
+    loss_link = _Link() if fold and tgt is not None and H.FOLD_TAIL != 3 else None
+    head_link = getattr(logit, "_tssep_head_link", None) if fold and H.FOLD_TAIL != 2 else None
+    out = _MaskISTFT.apply(logit, obs, wsyn, N, size, shift, fading, tgt, head_link, loss_link)
     y = out[0]
     if len(out) > 1:
         y._tssep_absdiff = (out[1], tgt.data_ptr(), tuple(tgt.shape))
+        y._tssep_loss_link = loss_link
     return y
 
 
@@ -477,43 +540,58 @@ def _fused_absdiff(est, tgt):
     return None
 
 
+def _loss_link(est, part):
+    """The hand-off to the fused tail that produced `est` (and `part` for this very target), if any."""
+    return getattr(est, "_tssep_loss_link", None) if part is not None else None
+
+
 class _LogMAE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, est, tgt, part=None):
+    def forward(ctx, est, tgt, part=None, link=None):
         if part is not None:
             loss, sums = H.logmae_finalize(part, *est.shape)
         else:
             loss, sums = H.logmae_fwd(est, tgt)
         ctx.save_for_backward(est, tgt, sums)
+        ctx.link = link
         return loss
 
     @staticmethod
     def backward(ctx, g):
         est, tgt, sums = ctx.saved_tensors
-        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), sums, g), None, None
+        if ctx.link is not None and ctx.link.payload is None:     # the tail's backward forms this gradient itself
+            ctx.link.payload = (est, tgt, sums, g)
+            return _dummy_grad(est), None, None, None
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), sums, g), None, None, None
 
 
 def log_mae(est, tgt):
-    return _LogMAE.apply(est, tgt, _fused_absdiff(est, tgt))
+    part = _fused_absdiff(est, tgt)
+    return _LogMAE.apply(est, tgt, part, _loss_link(est, part))
 
 
 class _MAE(torch.autograd.Function):
     """sum_k mean_n |e - t| (loss.py:214-216): the argument of LogMAE's logarithm."""
 
     @staticmethod
-    def forward(ctx, est, tgt, part=None):
+    def forward(ctx, est, tgt, part=None, link=None):
         _, sums = H.logmae_finalize(part, *est.shape) if part is not None else H.logmae_fwd(est, tgt)
         ctx.save_for_backward(est, tgt)
+        ctx.link = link
         return sums
 
     @staticmethod
     def backward(ctx, g):
         est, tgt = ctx.saved_tensors
-        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), None, g), None, None
+        if ctx.link is not None and ctx.link.payload is None:
+            ctx.link.payload = (est, tgt, None, g)
+            return _dummy_grad(est), None, None, None
+        return H.logmae_bwd(est.contiguous(), tgt.contiguous(), None, g), None, None, None
 
 
 def mae(est, tgt):
-    return _MAE.apply(est, tgt, _fused_absdiff(est, tgt))
+    part = _fused_absdiff(est, tgt)
+    return _MAE.apply(est, tgt, part, _loss_link(est, part))
 
 
 class _VadBCE(torch.autograd.Function):

@@ -193,17 +193,31 @@ def mask_istft_fwd(logit, obs, wsyn, N, size=1024, shift=256, fading=True, tgt=N
     return y, part
 
 
-def mask_istft_bwd(dy, logit, obs, wsyn, size=1024, shift=256, fading=True):
-    """dy [B,K,N] -> dlogit [B,K,T,F] through the iSTFT adjoint and the mask head's backward."""
+def mask_istft_bwd(dy, logit, obs, wsyn, size=1024, shift=256, fading=True, loss=None, iperm=None, bt_major=False):
+    """dy [B,K,N] -> dlogit [B,K,T,F] through the iSTFT adjoint and the mask head's backward.
+    loss = (est, tgt, sums or None, gout): the loss gradient is formed inside the kernel from the estimate
+    and the target instead of being read from `dy` (LogMAE; sums None: MAE).  bt_major: the result is laid
+    out [B*T, K*F] with speaker k at position iperm[b, k] -- what the final Linear's backward reads."""
     L = _lib.lib()
     B, K, T, F = logit.shape
-    dy = _f32(dy).contiguous()
     obs_r = torch.view_as_real(obs.contiguous())
-    dlogit = torch.empty_like(logit)
+    dlogit = torch.empty(B * T, K * F, device=logit.device, dtype=torch.float32) if bt_major else torch.empty_like(logit)
     with _timed("maskhead_bwd", 0, B * T * (16 * K * F + 8 * F)):
-        check(L.tssep_mask_istft_bwd(_p(dy), _p(logit), _p(obs_r), B, K, dy.shape[-1], size, shift,
-                                     int(fading), _p(wsyn), _p(fft_tables(size, logit.device)), _p(dlogit),
-                                     T, _stream()), "mask_istft_bwd")
+        if loss is None and not bt_major:
+            dy = _f32(dy).contiguous()
+            check(L.tssep_mask_istft_bwd(_p(dy), _p(logit), _p(obs_r), B, K, dy.shape[-1], size, shift,
+                                         int(fading), _p(wsyn), _p(fft_tables(size, logit.device)), _p(dlogit),
+                                         T, _stream()), "mask_istft_bwd")
+        else:
+            if loss is None:
+                x, tgt, sums, gout = _f32(dy).contiguous(), None, None, None
+            else:
+                x, tgt, sums, gout = (_f32(loss[0]).contiguous(), _f32(loss[1]).contiguous(), loss[2],
+                                      _f32(loss[3]).contiguous())
+            check(L.tssep_mask_istft_bwd_loss(_p(x), _p(tgt), _p(sums), _p(gout), _p(logit), _p(obs_r), B, K,
+                                              x.shape[-1], size, shift, int(fading), _p(wsyn),
+                                              _p(fft_tables(size, logit.device)), _p(iperm), int(bt_major),
+                                              _p(dlogit), T, _stream()), "mask_istft_bwd_loss")
     return dlogit
 
 
@@ -571,6 +585,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
+FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
 
 
 SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"
