@@ -19,6 +19,13 @@ done > $O/batch_sweep.jsonl
 # alternating A/B inside one job: wide GEMM tile, two-product weight gradients
 for w in 0 1 0 1; do TSSEP_GEMM_WIDE=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(gemm_wide=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], gemm_tflops=d['roofline']['achieved'])))"; done > $O/ab_gemm_wide.jsonl
+# round-2 fusions, each alternating in this one job: N = 513 as 256-wide tiles + a VALU column, Tanh backward in the
+# consumer's d(input) GEMM store, LogMAE backward + logit un-map inside the fused tail's backward
+for var in TSSEP_GEMM_XCOL TSSEP_FOLD_TANH TSSEP_FOLD_TAIL; do
+  for w in 0 1 0 1; do env $var=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(switch='$var', value=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], ms_per_step_median=d['ms_per_step_median'], gemm_tflops=d['roofline']['achieved'], mask_head_frac=d['roofline_mask_head']['frac'], mask_head_chain_frac=d['roofline_mask_head']['chain']['frac'])))"; done
+done > $O/ab_fusions.jsonl
+python tools/sweep_splitk.py 768 > $O/splitk_sweep.jsonl 2>/dev/null
 for w in 3 2 3 2; do TSSEP_WGRAD_PRODUCTS=$w python bench.py --steps 15 --warmup 3 --no-exact-f32 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); p=d['cpu_baseline']['parity_vs_hip']; print(json.dumps(dict(wgrad_products=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], max_rel_grad_err=p['max_rel_grad_err'], median_rel_grad_err=p['median_rel_grad_err'], worst=p['worst_gradient'])))"; done > $O/ab_wgrad_products.jsonl
 python bench.py --workload cfg4 --steps 40 --warmup 5 > $O/bench_cfg4.json 2>$O/bench_cfg4.err

@@ -935,6 +935,244 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_kernel(
 }
 #undef SGB
 
+// ------------------------------------------------------------------------------------------------
+// "Tall" weight-gradient variant: 256 (m) x 128 (n) output tile, wave tile 128 x 64, K staged 16 rows at a time
+// -- the row x row kernel's geometry applied to the k-major x k-major case.  Per MFMA it stages a quarter fewer
+// operand values (6 instead of 8 16-byte loads per thread and 24 MFMAs), issues a quarter fewer transpose reads
+// (24 instead of 32) and splits a quarter fewer values than the 128 x 128 kernel above; the d(gates) panel
+// (M = 2400 / 1200: every LSTM weight gradient) is split once per 128 output columns as before, the X panel once
+// per 256 instead of once per 128 gate columns.  Same staging ([k][m] bf16 rows, pitch 576 B for the 256-wide
+// A rows / 320 B for B, transpose reads), same masks, same pipeline (two LDS stages, one barrier per K tile,
+// loads of tile t + 2 in flight), same k order per output element -> bit-identical to the 128 x 128 kernel.
+// Used for the time-shifted dW_hh GEMMs (M = 1200: padding to 256 costs 6.7 %), where it takes 2.3 ms off the
+// step; for the unshifted ones (M = 2400) it measured 4-10 % slower standalone and 0.5 ms slower per step.
+constexpr int TTM = 256, TTK = 16;
+constexpr int TPA = 576;                 // bytes per k row of an A plane: 256 m x 2 B + 64
+constexpr int TTARR_A = TTK * TPA, TTARR_B = TTK * TNP;
+constexpr int TTSTAGE = 2 * 64 * EPITCH * 4;      // 34 816 B: the planes need 28 672, the epilogue two 64 x 64 scratches
+static_assert(2 * TTARR_A + 2 * TTARR_B <= TTSTAGE, "planes must fit in a stage");
+
+template <int PITCH>
+__device__ __forceinline__ bf16x8 tr_frag_p(const char* p) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * PITCH));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool SHIFT, bool TWO = false>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_tall_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
+    int64_t N, int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate,
+    int64_t ldc, int splitk, int64_t c_split_stride, TileMap tmap, int b_ones_col) {
+  constexpr int BK = TTK;
+  __shared__ __attribute__((aligned(16))) char lds0[TTSTAGE];      // A hi, A lo, B hi, B lo
+  __shared__ __attribute__((aligned(16))) char lds1[TTSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * TTM, n0 = (int64_t)nt * BN;
+  const int64_t ktiles = (K + BK - 1) / BK;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // loads: A thread <-> (k row tid/64 + 4 i, columns 4 (tid%64) .. +3), i < 4;
+  //        B thread <-> (k row tid/32 + 8 i, columns 4 (tid%32) .. +3), i < 2
+  const int krA = tid >> 6, cqA = (tid & 63) << 2;
+  const int krB = tid >> 5, cqB = (tid & 31) << 2;
+  const int64_t Nreal = N - (b_ones_col ? 1 : 0);
+  const int64_t Mp = (M + 3) & ~(int64_t)3, Np = (Nreal + 3) & ~(int64_t)3;
+  const int64_t ca = m0 + cqA <= Mp - 4 ? m0 + cqA : Mp - 4;
+  const int64_t cb = n0 + cqB <= Np - 4 ? n0 + cqB : Np - 4;
+  const char* abase = reinterpret_cast<const char*>(A);
+  const char* bbase = reinterpret_cast<const char*>(B);
+  const int64_t aoff0 = (krA * lda + ca) * 4, boff0 = (krB * ldb + cb) * 4;       // + k0 * ld * 4
+  bool am[4], bm[4], bone[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    am[e] = m0 + cqA + e < M;
+    bm[e] = n0 + cqB + e < Nreal;
+    bone[e] = b_ones_col && n0 + cqB + e == N - 1;
+  }
+  int ph[2] = {0, 0};                      // phase (k mod kperiod) of this thread's B rows of the tile in registers
+  const int phstep = SHIFT ? BK % kperiod : 0;
+  if (SHIFT) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ph[i] = (int)((kt_begin * BK + krB + 8 * i) % kperiod);
+  }
+  bool kokA[4] = {true, true, true, true}, kokB[2] = {true, true};    // row < K, of the tile held in registers
+
+  f32x4 ra[4], rb[2];
+  auto gload_full = [&](int64_t kt) {
+    const char* pa = abase + kt * BK * lda * 4 + aoff0;
+    const char* pb = bbase + (kt * BK + (SHIFT ? kshift : 0)) * ldb * 4 + boff0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(pa + (int64_t)i * 4 * lda * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const f32x4*>(pb + (int64_t)i * 8 * ldb * 4);
+  };
+  auto gload_any = [&](int64_t kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = kt * BK + krA + 4 * i;
+      ra[i] = *reinterpret_cast<const f32x4*>(abase + ((k < K ? k : K - 1) * lda + ca) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t k = kt * BK + krB + 8 * i;
+      int64_t kb = (k < K ? k : K - 1) + (SHIFT ? kshift : 0);
+      kb = kb < 0 ? 0 : (kb > K - 1 ? K - 1 : kb);
+      rb[i] = *reinterpret_cast<const f32x4*>(bbase + (kb * ldb + cb) * 4);
+    }
+  };
+  int64_t held = kt_begin - 1;
+  auto note_tile = [&](int64_t kt, bool full) {
+    if (SHIFT && held >= kt_begin) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ph[i] += phstep; ph[i] = ph[i] >= kperiod ? ph[i] - kperiod : ph[i]; }
+    }
+    held = kt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kokA[i] = full || kt * BK + krA + 4 * i < K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) kokB[i] = full || kt * BK + krB + 8 * i < K;
+  };
+  const int soffA = krA * TPA + (tid & 63) * 8, soffB = 2 * TTARR_A + krB * TNP + (tid & 31) * 8;
+  auto stage = [&](char* st, auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 a = ra[i];
+      if constexpr (EDGE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = (kokA[i] && am[e]) ? a[e] : 0.f;
+      }
+      unsigned h0, l0, h1, l1;
+      split2n(a[0], a[1], h0, l0);
+      split2n(a[2], a[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffA + i * 4 * TPA) = u32x2{h0, h1};
+      if (!TWO) *reinterpret_cast<u32x2*>(st + TTARR_A + soffA + i * 4 * TPA) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 b = rb[i];
+      if constexpr (EDGE) {
+        bool okb = kokB[i];
+        if (SHIFT) { const int q = ph[i] + kshift; okb = okb && q >= 0 && q < kperiod; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (okb && bm[e]) ? b[e] : ((bone[e] && kokB[i]) ? 1.f : 0.f);
+      } else if constexpr (SHIFT) {
+        const int q = ph[i] + kshift;
+        const bool okb = q >= 0 && q < kperiod;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = okb ? b[e] : 0.f;
+      }
+      unsigned h0, l0, h1, l1;
+      split2n(b[0], b[1], h0, l0);
+      split2n(b[2], b[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffB + i * 8 * TNP) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + TTARR_B + soffB + i * 8 * TNP) = u32x2{l0, l1};
+    }
+  };
+  // fragment address of this lane: 16-lane group g2 covers 16 m, lane ii = 4 (k row) + m quad
+  const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
+  const int fcol = (16 * g2 + 4 * (ii & 3)) * 2, frow = 8 * hk + (ii >> 2);
+  const int aoff = frow * TPA + fcol + wm * 128 * 2, boff = 2 * TTARR_A + frow * TNP + fcol + wn * 64 * 2;
+  auto compute = [&](const char* st) {
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = tr_frag_p<TPA>(st + aoff + i * 64);
+      if (!TWO) al[i] = tr_frag_p<TPA>(st + TTARR_A + aoff + i * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bh[j] = tr_frag_p<TNP>(st + boff + j * 64);
+      bl[j] = tr_frag_p<TNP>(st + TTARR_B + boff + j * 64);
+    }
+    if (!TWO) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  };
+#define TTPIPE(cur, nxt, kt_, EDGE_)                                                            \
+  do {                                                                                          \
+    compute(cur);                                                                               \
+    stage(nxt, std::integral_constant<bool, EDGE_>{});                                          \
+    gload_full((kt_) + 2);                                                                      \
+    note_tile((kt_) + 2, true);                                                                 \
+    __syncthreads();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  if (kt_begin < kt_end) {
+    gload_any(kt_begin);
+    note_tile(kt_begin, kt_begin < kt_full);
+    stage(lds0, std::true_type{});
+    if (kt_begin + 1 < kt_end) { gload_any(kt_begin + 1); note_tile(kt_begin + 1, kt_begin + 1 < kt_full); }
+    __syncthreads();
+    int64_t kt = kt_begin;
+    int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    // the pipelined loads read row k + kshift unconditionally (|kshift| <= 16 here): stay clear of the matrix's
+    // last tiles (they never see the first ones: they start at tile kt_begin + 2)
+    if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
+    const bool edge = SHIFT || m0 + TTM > M || n0 + BN > Nreal;
+    if (edge) {
+      for (; kt < lim; kt += 2) {
+        TTPIPE(lds0, lds1, kt, true);
+        TTPIPE(lds1, lds0, kt + 1, true);
+      }
+    } else {
+      for (; kt < lim; kt += 2) {
+        TTPIPE(lds0, lds1, kt, false);
+        TTPIPE(lds1, lds0, kt + 1, false);
+      }
+    }
+    for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
+      const char* cur = par ? lds1 : lds0;
+      char* nxt = par ? lds0 : lds1;
+      compute(cur);
+      if (kt + 1 < kt_end) stage(nxt, std::true_type{});
+      if (kt + 2 < kt_end) { gload_any(kt + 2); note_tile(kt + 2, kt + 2 < kt_full); }
+      __syncthreads();
+    }
+  }
+#undef TTPIPE
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  float* stg = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    f32x16 a2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
+    gemm_epilogue_rows(a2, stg, Cz, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane, nullptr, 0,
+                       accumulate, ldc, splitk == 1);
+  }
+}
+
 }  // namespace
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
@@ -982,6 +1220,21 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
       const char* pe = getenv("TSSEP_WGRAD_PRODUCTS");           // opt-in: 2 = drop the dY_lo * X_hi product
       const bool two = pe && pe[0] == '2';
+      const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
+      const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
+      // default 2: the time-shifted dW_hh GEMMs only (-2.3 ms per step, alternating A/B); the unshifted ones measured
+      // 0.5 ms SLOWER per step with this tile (1: all eligible, 3: unshifted only, 0: off)
+      const int tmode = te ? atoi(te) : 2;
+      if (tmode && (tmode == 1 || (tmode == 2) == shift) && g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16)) {
+        const TileMap tmt = make_tile_map(m256 / TTM, (g->N + BN - 1) / BN, splitk);
+        dim3 gridt((unsigned)tile_map_blocks(tmt));
+#define TT_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_tall_kernel<SH, TW>), gridt, dim3(NTHREADS), 0, s, \
+            g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, KS, KP, g->accumulate, sm.ldc, splitk, g->c_split_stride, tmt, ONES)
+        if (shift) { if (two) TT_LAUNCH(true, true, (int)g->b_kshift, (int)g->kperiod, 0); else TT_LAUNCH(true, false, (int)g->b_kshift, (int)g->kperiod, 0); }
+        else { if (two) TT_LAUNCH(false, true, 0, 1, g->b_ones_col); else TT_LAUNCH(false, false, 0, 1, g->b_ones_col); }
+#undef TT_LAUNCH
+        return tssep_launch_status();
+      }
 #define TN_LAUNCH(SH, TW, ...) hipLaunchKernelGGL((gemm_bf16x3_tn_kernel<SH, TW>), grid, dim3(NTHREADS), 0, s, __VA_ARGS__)
       if (shift) {
         if (two) TN_LAUNCH(true, true, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift,
