@@ -338,6 +338,7 @@ def main():
 
     def rooflines(dt, gemm_name):
         """Live HIP-event timings of this run -> (dominant MFMA kernel, mask head)."""
+        T = H.stft_frames(N_s)          # frames per chunk (the timed runs report the same number)
         traffic, mfma_busy = {}, None
         try:      # HBM bytes per launch from rocprofv3 PMC passes of this same command (separate --pmc runs)
             with open(newest_profile("traffic_pmc.json")) as f:

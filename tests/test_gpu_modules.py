@@ -1,6 +1,7 @@
 """Module-level parity on a real MI355X: the drop-in classes (tssep_amd.train.*) against
 (a) fixtures generated from the REFERENCE classes (tests/golden) and (b) the CPU oracle."""
 import glob
+import sys
 import os
 
 import numpy as np
@@ -798,3 +799,25 @@ def test_data_parallel_trainer_two_ranks_on_one_gpu(tmp_path):
     ck = torch.load(sd / "checkpoints" / "ckpt_latest.pth", map_location="cpu")
     assert ck["iteration"] == 3 and "mask_estimator.post_net.linear2.weight" in ck["model"]
     assert len(list((sd / "checkpoints").glob("ckpt_*.pth"))) >= 2         # ckpt_3 + the links, once
+
+
+def test_bench_default_flags_print_one_json_line():
+    """`python bench.py` with its default flags (split-bf16 line + the exact-fp32 secondary line + the rooflines)
+    at a small batch: ONE JSON line on stdout with the contract's keys.  (The exact-fp32 leg once crashed on a
+    variable the main leg defined later -- nothing else in the suite runs that leg.)"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--graph", "off"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_mask_head", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline_mask_head"]["bound"] == "hbm" and "chain" in d["roofline_mask_head"]
+    assert d["exact_f32"] is not None and d["exact_f32"]["roofline"]["peak"] == pytest.approx(157.3)
