@@ -253,14 +253,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        if dist.get_world_size() != args.gpus:
-            raise SystemExit(f"bench.py: RCCL sees {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    from tssep_amd import distributed as D
+    # RANK / LOCAL_RANK -> GPU + process group: "nccl" (= RCCL).  TSSEP_DIST_BACKEND=gloo (tests: several ranks
+    # share ONE GPU, which RCCL refuses; device tensors are then staged through the host) exercises the same code.
+    rank, world, local_rank = D.init_from_env()
+    dev = torch.device("cuda", local_rank)
+    if world > 1 and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     wl = WORKLOADS[args.workload]
     K, N_s = wl["K"], wl["N"]
@@ -273,7 +273,7 @@ def main():
     opt = Adam(gradient_clipping=10.0, lr=1e-5)          # clipping as tssep/exp/init_cfg_common.yaml:85-94
     opt.set_parameters(model.parameters())               # flat params + the flat gradient bucket
     if world > 1:                                        # identical replicas, as Trainer.train does
-        dist.broadcast(opt.flat_param, src=0)
+        D.broadcast_(opt.flat_param, src=0)
     obs, aux, tgt = synth_batch(B, K, N_s, seed=rank)    # each rank its own shard
     ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
                speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
@@ -331,7 +331,7 @@ def main():
             torch.cuda.synchronize()
             H.KERNEL_TIMING = False
         per_step = sorted(a.elapsed_time(b) for a, b in zip(marks, marks[1:]))      # device-side ms per step
-        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt_], device=dev if world == 1 or dist.get_backend() != "gloo" else "cpu", dtype=torch.float64)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), int(out.logit.shape[-2]), float(np.median(per_step))

@@ -821,3 +821,28 @@ def test_bench_default_flags_print_one_json_line():
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["roofline_mask_head"]["bound"] == "hbm" and "chain" in d["roofline_mask_head"]
     assert d["exact_f32"] is not None and d["exact_f32"]["roofline"]["peak"] == pytest.approx(157.3)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N > 1 path of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
+    --gpus 2`): rank-0 broadcast of the parameters, per-rank shards, barrier + max-over-ranks timing, the flat
+    gradient all-reduce inside the optimizer step, ONE JSON line from rank 0 with n_gpus = 2 and the doubled global
+    batch.  Two ranks share this box's single GPU, so the backend is gloo (RCCL refuses two ranks per device) and the
+    recurrences are the streaming ones (two processes must not run W-stationary launches concurrently)."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, TSSEP_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--recurrence", "stream",
+                        "--no-cpu-baseline", "--no-exact-f32", "--graph", "off"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
