@@ -332,6 +332,10 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     # 0..5 % of the best S on every shape of the step)
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
+    if SPLITK_BIGK and K >= 400000 and tiles >= 48:
+        # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
+        # smallest one -- 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
+        return 8
     s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
     if s > 1:        # multiples of the XCD count: split z runs on XCD z % 8 (gemm_common.h)
         s = min(round_up(s, 8), max(8, (ktiles // min_ktiles) // 8 * 8))
@@ -584,6 +588,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 # second HIP stream, overlapping the T-sequential recurrences of the layers still to come.
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
+SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
 
