@@ -18,6 +18,19 @@
 
 namespace {
 
+// Buffer resources for the frame streams: one 4-SGPR descriptor per row (base + byte range) and ONE 32-bit lane
+// offset; the r-th access of a lane is an immediate offset.  Out-of-range elements (the fading zeros in front of a
+// row, the padding behind it) read as 0 by the range check -- no per-load masks, no per-load 64-bit addresses.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ srd_t make_srd(const void* p, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffff ? 0x7fffffff : bytes), 0x00020000);
+}
+__device__ __forceinline__ float2 bload2(srd_t r, unsigned voff) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0);
+  return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
+}
+
 constexpr int NH = 512;          // complex FFT length
 constexpr int LINE = NH + NH / 8;  // padded LDS line (float2)
 #define PADI(i) ((i) + ((i) >> 3))
@@ -158,28 +171,25 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = make_float2(0.f, 0.f);
     } else if (fast) {
+      // (base + 2 lane + 128 r) may be negative or beyond the row: as an unsigned byte offset it then lies outside
+      // the descriptor's range and the pair reads as (0, 0)
+      const unsigned vo = (unsigned)((base + 2 * lane) * 4);
+      const srd_t sx = make_srd(xr, N * 4);
       float2 xv[8];
-      bool in[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int64_t i0 = base + 2 * (lane + 64 * r);
-        in[r] = i0 >= 0 && i0 + 1 < N;
-        xv[r] = *reinterpret_cast<const float2*>(xr + (in[r] ? i0 : 0));
-      }
+      for (int r = 0; r < 8; ++r) xv[r] = bload2(sx, vo + 512u * r);
       if (lossgrad) {
+        const srd_t st_ = make_srd(tr_, N * 4);
         float2 tv[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int64_t i0 = base + 2 * (lane + 64 * r);
-          tv[r] = *reinterpret_cast<const float2*>(tr_ + (in[r] ? i0 : 0));
-        }
+        for (int r = 0; r < 8; ++r) tv[r] = bload2(st_, vo + 512u * r);
 #pragma unroll
         for (int r = 0; r < 8; ++r) xv[r] = make_float2(lg(xv[r].x, tv[r].x), lg(xv[r].y, tv[r].y));
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
-        v[r] = make_float2(in[r] ? xv[r].x * wv.x : 0.f, in[r] ? xv[r].y * wv.y : 0.f);
+        v[r] = make_float2(xv[r].x * wv.x, xv[r].y * wv.y);
       }
     } else {
       float xa[8], xb[8];
