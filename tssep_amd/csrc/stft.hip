@@ -31,6 +31,13 @@ __device__ __forceinline__ float2 bload2(srd_t r, unsigned voff) {
   return make_float2(__uint_as_float(v[0]), __uint_as_float(v[1]));
 }
 
+__device__ __forceinline__ float bload1(srd_t r, unsigned voff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void bstore1(srd_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, 0, 0);
+}
+
 constexpr int NH = 512;          // complex FFT length
 constexpr int LINE = NH + NH / 8;  // padded LDS line (float2)
 #define PADI(i) ((i) + ((i) >> 3))
@@ -138,9 +145,10 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
   // (b,t) x (speaker position iperm[b,k], f) -- the inverse of the store remap of the forward
   // (net.py:637-641, 957-967) -- instead of [B,K,T,F] + tssep_logit_map_bwd.
   __shared__ float2 twl[NH];
-  __shared__ float2 line[4][LINE];
+  __shared__ float2 wl[NH];               // the window as sample pairs: read per frame from LDS -- as global loads the
+  __shared__ float2 line[4][LINE];        // compiler kept eight 64-bit per-lane addresses alive across the frame loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
+  for (int i = tid; i < NH; i += 256) { twl[i] = tw[i]; wl[i] = reinterpret_cast<const float2*>(window)[i]; }
   __syncthreads();
   const float2 tw2_lane = tw[NH + lane];
   const int64_t total = rows * T;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
+        const float2 wv = wl[lane + 64 * r];
         v[r] = make_float2(xv[r].x * wv.x, xv[r].y * wv.y);
       }
     } else {
@@ -204,7 +212,7 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int64_t i0 = base + 2 * (lane + 64 * r), i1 = i0 + 1;
-        const float2 wv = *reinterpret_cast<const float2*>(window + 2 * (lane + 64 * r));
+        const float2 wv = wl[lane + 64 * r];
         v[r] = make_float2((i0 >= 0 && i0 < N) ? xa[r] * wv.x : 0.f, (i1 >= 0 && i1 < N) ? xb[r] * wv.y : 0.f);
       }
     }
@@ -285,7 +293,8 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
     const float* __restrict__ logit, const float2* __restrict__ obs, int64_t Kspk) {
   __shared__ float2 twl[NH];
   __shared__ float2 line[4][LINE];
-  __shared__ __attribute__((aligned(16))) float fr[RING][1024];
+  __shared__ __attribute__((aligned(16))) float fr[RING][1024];       // (51 KB with the rest: three workgroups per CU --
+                                                                      // no room for the window table the rfft kernel keeps)
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t row = blockIdx.y;
@@ -301,6 +310,9 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
   const float inv = 1.0f / 512.0f;
   float* yr = y + row * N;
   const float* tr = tgt ? tgt + row * N : nullptr;
+  // the chunk's samples [n0, min(N, n0 + 256 hops)) of this row
+  const int64_t chunk_bytes = ((N - n0 < (int64_t)hops * 256 ? N - n0 : (int64_t)hops * 256)) * 4;
+  const srd_t sy = make_srd(yr + n0, chunk_bytes), str_ = make_srd(tr ? tr + n0 : yr + n0, chunk_bytes);
   float asum = 0.f;
   float2* buf = line[wave];
   for (int it = 0; it < iters; ++it) {
@@ -314,12 +326,19 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
       if (MASKED) {
         const float* Lr = logit + (row * T + t) * (NH + 1);
         const float2* Or = obs + ((row / Kspk) * T + t) * (NH + 1);
+        const srd_t sl = make_srd(Lr, (NH + 1) * 4), so = make_srd(Or, (NH + 1) * 8);
+        float lg8[8];
+        float2 ob8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
+          ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int k = lane + 64 * r;
-          const float m = sigmoidf_acc(Lr[k]);
-          const float2 ob = Or[k];
-          buf[PADI(k)] = make_float2(ob.x * m, ob.y * m);
+          const float m = sigmoidf_acc(lg8[r]);
+          buf[PADI(k)] = make_float2(ob8[r].x * m, ob8[r].y * m);
         }
         if (lane == 0) {
           const float m = sigmoidf_acc(Lr[NH]);
@@ -364,19 +383,19 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
     // compiler kept each load behind the previous store and waited for it (four serialised round trips
     // per iteration, a third of a workgroup's time).
     {
-      float tv[4] = {0.f, 0.f, 0.f, 0.f}, sv[4];
+      // y and the target through buffer resources whose range ends with this chunk's samples: hops in front of
+      // the chunk (h < 0 wraps to a huge offset) or behind it load 0 / are not stored -- no per-lane branches
+      float tv[4], sv[4];
       bool em[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int h = 4 * it - 3 + q;
-        const int64_t n = n0 + (int64_t)h * 256 + tid;
-        em[q] = h >= 0 && h < hops && n < N;
-        if (em[q] && tr) tv[q] = tr[n];
+        em[q] = h >= 0 && h < hops && n0 + (int64_t)h * 256 + tid < N;
+        tv[q] = tr ? bload1(str_, (unsigned)(((4 * it - 3 + q) * 256 + tid) * 4)) : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int h = 4 * it - 3 + q;
-        if (!em[q]) continue;
+        const int h = 4 * it - 3 + q + RING * 2;           // (non-negative index into the ring; RING * 2 > 3)
         float s = fr[h % RING][tid + 768];
         s += fr[(h + 1) % RING][tid + 512];
         s += fr[(h + 2) % RING][tid + 256];
@@ -385,10 +404,8 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (!em[q]) continue;
-        const int h = 4 * it - 3 + q;
-        yr[n0 + (int64_t)h * 256 + tid] = sv[q];
-        if (tr) asum += fabsf(sv[q] - tv[q]);
+        bstore1(sy, (unsigned)(((4 * it - 3 + q) * 256 + tid) * 4), sv[q]);
+        if (tr && em[q]) asum += fabsf(sv[q] - tv[q]);
       }
     }
     __syncthreads();        // the next iteration overwrites the slots of frames <= 4 it
@@ -444,7 +461,7 @@ extern "C" int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size,
   if (!x || !window || !tw || !X) return TSSEP_E_NULL;
   if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
   if (int e = check_plan(size, shift)) return e;
-  if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)window) & 7u)) return TSSEP_E_ALIGN;
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
@@ -462,7 +479,7 @@ extern "C" int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int siz
   if (!dy || !wsyn || !tw || !dX) return TSSEP_E_NULL;
   if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
   if (int e = check_plan(size, shift)) return e;
-  if ((((uintptr_t)dX) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  if ((((uintptr_t)dX) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
@@ -481,7 +498,7 @@ extern "C" int tssep_mask_istft_bwd(const float* dy, const float* logit, const f
   if (!dy || !logit || !obs || !wsyn || !tw || !dlogit) return TSSEP_E_NULL;
   if (B <= 0 || K <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
   if (int e = check_plan(size, shift)) return e;
-  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
   const int iters = 4;
   const int64_t rows = B * K, total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
@@ -502,7 +519,7 @@ extern "C" int tssep_mask_istft_bwd_loss(const float* est, const float* tgt, con
   if (!est || (tgt && !gout) || !logit || !obs || !wsyn || !tw || !dlogit) return TSSEP_E_NULL;
   if (B <= 0 || K <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
   if (int e = check_plan(size, shift)) return e;
-  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+  if ((((uintptr_t)obs) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
   const int iters = 4;
   const int64_t rows = B * K, total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
