@@ -67,7 +67,8 @@ def _worker(rank, world, port, q):
     bucket.zero()
     lin(x[lo:hi]).abs().sum().backward()          # loss summed over the shard
     bucket.all_reduce()
-    q.put((rank, bucket.flat.clone(), float(bucket.global_norm())))
+    # (numpy, not torch: a tensor travels through the queue as a shared-memory handle that dies with this process)
+    q.put((rank, bucket.flat.detach().numpy().copy(), float(bucket.global_norm())))
     dist.destroy_process_group()
 
 
@@ -110,7 +111,7 @@ def test_gradient_sum_allreduce_world2():
     lin(x).abs().sum().backward()
     ref = torch.cat([lin.weight.grad.flatten(), lin.bias.grad.flatten()])
     for _, flat, norm in res:
-        torch.testing.assert_close(flat, ref)
+        torch.testing.assert_close(torch.as_tensor(flat), ref)
         assert abs(norm - float(ref.norm())) < 1e-4
 
 
@@ -154,7 +155,7 @@ def _model_worker(rank, world, port, q):
     loss = _oracle_loss(p, obs, aux, tgt)
     loss.backward()
     bucket.all_reduce()
-    q.put((rank, bucket.flat.clone(), float(loss)))
+    q.put((rank, bucket.flat.detach().numpy().copy(), float(loss)))
     dist.destroy_process_group()
 
 
@@ -166,7 +167,7 @@ def test_model_level_data_parallel_equivalence():
     ref = torch.cat([v.grad.flatten() for v in leaves])
     assert float(ref.abs().max()) > 1e-4
     for _, flat, _ in res:
-        torch.testing.assert_close(flat, ref, rtol=2e-4, atol=2e-6 * float(ref.abs().max()) + 1e-9)
+        torch.testing.assert_close(torch.as_tensor(flat), ref, rtol=2e-4, atol=2e-6 * float(ref.abs().max()) + 1e-9)
     torch.testing.assert_close(torch.tensor(sum(r[2] for r in res)), torch.tensor(float(loss.detach())), rtol=1e-5, atol=1e-6)
 
 
