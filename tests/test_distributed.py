@@ -28,32 +28,57 @@ def _free_port():
     return p
 
 
+def _entry(name, rank, world, port, q, *args):
+    """Process target: run the named worker; an exception travels to the parent as the rank's result, so the
+    test fails at once with the worker's traceback instead of waiting for a result that never comes."""
+    import traceback
+    os.environ["TSSEP_DIST_BACKEND"] = "gloo"      # CPU tensors: never nccl, also on a box that has a GPU
+    os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        globals()[name](rank, world, port, q, *args)
+    except BaseException:                           # noqa: BLE001
+        q.put((rank, "__error__", traceback.format_exc()))
+
+
 def _spawn(worker, world, *args):
     """Start `world` ranks and collect one result per rank.  The rendezvous port is found by binding to 0 and
     closing again, so another process can take it before gloo does (seen once in ~30 runs of this suite on a busy
-    box): a round whose ranks die without reporting is repeated on a fresh port, an assertion inside a worker
-    still fails the test through its missing result."""
+    box): ONLY that failure (address in use) is repeated, on a fresh port; any other exception of a worker
+    fails the test with the worker's traceback, and so does a rank that dies without reporting."""
     import queue
     ctx = mp.get_context("spawn")
-    last = None
     for attempt in range(3):
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=worker, args=(r, world, port, q, *args)) for r in range(world)]
+        procs = [ctx.Process(target=_entry, args=(worker.__name__, r, world, port, q, *args)) for r in range(world)]
         for p in procs:
             p.start()
+        res, failure = [], None
         try:
-            res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+            while len(res) < world and failure is None:
+                try:
+                    r = q.get(timeout=5)
+                except queue.Empty:
+                    if all(not p.is_alive() for p in procs) and q.empty():
+                        failure = "a rank died without reporting (exit codes %s)" % [p.exitcode for p in procs]
+                    continue
+                if len(r) == 3 and isinstance(r[1], str) and r[1] == "__error__":
+                    failure = f"rank {r[0]} raised:\n{r[2]}"
+                else:
+                    res.append(r)
+        finally:
             for p in procs:
-                p.join(60)
-            return res
-        except queue.Empty as e:
-            last = e
-            for p in procs:
+                p.join(60 if failure is None else 1)
                 if p.is_alive():
                     p.terminate()
-                p.join(10)
-    raise last
+                    p.join(10)
+        if failure is None:
+            return sorted(res, key=lambda r: r[0])
+        if "EADDRINUSE" in failure or "Address already in use" in failure:
+            continue
+        raise AssertionError(failure)
+    raise AssertionError(failure)
 
 
 def _worker(rank, world, port, q):
@@ -187,6 +212,61 @@ def test_broadcast_and_replica_check_world2():
     res = _spawn(_replica_worker, 2)
     for rank, before, after, values in res:
         assert before is False and after is True and values == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+def _failure_worker(rank, world, port, q):
+    from tssep_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env()
+    fine = D.agree_on_failure(0)
+    one_failed = D.agree_on_failure(3 if rank == 1 else 0)
+    q.put((rank, fine, one_failed, D.same_on_all_ranks(17), D.same_on_all_ranks(5 + rank)))
+    dist.destroy_process_group()
+
+
+def test_failure_flag_and_batch_count_exchange_world2():
+    """ADVICE r2: a rank that raises alone leaves its peers in the next all-reduce until the watchdog fires;
+    every rank must learn of a failure (and of unequal batch counts) at the same program point."""
+    for rank, fine, one_failed, same, differ in _spawn(_failure_worker, 2):
+        assert fine == (0, -1) and one_failed == (3, 1) and same is True and differ is False
+
+
+def _trainer_failure_worker(rank, world, port, q):
+    """The Trainer's collective check: rank 1's device flag is set -> BOTH ranks raise."""
+    from tssep_amd import distributed as D
+    from tssep_amd.train.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env()
+    t = Trainer(model=torch.nn.Linear(2, 2), storage_dir="/tmp", optimizer=None)
+    t.agree_on_failure()                                    # nobody failed: returns
+    if rank == 1:
+        def boom():
+            raise RuntimeError("cluster recurrence kernel timed out waiting for a peer (code 7)")
+        t.check_device_errors = boom
+    try:
+        t.agree_on_failure()
+        msg = "returned"
+    except RuntimeError as e:
+        msg = str(e)
+    # the chief's checkpoint block: rank 0 fails inside it, rank 1 (which does not enter it) leaves too
+    t.check_device_errors = lambda: None
+    t.save_checkpoint = lambda v: (_ for _ in ()).throw(OSError("disk full"))
+    t.validate = lambda: 0.0
+    try:
+        t._chief_checkpoint(rank == 0)
+        msg2 = "returned"
+    except (RuntimeError, OSError) as e:
+        msg2 = str(e)
+    q.put((rank, msg, msg2))
+    dist.destroy_process_group()
+
+
+def test_trainer_ranks_fail_together_world2():
+    res = _spawn(_trainer_failure_worker, 2)
+    assert "rank 1 failed" in res[0][1] and "timed out" in res[1][1]
+    assert "disk full" in res[0][2] and "rank 0 failed" in res[1][2]
 
 
 def test_bucket_grads_are_views():

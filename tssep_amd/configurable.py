@@ -33,7 +33,9 @@ def resolve(factory):
 def factory_path(cls):
     """Report the reference's import path for our drop-in classes (config round trips)."""
     path = f"{cls.__module__}.{cls.__qualname__}"
-    for old, new in _ALIASES:
+    # most specific alias first: tssep_amd.train.trainer.Trainer is padertorch's Trainer in the
+    # reference's frozen config (init_cfg_common.yaml:9,86), not a `tssep.train.trainer` module
+    for old, new in sorted(_ALIASES, key=lambda a: -len(a[1])):
         if path.startswith(new):
             return old + path[len(new):]
     return path

@@ -91,8 +91,39 @@ def init_from_env(backend=None):
         # TSSEP_DIST_BACKEND=gloo: several ranks on ONE GPU (tests, debugging; RCCL refuses that)
         backend = backend or os.environ.get("TSSEP_DIST_BACKEND") or ("nccl" if on_gpu else "gloo")
         kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # Only rank 0 validates and writes checkpoints while its peers wait in the next collective: the
+        # watchdog's default (10 min for nccl) is shorter than a validation pass over a real corpus.
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("TSSEP_DIST_TIMEOUT_S", 4 * 3600)))
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout, **kw)
     return rank, world, local_rank
+
+
+def agree_on_failure(code, device=None):
+    """Collective: MAX over ranks of a small non-negative failure code (0 = fine).  Every rank learns that
+    SOME rank failed and can leave together instead of waiting in the next all-reduce until the watchdog
+    fires.  Also a barrier.  -> (max code, rank that reported it or -1)."""
+    if world_size() == 1:
+        return int(code), (0 if code else -1)
+    rank = get_rank()
+    t = torch.tensor([int(code), (rank + 1) if code else 0], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst, who = (int(v) for v in t.cpu())
+    return worst, who - 1
+
+
+def same_on_all_ranks(value):
+    """Collective: True when the integer `value` is the same on every rank."""
+    if world_size() == 1:
+        return True
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, neg_lo = (int(v) for v in t.cpu())
+    return hi == -neg_lo
 
 
 def _staged(tensor):

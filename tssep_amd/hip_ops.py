@@ -472,12 +472,19 @@ def _err_flag(device):
     return _ERR[key]
 
 
-def check_cluster_errors(device="cuda"):
-    """Synchronising check of the cluster kernels' timeout flag (tests / end of a bench run)."""
+def cluster_error_code(device="cuda"):
+    """Synchronising read-and-clear of the cluster kernels' timeout flag: 0 = no launch gave up."""
     f = _err_flag(device)
     v = int(f[0].item())
     if v:
         f[0].zero_()
+    return v
+
+
+def check_cluster_errors(device="cuda"):
+    """Synchronising check of the cluster kernels' timeout flag (tests / end of a bench run)."""
+    v = cluster_error_code(device)
+    if v:
         raise RuntimeError(f"cluster recurrence kernel timed out waiting for a peer (code {v})")
 
 

@@ -7,6 +7,7 @@
 
 YAML files are merged left to right, then ``key=value`` overrides (dotted paths, YAML values)."""
 import datetime
+import os
 import shlex
 import sys
 from pathlib import Path
@@ -43,15 +44,34 @@ def build_config(args):
     return cfg
 
 
+def write_text_atomic(path, text):
+    """The reference writes config.yaml through paderbox's ``write_text_atomic`` (run.py:145-151): a
+    reader -- another rank of a torchrun job parsing config.yaml at the same moment -- sees the old or
+    the new file, never a truncated one."""
+    path = Path(path)
+    tmp = path.with_name(f".{path.name}.{os.getpid()}.tmp")
+    tmp.write_text(text)
+    os.replace(tmp, path)
+
+
+def _chief():
+    """Under torchrun every rank enters this module with the same argv; only rank 0 writes into the
+    storage dir (config.yaml, backups, Makefile, python_history.txt, log/), the others only read."""
+    return int(os.environ.get("RANK", 0)) == 0
+
+
 def dump_config(storage_dir, cfg):                      # run.py:138-151 (+ backup :104-135)
     storage_dir = Path(storage_dir)
     path = storage_dir / "config.yaml"
     text = yaml.safe_dump(cfg, sort_keys=False)
-    if path.exists() and path.read_text() != text:
+    old = path.read_text() if path.exists() else None
+    if old == text:
+        return
+    if old is not None:
         stamp = datetime.datetime.today().strftime("%Y_%m_%d_%H_%M_%S")
         (storage_dir / "backup").mkdir(exist_ok=True)
-        (storage_dir / "backup" / f"config_{stamp}.yaml").write_text(path.read_text())
-    path.write_text(text)
+        write_text_atomic(storage_dir / "backup" / f"config_{stamp}.yaml", old)
+    write_text_atomic(path, text)
 
 
 def makefile(cfg, dump=True):
@@ -65,20 +85,22 @@ def makefile(cfg, dump=True):
     text = "SHELL := /bin/bash\n"
     for name, recipe in targets:
         text += f"\n.PHONY: {name}\n{name}:\n" + "".join(f"\t{line}\n" for line in recipe)
-    if dump:
-        (Path(cfg["eg"]["trainer"]["storage_dir"]) / "Makefile").write_text(text)
+    if dump and _chief():
+        write_text_atomic(Path(cfg["eg"]["trainer"]["storage_dir"]) / "Makefile", text)
     return text
 
 
 def init(cfg):
     storage_dir = Path(cfg["eg"]["trainer"]["storage_dir"])
+    cwd = Path.cwd()                                   # run.py:167-172: a sibling directory of the
+    if cwd.parts[:-1] == storage_dir.parts[:-1]:       # storage dir is almost certainly a mistake
+        assert cwd == storage_dir, (cwd, storage_dir)
+    if not _chief():                                   # ranks > 0 of a torchrun job: read-only
+        return Experiment.from_config(cfg["eg"])
     storage_dir.mkdir(exist_ok=True, parents=True)
     with open(storage_dir / "python_history.txt", "a") as fd:      # run.py:159-165
         print(f"{shlex.join(sys.argv)}  # {datetime.datetime.today():%Y.%m.%d %H:%M:%S}  # {Path.cwd()}",
               file=fd)
-    cwd = Path.cwd()                                   # run.py:167-172: a sibling directory of the
-    if cwd.parts[:-1] == storage_dir.parts[:-1]:       # storage dir is almost certainly a mistake
-        assert cwd == storage_dir, (cwd, storage_dir)
     dump_config(storage_dir, cfg)
     print(yaml.safe_dump(cfg, sort_keys=False))
     makefile(cfg)

@@ -62,11 +62,33 @@ class Trainer(Configurable):
     def check_device_errors(self):
         """Raise if a W-stationary recurrence launch gave up on a peer (include/tssep_hip.h: err[0]):
         everything computed since is garbage and must not be trained on or checkpointed.  One host
-        sync; called where the loop synchronises anyway (summary scalars, validation, checkpoints)."""
+        sync; called where the loop synchronises anyway (summary scalars, validation, checkpoints).
+        Local to this rank: use ``agree_on_failure`` where every rank passes."""
         p = next(self.model.parameters(), None)
         if p is not None and p.is_cuda:
             from .. import hip_ops
             hip_ops.check_cluster_errors(p.device)
+
+    def agree_on_failure(self, error=None):
+        """COLLECTIVE (every rank, same iteration): this rank's device error flag, or the exception
+        `error` it has already caught, is exchanged (all-reduce MAX) so that all ranks raise together --
+        a rank that raised alone would leave its peers in the next gradient all-reduce until the
+        watchdog fires.  Also the barrier that keeps the peers until rank 0 has validated / written."""
+        if error is None:
+            try:
+                self.check_device_errors()
+            except RuntimeError as e:
+                error = e
+        if _dist.world_size() == 1:
+            if error is not None:
+                raise error
+            return
+        p = next(self.model.parameters(), None)
+        _, who = _dist.agree_on_failure(0 if error is None else 1, device=p.device if p is not None and p.is_cuda else None)
+        if error is not None:
+            raise error
+        if who >= 0:
+            raise RuntimeError(f"rank {_dist.get_rank()}: leaving because rank {who} failed")
 
     def validate(self):
         self.model.eval()
@@ -97,6 +119,17 @@ class Trainer(Configurable):
             os.symlink(path.name, link)
         return path
 
+    def _chief_checkpoint(self, do_it):
+        """Rank 0 validates and writes the checkpoint; EVERY rank calls this and leaves it together
+        (``agree_on_failure`` is the barrier, and carries a failure of the chief to the others)."""
+        error = None
+        if do_it:
+            try:
+                self.save_checkpoint(self.validate())
+            except Exception as e:                    # noqa: BLE001 -- re-raised on every rank below
+                error = e
+        self.agree_on_failure(error)
+
     def load_checkpoint(self, path):
         sd = torch.load(str(path), map_location="cpu")
         self.model.load_state_dict(sd["model"])
@@ -123,6 +156,12 @@ class Trainer(Configurable):
         assert stop_unit == "iteration", self.stop_trigger
         self.optimizer.zero_grad()
         while self.iteration < stop_n:
+            if world > 1 and hasattr(train_dataset, "__len__"):
+                # one batch more on one rank = that rank alone in an all-reduce, for ever
+                n_batches = len(train_dataset)
+                if not _dist.same_on_all_ranks(n_batches):
+                    raise RuntimeError(f"rank {rank}: {n_batches} training batches in this epoch, another rank "
+                                       "has a different count (shard BEFORE any stage that drops examples)")
             for ex in train_dataset:
                 summary = self.model.review(ex, self.model(ex))
                 summary["loss"].backward()
@@ -132,15 +171,16 @@ class Trainer(Configurable):
                     self.optimizer.zero_grad()
                 if self._triggered(self.summary_trigger):
                     self.history.append((self.iteration, float(summary["loss"])))     # host sync
-                    self.check_device_errors()
-                if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None and chief:
-                    self.save_checkpoint(self.validate())
+                    self.agree_on_failure()
+                if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None:
+                    self._chief_checkpoint(chief)
                 if self.iteration >= stop_n:
                     break
             self.epoch += 1
-        self.check_device_errors()
-        if chief and self.validation_dataset is not None and not (self.checkpoint_dir / "ckpt_latest.pth").exists():
-            self.save_checkpoint(self.validate())
+        self.agree_on_failure()
+        if self.validation_dataset is not None:
+            need = chief and not (self.checkpoint_dir / "ckpt_latest.pth").exists()
+            self._chief_checkpoint(need)
         if chief:                                    # the summary scalars, for runs driven as child processes
             import json
             (self.storage_dir / "log").mkdir(parents=True, exist_ok=True)
