@@ -79,12 +79,15 @@ def build_model(K=None):
         enhancer=enhancer.Masking(), loss=loss.LogMAE())
 
 
-def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS):
-    """Dense-GEMM FLOPs per STFT frame, forward; backward = 2x."""
-    pre = 16 * H * (D + H) + 2 * 2 * H * F
-    b0 = 16 * H * (F + H) + 2 * 2 * H * P
-    b1 = 16 * H * (P + H) + 2 * 2 * H * P
-    b2 = 16 * H * (P * K + H) + 2 * 2 * H * P
+def flops_per_frame(K, H=UNITS, P=PROJS, D=553, F=FBINS, recurrent=True):
+    """Dense-contraction FLOPs per STFT frame, forward; backward = 2x.  `recurrent=False`
+    leaves out the T-sequential h.W_hh products (16 H H per BLSTM and frame), which run inside the
+    recurrence kernels, not in the GEMM family."""
+    hh = H if recurrent else 0
+    pre = 16 * H * (D + hh) + 2 * 2 * H * F
+    b0 = 16 * H * (F + hh) + 2 * 2 * H * P
+    b1 = 16 * H * (P + hh) + 2 * 2 * H * P
+    b2 = 16 * H * (P * K + hh) + 2 * 2 * H * P
     return pre + K * (b0 + b1) + b2 + 2 * P * F * K
 
 
@@ -116,22 +119,28 @@ def launch_ranks(n, argv):
     sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the pool's host driver supports dmabuf IPC only; with the legacy mode RCCL's
+    # intra-node transport fails in hipIpcGetMemHandle ("invalid argument").  The image exports it already; it is
+    # repeated here so that a launcher started from a scrubbed environment still gives it to every rank.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
+def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16):
     """The CPU oracle (a port of the reference's torch code path, pinned to it by tests) timed on
-    this host: same model size and chunk length, a bounded sample.  Thread count: torch's CPU LSTM
-    stops scaling (and collapses under oversubscription) well before the 256 hardware threads of
-    the GPU host, so the faster of 8 / 16 threads is reported together with the count used, plus
-    the single-thread figure (the reference's CI setting, README.md:51-56).  With `hip_model` the
-    same 4 utterances and the same weights also go through the HIP path and the parity of masks,
-    loss and parameter gradients is asserted in this run."""
+    this host: same model size and chunk length, a bounded sample of `batch` utterances.  Thread
+    count: a sweep over {8, 16, 32, 64} (capped at the host's logical CPUs) -- torch's CPU LSTM stops
+    scaling, and collapses under oversubscription, well before the 256 hardware threads of the GPU
+    host -- the winner is reported with the whole sweep beside it, plus the single-thread figure
+    (the reference's CI setting, README.md:51-56).  With `hip_model` 4 of the utterances and the
+    same weights also go through the HIP path and the parity of masks, loss and parameter gradients
+    is asserted in this run."""
     from oracle import model as omodel
     torch.manual_seed(0)
-    B = 4
-    obs, aux, tgt = synth_batch(B, K_SPK, N_SAMPLES, 1234)
+    B = 4                                    # parity sample; the timing sample below is `batch` utterances
+    obs, aux, tgt = synth_batch(max(B, batch), K_SPK, N_SAMPLES, 1234)
+    timing_x = [torch.as_tensor(a) for a in (obs, aux, tgt)]
+    obs, aux, tgt = obs[:B], aux[:B], tgt[:B]
     if hip_model is not None:
         p = {"mask_estimator." + k: v.detach().cpu().clone()
              for k, v in hip_model.mask_estimator.state_dict().items()}
@@ -143,10 +152,10 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
     cfg = dict(odim=FBINS, combination="mul", ts_vad=K_SPK, output_resolution="tf")
     x = [torch.as_tensor(a) for a in (obs, aux, tgt)]
 
-    def one_step(keep=False):
+    def one_step(keep=False, inputs=None):
         t0 = time.time()
         np.random.seed(4321)
-        o = omodel.forward_loss(p, *x, cfg=cfg, fast=True)
+        o = omodel.forward_loss(p, *(inputs or x), cfg=cfg, fast=True)
         o["loss"].sum().backward()
         dt_ = time.time() - t0
         if not keep:
@@ -186,28 +195,30 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=15.0):
             v.grad = None
         opt.zero_grad()
 
-    best = None
-    t_all = time.time()
-    for nt in sorted({min(8, os.cpu_count() or 1), min(16, os.cpu_count() or 1)}):
+    best, sweep = None, {}
+    Bt = timing_x[0].shape[0]
+    counts = sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64)})
+    for nt in counts:
         torch.set_num_threads(nt)
+        t_all = time.time()
         times = []
-        while len(times) < 3 or (time.time() - t_all < seconds_budget / 2 and len(times) < 20):
-            dt_, o = one_step()
+        while len(times) < 2 or (time.time() - t_all < seconds_budget / len(counts) and len(times) < 10):
+            dt_, o = one_step(inputs=timing_x)
             times.append(dt_)
-            if time.time() - t_all > 4 * seconds_budget:        # hard stop on a slow host
+            if time.time() - t_all > 2 * seconds_budget:        # hard stop on a slow host
                 break
         cand = (min(times[1:]) if len(times) > 1 else times[0], nt, len(times), o["mask"].shape[-2])
+        sweep[str(nt)] = round(Bt * cand[3] / cand[0], 1)
         best = cand if best is None or cand[0] < best[0] else best
-        t_all = time.time()
     step_s, nt, n, T = best
     torch.set_num_threads(1)
-    one_step()
-    st_s, _ = one_step()
+    st_s = min(one_step()[0], one_step()[0])                    # 4 utterances: a single thread is slow
     torch.set_num_threads(nt)
-    return dict(value=round(B * T / step_s, 1), unit="frames/s", cores=nt, kind="port", cpu_model=cpu_model(),
-                single_thread_value=round(B * T / st_s, 1),
-                sample=f"CPU oracle fwd+bwd, batch {B} x 4 s, best of {n} steps = {step_s:.3f} s, "
-                       f"torch {torch.__version__}, {nt} threads of {os.cpu_count()} logical CPUs",
+    return dict(value=round(Bt * T / step_s, 1), unit="frames/s", cores=nt, kind="port", cpu_model=cpu_model(),
+                thread_sweep_frames_per_s=sweep, single_thread_value=round(B * T / st_s, 1),
+                sample=f"CPU oracle fwd+bwd, batch {Bt} x 4 s, best of {n} steps = {step_s:.3f} s, "
+                       f"torch {torch.__version__}, {nt} threads (the fastest of {counts}) of {os.cpu_count()} "
+                       f"logical CPUs; single thread on batch {B}",
                 parity_vs_hip=parity)
 
 
@@ -314,6 +325,7 @@ def main():
             out = step()
         H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear()
         H.KERNEL_TIMING = gstep is None      # events cannot be read back out of a graph replay: see below
+        opt.allreduce_events = [] if world > 1 else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         barrier()
         t0 = time.perf_counter()
@@ -339,8 +351,9 @@ def main():
     def rooflines(dt, gemm_name):
         """Live HIP-event timings of this run -> (dominant MFMA kernel, mask head)."""
         T = H.stft_frames(N_s)          # frames per chunk (the timed runs report the same number)
-        traffic, mfma_busy = {}, None
+        traffic, mfma_busy, traffic_src, mfma_src = {}, None, None, None
         try:      # HBM bytes per launch from rocprofv3 PMC passes of this same command (separate --pmc runs)
+            traffic_src = os.path.relpath(newest_profile("traffic_pmc.json"), ROOT)
             with open(newest_profile("traffic_pmc.json")) as f:
                 tp = json.load(f)
             c = tp["config"]
@@ -349,6 +362,7 @@ def main():
         except (OSError, KeyError, ValueError, TypeError):
             pass
         try:      # MFMA-pipe busy share of the GEMM kernels from an SQ-counter pass of this same command
+            mfma_src = os.path.relpath(newest_profile("mfma_pmc.json"), ROOT)
             with open(newest_profile("mfma_pmc.json")) as f:
                 mp = json.load(f)
             c = mp["config"]
@@ -370,7 +384,16 @@ def main():
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                             frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
                             avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
+                            tflop_per_step_launched=round(H.KERNEL_FLOPS[name] / max(args.steps if gstep is None else min(args.steps, 10), 1) / 1e12, 4),
                             mfma_pipe_busy_frac_pmc=mfma_busy if name.startswith("gemm_") else None,
+                            pmc_source=dict(
+                                traffic=traffic_src if traffic.get(name) is not None else None,
+                                mfma_pipe_busy_frac_pmc=mfma_src if (mfma_busy is not None and name.startswith("gemm_")) else None,
+                                note="NOT measured in this run: counters need their own rocprofv3 --pmc passes; these "
+                                     "are the committed results of the same command line (tools/collect_profiles.sh)"),
+                            timing="HIP events around every launch of this kernel, recorded INSIDE the timed "
+                                   "region (their cost is part of ms_per_step)" if gstep is None else
+                                   "HIP events in an eager pass after the graph-replayed timed region",
                             note=("algorithmic 2MNK flops; the split-bf16 kernel executes 3x that on "
                                   "the bf16 MFMA, so frac <= 1/3" if split else "exact fp32 MFMA"))
         hb = [(k, ktimes[k]) for k in ("maskhead_fwd", "maskhead_bwd") if k in ktimes]
@@ -382,7 +405,9 @@ def main():
             mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
                              peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
                              frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
-                             traffic=traffic.get("maskhead_fwd+bwd"), launches=n_l,
+                             traffic=traffic.get("maskhead_fwd+bwd"),
+                             pmc_source=traffic_src if traffic.get("maskhead_fwd+bwd") is not None else None,
+                             launches=n_l,
                              avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l,
                              note="bytes = (16 K F + 8 F) per frame and direction: the UNFUSED mask head of "
                                   "net.py:983 + enhancer.py:98-100; the time is that of the FUSED kernels (mask "
@@ -425,6 +450,24 @@ def main():
     dt, T, med = timed_run(args.steps, args.warmup)
     H.check_cluster_errors(dev)
     roofline, mask_head = rooflines(dt, args.gemm)
+    collective = None
+    if world > 1:
+        # what the first hardware run of the RCCL path should show at a glance: the collective's own time (HIP
+        # events around the all-reduce on the compute stream, max over ranks), the world size the process group
+        # reports, and that the replicas -- identical at the start, fed with the same summed gradient every
+        # step -- still hold identical parameters after the timed region
+        ar = [a.elapsed_time(b) for a, b in (opt.allreduce_events or [])]
+        ar_ms = torch.tensor([float(np.mean(ar)) if ar else 0.0, float(np.max(ar)) if ar else 0.0], dtype=torch.float64,
+                             device=dev if dist.get_backend() != "gloo" else "cpu")
+        dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        collective = dict(op="all_reduce(SUM) of the flat fp32 gradient, once per step, in place",
+                          backend=dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (staged through the host: test configuration)"),
+                          process_group_world_size=dist.get_world_size(), bytes=int(opt.bucket.flat.numel()) * 4,
+                          allreduce_ms=round(float(ar_ms[0]), 4), allreduce_ms_max=round(float(ar_ms[1]), 4),
+                          launches=len(ar), replicas_agree=bool(D.replicas_agree(opt.flat_param)),
+                          overlap="none: issued after the last weight gradient (the clip needs the norm of the SUMMED gradient)")
+        if not collective["replicas_agree"]:
+            raise SystemExit(f"bench.py: rank {rank}: the parameter replicas diverged -- a lost or doubled all-reduce")
 
     if rank == 0:
         frames = B * world * T * args.steps
@@ -442,11 +485,17 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world,
                        "units": UNITS, "optimizer": "global-norm clip + Adam (fused), in the timed step",
                        "projs": PROJS, "parallelism": f"dp{world}",
-                       "collective": ("one RCCL all-reduce(SUM) of the flat fp32 gradient per step" if world > 1 else None),
+                       "collective": collective,
                        "arithmetic": arithmetic(args.gemm), "recurrence": args.recurrence,
                        "hip_graph": ("forward + loss + backward replayed as one captured hipGraph; optimizer eager; "
                                      "roofline timings from an eager pass after the timed region") if graphed else None,
-                       "gemm_tflops_per_step": round(3 * flops_per_frame(K) * B * T / 1e12, 4)},
+                       "tflop_per_step": dict(
+                           total=round(3 * flops_per_frame(K) * B * T / 1e12, 4),
+                           gemm_family=round((3 * flops_per_frame(K, recurrent=False) + 16 * UNITS * UNITS * (2 * K + 2))
+                                             * B * T / 1e12, 4),
+                           recurrence_kernels=round(2 * 16 * UNITS * UNITS * (2 * K + 2) * B * T / 1e12, 4),
+                           note="algorithmic, 2 flop per MAC, forward + backward (SURVEY 8d); the dW_hh weight "
+                                "gradients run as GEMMs, the h.W_hh products and their BPTT inside the recurrence kernels")},
             "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload == "cfg5")
             else cpu_baseline(model, opt),

@@ -846,3 +846,6 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    c = d["config"]["collective"]
+    assert c["process_group_world_size"] == 2 and c["replicas_agree"] is True and c["launches"] == 2
+    assert c["allreduce_ms"] > 0 and c["bytes"] > 4e7

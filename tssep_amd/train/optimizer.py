@@ -20,6 +20,7 @@ class Adam(Configurable):
         self.amsgrad = amsgrad
         self.bucket = None
         self.step_count = 0
+        self.allreduce_events = None      # a list here collects (start, end) HIP events around each all-reduce
 
     def set_parameters(self, parameters):
         """Flatten parameters (each ``p.data`` becomes a view of one buffer: names, shapes and
@@ -49,7 +50,15 @@ class Adam(Configurable):
     def step(self):
         """Clip to ``gradient_clipping`` (global L2 norm) and apply one Adam update.  Returns the
         pre-clip gradient norm as a device tensor (no host sync)."""
-        self.bucket.all_reduce()            # joins the side stream; SUM over ranks when distributed
+        if self.allreduce_events is not None and self.bucket.flat.is_cuda:
+            self.bucket.sync()              # the side stream's weight gradients are not the collective's time
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            self.bucket.all_reduce()
+            ev[1].record()
+            self.allreduce_events.append(tuple(ev))
+        else:
+            self.bucket.all_reduce()        # joins the side stream; SUM over ranks when distributed
         self.step_count += 1
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         rc = _lib.lib().tssep_adam_step(
