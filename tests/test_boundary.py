@@ -283,3 +283,35 @@ def test_only_rank_zero_writes_the_storage_dir(tmp_path):
     before = (sd / "python_history.txt").read_text()
     subprocess.run(cmd, check=True, env=dict(env, RANK="1", WORLD_SIZE="2"), cwd=tmp_path, stdout=subprocess.DEVNULL)
     assert (sd / "python_history.txt").read_text() == before and not (sd / "backup").exists()
+
+
+@pytest.mark.parametrize("fading", [True, False, "half"])
+@pytest.mark.parametrize("wl,sh", [(8, 2), (16, 4), (1024, 256), (64, 16)])
+def test_stft_vad_is_a_sampling_of_the_activity_at_the_frame_centres(wl, sh, fading):
+    """Self-consistency the reference's structure implies (tssep/util/utils.py:45-68): with the
+    frame-index map f(n) = index of the last frame whose centre is at or before sample n, the frames [f(s), f(e))
+    of a run [s, e) are exactly the frames t whose NEXT centre c(t+1) satisfies s < c(t+1) <= e -- so the frame
+    activity is the sample activity read at sample c(t+1) - 1, c(t) = t * shift - pad + window_length // 2, and a
+    one-hot activity at sample n marks at most the one frame with c(t+1) - 1 == n.  Checked by brute force over
+    every sample position (no use of the product's run / cumsum code, nor of the index formula's floor division)."""
+    from tssep_amd.util.utils import samples_to_stft_frames, stft_vad
+    pad = 0 if fading is False else (wl - sh) // (2 if fading == "half" else 1)
+    N = 5 * wl + 3
+    frames = samples_to_stft_frames(N, wl, sh, pad=True, fading=fading)
+    centre = lambda t: t * sh - pad + wl // 2                  # noqa: E731 -- first sample of the 2nd window half
+    onehot = np.eye(N, dtype=bool)
+    got = stft_vad(onehot, wl, sh, fading)
+    assert got.shape == (N, frames)
+    for n in range(N):
+        want = [t for t in range(frames) if centre(t + 1) - 1 == n]
+        assert np.nonzero(got[n])[0].tolist() == want, (n, want)
+        assert np.nonzero(ovad.stft_vad(onehot[n], wl, sh, fading))[0].tolist() == want
+    assert got.sum(0).max() <= 1 and got.sum(1).max() <= 1
+    # any activity: frame t is active iff sample c(t+1) - 1 is (samples outside [0, N) are inactive)
+    rng = np.random.RandomState(3)
+    v = np.repeat(rng.rand(6, -(-N // 11)) < 0.5, 11, axis=-1)[:, :N]
+    idx = np.array([centre(t + 1) - 1 for t in range(frames)])
+    ok = (idx >= 0) & (idx < N)
+    want = np.zeros((6, frames), dtype=bool)
+    want[:, ok] = v[:, idx[ok]]
+    np.testing.assert_array_equal(stft_vad(v, wl, sh, fading), want)

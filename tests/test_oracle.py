@@ -221,3 +221,48 @@ def test_mfcc_restatement_properties():
     db = 10 * torch.log10(torch.clamp((abs(X) ** 2) @ fb, min=1e-10))
     ref = torch.clamp(db, min=float(db.max()) - 80.0) @ dct
     np.testing.assert_allclose(m3.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_mfcc_restatement_against_independent_paths():
+    """torchaudio 2.0.2 is absent (parity unpinned, oracle/features.py header); what CAN be checked is checked
+    against independent routes: the DCT table against scipy's DCT-II, the mel filterbank against a
+    per-filter float64 construction from the HTK formula, the whole transform against power -> filters -> dB ->
+    scipy DCT, and AmplitudeToDB's batching rule (tssep/train/feature_extractor_torchaudio.py:93-106 feeds a 3-D
+    [B, n_mels, T] tensor, which torchaudio treats as the channels of ONE item: one floor for the whole batch; a
+    2-D input gets its own floor)."""
+    import scipy.fft
+    fb, dct = features.mfcc_tables(1024)
+    # create_dct(n_mfcc, n_mels, 'ortho')[n, k] = DCT-II basis: x @ dct == scipy.fft.dct(x, type=2, norm='ortho')
+    eye = np.eye(40)
+    np.testing.assert_allclose(dct.numpy(), scipy.fft.dct(eye, type=2, norm="ortho", axis=-1), atol=3e-6)
+    x = np.random.RandomState(0).randn(5, 40)
+    np.testing.assert_allclose(x @ dct.double().numpy(), scipy.fft.dct(x, type=2, norm="ortho", axis=-1), atol=2e-5)
+    # HTK mel filters, one triangle at a time in float64: centres equally spaced in mel between 40 Hz and
+    # 16000 - 400 = 15600 Hz (the negative f_max wraps, feature_extractor_torchaudio.py:57-60), bins at k * 8000 / 512
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)         # noqa: E731
+    inv = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)       # noqa: E731
+    pts = inv(np.linspace(mel(40.0), mel(15600.0), 42))
+    freqs = np.arange(513) * (8000.0 / 512)
+    want = np.zeros((513, 40))
+    for m in range(40):
+        lo, c, hi = pts[m:m + 3]
+        want[:, m] = np.maximum(0.0, np.minimum((freqs - lo) / (c - lo), (hi - freqs) / (hi - c)))
+    np.testing.assert_allclose(fb.numpy(), want, atol=2e-5)
+    dead = np.nonzero(want.sum(0) == 0)[0]
+    assert dead.tolist() == list(range(33, 40))                  # 7 filters lie wholly above Nyquist (App. A.2)
+    assert (fb.numpy()[:, dead] == 0).all() and pts[33] >= 8000.0 > pts[32]      # a filter is dead when its lower edge is at or above Nyquist
+    # the whole transform by the independent route, float64
+    rng = np.random.RandomState(1)
+    X = (rng.randn(3, 9, 513) + 1j * rng.randn(3, 9, 513)) * np.array([1.0, 1e-2, 3e-5])[:, None, None]
+    got = features.torch_mfcc(torch.as_tensor(X.astype(np.complex64)), fb, dct).numpy()
+    db = 10.0 * np.log10(np.maximum(((np.abs(X.astype(np.complex64)).astype(np.float64)) ** 2) @ want, 1e-10))
+    floor_batch = db.max() - 80.0                                # 3-D input: ONE floor for the batch
+    ref = scipy.fft.dct(np.maximum(db, floor_batch), type=2, norm="ortho", axis=-1)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-3)
+    assert (db[2] < floor_batch).all() and (db[0] > floor_batch).any()      # the quiet utterance is all floor
+    np.testing.assert_allclose(got[2, :, 1:], 0.0, atol=2e-3)               # a constant's DCT: only c0 is non-zero
+    # 2-D input (one utterance): its own floor -> the quiet utterance is NOT flattened
+    got2 = features.torch_mfcc(torch.as_tensor(X[2].astype(np.complex64)), fb, dct).numpy()
+    ref2 = scipy.fft.dct(np.maximum(db[2], db[2].max() - 80.0), type=2, norm="ortho", axis=-1)
+    np.testing.assert_allclose(got2, ref2, rtol=2e-4, atol=2e-3)
+    assert np.abs(got2[:, 1:]).max() > 1.0
