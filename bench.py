@@ -379,7 +379,7 @@ def main():
             name, (n_launch, total_ms) = max(mfma.items(), key=lambda kv: kv[1][1])
             avg_ms = total_ms / n_launch
             ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
-            split = name in ("gemm_bf16x3", "gemm_planes", "blstm_onchip_fwd", "blstm_onchip_bwd")
+            split = name in ("gemm_bf16x3", "blstm_onchip_fwd", "blstm_onchip_bwd")
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                             frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,

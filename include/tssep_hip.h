@@ -384,34 +384,6 @@ int tssep_mvdr_souden_fwd(const double* obs, const void* masks, int mask_f64, do
                           int F, int reference_channel, double eps, int masking,
                           double masking_eps, void* stream);
 
-/* ------------------------------------------------ experimental GEMM probes ----
- * Round-1 probe for the next GEMM design (DESIGN.md "Next" 1), not on the product path: operands
- * pre-split into bf16 hi / lo planes [rows][Kp], Kp = K rounded up to 16 (zero padded), staged by
- * asynchronous global -> LDS copies through a ring of `ring` (2 or 3) LDS stages.  Same tile and
- * MFMA order as the production split-bf16 kernel: C = A B^T bit-identical to tssep_gemm_f32 with
- * precision 1 (plain store, no bias / activation).  ring: 2 | 3 (256 x 128 tile) or 12 | 13 (256 x 256,
- * 8 waves), + 4096 when the planes are k-tile-major ([K/16][rows][16], ktile_major = 1 in the split),
- * + ablation flags 256 / 512 / 1024 / 2048 (timing experiments, see the source). */
-int tssep_probe_split_planes(const float* x, int64_t rows, int64_t K, int64_t ld, void* hi, void* lo,
-                             int ktile_major, void* stream);
-int tssep_probe_gemm_presplit(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
-                              float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int ring,
-                              void* stream);
-/* weight-gradient counterpart: C[M,N] (split-K partials [splitk][c_split_stride]) = A^T B with A = dY
- * [K rows][M], B = X [K rows][N] given as k-tile-major planes (tssep_probe_split_planes with
- * ktile_major = 1 on the [K][M] / [K][N] matrices); K must be a multiple of 32. */
-int tssep_probe_gemm_presplit_tn(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
-                                 float* C, int64_t M, int64_t N, int64_t K, int64_t ldc, int splitk,
-                                 int64_t c_split_stride, int ring, void* stream);
-/* The plane GEMMs behind the production argument block (groundwork for round 2, not yet called by the
- * product): g->A / g->B = HI planes, a_lo / b_lo = LO planes, k-tile-major (ktile_major = 1 above); lda / ldb
- * are ignored.  a_kmajor = b_kmajor = 0: C = epilogue(A B^T) with bias / tanh / accumulate / store remap as
- * tssep_gemm_f32.  a_kmajor = b_kmajor = 1: split-K partials of A^T B (K % 32 == 0, accumulate only).
- * Bit-identical to tssep_gemm_f32 with precision 1 on the same values. */
-int tssep_gemm_planes(const tssep_gemm_args* g, const void* a_lo, const void* b_lo, void* stream);
-
-
-
 /* -------------------------------------------------------------- optimizer -----
  * One optimizer step on flat fp32 buffers: global-norm gradient clipping
  * (torch.nn.utils.clip_grad_norm_, max_norm <= 0 disables) + Adam (torch.optim.Adam update rule,

@@ -857,127 +857,3 @@ def test_mae_loss(golden):
     ed = est.detach().cuda().requires_grad_()
     (Fn.mae(ed, tgt.cuda()) * gout.cuda()).sum().backward()
     close(ed.grad, est.grad, rtol=1e-6, atol=1e-12, name="mae grad")
-
-
-@pytest.mark.parametrize("M,N,K", [(1000, 300, 70), (2051, 390, 513), (300, 513, 33)])
-def test_presplit_gemm_probe_is_bit_identical(M, N, K):
-    """Experimental probe (csrc/gemm_presplit.hip): pre-split bf16 planes staged by asynchronous
-    global -> LDS copies, 256x128 / 256x256 tiles, 2- and 3-stage rings -- same MFMA order as the
-    production split-bf16 GEMM, so the results must be bit-identical to it."""
-    from tssep_amd import _lib
-    h, L = H(), _lib.lib()
-    old = h.GEMM_PRECISION
-    h.GEMM_PRECISION = "bf16x3"
-    try:
-        torch.manual_seed(0)
-        Kp4, Kp = h.round_up(K, 4), h.round_up(K, 16)
-        A = torch.zeros(M, Kp4, device="cuda"); A[:, :K] = torch.randn(M, K, device="cuda")
-        W = torch.zeros(N, Kp4, device="cuda"); W[:, :K] = torch.randn(N, K, device="cuda")
-        C0 = torch.empty(M, N, device="cuda")
-        if M >= 1024:
-            h.gemm(A, Kp4, W, Kp4, C0, N, M, N, K)              # the tall kernel: same tile, same order
-        planes = [torch.empty(r, Kp, device="cuda", dtype=torch.bfloat16) for r in (M, M, N, N)]
-        st = torch.cuda.current_stream().cuda_stream
-        h.check(L.tssep_probe_split_planes(A.data_ptr(), M, K, Kp4, planes[0].data_ptr(), planes[1].data_ptr(), 0, st), "split")
-        h.check(L.tssep_probe_split_planes(W.data_ptr(), N, K, Kp4, planes[2].data_ptr(), planes[3].data_ptr(), 0, st), "split")
-        hi, lo = planes[0].float(), planes[1].float()
-        assert float((hi[:, :K] + lo[:, :K] - A[:, :K]).abs().max()) <= float(A.abs().max()) * 2 ** -16
-        assert float(hi[:, K:].abs().max() if Kp > K else 0) == 0
-        ref = (A[:, :K].double() @ W[:, :K].double().t()).float()
-        outs = []
-        for ring in (2, 3, 12, 13):
-            C = torch.full((M, N), float("nan"), device="cuda")
-            h.check(L.tssep_probe_gemm_presplit(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                                                planes[3].data_ptr(), C.data_ptr(), M, N, K, N, ring, st), "probe")
-            close(C, ref, rtol=2e-4, atol=2e-4 * K ** 0.5, name=f"ring {ring}")
-            outs.append(C)
-        assert all(torch.equal(outs[0], o) for o in outs[1:])
-        if M >= 1024:
-            assert torch.equal(outs[0], C0)
-    finally:
-        h.GEMM_PRECISION = old
-
-
-@pytest.mark.parametrize("M,N,R", [(260, 130, 3200), (24, 12, 64), (513, 600, 960)])
-def test_presplit_tn_probe_is_bit_identical(M, N, R):
-    """Experimental plane-fed weight-gradient probe: same k-tile-major planes as the nt probe, fragments
-    by LDS transpose reads; split-K partials bit-identical to the production transpose-read kernel."""
-    from tssep_amd import _lib
-    h, L = H(), _lib.lib()
-    old = h.GEMM_PRECISION
-    h.GEMM_PRECISION = "bf16x3"
-    try:
-        torch.manual_seed(1)
-        dY = torch.zeros(R, h.round_up(M, 4), device="cuda"); dY[:, :M] = torch.randn(R, M, device="cuda") / R ** 0.5
-        X = torch.zeros(R, h.round_up(N, 4), device="cuda"); X[:, :N] = torch.randn(R, N, device="cuda")
-        part, S = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R)
-        st = torch.cuda.current_stream().cuda_stream
-        Mp, Np = h.round_up(M, 16), h.round_up(N, 16)
-        planes = [torch.empty((Mp // 16) * R * 16, device="cuda", dtype=torch.bfloat16) for _ in range(2)] + \
-                 [torch.empty((Np // 16) * R * 16, device="cuda", dtype=torch.bfloat16) for _ in range(2)]
-        h.check(L.tssep_probe_split_planes(dY.data_ptr(), R, M, dY.shape[1], planes[0].data_ptr(), planes[1].data_ptr(), 1, st), "split")
-        h.check(L.tssep_probe_split_planes(X.data_ptr(), R, N, X.shape[1], planes[2].data_ptr(), planes[3].data_ptr(), 1, st), "split")
-        ref = (dY[:, :M].double().t() @ X[:, :N].double()).float()
-        for ring in (2, 3):
-            C = torch.full((S, M * N), float("nan"), device="cuda")
-            h.check(L.tssep_probe_gemm_presplit_tn(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                                                   planes[3].data_ptr(), C.data_ptr(), M, N, R, N, S, M * N, ring, st), "probe")
-            assert torch.equal(C.view(S, M, N), part.view(S, M, N)), ring
-            close(C.view(S, M, N).sum(0), ref, rtol=2e-4, atol=2e-4, name=f"tn ring {ring}")
-        assert L.tssep_probe_gemm_presplit_tn(planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(),
-                                              planes[3].data_ptr(), C.data_ptr(), M, N, R + 1, N, S, M * N, 2, st) != 0
-    finally:
-        h.GEMM_PRECISION = old
-
-
-def test_gemm_planes_matches_production_gemm_feature_by_feature():
-    """tssep_gemm_planes (round-2 groundwork): plane operands behind the production argument block --
-    bias, tanh, accumulate, both store remaps and split-K weight gradients agree with h.gemm in split-bf16
-    arithmetic (bit-identical where production takes the same tile: M >= 1024 for nt, every tn shape)."""
-    h = H()
-    old = h.GEMM_PRECISION
-    h.GEMM_PRECISION = "bf16x3"
-    try:
-        torch.manual_seed(6)
-        # ---- nt: bias + tanh, then accumulate
-        M, N, K = 2051, 390, 513
-        A = torch.zeros(M, h.round_up(K, 4), device="cuda"); A[:, :K] = torch.randn(M, K, device="cuda")
-        W = torch.zeros(N, h.round_up(K, 4), device="cuda"); W[:, :K] = torch.randn(N, K, device="cuda") / K ** 0.5
-        bias = torch.randn(N, device="cuda")
-        Ap, Wp = h.split_planes(A, M, K), h.split_planes(W, N, K)
-        for kw in (dict(bias=bias), dict(bias=bias, act=1), dict(accumulate=True)):
-            C0 = torch.ones(M, N, device="cuda"); C1 = torch.ones(M, N, device="cuda")
-            h.gemm(A, A.shape[1], W, W.shape[1], C0, N, M, N, K, **kw)
-            h.gemm_planes(Ap, Wp, C1, N, M, N, K, **kw)
-            assert torch.equal(C0, C1), kw
-        # ---- nt: the two store remaps of the model (small M: numerically equal, other tile)
-        B, Kk, T, P, F = 2, 3, 5, 8, 9
-        A = torch.randn(B * Kk * T, 12, device="cuda"); W = torch.randn(P, 12, device="cuda"); bias = torch.randn(P, device="cuda")
-        rm = dict(T=T, K=Kk, sb=T * Kk * P, sk=P, st=Kk * P)
-        C0 = torch.full((B, T, Kk * P), float("nan"), device="cuda"); C1 = C0.clone()
-        h.gemm(A, 12, W, 12, C0, 0, B * Kk * T, P, 12, bias=bias, act=1, remap=rm)
-        h.gemm_planes(h.split_planes(A, B * Kk * T, 12), h.split_planes(W, P, 12), C1, 0, B * Kk * T, P, 12, bias=bias, act=1, remap=rm)
-        close(C1, C0, rtol=1e-5, atol=1e-5, name="combine remap")
-        A = torch.randn(B * T, 12, device="cuda"); W = torch.randn(Kk * F, 12, device="cuda"); bias = torch.randn(Kk * F, device="cuda")
-        perm = torch.stack([torch.randperm(Kk) for _ in range(B)]).int().cuda()
-        rm = dict(T=T, K=1, sb=Kk * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=Kk)
-        C0 = torch.full((B, Kk, T, F), float("nan"), device="cuda"); C1 = C0.clone()
-        h.gemm(A, 12, W, 12, C0, 0, B * T, Kk * F, 12, bias=bias, remap=rm)
-        h.gemm_planes(h.split_planes(A, B * T, 12), h.split_planes(W, Kk * F, 12), C1, 0, B * T, Kk * F, 12, bias=bias, remap=rm)
-        close(C1, C0, rtol=1e-5, atol=1e-5, name="logit remap")
-        # ---- tn: split-K partials, then accumulate into them
-        M, N, R = 260, 130, 3200
-        dY = torch.randn(R, M, device="cuda") / R ** 0.5
-        X = torch.zeros(R, h.round_up(N, 4), device="cuda"); X[:, :N] = torch.randn(R, N, device="cuda")
-        part, S = h.wgrad(dY, M, X, X.shape[1], M, N, R)
-        dYp, Xp = h.split_planes(dY, R, M), h.split_planes(X, R, N, ld=X.shape[1])
-        C1 = torch.full((S, M * N), float("nan"), device="cuda")
-        h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N)
-        assert torch.equal(C1, part.view(S, M * N))
-        h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N, accumulate=True)
-        assert torch.equal(C1, 2 * part.view(S, M * N))
-        with pytest.raises(RuntimeError):                          # time shift: not in the plane kernels yet
-            h.gemm_planes(dYp, Xp, C1, N, M, N, R, a_kmajor=True, b_kmajor=True, splitk=S, split_stride=M * N,
-                          b_kshift=1, kperiod=100)
-    finally:
-        h.GEMM_PRECISION = old

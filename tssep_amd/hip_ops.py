@@ -292,27 +292,6 @@ def gemm(A, lda, B, ldb, C, ldc, M, N, K, **kw):
         check(_lib.lib().tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
 
 
-def split_planes(x, rows, cols, ld=None, ktile_major=True):
-    """fp32 [rows, >= cols] -> (hi, lo) bf16 planes, k-tile-major [ceil(cols/16)][rows][16] (round-2 groundwork:
-    in production the planes will come from the producer kernels, this pass is for tests and probes)."""
-    ld = x.shape[-1] if ld is None else ld
-    n = round_up(cols, 16) * rows
-    hi = torch.empty(n, device=x.device, dtype=torch.bfloat16)
-    lo = torch.empty(n, device=x.device, dtype=torch.bfloat16)
-    check(_lib.lib().tssep_probe_split_planes(_p(x), rows, cols, ld, _p(hi), _p(lo), int(ktile_major), _stream()),
-          "split_planes")
-    return hi, lo
-
-
-def gemm_planes(A, B, C, ldc, M, N, K, **kw):
-    """The split-bf16 GEMM on plane operands (A, B = (hi, lo) pairs from split_planes / producer kernels);
-    same keywords and results as gemm() with GEMM_PRECISION = 'bf16x3' (bit-identical).  Not yet on the
-    product path."""
-    g = _gemm_args(A[0], 0, B[0], 0, C, ldc, M, N, K, **kw)
-    with _timed("gemm_planes", 2 * M * N * K):
-        check(_lib.lib().tssep_gemm_planes(ctypes.byref(g), _p(A[1]), _p(B[1]), _stream()), "gemm_planes")
-
-
 def transposed(w, rows, cols):
     """[rows, >= cols] weight view -> contiguous [cols, round_up(rows, 4)] copy (layout glue): the
     dgrad GEMMs then read BOTH operands k-contiguous with 16-byte loads (the k-major path reads
