@@ -277,3 +277,71 @@ def test_bucket_grads_are_views():
     assert float(b.flat.abs().sum()) > 0
     b.zero()
     assert float(lin.weight.grad.abs().sum()) == 0
+
+
+class _Ragged:
+    """A prepared dataset whose length is unknown (a `catch` stage may drop examples) and differs per rank."""
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        raise TypeError("the length of a dataset that may drop examples is unknown")
+
+    def __iter__(self):
+        return iter([torch.full((2, 3), float(i + 1)) for i in range(self.n)])
+
+
+class _ToyModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(3, 1)
+
+    def forward(self, ex):
+        return self.lin(ex)
+
+    def review(self, ex, out):
+        return dict(loss=out.sum())
+
+
+class _Sgd:
+    """Stands in for the fused optimizer (which needs the GPU library): flat bucket + all-reduce + step count."""
+    def __init__(self):
+        self.steps = 0
+
+    def set_parameters(self, params):
+        self.bucket = GradBucket(list(params))
+        self.flat_param = torch.cat([p.data.reshape(-1) for p in self.bucket.params])
+        self.exp_avg = torch.zeros(1)
+        self.exp_avg_sq = torch.zeros(1)
+
+    def zero_grad(self):
+        self.bucket.zero()
+
+    def step(self):
+        self.bucket.all_reduce()
+        self.steps += 1
+
+
+def _ragged_worker(rank, world, port, q, tmp):
+    from tssep_amd import distributed as D
+    from tssep_amd.train.trainer import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    D.init_from_env()
+    torch.manual_seed(0)
+    t = Trainer(model=_ToyModel(), storage_dir=tmp, optimizer=_Sgd(), stop_trigger=(7, "iteration"),
+                summary_trigger=(100, "iteration"), checkpoint_trigger=(100, "iteration"), virtual_minibatch_size=2)
+    t.model.to = lambda *_a, **_k: t.model                    # CPU run of the loop (the product path is GPU only)
+    t.train(_Ragged(5 if rank == 0 else 3), device="cpu")     # rank 1 runs out of batches two steps early
+    q.put((rank, t.iteration, t.epoch, t.optimizer.steps))
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_batch_counts_end_the_epoch_together(tmp_path):
+    """`equal_shard` equalises source examples only; a later stage that drops examples gives the ranks
+    different batch counts and the one with more waits for ever in the all-reduce.  With an unknown length the
+    ranks agree per micro-step: both stop each epoch after rank 1's 3 batches (the half-filled virtual minibatch
+    of 2 is dropped), so both take the same number of optimizer steps and reach the stop trigger together."""
+    res = _spawn(_ragged_worker, 2, str(tmp_path))
+    assert res[0][1:] == res[1][1:], res
+    assert res[0][1] == 7 and res[0][3] >= 3

@@ -156,17 +156,38 @@ class Trainer(Configurable):
         assert stop_unit == "iteration", self.stop_trigger
         self.optimizer.zero_grad()
         while self.iteration < stop_n:
-            if world > 1 and hasattr(train_dataset, "__len__"):
-                # one batch more on one rank = that rank alone in an all-reduce, for ever
-                n_batches = len(train_dataset)
-                if not _dist.same_on_all_ranks(n_batches):
-                    raise RuntimeError(f"rank {rank}: {n_batches} training batches in this epoch, another rank "
-                                       "has a different count (shard BEFORE any stage that drops examples)")
-            for ex in train_dataset:
+            # Every rank must run the same number of optimizer steps per epoch: one batch more on one rank is
+            # that rank alone in an all-reduce, for ever.  `Dataset.shard` equalises the SOURCE examples; when
+            # the length of the prepared dataset is known it is compared once per epoch, when a stage may drop
+            # examples (`catch`) the ranks agree before every micro-step on whether all of them still have data
+            # (one 16-byte all-reduce) and end the epoch together at the first one that has not.
+            agree_per_step = False
+            if world > 1:
+                try:
+                    n_batches = len(train_dataset)
+                except TypeError:
+                    n_batches = None
+                known = _dist.same_on_all_ranks(-1 if n_batches is None else 1)
+                if known and n_batches is not None:
+                    if not _dist.same_on_all_ranks(n_batches):
+                        raise RuntimeError(f"rank {rank}: {n_batches} training batches in this epoch, another "
+                                           "rank has a different count (shard BEFORE any stage that drops examples)")
+                else:
+                    agree_per_step = True
+            batches = iter(train_dataset)
+            while True:
+                ex = next(batches, None)
+                boundary = (self.iteration + 1) % self.virtual_minibatch_size == 0
+                if agree_per_step:
+                    if not _dist.same_on_all_ranks(0 if ex is None else 1) or ex is None:
+                        self.optimizer.zero_grad()       # an incomplete virtual minibatch is dropped everywhere
+                        break
+                elif ex is None:
+                    break
                 summary = self.model.review(ex, self.model(ex))
                 summary["loss"].backward()
                 self.iteration += 1
-                if self.iteration % self.virtual_minibatch_size == 0:
+                if boundary:
                     self.optimizer.step()            # all-reduce(SUM) over ranks, clip, Adam
                     self.optimizer.zero_grad()
                 if self._triggered(self.summary_trigger):
