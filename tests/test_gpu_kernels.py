@@ -164,6 +164,54 @@ def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (4096 + 255, 320, 600),
+                                   (3000, 129, 553), (1500, 2052, 31), (70000, 600, 64), (1280, 5, 2400)])
+def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
+    """The persistent streaming kernel (csrc/gemm_bf16x3_stream.hip: 256 x 128 tiles walked by one workgroup per
+    CU, two accumulator banks, C drained in paced 32 x 32 pieces while the next tile computes) against fp64, and bit
+    for bit against the tiled kernels it replaces (TSSEP_GEMM_STREAM=0): same K order and MFMA sequence per output
+    element, same epilogue arithmetic -- bias, tanh, accumulate, the folded Tanh backward; K tails (K % 32 != 0),
+    ragged last row / column tiles, more tiles than CUs (several tiles per workgroup) and fewer."""
+    import os
+    torch.manual_seed(4)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        ldy = ru(N, 4)
+        Y = torch.zeros(M, ldy); Y[:, :N] = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_STREAM"] = mode
+            ldc = ru(N, 4)                      # padded rows: the pad columns must stay untouched
+            C = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
+            C2 = torch.ones(M, N, device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+            C3 = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K, act=2, aux=(Yd, ldy))
+            C4 = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C4, N, M, N, K)
+            outs[mode] = (C, C2, C3, C4)
+        s1 = outs["1"]
+        close(s1[0][:, :N], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="stream nt+bias+tanh")
+        assert bool(torch.isnan(s1[0][:, N:]).all())
+        close(s1[1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="stream accumulate")
+        close(s1[2], (ref - bias) * (1 - Y[:, :N] ** 2), rtol=2e-4, atol=2e-4, name="stream (1 - y^2)")
+        close(s1[3], ref - bias, rtol=2e-4, atol=2e-4, name="stream plain")
+        for a, b in zip(outs["1"], outs["0"]):
+            assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+    finally:
+        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn_and_tn(M, N, K, gemm_precision):
     tol = gemm_precision

@@ -1,0 +1,44 @@
+"""Alternating A/B of a GEMM environment switch on the row x row shapes of the step (GPU box):
+   python tools/bench_gemm_ab.py TSSEP_GEMM_STREAM 1 0 [batch]"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tssep_amd import hip_ops as h
+
+var, va, vb = sys.argv[1], sys.argv[2], sys.argv[3]
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 768
+h.GEMM_PRECISION = "bf16x3"
+T, Kspk = 253, 4
+R1, R4 = B * T, B * Kspk * T
+SHAPES = [("pre_net in", R1, 2400, 553), ("birnn0 in", R4, 2400, 513), ("birnn1 in", R4, 2400, 320),
+          ("birnn2 in", R1, 2400, 1280), ("proj 600->320", R4, 320, 600), ("proj 600->513", R1, 513, 600),
+          ("linear2", R1, 2052, 320), ("dgrad birnn0 dx", R4, 513, 2400), ("dgrad birnn1 dx", R4, 320, 2400),
+          ("dgrad proj dh", R4, 600, 320), ("dgrad birnn2 dx", R1, 1280, 2400), ("dgrad linear2", R1, 320, 2052)]
+
+
+def timeit(fn, reps=5):
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+tot = {va: 0.0, vb: 0.0}
+for name, M, N, K in SHAPES:
+    A = torch.randn(M, h.round_up(K, 4), device="cuda"); W = torch.randn(N, h.round_up(K, 4), device="cuda")
+    C = torch.empty(M, N, device="cuda"); bias = torch.randn(N, device="cuda")
+    f = lambda: h.gemm(A, A.shape[1], W, W.shape[1], C, N, M, N, K, bias=bias)
+    best = {va: 1e9, vb: 1e9}
+    f(); torch.cuda.synchronize()
+    for _ in range(3):
+        for v in (va, vb):
+            os.environ[var] = v
+            f(); best[v] = min(best[v], timeit(f))
+    for v in (va, vb):
+        tot[v] += best[v]
+    print(json.dumps(dict(name=name, M=M, N=N, K=K, **{f"{var}={v}_ms": round(best[v], 3) for v in (va, vb)},
+                          **{f"{var}={v}_tflops": round(2 * M * N * K / best[v] / 1e9, 1) for v in (va, vb)})), flush=True)
+    del A, W, C
+print(json.dumps({f"total_{var}={v}_ms": round(t, 3) for v, t in tot.items()}))

@@ -40,42 +40,12 @@ template <int BK> struct Cfg {
   static constexpr int NC = BK / 2;              // scalar loads per thread, col operand
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// Buffer loads for the steady-state operand streams: one buffer resource (4 SGPRs: base + range) per operand,
-// ONE 32-bit VGPR byte offset per lane and operand, the per-load part of the address (row group, K tile) in an
-// SGPR.  With plain pointers the compiler kept a 64-bit VGPR address per load (8 in the weight-gradient kernel,
-// 6 in the tall one) and re-derived them with v_lshl_add_u64 / v_mov_b64 every K tile: 12-16 VGPRs and ~20 VALU
-// instructions per tile.  The range only has to cover one tile's rows (offsets stay far below 2 GB).
-typedef __amdgpu_buffer_rsrc_t srd_t;
-__device__ __forceinline__ srd_t make_srd(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 bload4(srd_t r, unsigned voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
-}
-__device__ __forceinline__ float bload1(srd_t r, unsigned voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
-}
-
 // ------------------------------------------------------------------------------------------------
 // Software pipeline: two LDS stages in SEPARATE arrays (so the compiler knows that the fragment
 // reads of stage t and the staging writes of stage t+1 never alias), one barrier per K tile, and
 // the split (VALU) + ds_write of tile t+1 and the global loads of tile t+2 interleaved between the
 // MFMAs of tile t.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but its issue slot for
 // 4: the ~110 VALU/LDS/VMEM instructions a wave needs per tile fit in the shadow of its 24 MFMAs.
-__device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned& lo) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  const f32x2 v = {a, b};
-  const bf16x2 h = __builtin_convertvector(v, bf16x2);          // v_cvt_pk_bf16_f32 (RNE)
-  const f32x2 hf = __builtin_convertvector(h, f32x2);
-  const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);     // v - hf is exact in fp32
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
 template <int BK>
 __device__ __forceinline__ void row_store_n(char* hi, char* lo, int tid, const f32x4 (&v)[Cfg<BK>::NL]) {
   constexpr int KQ = Cfg<BK>::KQ;
@@ -458,7 +428,12 @@ constexpr int TARR_A = TBM * TPITCH;
 // N - 1 of B, exact fp32; every workgroup computes it -- no branch inside the loop body the scheduler
 // interleaves, a uniform branch there measured 10 % slower -- and those of the last column tile store it).
 // The 256 x 128 variant has no registers left for this (248 VGPRs: it spilled inside the loop).
-template <int WN, bool XCOL = false>
+// HACK (experiment builds only, -DTSSEP_GEMM_EXP, results are garbage -- TIMING probes of where a tile's life goes):
+//   1 = operands addressed as if they were k-tile-major [K/16][rows][16] (every wave load = whole 128-B lines)
+//   2 = no epilogue stores      4 = no MFMAs      8 = no global loads
+//  16 = row-major full-line loads: half the rows, 32 k per row, alternating row halves (the access stream of a
+//       BK = 32 pipeline with half-stage staging)
+template <int WN, bool XCOL = false, int HACK = 0>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M,
     int64_t Nfull, int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act,
@@ -490,20 +465,22 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
   // SQ_LDS_BANK_CONFLICT was 11 % of the kernel's CU-busy cycles)
   const int kq = (tid & 3) << 2;
   const int lrow = ((tid >> 2) & ~7) | (((tid >> 2) & 3) << 1) | ((tid >> 4) & 1);
-  const char* abase = reinterpret_cast<const char*>(A + m0 * lda);
-  const char* bbase = reinterpret_cast<const char*>(B + n0 * ldb);
+  const char* abase = reinterpret_cast<const char*>(A + m0 * ((HACK & 1) ? 16 : lda));
+  const char* bbase = reinterpret_cast<const char*>(B + n0 * ((HACK & 1) ? 16 : ldb));
   unsigned aoffs[NA], boffs[NB];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int64_t r = m0 + lrow + RSTEP * i;
     r = r > M - 1 ? M - 1 : r;
-    aoffs[i] = (unsigned)(((r - m0) * lda + kq) * 4);
+    aoffs[i] = (unsigned)(((r - m0) * ((HACK & 1) ? 16 : lda) + kq) * 4);
+    if (HACK & 16) aoffs[i] = (unsigned)((((tid >> 3) + (NT / 8) * i) * lda + ((tid & 7) << 2)) * 4);
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     int64_t r = n0 + lrow + RSTEP * i;
     r = r > N - 1 ? N - 1 : r;
-    boffs[i] = (unsigned)(((r - n0) * ldb + kq) * 4);
+    boffs[i] = (unsigned)(((r - n0) * ((HACK & 1) ? 16 : ldb) + kq) * 4);
+    if (HACK & 16) boffs[i] = (unsigned)((((tid >> 3) + (NT / 8) * i) * ldb + ((tid & 7) << 2)) * 4);
   }
   f32x4 ra[NA], rb[NB];
   const bool xwg = XCOL && nt == tmap.NT - 1;           // workgroup-uniform
@@ -516,11 +493,18 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     const int64_t k0 = kt * TBK, k = k0 + kq;
     // (tail) a 16-byte load that starts at or beyond K would leave the row: read the row start
     const unsigned fix = (!tail || k < K) ? 0u : (unsigned)(-(k0 + kq) * 4);     // per lane, wraps with the offsets
-    const int so = (int)(k0 * 4);
+    int so = (int)(k0 * 4), sob = so;
+    if (HACK & 1) { so = (int)(kt * M * 64); sob = (int)(kt * Nfull * 64); }
+    if (HACK & 16) {      // rows (kt & 1) * TBM/2 .. of the tile, k = 32 (kt / 2) .. + 31
+      so = (int)((kt >> 1) * 128 + (kt & 1) * (TBM / 2) * lda * 4);
+      sob = (int)((kt >> 1) * 128 + (kt & 1) * (TBN / 2) * ldb * 4);
+    }
+    if (!(HACK & 8)) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = bload4(asrd, aoffs[i] + fix, so);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = bload4(bsrd, boffs[i] + fix, so);
+    for (int i = 0; i < NB; ++i) rb[i] = bload4(bsrd, boffs[i] + fix, sob);
+    }
     if constexpr (decltype(xtag)::value) rx = bload4(xsrd, (unsigned)(kq * 4) + fix, so);   // (ra is zeroed in the tail)
     if (tail) {
 #pragma unroll
@@ -570,6 +554,13 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
     for (int j = 0; j < 2; ++j) {
       bh[j] = *reinterpret_cast<const bf16x8*>(st + boff + j * 32 * TPITCH);
       bl[j] = *reinterpret_cast<const bf16x8*>(st + TARR_B + boff + j * 32 * TPITCH);
+    }
+    if (HACK & 4) {       // keep the fragment reads alive without matrix work
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[i][0][0] += (float)ah[i][0] + (float)al[i][1]; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { acc[0][j][1] += (float)bh[j][0] + (float)bl[j][1]; }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -661,6 +652,17 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
   // array holds two of them, so the 8 waves of the wide tile take turns in two phases of 4
   static_assert(2 * 64 * EPITCH * 4 <= TSTAGE, "epilogue scratch must fit in one stage");
   float* stage = reinterpret_cast<float*>((wave & 2) ? lds1 : lds0) + (wave & 1) * 64 * EPITCH;
+  if ((HACK & 2) && K >= 0) {        // no stores (K >= 0 always: the accumulators stay live)
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    if (sacc == 123.456f) C[tid] = sacc;
+    return;
+  }
 #pragma unroll 1
   for (int phase = 0; phase < WN / 2; ++phase) {
     if (WN > 2 && phase) __syncthreads();
@@ -673,8 +675,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][j];
       if (!sm.remap)
-        gemm_epilogue_rows(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
-                           bias, act, accumulate, sm.ldc, true, sm.aux, sm.ldaux);
+        gemm_epilogue_rows(a2, stage, C, M, (HACK & 32) ? 0 : N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64, lane,
+                           bias, act, (HACK & 64) ? 2 : accumulate, sm.ldc, true, sm.aux, sm.ldaux);
       else if (remap_vec_ok(sm, C))
         gemm_epilogue_rows_remap_vec(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
                                      lane, bias, act, accumulate, sm);
@@ -1182,6 +1184,16 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   if (g->b_ones_col && (!g->b_kmajor || shift || g->N < 2)) return TSSEP_E_UNSUPPORTED;
   static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
   if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+    // persistent streaming kernel (gemm_bf16x3_stream.hip): plain row-major stores; the N = 256 q + 1 shapes keep
+    // the wide tile with its VALU column.  TSSEP_GEMM_STREAM is read per call (alternating A/B runs toggle it)
+    {
+      const char* se = getenv("TSSEP_GEMM_STREAM");
+      const int smode = se ? atoi(se) : 1;
+      if (smode && !sm.remap && !(g->N > 256 && g->N % 256 == 1)) {
+        const int rc = tssep_gemm_bf16x3_stream_launch(g, sm, stream);
+        if (rc != TSSEP_E_UNSUPPORTED) return rc;
+      }
+    }
     // wide (256 x 256) tile where rounding N up to 256 wastes < 10 % of the columns (N = 2400, 1280 of the
     // step; not 513 / 320 / 600 / 2052)
     const char* wide_env = getenv("TSSEP_GEMM_WIDE");          // read per call: A/B runs toggle it in-process
@@ -1189,6 +1201,16 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     const int64_t n256 = (g->N + 255) / 256 * 256;
     if (wide && g->N >= 1024 && n256 * 10 <= g->N * 11) {
       const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
+#ifdef TSSEP_GEMM_EXP
+      {
+        const char* he = getenv("TSSEP_GEMM_HACK");
+        const int hack = he ? atoi(he) : 0;
+#define HK(H_) case H_: hipLaunchKernelGGL((gemm_bf16x3_tall_kernel<4, false, H_>), dim3((unsigned)tile_map_blocks(tm4)), dim3(512), 0, s, \
+                         g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tm4); return tssep_launch_status();
+        switch (hack) { HK(1) HK(2) HK(3) HK(4) HK(6) HK(8) HK(10) HK(12) HK(14) HK(16) HK(18) HK(32) HK(64) default: break; }
+#undef HK
+      }
+#endif
       hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<4>, dim3((unsigned)tile_map_blocks(tm4)), dim3(512), 0, s,
                          g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
                          g->accumulate, sm, tm4);

@@ -186,8 +186,9 @@ __device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], fl
     }
     float* dst = Cz + m * ldc + n;
     if (vec) {
-      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+      if (accumulate == 1) v += *reinterpret_cast<const f32x4*>(dst);
+      if (accumulate == 2) *reinterpret_cast<f32x4*>(dst) = v;      // (experiment builds: temporal stores)
+      else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -317,8 +318,44 @@ __device__ __forceinline__ void gemm_epilogue_rows_remap_vec(const f32x16 (&acc)
   }
 }
 
+// ---- pieces shared by the split-bf16 kernels (gemm_bf16x3.hip, gemm_bf16x3_stream.hip) -------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Buffer loads for the steady-state operand streams: one buffer resource (4 SGPRs: base + range) per operand,
+// ONE 32-bit VGPR byte offset per lane and operand, the per-load part of the address (row group, K tile) in an
+// SGPR.  With plain pointers the compiler kept a 64-bit VGPR address per load (8 in the weight-gradient kernel,
+// 6 in the tall one) and re-derived them with v_lshl_add_u64 / v_mov_b64 every K tile: 12-16 VGPRs and ~20 VALU
+// instructions per tile.  The range only has to cover one tile's rows (offsets stay far below 2 GB).
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(srd_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ float bload1(srd_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+
+// hi = bf16_rne(x), lo = bf16_rne(x - hi) for two values, packed as the MFMA operands want them
+__device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned& lo) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);          // v_cvt_pk_bf16_f32 (RNE)
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);     // v - hf is exact in fp32
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 }  // namespace gemm_detail
 
 // split-bf16 (bf16x3) variant, defined in gemm_bf16x3.hip
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
                              void* stream);
+// persistent streaming variant (row x row, plain store), defined in gemm_bf16x3_stream.hip: returns
+// TSSEP_E_UNSUPPORTED when the arguments are outside what it covers
+int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
