@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void maskhead_fwd_kernel(
       Pos q = h ? p1 : p0;
       if (e + 2 <= total) {
         const f32x2 lg = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(logit + e));
-        const float m0 = sigmoidf_acc(lg[0]), m1 = sigmoidf_acc(lg[1]);
+        const float m0 = sigmoidf_mask(lg[0]), m1 = sigmoidf_mask(lg[1]);
         const float2 x0 = obs[q.ob + q.tf];
         q.advance(1, 1, KTF, TF);
         const float2 x1 = obs[q.ob + q.tf];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void maskhead_fwd_kernel(
         __builtin_nontemporal_store(f32x4{x0.x * m0, x0.y * m0, x1.x * m1, x1.y * m1},
                                     reinterpret_cast<f32x4*>(est + e));
       } else if (e < total) {
-        const float m0 = sigmoidf_acc(logit[e]);
+        const float m0 = sigmoidf_mask(logit[e]);
         const float2 x0 = obs[q.ob + q.tf];
         mask[e] = m0;
         est[e] = make_float2(x0.x * m0, x0.y * m0);

@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
   __shared__ float2 twl[NH];
   __shared__ float2 wl[NH];               // the window as sample pairs: read per frame from LDS -- as global loads the
   __shared__ float2 line[4][LINE];        // compiler kept eight 64-bit per-lane addresses alive across the frame loop
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (wave-uniform; through readfirstlane so that the per-frame buffer resources below are built in SGPRs -- from a
+  // VGPR the compiler wraps EVERY buffer access in a waterfall loop: ~10 extra instructions and a serialisation each)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < NH; i += 256) { twl[i] = tw[i]; wl[i] = reinterpret_cast<const float2*>(window)[i]; }
   __syncthreads();
   const float2 tw2_lane = tw[NH + lane];
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
       }
       auto emit = [&](int k, float2 o) {
         if (MASKED) {
-          const float m = sigmoidf_acc(Lr[k]);
+          const float m = sigmoidf_mask(Lr[k]);
           const float2 ob = Or[k];
           Dr[k] = (ob.x * o.x + ob.y * o.y) * m * (1.0f - m);
         } else {
@@ -296,7 +299,10 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
   __shared__ __attribute__((aligned(16))) float fr[RING][1024];       // (51 KB with the rest: three workgroups per CU --
                                                                       // no room for the window table the rfft kernel keeps)
   __shared__ float red[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (wave-uniform; through readfirstlane so that the per-frame buffer resources below are built in SGPRs -- from a
+  // VGPR the compiler wraps EVERY buffer access in a waterfall loop: ~10 extra instructions and a serialisation each)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t row = blockIdx.y;
   const int c = blockIdx.x;
   for (int i = tid; i < NH; i += 256) twl[i] = tw[i];
@@ -337,11 +343,11 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int k = lane + 64 * r;
-          const float m = sigmoidf_acc(lg8[r]);
+          const float m = sigmoidf_mask(lg8[r]);
           buf[PADI(k)] = make_float2(ob8[r].x * m, ob8[r].y * m);
         }
         if (lane == 0) {
-          const float m = sigmoidf_acc(Lr[NH]);
+          const float m = sigmoidf_mask(Lr[NH]);
           const float2 ob = Or[NH];
           xnyq = make_float2(ob.x * m, ob.y * m);
         }
