@@ -220,22 +220,37 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
       }
     }
     float2* buf = line[wave];
+    // MASKED: row = (utterance b, speaker); the observation frame is the utterance's.  The epilogue's logit and
+    // observation bins do not depend on the transform: requested BEFORE it (24 registers), their latency hides
+    // behind the FFT instead of ending every frame with a round trip to memory
+    const float* Lr = MASKED ? logit + fidx * (NH + 1) : nullptr;
+    const float2* Or = MASKED ? obs + ((row / Kspk) * T + t) * (NH + 1) : nullptr;
+    float lg8[8];
+    float2 ob8[8];
+    if (MASKED && valid) {
+      __builtin_amdgcn_sched_barrier(0);      // (not above the sample loads: the kernel is at its register ceiling there)
+      const srd_t sl = make_srd(Lr, (NH + 1) * 4), so = make_srd(Or, (NH + 1) * 8);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
+      (void)sl;
+    }
     fft512_wave(v, buf, twl, lane);
+    if (MASKED && valid) {
+      const srd_t sl = make_srd(Lr, (NH + 1) * 4);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
+    }
     if (valid) {
       float2* Xo = MASKED ? nullptr : X + fidx * (NH + 1);
-      // MASKED: row = (utterance b, speaker); the observation frame is the utterance's
-      const float* Lr = MASKED ? logit + fidx * (NH + 1) : nullptr;
-      const float2* Or = MASKED ? obs + ((row / Kspk) * T + t) * (NH + 1) : nullptr;
       float* Dr = MASKED ? dlogit + fidx * (NH + 1) : nullptr;
       if (MASKED && bt_major) {
         const int64_t b = row / Kspk, j = row - b * Kspk;
         const int64_t kpos = iperm ? (int64_t)iperm[b * Kspk + j] : j;
         Dr = dlogit + ((b * T + t) * Kspk + kpos) * (NH + 1);
       }
-      auto emit = [&](int k, float2 o) {
+      auto emit = [&](int k, float2 o, float lgk, float2 ob) {
         if (MASKED) {
-          const float m = sigmoidf_mask(Lr[k]);
-          const float2 ob = Or[k];
+          const float m = sigmoidf_mask(lgk);
           Dr[k] = (ob.x * o.x + ob.y * o.y) * m * (1.0f - m);
         } else {
           Xo[k] = o;
@@ -255,11 +270,11 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
         } else {
           o.x *= s_in; o.y *= s_in;
         }
-        emit(k, o);
+        emit(k, o, MASKED ? lg8[r] : 0.f, MASKED ? ob8[r] : make_float2(0.f, 0.f));
       }
       if (lane == 0) {
         const float2 z0 = buf[0];
-        emit(NH, make_float2((z0.x - z0.y) * s_edge, 0.f));
+        emit(NH, make_float2((z0.x - z0.y) * s_edge, 0.f), MASKED ? Lr[NH] : 0.f, MASKED ? Or[NH] : make_float2(0.f, 0.f));
       }
     }
     WAVE_SYNC();          // the line is rewritten by this wave's next frame
