@@ -7,6 +7,7 @@ from tssep_amd import hip_ops as h
 
 var, va, vb = sys.argv[1], sys.argv[2], sys.argv[3]
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 768
+KIND = sys.argv[5] if len(sys.argv) > 5 else "nt"          # "nt": forward / d(input) shapes, "tn": weight gradients
 h.GEMM_PRECISION = "bf16x3"
 T, Kspk = 253, 4
 R1, R4 = B * T, B * Kspk * T
@@ -14,6 +15,12 @@ SHAPES = [("pre_net in", R1, 2400, 553), ("birnn0 in", R4, 2400, 513), ("birnn1 
           ("birnn2 in", R1, 2400, 1280), ("proj 600->320", R4, 320, 600), ("proj 600->513", R1, 513, 600),
           ("linear2", R1, 2052, 320), ("dgrad birnn0 dx", R4, 513, 2400), ("dgrad birnn1 dx", R4, 320, 2400),
           ("dgrad proj dh", R4, 600, 320), ("dgrad birnn2 dx", R1, 1280, 2400), ("dgrad linear2", R1, 320, 2052)]
+
+
+TN_SHAPES = [("wgrad W_ih pre_net", 2400, 553, R1, True), ("wgrad W_ih birnn0", 2400, 513, R4, True),
+             ("wgrad W_ih birnn1", 2400, 320, R4, True), ("wgrad W_ih birnn2", 2400, 1280, R1, True),
+             ("wgrad proj 320", 320, 600, R4, True), ("wgrad proj 513", 513, 600, R1, True),
+             ("wgrad linear2", 2052, 320, R1, True)]
 
 
 def timeit(fn, reps=5):
@@ -26,10 +33,17 @@ def timeit(fn, reps=5):
 
 
 tot = {va: 0.0, vb: 0.0}
-for name, M, N, K in SHAPES:
-    A = torch.randn(M, h.round_up(K, 4), device="cuda"); W = torch.randn(N, h.round_up(K, 4), device="cuda")
-    C = torch.empty(M, N, device="cuda"); bias = torch.randn(N, device="cuda")
-    f = lambda: h.gemm(A, A.shape[1], W, W.shape[1], C, N, M, N, K, bias=bias)
+for shape in (SHAPES if KIND == "nt" else TN_SHAPES):
+    if KIND == "nt":
+        name, M, N, K = shape
+        A = torch.randn(M, h.round_up(K, 4), device="cuda"); W = torch.randn(N, h.round_up(K, 4), device="cuda")
+        C = torch.empty(M, N, device="cuda"); bias = torch.randn(N, device="cuda")
+        f = lambda: h.gemm(A, A.shape[1], W, W.shape[1], C, N, M, N, K, bias=bias)
+    else:
+        name, M, N, K, colsum = shape
+        A = torch.randn(K, h.round_up(M, 4), device="cuda"); W = torch.randn(K, h.round_up(N, 4), device="cuda")
+        C = None
+        f = lambda: h.wgrad(A, A.shape[1], W, W.shape[1], M, N, K, with_colsum=colsum)
     best = {va: 1e9, vb: 1e9}
     f(); torch.cuda.synchronize()
     for _ in range(3):
