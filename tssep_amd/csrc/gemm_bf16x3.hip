@@ -1244,10 +1244,16 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       const bool two = pe && pe[0] == '2';
       const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
       const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
-      // default 2: the time-shifted dW_hh GEMMs only (-2.3 ms per step, alternating A/B); the unshifted ones measured
-      // 0.5 ms SLOWER per step with this tile (1: all eligible, 3: unshifted only, 0: off)
-      const int tmode = te ? atoi(te) : 2;
-      if (tmode && (tmode == 1 || (tmode == 2) == shift) && g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16)) {
+      // default 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones
+      // with at most 3 or at least 9 column tiles (dW_ih of birnn1: N = 321, birnn2: N = 1281 -- 4.89 vs 5.27 ms and
+      // 4.28 vs 4.55 ms with the split counts hip_ops.pick_splitk gives them, profiles/r3_wgrad_tile_sweep.jsonl);
+      // the 5-column-tile shapes (N = 514 / 554) stay on the 128 x 128 tile: there the larger tile measured equal or
+      // slower at every split count.  (1: all eligible, 2: shifted only, 3: unshifted only, 0: off)
+      const int tmode = te ? atoi(te) : 4;
+      const int64_t ntl = (g->N + BN - 1) / BN;
+      const bool want = tmode == 1 || (tmode == 2 && shift) || (tmode == 3 && !shift) ||
+                        (tmode == 4 && (shift || ntl <= 3 || ntl >= 9));
+      if (want && g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16)) {
         const TileMap tmt = make_tile_map(m256 / TTM, (g->N + BN - 1) / BN, splitk);
         dim3 gridt((unsigned)tile_map_blocks(tmt));
 #define TT_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_tall_kernel<SH, TW>), gridt, dim3(NTHREADS), 0, s, \
