@@ -212,6 +212,57 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (3000, 2052, 31),
+                                   (70000, 1280, 64), (1500, 2400, 2400)])
+def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
+    """The 256 x 256 tile with 128 x 128 wave tiles, one wave per SIMD (csrc/gemm_bf16x3_big.hip) against fp64, and
+    bit for bit against the 8-wave tiled kernels (TSSEP_GEMM_BIG=0, TSSEP_GEMM_STREAM=0): same K order and MFMA
+    sequence per output element, the shared epilogue -- bias + tanh, accumulate, the folded Tanh backward, the
+    speaker-combination store remap; K tails (K % 32 != 0, K < 32), ragged last row / column tiles."""
+    import os
+    torch.manual_seed(5)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    os.environ["TSSEP_GEMM_STREAM"] = "0"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        ldy = ru(N, 4)
+        Y = torch.zeros(M, ldy); Y[:, :N] = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        Kspk, T = 4, M // 8
+        R = 2 * Kspk * T
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_BIG"] = mode
+            C = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
+            C2 = torch.ones(M, N, device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+            C3 = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K, act=2, aux=(Yd, ldy))
+            C4 = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C4, 0, R, N, K, bias=bd,
+                   remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+            outs[mode] = (C, C2, C3, C4)
+        b = outs["1"]
+        close(b[0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="big nt+bias+tanh")
+        close(b[1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="big accumulate")
+        close(b[2], (ref - bias) * (1 - Y[:, :N] ** 2), rtol=2e-4, atol=2e-4, name="big (1 - y^2)")
+        want = ref[:R].view(2, Kspk, T, N).permute(0, 2, 1, 3).reshape(2 * T, Kspk * N)
+        close(b[3], want, rtol=2e-4, atol=2e-4, name="big remap")
+        for x, y in zip(outs["1"], outs["0"]):
+            assert torch.equal(x, y)
+    finally:
+        os.environ.pop("TSSEP_GEMM_BIG", None)
+        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn_and_tn(M, N, K, gemm_precision):
     tol = gemm_precision

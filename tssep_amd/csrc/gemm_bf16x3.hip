@@ -1184,6 +1184,20 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   if (g->b_ones_col && (!g->b_kmajor || shift || g->N < 2)) return TSSEP_E_UNSUPPORTED;
   static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
   if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+    // big-tile kernel (gemm_bf16x3_big.hip) where the wide tile applies (N >= 1024, < 10 % column padding).
+    // TSSEP_GEMM_BIG is read per call (alternating A/B runs toggle it)
+    {
+      const char* be = getenv("TSSEP_GEMM_BIG");
+      const int bmode = be ? atoi(be) : 1;
+      const int64_t n256b = (g->N + 255) / 256 * 256;
+      // (K < 448: a tile's life is mostly its C store there -- the streaming kernel, which hides it, measured
+      // 4.14 against 4.56 ms at K = 320, N = 2400; from K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280,
+      // 2.75 / 3.29 at K = 2400, N = 1280; bmode 2 = regardless of K)
+      if (bmode && (g->K >= 448 || bmode == 2) && g->N >= 1024 && n256b * 10 <= g->N * 11) {
+        const int rc = tssep_gemm_bf16x3_big_launch(g, sm, stream);
+        if (rc != TSSEP_E_UNSUPPORTED) return rc;
+      }
+    }
     // persistent streaming kernel (gemm_bf16x3_stream.hip): plain row-major stores; the N = 256 q + 1 shapes keep
     // the wide tile with its VALU column.  TSSEP_GEMM_STREAM is read per call (alternating A/B runs toggle it)
     {

@@ -359,3 +359,5 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
 // persistent streaming variant (row x row, plain store), defined in gemm_bf16x3_stream.hip: returns
 // TSSEP_E_UNSUPPORTED when the arguments are outside what it covers
 int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
+// 256 x 256 tile with 128 x 128 wave tiles, one wave per SIMD (gemm_bf16x3_big.hip); every epilogue option
+int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
