@@ -263,6 +263,45 @@ def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(3000, 513, 600), (1100, 769, 2400), (2048, 513, 448)])
+def test_gemm_big_tile_extra_column(M, N, K):
+    """N = 256 q + 1 in the big-tile kernel: q MFMA tiles + column N - 1 on the VALU (exact fp32 products).  The
+    first N - 1 columns agree bit for bit with the 8-wave kernel's (TSSEP_GEMM_BIG=0), the last one with fp64;
+    bias, the folded Tanh backward (aux), padded rows of C untouched."""
+    import os
+    torch.manual_seed(8)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    os.environ["TSSEP_GEMM_STREAM"] = "0"
+    try:
+        ru = h.round_up
+        A = torch.randn(M, K); W = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        ldc = ru(N, 4)
+        Y = torch.zeros(M, ldc); Y[:, :N] = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
+        ref = A.double() @ W.double().t()
+        outs = {}
+        for mode in ("2", "0"):
+            os.environ["TSSEP_GEMM_BIG"] = mode
+            C = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(Ad, K, Wd, K, C, ldc, M, N, K, bias=bd)
+            C2 = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(Ad, K, Wd, K, C2, ldc, M, N, K, act=2, aux=(Yd, ldc))
+            outs[mode] = (C, C2)
+        b = outs["2"]
+        close(b[0][:, :N], (ref + bias.double()).float(), rtol=2e-4, atol=2e-4, name="big xcol + bias")
+        close(b[1][:, :N], (ref * (1 - Y[:, :N].double() ** 2)).float(), rtol=2e-4, atol=2e-4, name="big xcol (1 - y^2)")
+        assert bool(torch.isnan(b[0][:, N:]).all()) and bool(torch.isnan(b[1][:, N:]).all())
+        for x, y in zip(outs["2"], outs["0"]):
+            assert torch.equal(x[:, :N - 1], y[:, :N - 1])
+    finally:
+        os.environ.pop("TSSEP_GEMM_BIG", None)
+        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn_and_tn(M, N, K, gemm_precision):
     tol = gemm_precision

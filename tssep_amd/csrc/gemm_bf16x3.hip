@@ -1193,7 +1193,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       // (K < 448: a tile's life is mostly its C store there -- the streaming kernel, which hides it, measured
       // 4.14 against 4.56 ms at K = 320, N = 2400; from K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280,
       // 2.75 / 3.29 at K = 2400, N = 1280; bmode 2 = regardless of K)
-      if (bmode && (g->K >= 448 || bmode == 2) && g->N >= 1024 && n256b * 10 <= g->N * 11) {
+      const bool xcol_shape = g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0;      // N = 513: two tiles + a VALU column
+      if (bmode && (g->K >= 448 || bmode == 2) && ((g->N >= 1024 && n256b * 10 <= g->N * 11) || xcol_shape)) {
         const int rc = tssep_gemm_bf16x3_big_launch(g, sm, stream);
         if (rc != TSSEP_E_UNSUPPORTED) return rc;
       }

@@ -45,11 +45,16 @@ constexpr unsigned GOOR = 0x80000000u;                      // buffer offset bey
 
 // PROBE (experiment builds only, -DTSSEP_GEMM_EXP; garbage results, TIMING probes): 1 = no barriers, 2 = no global
 // loads, 4 = no staging, 8 = no epilogue stores, 16 = no MFMAs
-template <int PROBE>
+// XCOL (N = 256 q + 1: the 513 frequency bins of `dgrad birnn0 dx` and of the pre-net projection): the MFMA tiles
+// cover the first N - 1 columns and column N - 1 is computed on the VALU from the raw fp32 A values every thread
+// stages anyway (32 FMAs per thread and stage against row N - 1 of B, exact fp32; every workgroup computes it --
+// branch-free -- and those of the last column tile store it), instead of a third 256-wide tile for ONE column.
+template <int PROBE, bool XCOL>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull,
     int64_t K, int64_t lda, int64_t ldb, const float* __restrict__ bias, int act, int accumulate, StoreMap sm,
     TileMap tmap) {
+  const int64_t N = XCOL ? Nfull - 1 : Nfull;          // columns of the MFMA tiles
   __shared__ __attribute__((aligned(16))) char lds[2 * GSTAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,6 +87,12 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     return (kt >= KT || (tail_out && kt == KT - 1)) ? GOOR : 0u;
   };
   f32x4 ra[8], rb[8];
+  // XCOL: row N - 1 of B, this lane's chunk: rx belongs to the stage held in ra, rxn to the one being loaded
+  const srd_t xsrd = make_srd(B + N * ldb);
+  f32x4 rx = {0.f, 0.f, 0.f, 0.f}, rxn = rx;
+  float xacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xacc[i] = 0.f;
 
   // ---- staging: 4 consecutive k of one row = 8 bytes of bf16, chunk (k / 8) ^ ((row >> 2) & 3) of the row
   const int soff = lrow * GROWB + (((lch >> 1) ^ ((tid >> 5) & 3)) << 4) + ((lch & 1) << 3);
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     const int fo0 = fsw, fo1 = fsw ^ 32;
     const int so = kt_load * GBK * 4;
     const unsigned tmask = load_mask(kt_load);
+    if constexpr (XCOL) rxn = bload4(xsrd, (unsigned)(lch * 16) | tmask, so);
 #define SB __builtin_amdgcn_sched_barrier(0)
 #define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
 #define MM(x, y, i, j) if (PROBE & 16) acc[i][j][0] += (float)x[i][0] + (float)y[j][1]; else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0)
@@ -141,7 +153,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     // matrix pipe idle): split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
 #define SPL(a_, b_, h_, l_) if (PROBE & 32) split2n_trunc(a_, b_, h_, l_); else split2n(a_, b_, h_, l_)
-#define SA1(i) if (!(PROBE & 4)) SPL(ra[i][0], ra[i][1], sh0, sl0)
+#define SA1(i) if constexpr (XCOL) xacc[i] = fmaf(ra[i][3], rx[3], fmaf(ra[i][2], rx[2], fmaf(ra[i][1], rx[1], fmaf(ra[i][0], rx[0], xacc[i])))); \
+               if (!(PROBE & 4)) SPL(ra[i][0], ra[i][1], sh0, sl0)
 #define SA2(i) if (!(PROBE & 4)) SPL(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) if (!(PROBE & 4)) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
                *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     MM(ah1, bh1, 3, 1); SB2(7); SB;
     MM(ah1, bh1, 3, 2); SB3(7); SB;
     MM(ah1, bh1, 3, 3); SB;
+    if constexpr (XCOL) rx = rxn;
 #undef SPL
 #undef SB3
 #undef SB2
@@ -267,12 +281,19 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     const unsigned t0 = load_mask(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t0, 0); rb[i] = bload4(bsrd, boffs[i] | t0, 0); }
+    if constexpr (XCOL) {
+      rx = bload4(xsrd, (unsigned)(lch * 16) | t0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        xacc[i] = fmaf(ra[i][3], rx[3], fmaf(ra[i][2], rx[2], fmaf(ra[i][1], rx[1], fmaf(ra[i][0], rx[0], xacc[i]))));
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { stage_a(lds, i); stage_b(lds, i); }
     if (ktail && KT == 1) fix_tail(lds);
     const unsigned t1 = load_mask(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t1, GBK * 4); rb[i] = bload4(bsrd, boffs[i] | t1, GBK * 4); }
+    if constexpr (XCOL) rx = bload4(xsrd, (unsigned)(lch * 16) | t1, GBK * 4);
   }
   __syncthreads();
   int par = 0;
@@ -285,6 +306,38 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
     par ^= 1;
   }
 
+  if (XCOL && nt == tmap.NT - 1) {
+    // column N of the full matrix: the 8 lanes of a row hold its eight 16-byte k chunks (same summation tree for
+    // every row; exact fp32 products, not bit-comparable with the MFMA columns' split arithmetic -- like the 8-wave
+    // kernel's extra column)
+    const int64_t n = N;
+    const float bv = bias ? bias[n] : 0.f;
+    const int64_t cq = sm.remap ? n / sm.cm : 0, cr = sm.remap ? n - cq * sm.cm : n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = xacc[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const int64_t m = m0 + lrow + 32 * i;
+      if (lch == 0 && m < M) {
+        int64_t a;
+        if (sm.remap) {
+          const int64_t t = m % sm.T, q = m / sm.T;
+          const int64_t k = q % sm.K, b = q / sm.K;
+          const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq] : cq;
+          a = b * sm.sb + k * sm.sk + t * sm.st + cqq * sm.co + cr;
+        } else {
+          a = m * sm.ldc + n;
+        }
+        v += bv;
+        if (act == 1) v = tanhf(v);
+        if (act == 2) { const float y = sm.aux[m * sm.ldaux + n]; v *= 1.f - y * y; }
+        if (accumulate) v += C[a];
+        C[a] = v;
+      }
+    }
+  }
   // ---- epilogue: four 64 x 64 blocks per wave through a private 17-KB scratch in the (now free) stage memory
   static_assert(4 * 64 * EPITCH * 4 <= 2 * GSTAGE, "epilogue scratch must fit in the stages");
   if ((PROBE & 8) && K >= 0) {
@@ -327,7 +380,14 @@ int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::St
   if ((int64_t)GM * g->lda * 4 + g->K * 4 >= (int64_t)1 << 31 || (int64_t)GN * g->ldb * 4 + g->K * 4 >= (int64_t)1 << 31)
     return TSSEP_E_UNSUPPORTED;
   const TileMap tm = make_tile_map((g->M + GM - 1) / GM, (g->N + GN - 1) / GN, 1);
-#define GLAUNCH(P_) hipLaunchKernelGGL(gemm_bf16x3_big_kernel<P_>, dim3((unsigned)tile_map_blocks(tm)), dim3(GNT), 0, (hipStream_t)stream, \
+  if (g->N > 256 && g->N % 256 == 1) {        // 256 q + 1 columns: q tiles + one VALU column
+    if (g->K & 3) return TSSEP_E_UNSUPPORTED;
+    const TileMap tmx = make_tile_map((g->M + GM - 1) / GM, (g->N - 1) / GN, 1);
+    hipLaunchKernelGGL((gemm_bf16x3_big_kernel<0, true>), dim3((unsigned)tile_map_blocks(tmx)), dim3(GNT), 0, (hipStream_t)stream,
+                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tmx);
+    return tssep_launch_status();
+  }
+#define GLAUNCH(P_) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<P_, false>), dim3((unsigned)tile_map_blocks(tm)), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tm)
 #ifdef TSSEP_GEMM_EXP
   {
