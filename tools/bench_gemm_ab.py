@@ -33,6 +33,7 @@ def timeit(fn, reps=5):
 
 
 tot = {va: 0.0, vb: 0.0}
+os.environ.setdefault(var, va)
 for shape in (SHAPES if KIND == "nt" else TN_SHAPES):
     if KIND == "nt":
         name, M, N, K = shape
