@@ -44,6 +44,13 @@ for N in [int(a) for a in sys.argv[1:]] or [8, 32, 64, 128, 256, 512, 1024]:
     h.check_cluster_errors()
     res["onchip_bwd_ms"] = round(timeit(lambda: h.blstm_onchip_bwd(g, cell, dh, 2 * Hh, Hh, wb3, N, T, Hh)), 3)
     h.check_cluster_errors()
+    # microseconds per time step and resident round (48 XCD-local clusters x 32 sequences x 1 direction = 768
+    # sequences per round): "unloaded" = a launch of <= 32 sequences (one or two clusters, the exchange chain alone),
+    # "loaded" = full rounds (all clusters streaming their activations through the same L2s / HBM)
+    rounds = -(-(2 * -(-N // 32)) // 48)
+    res["rounds"] = rounds
+    res["onchip_fwd_us_per_step"] = round(res["onchip_fwd_ms"] * 1e3 / (T * rounds), 2)
+    res["onchip_bwd_us_per_step"] = round(res["onchip_bwd_ms"] * 1e3 / (T * rounds), 2)
     for lay in [int(a) for a in os.environ.get("LAYOUTS", "").split(",") if a]:
         g = g0.clone()
         res["onchip_fwd_lay%d_ms" % lay] = round(timeit(lambda: h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh, lay)), 3)
