@@ -302,6 +302,37 @@ def test_gemm_big_tile_extra_column(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("R,M,N,S", [(4096, 2400, 321, 8), (2048, 1024, 130, 1), (6400, 2400, 514, 4), (1024 * 3, 1100, 129, 2),
+                                     (16 * 70, 2400, 1281, 1)])
+def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
+    """The 512 x 128 weight-gradient tile with 128 x 128 wave tiles and three LDS stages
+    (csrc/gemm_bf16x3_tn_big.hip) against fp64 and bit for bit against the 128 x 128 / 256 x 128 tn kernels
+    (TSSEP_GEMM_TN_BIG=0; the split-K boundaries of the two coincide for these R): ragged last row / column tiles,
+    the fused ones column (bias gradient), splits shorter than the three-stage pipeline."""
+    import os
+    torch.manual_seed(11)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        dY = torch.randn(R, h.round_up(M, 4), device="cuda"); X = torch.full((R, h.round_up(N, 4)), 3.0, device="cuda")
+        X[:, :N - 1] = torch.randn(R, N - 1, device="cuda")
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_TN_BIG"] = mode
+            part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
+            outs[mode] = part.clone()
+        ldp = h.round_up(N, 4)                  # (columns N .. ldp - 1 of the partials are never written)
+        assert torch.equal(outs["1"].view(S, M, ldp)[:, :, :N], outs["0"].view(S, M, ldp)[:, :, :N])
+        got = outs["1"].view(S, M, ldp).double().sum(0)
+        ref = dY[:, :M].double().t() @ X[:, :N - 1].double()
+        close(got[:, :N - 1].float(), ref.float(), rtol=2e-4, atol=3e-3, name="big wgrad")
+        close(got[:, N - 1].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="big wgrad column sums")
+    finally:
+        os.environ.pop("TSSEP_GEMM_TN_BIG", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn_and_tn(M, N, K, gemm_precision):
     tol = gemm_precision

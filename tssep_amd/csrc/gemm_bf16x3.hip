@@ -1257,6 +1257,15 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
       const char* pe = getenv("TSSEP_WGRAD_PRODUCTS");           // opt-in: 2 = drop the dY_lo * X_hi product
       const bool two = pe && pe[0] == '2';
+      {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by < 10 % (the four dW_ih GEMMs: M = 2400)
+        const char* tbe = getenv("TSSEP_GEMM_TN_BIG");            // read per call (alternating A/B)
+        const int tbig = tbe ? atoi(tbe) : 1;
+        const int64_t m512 = (g->M + 511) / 512 * 512;
+        if (tbig && !shift && !two && g->M >= 1024 && m512 * 10 <= g->M * 11) {
+          const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, stream);
+          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        }
+      }
       const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
       const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
       // default 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones

@@ -309,6 +309,13 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
     # workgroups predicts up to 20 % from other factors; measured, the large-K shapes get SLOWER with more splits
     # -- the tiles of a K slab share it through one L2 only while they run together -- and this rule is within
     # 0..5 % of the best S on every shape of the step)
+    if TN_BIG and GEMM_PRECISION == "bf16x3" and M >= 1024 and M % 4 == 0 and K % 16 == 0 \
+            and round_up(M, 512) * 10 <= M * 11 and K >= 16 * 64:
+        # the big-tile weight-gradient kernel (csrc/gemm_bf16x3_tn_big.hip): 512 x 128 tiles, ONE workgroup per CU, the
+        # tiles of a K slab on one XCD (32 CUs) -> as many slabs per XCD as fill its CUs best; multiples of 8 only
+        tiles = math.ceil(M / 512) * math.ceil(N / 128)
+        best = min((8, 16, 24, 32), key=lambda S: (math.ceil(tiles * (S // 8) / 32) * 32) / (tiles * (S // 8)))
+        return best
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
     if SPLITK_BIGK and M >= 2048 and N >= 1152 and K < 400000:
@@ -579,6 +586,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
+TN_BIG = _os.environ.get("TSSEP_GEMM_TN_BIG", "1") != "0"        # (the split rule follows the kernel the dispatcher picks)
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
 
