@@ -328,7 +328,16 @@ def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
         ref = dY[:, :M].double().t() @ X[:, :N - 1].double()
         close(got[:, :N - 1].float(), ref.float(), rtol=2e-4, atol=3e-3, name="big wgrad")
         close(got[:, N - 1].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="big wgrad column sums")
+        # the opt-in two-product arithmetic (dY as plain bf16): same kernel, a third of the MFMAs dropped
+        os.environ["TSSEP_WGRAD_PRODUCTS"] = "2"
+        two = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_TN_BIG"] = mode
+            two[mode] = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)[0].clone()
+        assert torch.equal(two["1"].view(S, M, ldp)[:, :, :N], two["0"].view(S, M, ldp)[:, :, :N])
+        close(two["1"].view(S, M, ldp).double().sum(0)[:, :N - 1].float(), ref.float(), rtol=5e-3, atol=1.5, name="big wgrad, two products")
     finally:
+        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
         os.environ.pop("TSSEP_GEMM_TN_BIG", None)
         h.GEMM_PRECISION = old
 

@@ -9,7 +9,7 @@ mm = []
 for (x, y) in (("al", "bh"), ("ah", "bl"), ("ah", "bh")):
     for i in range(4):
         for j in range(4):
-            mm.append(f"MM({x}, {y}, {i}, {j});")
+            mm.append(f"{'MM1' if x == 'al' else 'MM'}({x}, {y}, {i}, {j});")
 att = {k: [] for k in range(48)}
 # current stage: a_hi / b_lo, in the order P2 needs them (ah0, bl0..3, ah1..3); two transpose reads each
 cur = ["FA(ah, 0, 0)", "FB(bl, 0, 1)", "FB(bl, 1, 1)", "FB(bl, 2, 1)", "FB(bl, 3, 1)", "FA(ah, 1, 0)", "FA(ah, 2, 0)", "FA(ah, 3, 0)"]

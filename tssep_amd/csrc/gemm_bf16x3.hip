@@ -1261,8 +1261,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         const char* tbe = getenv("TSSEP_GEMM_TN_BIG");            // read per call (alternating A/B)
         const int tbig = tbe ? atoi(tbe) : 1;
         const int64_t m512 = (g->M + 511) / 512 * 512;
-        if (tbig && !shift && !two && g->M >= 1024 && m512 * 10 <= g->M * 11) {
-          const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, stream);
+        if (tbig && !shift && g->M >= 1024 && m512 * 10 <= g->M * 11) {
+          const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, two ? 1 : 0, stream);
           if (rc != TSSEP_E_UNSUPPORTED) return rc;
         }
       }

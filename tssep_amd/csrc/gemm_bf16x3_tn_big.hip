@@ -43,6 +43,9 @@ __device__ __forceinline__ bf16x8 trf(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// TWO (opt-in, TSSEP_WGRAD_PRODUCTS=2): the a_lo x b_hi product is dropped -- dY enters as plain bf16, X keeps hi + lo:
+// 32 instead of 48 MFMAs per stage, no lo plane of A staged or read (as in the tn kernels' TWO variant).
+template <bool TWO>
 __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
     int64_t K, int64_t lda, int64_t ldb, int accumulate, int64_t ldc, int splitk, int64_t c_split_stride,
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
     bf16x8 al[4], bh[4], ah[4], bl[4], aln[4], bhn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      al[i] = trf<WPA>(lds + WARR_A + aoff + i * 64);
+      if constexpr (!TWO) al[i] = trf<WPA>(lds + WARR_A + aoff + i * 64);
       bh[i] = trf<WPB>(lds + boff + i * 64);
     }
     int c0 = 0, c1 = 1, c2 = 2;          // ring positions of stages s, s + 1, s + 2
@@ -150,14 +153,15 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
       f32x4 bmk = {0.f, 0.f, 0.f, 0.f};
 #define SLOT __builtin_amdgcn_sched_barrier(0)
 #define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0)
+#define MM1(x, y, i, j) if constexpr (!TWO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0)
 #define FA(dst, i, lo) dst[i] = trf<WPA>(cur + (lo) * WARR_A + aoff + (i) * 64)
 #define FB(dst, i, lo) dst[i] = trf<WPB>(cur + (lo) * WARR_B + boff + (i) * 64)
-#define NA(dst, i, lo) dst[i] = trf<WPA>(nx1 + (lo) * WARR_A + aoff + (i) * 64)
+#define NA(dst, i, lo) if constexpr (!TWO || (lo) == 0) dst[i] = trf<WPA>(nx1 + (lo) * WARR_A + aoff + (i) * 64)
 #define NB(dst, i, lo) dst[i] = trf<WPB>(nx1 + (lo) * WARR_B + boff + (i) * 64)
 #define SA1(i) split2n(ra[i][0], ra[i][1], sh0, sl0)
 #define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) *reinterpret_cast<u32x2*>(nx2 + soffA + (i) * 2 * WPA) = u32x2{sh0, sh1};            \
-               *reinterpret_cast<u32x2*>(nx2 + WARR_A + soffA + (i) * 2 * WPA) = u32x2{sl0, sl1};   \
+               if constexpr (!TWO) *reinterpret_cast<u32x2*>(nx2 + WARR_A + soffA + (i) * 2 * WPA) = u32x2{sl0, sl1};   \
                ra[i] = bload4(asrd, (avo + (unsigned)((i) * 2 * lda * 4)) | tm, soa)
 #define SB1(i) bmk = maskb(rb[i], rows2); split2n(bmk[0], bmk[1], sh0, sl0)
 #define SB2(i) split2n(bmk[2], bmk[3], sh1, sl1)
@@ -165,22 +169,22 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
                *reinterpret_cast<u32x2*>(nx2 + WARR_B + soffB + (i) * 8 * WPB) = u32x2{sl0, sl1};   \
                rb[i] = bload4(bsrd, (bvo + (unsigned)((i) * 8 * ldb * 4)) | tm, sob)
       // GENERATED-BODY-BEGIN (tools/gen/gen_tn_big_body.py)
-    MM(al, bh, 0, 0); FA(ah, 0, 0); SLOT;
-    MM(al, bh, 0, 1); SA1(0); SLOT;
-    MM(al, bh, 0, 2); FB(bl, 0, 1); SLOT;
-    MM(al, bh, 0, 3); SA2(0); SLOT;
-    MM(al, bh, 1, 0); FB(bl, 1, 1); SLOT;
-    MM(al, bh, 1, 1); SA3(0); SLOT;
-    MM(al, bh, 1, 2); FB(bl, 2, 1); SLOT;
-    MM(al, bh, 1, 3); SA1(1); SLOT;
-    MM(al, bh, 2, 0); FB(bl, 3, 1); SLOT;
-    MM(al, bh, 2, 1); SA2(1); SLOT;
-    MM(al, bh, 2, 2); FA(ah, 1, 0); SLOT;
-    MM(al, bh, 2, 3); SA3(1); SLOT;
-    MM(al, bh, 3, 0); FA(ah, 2, 0); SLOT;
-    MM(al, bh, 3, 1); SA1(2); SLOT;
-    MM(al, bh, 3, 2); FA(ah, 3, 0); SLOT;
-    MM(al, bh, 3, 3); SA2(2); SLOT;
+    MM1(al, bh, 0, 0); FA(ah, 0, 0); SLOT;
+    MM1(al, bh, 0, 1); SA1(0); SLOT;
+    MM1(al, bh, 0, 2); FB(bl, 0, 1); SLOT;
+    MM1(al, bh, 0, 3); SA2(0); SLOT;
+    MM1(al, bh, 1, 0); FB(bl, 1, 1); SLOT;
+    MM1(al, bh, 1, 1); SA3(0); SLOT;
+    MM1(al, bh, 1, 2); FB(bl, 2, 1); SLOT;
+    MM1(al, bh, 1, 3); SA1(1); SLOT;
+    MM1(al, bh, 2, 0); FB(bl, 3, 1); SLOT;
+    MM1(al, bh, 2, 1); SA2(1); SLOT;
+    MM1(al, bh, 2, 2); FA(ah, 1, 0); SLOT;
+    MM1(al, bh, 2, 3); SA3(1); SLOT;
+    MM1(al, bh, 3, 0); FA(ah, 2, 0); SLOT;
+    MM1(al, bh, 3, 1); SA1(2); SLOT;
+    MM1(al, bh, 3, 2); FA(ah, 3, 0); SLOT;
+    MM1(al, bh, 3, 3); SA2(2); SLOT;
     MM(ah, bl, 0, 0); SA3(2); SLOT;
     MM(ah, bl, 0, 1); SA1(3); SLOT;
     MM(ah, bl, 0, 2); SA2(3); SLOT;
@@ -224,10 +228,11 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
 #undef NA
 #undef FB
 #undef FA
+#undef MM1
 #undef MM
 #undef SLOT
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { al[i] = aln[i]; bh[i] = bhn[i]; }
+      for (int i = 0; i < 4; ++i) { if constexpr (!TWO) al[i] = aln[i]; bh[i] = bhn[i]; }
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       const int t = c0; c0 = c1; c1 = c2; c2 = t;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
 
 }  // namespace
 
-int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, void* stream) {
+int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream) {
   using namespace gemm_detail;
   if (!g->a_kmajor || !g->b_kmajor || sm.remap || g->bias || g->act || g->kperiod > 0) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B) || (g->M & 3) || (g->K % WBK)) return TSSEP_E_UNSUPPORTED;
@@ -264,8 +269,13 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
   // 32-bit buffer offsets: one split's rows must stay below 2 GB
   if ((per + 4) * WBK * (g->lda > g->ldb ? g->lda : g->ldb) * 4 >= (int64_t)1 << 31) return TSSEP_E_UNSUPPORTED;
   const TileMap tm = make_tile_map((g->M + WM - 1) / WM, (g->N + WN - 1) / WN, splitk);
-  hipLaunchKernelGGL(gemm_bf16x3_tn_big_kernel, dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, (hipStream_t)stream,
-                     g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk,
-                     g->c_split_stride, tm, g->b_ones_col);
+  if (two)
+    hipLaunchKernelGGL(gemm_bf16x3_tn_big_kernel<true>, dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, (hipStream_t)stream,
+                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk,
+                       g->c_split_stride, tm, g->b_ones_col);
+  else
+    hipLaunchKernelGGL(gemm_bf16x3_tn_big_kernel<false>, dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, (hipStream_t)stream,
+                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk,
+                       g->c_split_stride, tm, g->b_ones_col);
   return tssep_launch_status();
 }

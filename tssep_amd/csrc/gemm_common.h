@@ -363,4 +363,4 @@ int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail:
 int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
 // weight gradients (both operands k-major, no time shift): 512 x 128 tile, 128 x 128 wave tiles, three LDS stages
 // (gemm_bf16x3_tn_big.hip)
-int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, void* stream);
+int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
