@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
   __shared__ f32x4 xg[3][SEQS * UPW];
   __shared__ int s_fail, s_mem[4];
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: SGPR)
   if (tid == 0) s_fail = 0;
   const bool stream_nt = (layout & 16) != 0;           // non-temporal activation stream (host: N >= 160)
   layout &= 1;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
   __shared__ f32x4 carry[2 * 512];
   __shared__ int s_fail, s_mem[4];
   constexpr int AUXL = SC1, AUXS = XCD ? SC0 : SC1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (wave-uniform: SGPR)
   if (tid == 0) s_fail = 0;
   const int64_t ngroups = (N + SEQS - 1) / SEQS;
   const Membership mem = join_cluster<XCD>(xhead, G, (int)(2 * ngroups), s_mem);
