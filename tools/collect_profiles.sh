@@ -12,17 +12,18 @@ TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 768 2>/dev/null | grep name 
 # round 3: the streaming and the big-tile kernel against the tiled kernels they replace, shape by shape, alternating
 TSSEP_GEMM_BIG=0 python tools/bench_gemm_ab.py TSSEP_GEMM_STREAM 1 0 > $O/ab_gemm_stream_shapes.jsonl 2>/dev/null
 TSSEP_GEMM_STREAM=1 python tools/bench_gemm_ab.py TSSEP_GEMM_BIG 1 0 > $O/ab_gemm_big_shapes.jsonl 2>/dev/null
+python tools/bench_gemm_ab.py TSSEP_GEMM_TN_BIG 1 0 768 tn > $O/ab_wgrad_big_shapes.jsonl 2>/dev/null
 python tools/bench_tail.py > $O/tail_microbench.jsonl 2>/dev/null
 python tools/grad_parity.py 4 > $O/parity_full_size.jsonl 2>/dev/null
 for b in 8 32 64 128 256 384 512 768 1152 1536; do
   python bench.py --batch $b --steps 20 --warmup 4 $B 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
 # round-3 kernel changes, each alternating off / on in this one job (the switches are read per call)
-for var in TSSEP_GEMM_STREAM TSSEP_GEMM_BIG; do
+for var in TSSEP_GEMM_STREAM TSSEP_GEMM_BIG TSSEP_GEMM_TN_BIG; do
   for w in 0 1 0 1; do env $var=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(switch='$var', value=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], ms_per_step_median=d['ms_per_step_median'], gemm_tflops=d['roofline']['achieved'], mask_head_frac=d['roofline_mask_head']['frac'])))"; done
 done > $O/ab_gemm_kernels.jsonl
-for w in 2 4 2 4; do TSSEP_GEMM_TN_TALL=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
+for w in 2 4 2 4; do TSSEP_GEMM_TN_BIG=0 TSSEP_GEMM_TN_TALL=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(switch='TSSEP_GEMM_TN_TALL', value=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], gemm_tflops=d['roofline']['achieved'])))"; done > $O/ab_wgrad_tile.jsonl
 for w in 3 2 3 2; do TSSEP_WGRAD_PRODUCTS=$w python bench.py --steps 15 --warmup 3 --no-exact-f32 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); p=d['cpu_baseline']['parity_vs_hip']; print(json.dumps(dict(wgrad_products=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], max_rel_grad_err=p['max_rel_grad_err'], median_rel_grad_err=p['median_rel_grad_err'], worst=p['worst_gradient'])))"; done > $O/ab_wgrad_products.jsonl
