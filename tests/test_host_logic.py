@@ -37,6 +37,16 @@ def test_splitk_choice():
     s = H.pick_splitk(2400, 513, 194304)
     assert s > 1 and s % 8 == 0 and s <= 64
     assert H.pick_splitk(24, 12, 35) == 1
+    # the big-tile weight-gradient kernel (512 x 128 tiles, one workgroup per CU, a K slab per XCD): as many slabs per
+    # XCD as fill its 32 CUs best -- 15 tiles -> 2 slabs (30 / 32), 25 tiles -> 1 (25 / 32), 55 tiles -> 4 (220 / 224)
+    old = H.GEMM_PRECISION
+    H.GEMM_PRECISION = "bf16x3"
+    try:
+        assert H.pick_splitk(2400, 321, 777216) == 16 and H.pick_splitk(2400, 514, 777216) == 8
+        assert H.pick_splitk(2400, 1281, 194304) == 32
+        assert H.pick_splitk(1200, 300, 777216) % 8 == 0          # dW_hh: not the big tile (M pads to 1536)
+    finally:
+        H.GEMM_PRECISION = old
 
 
 def test_onchip_workspace_sizes():

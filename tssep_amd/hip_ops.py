@@ -318,10 +318,6 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
         return best
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
-    if SPLITK_BIGK and M >= 2048 and N >= 1152 and K < 400000:
-        # dW_ih of the combination layer (2400 x 1281, K = 194 304) on the 256 x 128 tile: 16 splits 4.28 ms against
-        # 4.56 at 8 (profiles/r3_wgrad_tile_sweep.jsonl)
-        return 16
     if SPLITK_BIGK and K >= 400000 and tiles >= 48:
         # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
         # smallest one -- 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
