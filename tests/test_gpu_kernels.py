@@ -323,7 +323,13 @@ def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
             part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
             outs[mode] = part.clone()
         ldp = h.round_up(N, 4)                  # (columns N .. ldp - 1 of the partials are never written)
-        assert torch.equal(outs["1"].view(S, M, ldp)[:, :, :N], outs["0"].view(S, M, ldp)[:, :, :N])
+        # N = 128 q + 1 | 2: the last columns are summed on the VALU in fp32 (exact products), not through the MFMAs
+        nb = N - N % 128 if N > 128 and 1 <= N % 128 <= 2 else N
+        assert torch.equal(outs["1"].view(S, M, ldp)[:, :, :nb], outs["0"].view(S, M, ldp)[:, :, :nb])
+        os.environ["TSSEP_GEMM_TN_XC"] = "0"     # ... unless switched off: then every column is bit-identical
+        part, _ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
+        os.environ.pop("TSSEP_GEMM_TN_XC")
+        assert torch.equal(part.view(S, M, ldp)[:, :, :N], outs["0"].view(S, M, ldp)[:, :, :N])
         got = outs["1"].view(S, M, ldp).double().sum(0)
         ref = dY[:, :M].double().t() @ X[:, :N - 1].double()
         close(got[:, :N - 1].float(), ref.float(), rtol=2e-4, atol=3e-3, name="big wgrad")
@@ -334,11 +340,12 @@ def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
         for mode in ("1", "0"):
             os.environ["TSSEP_GEMM_TN_BIG"] = mode
             two[mode] = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)[0].clone()
-        assert torch.equal(two["1"].view(S, M, ldp)[:, :, :N], two["0"].view(S, M, ldp)[:, :, :N])
+        assert torch.equal(two["1"].view(S, M, ldp)[:, :, :nb], two["0"].view(S, M, ldp)[:, :, :nb])
         close(two["1"].view(S, M, ldp).double().sum(0)[:, :N - 1].float(), ref.float(), rtol=5e-3, atol=1.5, name="big wgrad, two products")
     finally:
         os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
         os.environ.pop("TSSEP_GEMM_TN_BIG", None)
+        os.environ.pop("TSSEP_GEMM_TN_XC", None)
         h.GEMM_PRECISION = old
 
 

@@ -38,12 +38,14 @@ def test_splitk_choice():
     assert s > 1 and s % 8 == 0 and s <= 64
     assert H.pick_splitk(24, 12, 35) == 1
     # the big-tile weight-gradient kernel (512 x 128 tiles, one workgroup per CU, a K slab per XCD): as many slabs per
-    # XCD as fill its 32 CUs best -- 15 tiles -> 2 slabs (30 / 32), 25 tiles -> 1 (25 / 32), 55 tiles -> 4 (220 / 224)
+    # XCD as fill its 32 CUs best -- 15 tiles -> 2 slabs (30 / 32); N = 514 = 4 x 128 + 2 and 1281 = 10 x 128 + 1 keep
+    # their last columns on the VALU of the last full column tile: 20 and 50 tiles -> 3 slabs (60 / 64, 150 / 160)
     old = H.GEMM_PRECISION
     H.GEMM_PRECISION = "bf16x3"
     try:
-        assert H.pick_splitk(2400, 321, 777216) == 16 and H.pick_splitk(2400, 514, 777216) == 8
-        assert H.pick_splitk(2400, 1281, 194304) == 32
+        assert H.pick_splitk(2400, 321, 777216) == 16 and H.pick_splitk(2400, 514, 777216) == 24
+        assert H.pick_splitk(2400, 1281, 194304) == 24
+        assert H.pick_splitk(2400, 554, 194304) == 8               # 25 tiles -> 1 slab (25 / 32)
         assert H.pick_splitk(1200, 300, 777216) % 8 == 0          # dW_hh: not the big tile (M pads to 1536)
     finally:
         H.GEMM_PRECISION = old

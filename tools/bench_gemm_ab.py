@@ -50,6 +50,8 @@ for shape in (SHAPES if KIND == "nt" else TN_SHAPES):
     for _ in range(3):
         for v in (va, vb):
             os.environ[var] = v
+            if var == "TSSEP_GEMM_TN_XC":          # (the split rule follows the tile count of the kernel)
+                h.TN_XC = v != "0"
             f(); best[v] = min(best[v], timeit(f))
     for v in (va, vb):
         tot[v] += best[v]

@@ -45,7 +45,11 @@ __device__ __forceinline__ bf16x8 trf(const char* p) {
 
 // TWO (opt-in, TSSEP_WGRAD_PRODUCTS=2): the a_lo x b_hi product is dropped -- dY enters as plain bf16, X keeps hi + lo:
 // 32 instead of 48 MFMAs per stage, no lo plane of A staged or read (as in the tn kernels' TWO variant).
-template <bool TWO>
+// XC = 10 XR + XO: N = 128 q + XR + XO -- the q column tiles go through the MFMAs and the last columns (XR <= 1 real
+// columns of X, then XO <= 1 virtual ones column: dW_ih of birnn0 has N = 513 + 1, of birnn2 1280 + 1) are accumulated on the VALU
+// from the raw dY values the workgroups of the LAST column tile stage anyway (exact fp32 FMA chains, 32 XC per thread
+// and stage) instead of a whole extra column tile for one or two columns: a fifth / an eleventh of the GEMM.
+template <bool TWO, int XC>
 __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
     int64_t K, int64_t lda, int64_t ldb, int accumulate, int64_t ldc, int splitk, int64_t c_split_stride,
@@ -127,13 +131,48 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (nst > 0) {
+  // extra columns (XC > 0, last column tile only): column ce = nfull + e is real (< Nreal: read from B) or the ones column
+  constexpr int XR = XC / 10, XO = XC % 10, XN = XR + XO;
+  const int64_t nfull = (int64_t)tmap.NT * WN;
+  float xacc[XN > 0 ? XN : 1][4];
+  float rx[XR > 0 ? XR : 1][8];
+#pragma unroll
+  for (int e = 0; e < (XN > 0 ? XN : 1); ++e)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xacc[e][c] = 0.f;
+  auto main_loop = [&](auto xc_tag) __attribute__((always_inline)) {
+    constexpr int XCV = decltype(xc_tag)::value;      // 0 (no extra columns in this workgroup) or XC
+    constexpr int XRV = XCV / 10, XOV = XCV % 10;
+    srd_t xsrd[XRV > 0 ? XRV : 1];
+#pragma unroll
+    for (int e = 0; e < XRV; ++e) xsrd[e] = make_srd(B + kt_begin * WBK * ldb + nfull + e);
+    auto xload = [&](int st) __attribute__((always_inline)) {          // x[k row][nfull + e] of stage st, this thread's 8 rows
+      const unsigned tmx = load_mask(st);
+      const int sox = (int)((int64_t)st * WBK * ldb * 4);
+#pragma unroll
+      for (int e = 0; e < XRV; ++e)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rx[e][i] = bload1(xsrd[e], (unsigned)((krA + 2 * i) * ldb * 4) | tmx, sox);
+    };
+    auto xfma = [&](int i) __attribute__((always_inline)) {             // piece i of the stage held in registers
+#pragma unroll
+      for (int e = 0; e < XRV; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xacc[e][c] = fmaf(ra[i][c], rx[e][i], xacc[e][c]);
+      if constexpr (XOV > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xacc[XRV][c] += ra[i][c];
+      }
+    };
     // ---- prologue: stages 0 and 1 -> LDS, stage 2 -> registers, first fragments of stage 0
     gload(0);
+    if constexpr (XCV > 0) { xload(0); for (int i = 0; i < 8; ++i) xfma(i); }
     stage_all(lds, true);
     gload(1);
+    if constexpr (XCV > 0) { xload(1); for (int i = 0; i < 8; ++i) xfma(i); }
     stage_all(lds + WSTAGE, 1 < nst);
     gload(2);
+    if constexpr (XCV > 0) xload(2);
     __syncthreads();
     bf16x8 al[4], bh[4], ah[4], bl[4], aln[4], bhn[4];
 #pragma unroll
@@ -151,6 +190,8 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
       const int soa = (int)((int64_t)(s + 3) * WBK * lda * 4), sob = (int)((int64_t)(s + 3) * WBK * ldb * 4);
       unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
       f32x4 bmk = {0.f, 0.f, 0.f, 0.f};
+      const unsigned tmx = tm;
+      const int sox = sob;
 #define SLOT __builtin_amdgcn_sched_barrier(0)
 #define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0)
 #define MM1(x, y, i, j) if constexpr (!TWO) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[i][j], 0, 0, 0)
@@ -158,11 +199,13 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
 #define FB(dst, i, lo) dst[i] = trf<WPB>(cur + (lo) * WARR_B + boff + (i) * 64)
 #define NA(dst, i, lo) if constexpr (!TWO || (lo) == 0) dst[i] = trf<WPA>(nx1 + (lo) * WARR_A + aoff + (i) * 64)
 #define NB(dst, i, lo) dst[i] = trf<WPB>(nx1 + (lo) * WARR_B + boff + (i) * 64)
-#define SA1(i) split2n(ra[i][0], ra[i][1], sh0, sl0)
+#define SA1(i) if constexpr (XCV > 0) xfma(i); split2n(ra[i][0], ra[i][1], sh0, sl0)
 #define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) *reinterpret_cast<u32x2*>(nx2 + soffA + (i) * 2 * WPA) = u32x2{sh0, sh1};            \
                if constexpr (!TWO) *reinterpret_cast<u32x2*>(nx2 + WARR_A + soffA + (i) * 2 * WPA) = u32x2{sl0, sl1};   \
-               ra[i] = bload4(asrd, (avo + (unsigned)((i) * 2 * lda * 4)) | tm, soa)
+               ra[i] = bload4(asrd, (avo + (unsigned)((i) * 2 * lda * 4)) | tm, soa);                                   \
+               if constexpr (XRV > 0) { _Pragma("unroll") for (int e_ = 0; e_ < XRV; ++e_)                             \
+                   rx[e_][i] = bload1(xsrd[e_], (unsigned)((krA + 2 * (i)) * ldb * 4) | tmx, sox); }
 #define SB1(i) bmk = maskb(rb[i], rows2); split2n(bmk[0], bmk[1], sh0, sl0)
 #define SB2(i) split2n(bmk[2], bmk[3], sh1, sl1)
 #define SB3(i) *reinterpret_cast<u32x2*>(nx2 + soffB + (i) * 8 * WPB) = u32x2{sh0, sh1};            \
@@ -237,11 +280,39 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
       __builtin_amdgcn_sched_barrier(0);
       const int t = c0; c0 = c1; c1 = c2; c2 = t;
     }
+  };
+  const bool xwg = XC > 0 && nt == tmap.NT - 1;          // workgroup-uniform
+  if (nst > 0) {
+    if (xwg) main_loop(std::integral_constant<int, XC>{});
+    else main_loop(std::integral_constant<int, 0>{});
+  }
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  if (xwg) {
+    // the two k-row halves of the workgroup hold partial sums of the same 512 x XC outputs
+    float* xs = reinterpret_cast<float*>(lds + 4 * 64 * EPITCH * 4);
+#pragma unroll
+    for (int e = 0; e < XN; ++e)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xs[((krA * 128 + (tid & 127)) * (XN > 0 ? XN : 1) + e) * 4 + c] = xacc[e][c];
+    __syncthreads();
+    if (krA == 0) {
+#pragma unroll
+      for (int e = 0; e < XN; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t m = m0 + cqA + c;
+          if (m < M) {
+            const float v = xacc[e][c] + xs[((128 + (tid & 127)) * (XN > 0 ? XN : 1) + e) * 4 + c];
+            float* dst = Cz + m * ldc + nfull + e;
+            *dst = accumulate ? *dst + v : v;
+          }
+        }
+    }
+    __syncthreads();
   }
 
   // ---- epilogue: four 64 x 64 blocks per wave through a private 17-KB scratch in the (now free) stage memory
-  static_assert(4 * 64 * EPITCH * 4 <= 3 * WSTAGE, "epilogue scratch must fit in the stages");
-  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  static_assert(4 * 64 * EPITCH * 4 + 2 * 128 * 2 * 4 * 4 <= 3 * WSTAGE, "epilogue scratch must fit in the stages");
   float* stage = reinterpret_cast<float*>(lds) + wave * 64 * EPITCH;
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih)
@@ -252,7 +323,7 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) a2[i][j] = acc[2 * ih + i][2 * jh + j];
-      gemm_epilogue_rows(a2, stage, Cz, M, N, m0 + (int64_t)wave * 128 + ih * 64, n0 + jh * 64, lane, nullptr, 0,
+      gemm_epilogue_rows(a2, stage, Cz, M, XC > 0 ? nfull : N, m0 + (int64_t)wave * 128 + ih * 64, n0 + jh * 64, lane, nullptr, 0,
                          accumulate, ldc, splitk == 1);
     }
 }
@@ -268,14 +339,20 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
   const int64_t ktiles = g->K / WBK, per = (ktiles + splitk - 1) / splitk;
   // 32-bit buffer offsets: one split's rows must stay below 2 GB
   if ((per + 4) * WBK * (g->lda > g->ldb ? g->lda : g->ldb) * 4 >= (int64_t)1 << 31) return TSSEP_E_UNSUPPORTED;
-  const TileMap tm = make_tile_map((g->M + WM - 1) / WM, (g->N + WN - 1) / WN, splitk);
-  if (two)
-    hipLaunchKernelGGL(gemm_bf16x3_tn_big_kernel<true>, dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, (hipStream_t)stream,
-                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk,
-                       g->c_split_stride, tm, g->b_ones_col);
-  else
-    hipLaunchKernelGGL(gemm_bf16x3_tn_big_kernel<false>, dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, (hipStream_t)stream,
-                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk,
-                       g->c_split_stride, tm, g->b_ones_col);
+  // N = 128 q + 1 or + 2 (q >= 1): the last one / two columns on the VALU instead of a column tile of their own
+  // (one real column at most; the ones column of b_ones_col is the last column)
+  const char* xe = getenv("TSSEP_GEMM_TN_XC");
+  const int rem = (int)(g->N % WN), ones = g->b_ones_col ? 1 : 0;
+  int xc = 0;
+  if ((!xe || xe[0] != '0') && g->N > WN && rem >= 1 && rem <= 2 && rem - ones <= 1)
+    xc = 10 * (rem - ones) + ones;
+  const TileMap tm = make_tile_map((g->M + WM - 1) / WM, xc ? g->N / WN : (g->N + WN - 1) / WN, splitk);
+#define TNB_LAUNCH(TW, XC_) hipLaunchKernelGGL((gemm_bf16x3_tn_big_kernel<TW, XC_>), dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, \
+      (hipStream_t)stream, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, g->b_ones_col)
+#define TNB_XC(TW) do { if (xc == 11) TNB_LAUNCH(TW, 11); else if (xc == 10) TNB_LAUNCH(TW, 10); else if (xc == 1) TNB_LAUNCH(TW, 1); \
+                        else TNB_LAUNCH(TW, 0); } while (0)
+  if (two) TNB_XC(true); else TNB_XC(false);
+#undef TNB_XC
+#undef TNB_LAUNCH
   return tssep_launch_status();
 }

@@ -313,7 +313,9 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
             and round_up(M, 512) * 10 <= M * 11 and K >= 16 * 64:
         # the big-tile weight-gradient kernel (csrc/gemm_bf16x3_tn_big.hip): 512 x 128 tiles, ONE workgroup per CU, the
         # tiles of a K slab on one XCD (32 CUs) -> as many slabs per XCD as fill its CUs best; multiples of 8 only
-        tiles = math.ceil(M / 512) * math.ceil(N / 128)
+        # (N = 128 q + 1 | 2: the last columns ride on the VALU of the q-th column tile, no tile of their own)
+        ntile = N // 128 if TN_XC and N > 128 and 1 <= N % 128 <= 2 else math.ceil(N / 128)
+        tiles = math.ceil(M / 512) * ntile
         best = min((8, 16, 24, 32), key=lambda S: (math.ceil(tiles * (S // 8) / 32) * 32) / (tiles * (S // 8)))
         return best
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
@@ -582,6 +584,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
+TN_XC = _os.environ.get("TSSEP_GEMM_TN_XC", "1") != "0"
 TN_BIG = _os.environ.get("TSSEP_GEMM_TN_BIG", "1") != "0"        # (the split rule follows the kernel the dispatcher picks)
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
