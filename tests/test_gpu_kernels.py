@@ -394,6 +394,60 @@ def test_gemm_tn_time_shift(n, T, Mg, Hh, gemm_precision):
         close(out.view(Mg, Hh), ref.float(), rtol=tol, atol=tol, name=f"shift {shift}")
 
 
+@pytest.mark.parametrize("n,T,M,N,S", [(24, 253, 1200, 300, 8), (3, 70, 1200, 300, 1), (40, 33, 1100, 150, 3), (9, 253, 2300, 620, 2)])
+def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
+    """The 256 x 160 weight-gradient tile (csrc/gemm_bf16x3_tn_w160.hip: the dW_hh shape M = 1200, N = 300 pads to
+    2 x 160 instead of 3 x 128 columns) bit for bit against the 256 x 128 / 128 x 128 tn kernels (TSSEP_GEMM_TN_W160=0)
+    and against fp64: time shifts -1 / +1 inside sequences of T, unshifted with the fused ones column, ragged row
+    and column tiles, splits with K tails."""
+    import os
+    torch.manual_seed(13)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        R = n * T
+        dg = torch.randn(R, h.round_up(M, 4), device="cuda")
+        hh = torch.randn(R, h.round_up(N, 4), device="cuda") / R ** 0.5
+        for shift in (-1, 1, 0):
+            outs = {}
+            for mode in ("1", "0"):
+                os.environ["TSSEP_GEMM_TN_W160"] = mode
+                if shift:
+                    part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=shift, kperiod=T, splitk=S)
+                else:
+                    part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, with_colsum=True, splitk=S)
+                outs[mode] = part.clone()
+            Nc = N if shift else N + 1
+            ldp = outs["1"].numel() // (S * M)
+            a, b = outs["1"].view(S, M, ldp)[:, :, :Nc], outs["0"].view(S, M, ldp)[:, :, :Nc]
+            assert torch.equal(a, b), f"shift {shift}: {(a != b).sum().item()} differ"
+            hs = torch.zeros(n, T, N, device="cuda", dtype=torch.float64)
+            hv = hh[:, :N].double().view(n, T, N)
+            if shift == -1:
+                hs[:, 1:] = hv[:, :-1]
+            elif shift == 1:
+                hs[:, :-1] = hv[:, 1:]
+            else:
+                hs = hv
+            ref = dg[:, :M].double().t() @ hs.reshape(R, N)
+            close(a.double().sum(0)[:, :N].float(), ref.float(), rtol=2e-4, atol=2e-4, name=f"w160 shift {shift}")
+            if not shift:
+                close(a.double().sum(0)[:, N].float(), dg[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="w160 column sums")
+        # the opt-in two-product arithmetic through the same tile
+        os.environ["TSSEP_WGRAD_PRODUCTS"] = "2"
+        two = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_TN_W160"] = mode
+            two[mode] = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=-1, kperiod=T, splitk=S)[0].clone()
+        ldp = two["1"].numel() // (S * M)
+        assert torch.equal(two["1"].view(S, M, ldp)[:, :, :N], two["0"].view(S, M, ldp)[:, :, :N])
+    finally:
+        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
+        os.environ.pop("TSSEP_GEMM_TN_W160", None)
+        h.GEMM_PRECISION = old
+
+
 def test_gemm_wgrad_with_fused_column_sums():
     """Split-bf16 weight-gradient GEMM with the virtual all-ones column: column N of the partials
     is the column sum of dY (bias gradient), columns < N the weight gradient."""

@@ -46,7 +46,8 @@ def test_splitk_choice():
         assert H.pick_splitk(2400, 321, 777216) == 16 and H.pick_splitk(2400, 514, 777216) == 24
         assert H.pick_splitk(2400, 1281, 194304) == 24
         assert H.pick_splitk(2400, 554, 194304) == 8               # 25 tiles -> 1 slab (25 / 32)
-        assert H.pick_splitk(1200, 300, 777216) % 8 == 0          # dW_hh: not the big tile (M pads to 1536)
+        # dW_hh: not the big tile (M pads to 1536) but the 256 x 160 one: 10 tiles, two workgroups per CU -> 48 splits
+        assert H.pick_splitk(1200, 300, 777216) == 48 and H.pick_splitk(1200, 300, 194304) == 48
     finally:
         H.GEMM_PRECISION = old
 

@@ -17,6 +17,7 @@ SHAPES = [("pre_net in", R1, 2400, 553), ("birnn0 in", R4, 2400, 513), ("birnn1 
           ("dgrad proj dh", R4, 600, 320), ("dgrad birnn2 dx", R1, 1280, 2400), ("dgrad linear2", R1, 320, 2052)]
 
 
+TN_SHIFT = [("wgrad W_hh birnn0/1", 1200, 300, R4, 253), ("wgrad W_hh birnn2", 1200, 300, R1, 253)]
 TN_SHAPES = [("wgrad W_ih pre_net", 2400, 553, R1, True), ("wgrad W_ih birnn0", 2400, 513, R4, True),
              ("wgrad W_ih birnn1", 2400, 320, R4, True), ("wgrad W_ih birnn2", 2400, 1280, R1, True),
              ("wgrad proj 320", 320, 600, R4, True), ("wgrad proj 513", 513, 600, R1, True),
@@ -34,8 +35,13 @@ def timeit(fn, reps=5):
 
 tot = {va: 0.0, vb: 0.0}
 os.environ.setdefault(var, va)
-for shape in (SHAPES if KIND == "nt" else TN_SHAPES):
-    if KIND == "nt":
+for shape in (SHAPES if KIND == "nt" else TN_SHIFT if KIND == "shift" else TN_SHAPES):
+    if KIND == "shift":
+        name, M, N, K, T = shape
+        A = torch.randn(K, M, device="cuda"); W = torch.randn(K, N, device="cuda")
+        C = None
+        f = lambda: h.wgrad(A, M, W, N, M, N, K, b_kshift=-1, kperiod=T)
+    elif KIND == "nt":
         name, M, N, K = shape
         A = torch.randn(M, h.round_up(K, 4), device="cuda"); W = torch.randn(N, h.round_up(K, 4), device="cuda")
         C = torch.empty(M, N, device="cuda"); bias = torch.randn(N, device="cuda")
@@ -52,6 +58,8 @@ for shape in (SHAPES if KIND == "nt" else TN_SHAPES):
             os.environ[var] = v
             if var == "TSSEP_GEMM_TN_XC":          # (the split rule follows the tile count of the kernel)
                 h.TN_XC = v != "0"
+            if var == "TSSEP_GEMM_TN_W160":
+                h.TN_W160 = v != "0"
             f(); best[v] = min(best[v], timeit(f))
     for v in (va, vb):
         tot[v] += best[v]

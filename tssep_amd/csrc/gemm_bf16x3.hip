@@ -1266,6 +1266,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
           if (rc != TSSEP_E_UNSUPPORTED) return rc;
         }
       }
+      {   // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (dW_hh: N = 300)
+        const char* we = getenv("TSSEP_GEMM_TN_W160");            // read per call (alternating A/B)
+        const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
+        if ((!we || we[0] != '0') && n160 * 11 <= n128 * 10) {
+          const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, stream);
+          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        }
+      }
       const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
       const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
       // default 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones

@@ -1,0 +1,298 @@
+// Weight-gradient GEMM with a 256 (m) x 160 (n) output tile: C[M,N] (split-K partials) = A^T B, both operands
+// k-major (A = d(gates) [K rows][M], B = h or X [K rows][N]), for the column counts the 128-wide tiles fit badly --
+// the time-shifted dW_hh GEMMs of every BLSTM layer (tssep/train/rnnp.py:88-96, backward: M = 4 H = 1200 gate columns
+// of one direction, N = H = 300 hidden units, rows = time steps paired with their neighbour t -/+ 1).  N = 300 pads to
+// 3 x 128 = 384 (78 %) but to 2 x 160 = 320 (94 %); with M = 1200 -> 5 x 256 the tile utilisation goes from 73 % to 88 %.
+//  * FOUR waves stacked along m, wave tile 64 x 160 = 2 x 5 MFMA tiles (160 accumulators; 14 fragment reads per 30
+//    MFMAs, the 128 x 64 wave tile of the 256 x 128 kernel has 12 per 24), two workgroups per CU;
+//  * staging, transpose reads, masks, time shift (phase of each staged B row inside its sequence) and the two-stage
+//    pipeline are those of gemm_bf16x3_tn_tall_kernel (gemm_bf16x3.hip); a k row of B is 160 columns = 40 threads, so
+//    the 16 rows of a stage are 640 four-column pieces: three per thread for the first 128 threads, two for the rest;
+//    the B planes keep the 320-byte pitch (160 x 2 B, = 64 B mod 256 B: conflict-free transpose reads without padding);
+//  * same k order and MFMA sequence per output element as the other tn kernels -> bit-identical results.
+#include <cstdlib>
+#include <type_traits>
+#include "gemm_common.h"
+
+namespace {
+
+using namespace gemm_detail;
+
+constexpr int VM = 256, VN = 160, VBK = 16, VNT = 256;
+constexpr int VPA = VM * 2 + 64;                // 576 bytes per k row of an A plane
+constexpr int VPB = VN * 2;                     // 320
+constexpr int VARR_A = VBK * VPA, VARR_B = VBK * VPB;
+constexpr int VSTAGE = 2 * 64 * EPITCH * 4;     // 34 816 B: the planes need 28 672, the epilogue two 64 x 64 scratches
+static_assert(2 * VARR_A + 2 * VARR_B <= VSTAGE, "planes must fit in a stage");
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+template <int PITCH>
+__device__ __forceinline__ bf16x8 trv(const char* p) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * PITCH));
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool SHIFT, bool TWO>
+__global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
+    int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
+    int64_t c_split_stride, TileMap tmap, int b_ones_col) {
+  constexpr int BK = VBK;
+  __shared__ __attribute__((aligned(16))) char lds0[VSTAGE];      // A hi, A lo, B hi, B lo
+  __shared__ __attribute__((aligned(16))) char lds1[VSTAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * VM, n0 = (int64_t)nt * VN;
+  const int64_t ktiles = (K + BK - 1) / BK;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // loads: A thread <-> (k row tid/64 + 4 i, columns 4 (tid%64) .. +3), i < 4;
+  //        B piece p = tid + 256 i (i < 3, p < 640) <-> (k row p / 40, columns 4 (p % 40) .. +3)
+  const int krA = tid >> 6, cqA = (tid & 63) << 2;
+  int krB[3], cqB[3];
+  bool pv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = tid + 256 * i;
+    pv[i] = p < 640;
+    krB[i] = pv[i] ? p / 40 : 0;
+    cqB[i] = pv[i] ? (p % 40) << 2 : 0;
+  }
+  const bool ones = !SHIFT && b_ones_col;         // (the fused ones column only exists for unshifted GEMMs)
+  const int64_t Nreal = N - (ones ? 1 : 0);
+  const int64_t Mp = (M + 3) & ~(int64_t)3, Np = (Nreal + 3) & ~(int64_t)3;
+  const int64_t ca = m0 + cqA <= Mp - 4 ? m0 + cqA : Mp - 4;
+  // buffer loads relative to the first row of this split (the launcher bounds a split's bytes by 2^31): scalar base
+  // and stage offset, 32-bit lane offsets
+  const int64_t k_begin = kt_begin * BK;
+  const srd_t asrd = make_srd(A + k_begin * lda);
+  const srd_t bsrd = make_srd(B + (k_begin + (SHIFT ? kshift : 0)) * ldb);
+  const unsigned avo = (unsigned)((krA * lda + ca) * 4);
+  unsigned bvo[3], bm[3], bone[3];           // bit e of bm / bone: column e of the piece is a real column / the ones column
+  unsigned am = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) am |= (m0 + cqA + e < M ? 1u : 0u) << e;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int64_t cb = n0 + cqB[i] <= Np - 4 ? n0 + cqB[i] : Np - 4;
+    bvo[i] = (unsigned)((krB[i] * ldb + cb) * 4);
+    bm[i] = 0; bone[i] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bm[i] |= (n0 + cqB[i] + e < Nreal ? 1u : 0u) << e;
+      bone[i] |= ((ones && n0 + cqB[i] + e == N - 1) ? 1u : 0u) << e;
+    }
+  }
+  int ph[3] = {0, 0, 0};                   // phase (k mod kperiod) of this thread's B rows of the tile in registers
+  const int phstep = SHIFT ? BK % kperiod : 0;
+  if (SHIFT) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ph[i] = (int)((k_begin + krB[i]) % kperiod);
+  }
+  bool kokA[4] = {true, true, true, true}, kokB[3] = {true, true, true};    // row < K, of the tile held in registers
+
+  f32x4 ra[4], rb[3];
+  auto gload_full = [&](int64_t kt) __attribute__((always_inline)) {
+    const int soa = (int)((kt - kt_begin) * BK * lda * 4), sob = (int)((kt - kt_begin) * BK * ldb * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = bload4(asrd, avo + (unsigned)(i * 4 * lda * 4), soa);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rb[i] = bload4(bsrd, bvo[i], sob);
+  };
+  auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {       // rows clamped into the matrix
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t k = kt * BK + krA + 4 * i;
+      ra[i] = bload4(asrd, (unsigned)((((k < K ? k : K - 1) - k_begin) * lda + ca) * 4), 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t k = kt * BK + krB[i];
+      int64_t kb = (k < K ? k : K - 1) + (SHIFT ? kshift : 0);
+      kb = kb < 0 ? 0 : (kb > K - 1 ? K - 1 : kb);
+      rb[i] = bload4(bsrd, bvo[i] + (unsigned)((kb - (SHIFT ? kshift : 0) - k_begin - krB[i]) * ldb * 4), 0);
+    }
+  };
+  int64_t held = kt_begin - 1;
+  auto note_tile = [&](int64_t kt, bool full) __attribute__((always_inline)) {
+    if (SHIFT && held >= kt_begin) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { ph[i] += phstep; ph[i] = ph[i] >= kperiod ? ph[i] - kperiod : ph[i]; }
+    }
+    held = kt;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kokA[i] = full || kt * BK + krA + 4 * i < K;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) kokB[i] = full || kt * BK + krB[i] < K;
+  };
+  const int soffA = krA * VPA + (tid & 63) * 8;
+  int soffB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) soffB[i] = 2 * VARR_A + krB[i] * VPB + cqB[i] * 2;
+  auto stage = [&](char* st, auto edge_tag, auto full_tag) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    constexpr bool FULL = decltype(full_tag)::value;       // every k row of the tile in registers is a row of the matrix
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 a = ra[i];
+      if constexpr (EDGE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = ((FULL || kokA[i]) && ((am >> e) & 1)) ? a[e] : 0.f;
+      }
+      unsigned h0, l0, h1, l1;
+      split2n(a[0], a[1], h0, l0);
+      split2n(a[2], a[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffA + i * 4 * VPA) = u32x2{h0, h1};
+      if (!TWO) *reinterpret_cast<u32x2*>(st + VARR_A + soffA + i * 4 * VPA) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i == 2 && !pv[2]) break;
+      f32x4 b = rb[i];
+      if constexpr (EDGE) {
+        const bool kok = FULL || kokB[i];
+        bool okb = kok;
+        if (SHIFT) { const int q = ph[i] + kshift; okb = okb && q >= 0 && q < kperiod; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          b[e] = (okb && ((bm[i] >> e) & 1)) ? b[e] : ((((bone[i] >> e) & 1) && kok) ? 1.f : 0.f);
+      } else if constexpr (SHIFT) {
+        const int q = ph[i] + kshift;
+        const bool okb = q >= 0 && q < kperiod;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = okb ? b[e] : 0.f;
+      }
+      unsigned h0, l0, h1, l1;
+      split2n(b[0], b[1], h0, l0);
+      split2n(b[2], b[3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffB[i]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + VARR_B + soffB[i]) = u32x2{l0, l1};
+    }
+  };
+  // fragment address of this lane: 16-lane group g2 covers 16 m, lane ii = 4 (k row) + m quad
+  const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
+  const int fcol = (16 * g2 + 4 * (ii & 3)) * 2, frow = 8 * hk + (ii >> 2);
+  const int aoff = frow * VPA + fcol + wave * 64 * 2, boff = 2 * VARR_A + frow * VPB + fcol;
+  auto compute = [&](const char* st) __attribute__((always_inline)) {
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = trv<VPA>(st + aoff + i * 64);
+      if (!TWO) al[i] = trv<VPA>(st + VARR_A + aoff + i * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bf16x8 bh = trv<VPB>(st + boff + j * 64);
+      const bf16x8 bl = trv<VPB>(st + VARR_B + boff + j * 64);
+      if (!TWO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+    }
+  };
+#define VPIPE(cur, nxt, kt_, EDGE_)                                                             \
+  do {                                                                                          \
+    compute(cur);                                                                               \
+    stage(nxt, std::integral_constant<bool, EDGE_>{}, std::true_type{});                        \
+    gload_full((kt_) + 2);                                                                      \
+    note_tile((kt_) + 2, true);                                                                 \
+    __syncthreads();                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  if (kt_begin < kt_end) {
+    gload_any(kt_begin);
+    note_tile(kt_begin, kt_begin < kt_full);
+    stage(lds0, std::true_type{}, std::false_type{});
+    if (kt_begin + 1 < kt_end) { gload_any(kt_begin + 1); note_tile(kt_begin + 1, kt_begin + 1 < kt_full); }
+    __syncthreads();
+    int64_t kt = kt_begin;
+    int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
+    // the pipelined loads read row k + kshift unconditionally (|kshift| <= 16 here): stay clear of the matrix's
+    // last tiles (they never see the first ones: they start at tile kt_begin + 2)
+    if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
+    const bool edge = SHIFT || m0 + VM > M || n0 + VN > Nreal;
+    if (edge) {
+      for (; kt < lim; kt += 2) {
+        VPIPE(lds0, lds1, kt, true);
+        VPIPE(lds1, lds0, kt + 1, true);
+      }
+    } else {
+      for (; kt < lim; kt += 2) {
+        VPIPE(lds0, lds1, kt, false);
+        VPIPE(lds1, lds0, kt + 1, false);
+      }
+    }
+    for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
+      const char* cur = par ? lds1 : lds0;
+      char* nxt = par ? lds0 : lds1;
+      compute(cur);
+      if (kt + 1 < kt_end) stage(nxt, std::true_type{}, std::false_type{});
+      if (kt + 2 < kt_end) { gload_any(kt + 2); note_tile(kt + 2, kt + 2 < kt_full); }
+      __syncthreads();
+    }
+  }
+#undef VPIPE
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  float* stg = reinterpret_cast<float*>(wave < 2 ? lds0 : lds1) + (wave & 1) * 64 * EPITCH;
+  const int64_t nlim = n0 + VN < N ? n0 + VN : N;       // (the third 64-column block is half a block)
+#pragma unroll
+  for (int jh = 0; jh < 3; ++jh) {
+    f32x16 a2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a2[i][0] = acc[i][2 * jh];
+      if (jh < 2) a2[i][1] = acc[i][2 * jh + 1];
+      else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a2[i][1][e] = 0.f;
+      }
+    }
+    gemm_epilogue_rows(a2, stg, Cz, M, nlim, m0 + (int64_t)wave * 64, n0 + jh * 64, lane, nullptr, 0, accumulate, ldc,
+                       splitk == 1);
+  }
+}
+
+}  // namespace
+
+// Returns TSSEP_E_UNSUPPORTED where the geometry does not apply: the caller (gemm_bf16x3.hip) has already checked the
+// operand layout of the tn kernels (k-major operands, 16-byte rows, no bias / activation / remapped store).
+int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two,
+                                     void* stream) {
+  const bool shift = g->kperiod > 0;
+  const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
+  const int64_t m256 = (g->M + VM - 1) / VM * VM;
+  if (g->M < 1024 || (m256 - g->M) * 100 > 8 * g->M || (shift && ks > 16) || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
+  // 32-bit buffer offsets inside a split
+  const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
+  const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
+  if ((per + 4) * VBK * ldmax * 4 >= ((int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
+  const TileMap tm = make_tile_map(m256 / VM, (g->N + VN - 1) / VN, splitk);
+  const dim3 grid((unsigned)tile_map_blocks(tm));
+#define V_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_w160_kernel<SH, TW>), grid, dim3(VNT), 0, (hipStream_t)stream, \
+      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, KS, KP, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, ONES)
+  if (shift) { if (two) V_LAUNCH(true, true, (int)g->b_kshift, (int)g->kperiod, 0); else V_LAUNCH(true, false, (int)g->b_kshift, (int)g->kperiod, 0); }
+  else { if (two) V_LAUNCH(false, true, 0, 1, g->b_ones_col); else V_LAUNCH(false, false, 0, 1, g->b_ones_col); }
+#undef V_LAUNCH
+  return tssep_launch_status();
+}

@@ -364,3 +364,5 @@ int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::St
 // weight gradients (both operands k-major, no time shift): 512 x 128 tile, 128 x 128 wave tiles, three LDS stages
 // (gemm_bf16x3_tn_big.hip)
 int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
+// (gemm_bf16x3_tn_w160.hip)
+int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);

@@ -318,8 +318,15 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
         tiles = math.ceil(M / 512) * ntile
         best = min((8, 16, 24, 32), key=lambda S: (math.ceil(tiles * (S // 8) / 32) * 32) / (tiles * (S // 8)))
         return best
-    tiles = math.ceil(M / 128) * math.ceil(N / 128)
     ktiles = math.ceil(K / 16)
+    n160, n128 = round_up(N, 160), round_up(N, 128)
+    if TN_W160 and GEMM_PRECISION == "bf16x3" and M >= 1024 and (round_up(M, 256) - M) * 100 <= 8 * M \
+            and n160 * 11 <= n128 * 10 and ktiles >= 64 * 8:
+        # the 256 x 160 tile (csrc/gemm_bf16x3_tn_w160.hip; dW_hh: M = 1200, N = 300 -> 10 tiles): two workgroups per CU,
+        # one round of at most 512 (tools/sweep_wgrad_splits.py: 2.00 ms at S = 48, 2.30 at 40, 3.13 at 56)
+        tiles = (round_up(M, 256) // 256) * (n160 // 160)
+        return max(8, min(512 // tiles // 8 * 8, ktiles // 64 // 8 * 8))
+    tiles = math.ceil(M / 128) * math.ceil(N / 128)
     if SPLITK_BIGK and K >= 400000 and tiles >= 48:
         # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
         # smallest one -- 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
@@ -584,6 +591,7 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
+TN_W160 = _os.environ.get("TSSEP_GEMM_TN_W160", "1") != "0"
 TN_XC = _os.environ.get("TSSEP_GEMM_TN_XC", "1") != "0"
 TN_BIG = _os.environ.get("TSSEP_GEMM_TN_BIG", "1") != "0"        # (the split rule follows the kernel the dispatcher picks)
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
