@@ -220,12 +220,16 @@ __device__ __forceinline__ void gemm_epilogue_rows_remap(const f32x16 (&acc)[2][
   if (n >= N) return;
   const int64_t cq = n / sm.cm, cr = n - cq * sm.cm;
   const float bv = bias ? bias[n] : 0.f;
+  // (b, k, t) of the block's first row by division, of the following rows by carries (wave-uniform): the per-row
+  // 64-bit divisions cost the logit GEMM (K = 320) as much as its MFMAs
+  int64_t t = mrow0 % sm.T;
+  const int64_t q0 = mrow0 / sm.T;
+  int64_t k = q0 % sm.K, b = q0 / sm.K;
   int64_t bprev = -1, coff = 0;
+  float* rowp = Cz + b * sm.sb + k * sm.sk + t * sm.st;
   for (int row = 0; row < 64; ++row) {
     const int64_t m = mrow0 + row;
     if (m >= M) break;
-    const int64_t t = m % sm.T, q = m / sm.T;
-    const int64_t k = q % sm.K, b = q / sm.K;
     if (b != bprev) {            // wave-uniform: the speaker permutation changes with the utterance
       const int64_t cqq = sm.perm ? (int64_t)sm.perm[b * sm.perm_ld + cq] : cq;
       coff = cqq * sm.co + cr;
@@ -234,9 +238,15 @@ __device__ __forceinline__ void gemm_epilogue_rows_remap(const f32x16 (&acc)[2][
     float v = stage[row * EPITCH + lane] + bv;
     if (act == 1) v = tanhf(v);
     if (act == 2) { const float y = sm.aux[m * sm.ldaux + n]; v *= 1.f - y * y; }
-    float* dst = Cz + b * sm.sb + k * sm.sk + t * sm.st + coff;
+    float* dst = rowp + coff;
     if (accumulate) v += *dst;
     *dst = v;
+    rowp += sm.st;
+    if (++t == sm.T) {
+      t = 0;
+      if (++k == sm.K) { k = 0; ++b; }
+      rowp = Cz + b * sm.sb + k * sm.sk;
+    }
   }
 }
 
