@@ -23,7 +23,11 @@ __device__ __forceinline__ float sigmoidf_acc(float x) {
 // accurate expf and the IEEE division (8 per lane and frame in the fused FFT kernels, a fifth of their vector
 // instructions); relative error ~2^-22, the same value in the fused and the unfused mask-head kernels
 __device__ __forceinline__ float sigmoidf_mask(float x) {
-  return __frcp_rn(1.0f + __expf(-x));
+  // v_exp_f32 and v_rcp_f32 themselves (1 ulp each): __expf adds a range fix-up of compares and selects that the
+  // sigmoid does not need (exp2 -> inf gives 0, -> 0 gives 1), and __frcp_rn expands to the ten-instruction IEEE
+  // division -- together a tenth of the vector instructions of the fused FFT kernels, which are VALU-bound
+  // (SQ_ACTIVE_INST_VALU x 3 waves per SIMD = 0.6-0.7, profiles/r3_sq_wave_states.jsonl)
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -84,6 +84,15 @@ __device__ __forceinline__ float2 tw16(int r) {
   return make_float2(c[r], sn[r]);
 }
 
+// w[r] = tw2_lane * exp(-2 pi i r / 16), r < 8: three complex products (r = 1, 2, 3); r + 4 is a further factor -i
+__device__ __forceinline__ void lane_twiddles(float2 tw2_lane, float2 (&w)[8]) {
+  w[0] = tw2_lane;
+#pragma unroll
+  for (int r = 1; r < 4; ++r) w[r] = cmul(tw2_lane, tw16(r));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w[r + 4] = mul_mi(w[r]);
+}
+
 // 512-point forward FFT by one wave.  In: v[r] = z[lane + 64 r].  Out: buf[PADI(k)] = Z[k].
 // twl[k] = exp(-2 pi i k / 512) (LDS copy).  The line is private to the wave: LDS operations of one
 // wave execute in order, so the hand-offs between lanes need only a wave-level fence (the compiler
@@ -231,15 +240,12 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
       __builtin_amdgcn_sched_barrier(0);      // (not above the sample loads: the kernel is at its register ceiling there)
       const srd_t sl = make_srd(Lr, (NH + 1) * 4), so = make_srd(Or, (NH + 1) * 8);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
-      (void)sl;
+      for (int r = 0; r < 8; ++r) {
+        ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
+        lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
+      }
     }
     fft512_wave(v, buf, twl, lane);
-    if (MASKED && valid) {
-      const srd_t sl = make_srd(Lr, (NH + 1) * 4);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
-    }
     if (valid) {
       float2* Xo = MASKED ? nullptr : X + fidx * (NH + 1);
       float* Dr = MASKED ? dlogit + fidx * (NH + 1) : nullptr;
@@ -256,6 +262,9 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
           Xo[k] = o;
         }
       };
+      float2 wr[8];
+      lane_twiddles(tw2_lane, wr);
+      const float hs_in = 0.5f * s_in;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(256, TSSEP_RFFT_OCC) void rfft_frames_kernel(
         const int km = (NH - k) & (NH - 1);
         float2 zm = buf[PADI(km)];
         zm.y = -zm.y;
-        const float2 u = cmul(cmul(tw2_lane, tw16(r)), csub(zk, zm));
-        float2 o = make_float2(0.5f * (zk.x + zm.x + u.y), 0.5f * (zk.y + zm.y - u.x));
+        const float2 u = cmul(wr[r], csub(zk, zm));
+        float2 o = make_float2(zk.x + zm.x + u.y, zk.y + zm.y - u.x);
         if (k == 0) {
-          o.x *= s_edge; o.y = 0.f;
+          o.x *= 0.5f * s_edge; o.y = 0.f;
         } else {
-          o.x *= s_in; o.y *= s_in;
+          o.x *= hs_in; o.y *= hs_in;
         }
         emit(k, o, MASKED ? lg8[r] : 0.f, MASKED ? ob8[r] : make_float2(0.f, 0.f));
       }
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
   const int64_t total_hops = (N + 255) / 256;
   const int hops = (int)(total_hops - t_lo < hcb ? total_hops - t_lo : hcb);
   const int iters = (hops + 3 + 3) / 4;    // frames 0 .. hops + 2
-  const float inv = 1.0f / 512.0f;
+  const float hinv = 0.5f / 512.0f;
   float* yr = y + row * N;
   const float* tr = tgt ? tgt + row * N : nullptr;
   // the chunk's samples [n0, min(N, n0 + 256 hops)) of this row
@@ -336,39 +345,55 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
   const srd_t sy = make_srd(yr + n0, chunk_bytes), str_ = make_srd(tr ? tr + n0 : yr + n0, chunk_bytes);
   float asum = 0.f;
   float2* buf = line[wave];
+  // MASKED: the logits and observation bins of a frame are requested one iteration ahead (27 registers), right after
+  // the previous frame's have been consumed: their latency hides behind that frame's transform and the hop emission
+  // instead of opening every iteration (out-of-range frames get an empty resource: the loads return 0)
+  float lg8[8], lgn = 0.f;
+  float2 ob8[8], obn = make_float2(0.f, 0.f);
+  const int64_t urow = MASKED ? row / Kspk : 0;        // the utterance of this (utterance, speaker) row
+  auto request = [&](int it_) __attribute__((always_inline)) {
+    const int lf_ = it_ * 4 + wave;
+    const int64_t t_ = t_lo + lf_;
+    const bool ok = it_ < iters && t_ < T && lf_ < hops + 3;
+    const int64_t tt = ok ? t_ : 0;
+    const srd_t sl = make_srd(logit + (row * T + tt) * (NH + 1), ok ? (NH + 1) * 4 : 0);
+    const srd_t so = make_srd(obs + (urow * T + tt) * (NH + 1), ok ? (NH + 1) * 8 : 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
+      ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
+    }
+    lgn = bload1(sl, (unsigned)(NH * 4));          // bin 512 (every lane the same address; lane 0 uses it)
+    obn = bload2(so, (unsigned)(NH * 8));
+  };
+  if (MASKED) request(0);
   for (int it = 0; it < iters; ++it) {
     const int lf = it * 4 + wave;
     const int64_t t = t_lo + lf;
     const bool valid = t < T && lf < hops + 3;
     float* slot = fr[lf % RING];
-    if (valid) {
-      float2 v[8];
-      float2 xnyq = make_float2(0.f, 0.f);              // MASKED: X[512], needed by lane 0 only
-      if (MASKED) {
-        const float* Lr = logit + (row * T + t) * (NH + 1);
-        const float2* Or = obs + ((row / Kspk) * T + t) * (NH + 1);
-        const srd_t sl = make_srd(Lr, (NH + 1) * 4), so = make_srd(Or, (NH + 1) * 8);
-        float lg8[8];
-        float2 ob8[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          lg8[r] = bload1(sl, (unsigned)(lane * 4 + 256 * r));
-          ob8[r] = bload2(so, (unsigned)(lane * 8 + 512 * r));
-        }
+    float2 xnyq = make_float2(0.f, 0.f);              // MASKED: X[512], needed by lane 0 only
+    if (MASKED) {
+      if (valid) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int k = lane + 64 * r;
           const float m = sigmoidf_mask(lg8[r]);
           buf[PADI(k)] = make_float2(ob8[r].x * m, ob8[r].y * m);
         }
-        if (lane == 0) {
-          const float m = sigmoidf_mask(Lr[NH]);
-          const float2 ob = Or[NH];
-          xnyq = make_float2(ob.x * m, ob.y * m);
-        }
+        const float m = sigmoidf_mask(lgn);
+        xnyq = make_float2(obn.x * m, obn.y * m);
         WAVE_SYNC();
       }
+      __builtin_amdgcn_sched_barrier(0);
+      request(it + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (valid) {
+      float2 v[8];
       const float2* Xr = MASKED ? nullptr : X + (row * T + t) * (NH + 1);
+      float2 wr[8];
+      lane_twiddles(tw2_lane, wr);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r;
@@ -376,10 +401,10 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
         float2 xm = MASKED ? (k == 0 ? xnyq : buf[PADI(NH - k)]) : Xr[NH - k];
         xm.y = -xm.y;
         if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
-        const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
-        float2 w = cmul(tw2_lane, tw16(r));
-        w.y = -w.y;
-        const float2 o = cmul(make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y)), w);
+        // (the 1/512 of the inverse transform rides on the 1/2 of the even / odd split: a power of two, exact)
+        const float2 e = make_float2(hinv * (xk.x + xm.x), hinv * (xk.y + xm.y));
+        const float2 w = make_float2(wr[r].x, -wr[r].y);
+        const float2 o = cmul(make_float2(hinv * (xk.x - xm.x), hinv * (xk.y - xm.y)), w);
         // Zi = E + i O ; feed conj(Zi) to the forward FFT
         v[r] = make_float2(e.x - o.y, -(e.y + o.x));
       }
@@ -390,7 +415,7 @@ __global__ __launch_bounds__(256, TSSEP_ISTFT_OCC) void istft_kernel(
         const int n = lane + 64 * r;
         const float2 z = buf[PADI(n)];
         const float2 w = *reinterpret_cast<const float2*>(wsyn + 2 * n);
-        *reinterpret_cast<float2*>(&slot[2 * n]) = make_float2(z.x * inv * w.x, -z.y * inv * w.y);
+        *reinterpret_cast<float2*>(&slot[2 * n]) = make_float2(z.x * w.x, -z.y * w.y);
       }
       WAVE_SYNC();          // the wave's line is reused by its next frame; ring slots are disjoint
     } else {
