@@ -143,25 +143,31 @@ __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restric
     amax = wave_max(amax);
     if (lane == 0) atomicMax(w.umax + frame / T, ord(amax));
     if (n_mfcc > 0) {
-      // all 64 lanes share every filter's band (fixed-order butterfly sum: deterministic); lane
-      // m % 64 keeps the result
+      // one lane per filter walks its own band front to back (<= 64 bins for the widest filters): ~3 instructions per
+      // bin on 40 lanes.  (Rounds 1-2: all 64 lanes shared each band and a butterfly summed them -- ~25 instructions
+      // per FILTER and frame, 1000 per frame: the kernel was VALU-bound at a quarter of the HBM rate.)
       for (int m0 = 0; m0 < n_mels; m0 += 64) {
         float mine = 0.f;
         const int mm = n_mels - m0 < 64 ? n_mels - m0 : 64;
-        for (int j = 0; j < mm; ++j) {
-          const int m = m0 + j;
-          float s = 0.f;
-          if (packed) {
-            const int lo = clo[m], hi = chi[m];
-            const float* frow = cw + coff[m] - lo;
-            for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
-          } else {
-            const int lo = w.range[2 * m], hi = w.range[2 * m + 1];
-            const float* frow = w.fbT + (int64_t)m * MAXF;
-            for (int f = lo + lane; f < hi; f += 64) s = fmaf(pw[wave][f], frow[f], s);
+        if (lane < mm) {
+          const int m = m0 + lane;
+          // four interleaved partial sums (bins f, f+1, f+2, f+3 mod 4 from the band's start): eight LDS reads in
+          // flight per trip instead of a dependent read -> fma chain per bin
+          const int lo = packed ? clo[m] : w.range[2 * m], hi = packed ? chi[m] : w.range[2 * m + 1];
+          const float* frow = packed ? cw + coff[m] - lo : w.fbT + (int64_t)m * MAXF;
+          const float* prow = pw[wave];
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+          int f = lo;
+          for (; f + 3 < hi; f += 4) {
+            s0 = fmaf(prow[f], frow[f], s0);
+            s1 = fmaf(prow[f + 1], frow[f + 1], s1);
+            s2 = fmaf(prow[f + 2], frow[f + 2], s2);
+            s3 = fmaf(prow[f + 3], frow[f + 3], s3);
           }
-          s = wave_sum(s);
-          if (lane == j) mine = s;
+          if (f < hi) s0 = fmaf(prow[f], frow[f], s0);
+          if (f + 1 < hi) s1 = fmaf(prow[f + 1], frow[f + 1], s1);
+          if (f + 2 < hi) s2 = fmaf(prow[f + 2], frow[f + 2], s2);
+          mine = (s0 + s1) + (s2 + s3);
         }
         if (lane < mm) {
           const float db = 10.0f * log10f(fmaxf(mine, 1e-10f));

@@ -61,12 +61,15 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast
 // of instructions instead of ~25-40 for the OCML expf / tanhf the other kernels use.  4 cells per
 // lane and step make the transcendental work visible here (~1.2 us of a 7 us step).  Relative error
 // ~2^-22 -- the same class as the split-bf16 product, two orders inside the 1e-3 parity bar.
+// (v_exp_f32 / v_rcp_f32 through the builtins: `__frcp_rn` is the correctly rounded reciprocal = the ten-instruction
+// IEEE division sequence, and `__expf` adds a range fix-up -- 20 divisions per lane and step in the forward kernel,
+// half of the cell update's vector instructions, on the critical path between the MFMAs and the publish.)
 __device__ __forceinline__ float fast_sigmoid(float x) {
-  return __frcp_rn(1.0f + __expf(-x));
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
 }
 __device__ __forceinline__ float fast_tanh(float x) {
   // 1 - 2/(1 + e^{2x}); saturates correctly for large |x| (e^{2x} -> inf or 0)
-  return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
 }
 #define SC1 16
 #define SC0 1
