@@ -1,8 +1,10 @@
-"""Fills the R3_* placeholders of DESIGN.md section 5 from profiles/r3_* (run after tools/install_profiles.sh 3)."""
+"""Regenerates the round-3 results block of DESIGN.md section 5 (between the R3-RESULTS markers) from
+tools/design_r3_results.tmpl.md and profiles/r3_* (run after tools/install_profiles.sh 3 and the default bench line)."""
 import json, os, re
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = lambda f: os.path.join(R, "profiles", f)
-s = open(os.path.join(R, "DESIGN.md")).read()
+design = open(os.path.join(R, "DESIGN.md")).read()
+s = open(os.path.join(R, "tools", "design_r3_results.tmpl.md")).read()
 sweep = {json.loads(l)["config"]["batch_per_gpu"]: json.loads(l) for l in open(P("r3_batch_sweep.jsonl"))}
 bs = [8, 32, 64, 128, 256, 384, 512, 768, 1152, 1536]
 s = s.replace("R3_MS", " | ".join(("**%.1f**" if b == 768 else "%.1f") % sweep[b]["ms_per_step"] for b in bs))
@@ -30,7 +32,8 @@ def tot(pred):
 allk = tot(lambda n: True)
 fam = {"big-tile": tot(lambda n: "big_kernel" in n and "tn_big" not in n), "streaming": tot(lambda n: "stream_kernel" in n),
        "8-wave tiled": tot(lambda n: "tall_kernel<" in n and "tn_tall" not in n), "weight gradients big-tile": tot(lambda n: "tn_big" in n),
-       "weight gradients 256 x 128 (dW_hh)": tot(lambda n: "tn_tall" in n), "weight gradients 128 x 128": tot(lambda n: "tn_kernel" in n)}
+       "weight gradients 256 x 160 (dW_hh)": tot(lambda n: "tn_w160" in n), "weight gradients 256 x 128": tot(lambda n: "tn_tall" in n),
+       "weight gradients 128 x 128": tot(lambda n: "tn_kernel" in n)}
 g = sum(fam.values()); rec_f = tot(lambda n: "onchip_fwd" in n); rec_b = tot(lambda n: "onchip_bwd" in n)
 tail = tot(lambda n: "rfft_frames_kernel<true>" in n or "istft_kernel<true>" in n)
 s = s.replace("R3_SHARES", f"{allk:.1f} ms of kernel time per step: GEMMs {100 * g / allk:.1f} % ({g:.1f} ms: " +
@@ -42,5 +45,7 @@ c4, c4n, c5 = (json.load(open(P(f))) for f in ("r3_bench_cfg4.json", "r3_bench_c
 s = s.replace("R3_OTHER", f"cfg4 (8 utterances per GPU, hipGraph replay) {c4['ms_per_step']:.2f} ms/step, {c4['value'] / 1e3:.0f} k frames/s (eager {c4n['ms_per_step']:.2f}; round 2: 14.11); "
               f"cfg5 (8 speakers × 30 s, batch 96) {c5['ms_per_step']:.1f} ms/step, {c5['value'] / 1e3:.0f} k frames/s, mask head {c5['roofline_mask_head']['frac']:.2f} (round 2: 259.6 ms, 0.45); "
               f"`--gemm f32` {ex['ms_per_step']:.1f} ms/step.")
-open(os.path.join(R, "DESIGN.md"), "w").write(s)
+a = design.index("<!-- R3-RESULTS-BEGIN"); a = design.index("\n", a) + 1
+b = design.index("<!-- R3-RESULTS-END -->")
+open(os.path.join(R, "DESIGN.md"), "w").write(design[:a] + s + design[b:])
 print("filled; remaining placeholders:", re.findall(r"R3_[A-Z]+", s))
