@@ -269,6 +269,21 @@ int tssep_blstm_onchip_bwd(float* gates, const float* cell, const float* dhout, 
                            int64_t dstride, const float* wb, void* xbuf, int* err, int64_t N,
                            int64_t T, int H, int max_wgs, int layout, void* stream);
 
+/* Interleaved forward of the same recurrence (round 3): `groups` (4, 2 or 1) independent groups of 16 sequences per
+ * cluster share the stationary W_hh in rotation, so that a group's exchange of h overlaps the other groups' MFMAs and
+ * cell updates (the kernel above walks one group of 32 sequences through a serial chain).  Same tensors, same
+ * semantics, same err / concurrency contract; own weight pack (16 x 16 x 32 MFMA fragments) and own exchange
+ * buffer layout.  tssep_blstm_onchip16_groups(): the group count the launcher uses for N sequences on max_wgs CUs
+ * (0: shape not supported -- H % 4, H > 320 -- call tssep_blstm_onchip_fwd instead); groups = 0 in the launch = that
+ * choice.  ldo, dstride multiples of 4; gates / cell / hout 16-byte aligned; XCD-local clusters only. */
+int64_t tssep_lstm_onchip16_pack_floats(int H);
+int tssep_lstm_pack_onchip16(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream);
+int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H);
+int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs);
+int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+                             const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
+                             int max_wgs, int layout, int groups, void* stream);
+
 /* ---------------------------------------------------------- elementwise ------*/
 /* d(pre-tanh) = dy * (1 - y^2) for the Tanh between post-net layers (tssep/train/net.py:623-625).
  * dz rows are (b,k,t) x P; combined_in != 0: dy and y live in the speaker-combined layout

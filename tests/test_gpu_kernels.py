@@ -968,6 +968,38 @@ def test_blstm_onchip_kernels(N, T, I, Hh, mode):
     close(gates, g_stream, rtol=2e-4, atol=2e-6, name="dgates")
 
 
+@pytest.mark.parametrize("N,T,Hh,groups", [(16, 5, 300, 1), (64, 9, 300, 4), (64, 6, 300, 2), (40, 7, 300, 1), (96, 1, 300, 2),
+                                           (128, 11, 300, 4), (200, 4, 300, 1), (63, 8, 128, 4), (768, 3, 300, 2), (768, 5, 300, 4)])
+def test_blstm_onchip_interleaved_forward(N, T, Hh, groups):
+    """The interleaved forward recurrence (groups of 16 sequences in rotation on one stationary W_hh, 16x16x32 MFMAs,
+    asynchronous gate-tile ring) against the exact-fp32 streaming kernel: hidden states, cell states and the saved
+    gate activations; ragged last group (N % 16), T tails of the 2- and 1-group schedules (T odd / T % 4), H < 300."""
+    h = H()
+    I = 12
+    p, x = _lstm_case(N, T, I, Hh, 17)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    wf16 = h.lstm_pack_onchip16(p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda(), Hh)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    g_stream = gates.clone()
+    Hp = h.round_up(Hh, 4)
+    cell = torch.full((N, T, 2, Hh), float("nan"), device="cuda")
+    hout = torch.zeros(N, T, 2 * Hp, device="cuda")
+    if ((N + 15) // 16) % groups:
+        pytest.skip("group count must divide the number of 16-sequence groups")
+    h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16, N, T, Hh, groups)
+    h.check_cluster_errors()
+    cell2 = torch.empty_like(cell); hout2 = torch.zeros_like(hout)
+    h.blstm_fwd(g_stream, cell2, hout2, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+    close(hout, hout2, rtol=1e-4, atol=1e-5, name="h")
+    close(cell, cell2, rtol=1e-4, atol=1e-5, name="cell")
+    close(gates, g_stream, rtol=1e-4, atol=1e-5, name="gate activations")
+
+
 # ------------------------------------------------------------------ mask-based MVDR (TorchBF)
 def _bf_case(B, K, M, D, T, F, seed, mdt=torch.float32):
     g = torch.Generator().manual_seed(seed)

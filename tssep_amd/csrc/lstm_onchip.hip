@@ -28,6 +28,7 @@
 // then gives every lane the 4 gates of the 4 CONSECUTIVE units 4*half .. 4*half+3 of one sequence,
 // so the cell update is lane-local and every global / exchange access is a 16-byte vector.
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -860,6 +861,378 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
   }
 }
 
+
+// =====================================================================================================
+// Forward recurrence, interleaved variant (round 3): NGA groups of 16 sequences per cluster instead of one
+// group of 32.  A step of the kernel above is a serial chain -- gather h (two L2 round trips, 3-4 us under
+// load) -> MFMAs (1.7 us) -> cell update (0.9 us) -> publish -- in which the matrix cores and the vector
+// ALUs idle through the exchange and the exchange idles through the arithmetic.  Here the SAME stationary
+// W serves NGA independent sequence groups in rotation: while group p's h travels, the other groups compute,
+// so a group's gather is issued a phase ahead of its use and has NGA - 1 phases to arrive.
+//  * group = 16 sequences: `v_mfma_f32_16x16x32_bf16` (A = 16 gate rows x 32 k, B = 32 k x 16 sequences;
+//    a wave owns 2 row blocks = 8 units x 4 gates, 2 x 10 x 3 = 60 MFMAs per phase), K padded to 320;
+//    row r of a block = 4 u' + gate, so lane (u' = lane / 16, sequence = lane % 16) receives the four gates
+//    of unit 8 wave + 4 rb + u' in its four accumulator registers: the cell update stays lane-local (two
+//    cells per lane and phase);
+//  * LDS: the h operand image of every group (NGA x 21 KB), ONE h / c staging tile, and a ring of four
+//    16-KB gate tiles in SEPARATE arrays indexed by the phase (static: the compiler's alias analysis then
+//    knows which LDS-DMA a read can depend on): the tile of phase n + 2 is requested after the flush of
+//    phase n -- two phases of latency budget for the asynchronous copy, four tiles live;
+//  * barriers are `s_waitcnt lgkmcnt(0); s_barrier` in inline assembly: `__syncthreads()` waits for every
+//    outstanding LDS-DMA (vmcnt(0)), i.e. it would put an HBM round trip into every phase; the io waves
+//    wait for the copy they need with an explicit `vmcnt(10)` (the six stores and four copies queued behind it
+//    may still be in flight: the counter retires in order, and all vector-memory instructions of the io arm
+//    are unconditional -- lanes outside N / H store to out-of-range buffer offsets / copy a dummy address);
+//  * work: bundles of NGA consecutive sequence groups of ONE direction (W is per direction); the launcher picks
+//    NGA so that it divides the number of groups (every bundle is full).
+// NGA = 4: four phases per step; NGA = 2: the four phases are two steps; NGA = 1: four steps (T-tail masked).
+#ifndef ONCHIP16_ABL
+#define ONCHIP16_ABL 0   // experiment builds (results wrong): 1 no MFMAs, 2 no cell arithmetic, 4 no io arm, 8 no exchange, 16 no tag polling
+#endif
+constexpr int SQ = 16;
+constexpr int KP2 = 320, KS2 = 10;
+constexpr int HP2 = KP2 * 2 + 16;            // 656 B: 16 rows x 16 B conflict-free (164 dwords = 36 mod 64)
+constexpr int TILE4 = SQ * UPW;              // f32x4 per gate tile (16 KB)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G, u32x4* wf) {
+  // wf[dir][g][wave 8][rb 2][ks 10][hl 2][lane 64]: A fragment (16 rows x 32 k) of row block rb, k-step ks:
+  // lane (i = lane % 16, kg = lane / 16) holds W_hh[gate * H + unit][32 ks + 8 kg + 0..7], i = 4 u' + gate,
+  // unit = 64 g + 8 wave + 4 rb + u'
+  const int64_t n = (int64_t)2 * G * 8 * 2 * KS2 * 2 * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int hl = (int)(r & 1); r >>= 1;
+    const int ks = (int)(r % KS2); r /= KS2;
+    const int rb = (int)(r & 1); r >>= 1;
+    const int wave = (int)(r & 7); r >>= 3;
+    const int g = (int)(r % G);
+    const int d = (int)(r / G);
+    const int i = lane & 15, kg = lane >> 4;
+    const int unit = 64 * g + 8 * wave + 4 * rb + (i >> 2), gate = i & 3;
+    const float* w = d ? w_hh_r : w_hh_f;
+    float x[8];
+    for (int j = 0; j < 8; ++j) x[j] = unit < H ? w_at(w, H, gate * H + unit, 32 * ks + 8 * kg + j) : 0.f;
+    unsigned h[4], l[4];
+    for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], h[j], l[j]);
+    wf[e] = hl ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{h[0], h[1], h[2], h[3]};
+  }
+}
+
+#define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+template <int NGA, bool NT>
+__global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
+    float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
+    int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
+    float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters,
+    int layout) {
+  const unsigned tagbase = tag16_base(err);
+  __shared__ __attribute__((aligned(16))) char hs[NGA * 2 * SQ * HP2];       // [group][hi | lo][seq][k] bf16
+  __shared__ __attribute__((aligned(16))) float pub[SQ * PUBPITCH];          // h_t [seq][unit] of the phase
+  __shared__ __attribute__((aligned(16))) float cellb[SQ * PUBPITCH];        // c_t
+  __shared__ f32x4 ring0[TILE4], ring1[TILE4], ring2[TILE4], ring3[TILE4];    // gate tiles of phases 0..3
+  __shared__ int s_fail, s_mem[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_fail = 0;
+  layout &= 1;
+  const int64_t ng16 = (N + SQ - 1) / SQ;                    // sequence groups
+  const int64_t nb_dir = (ng16 + NGA - 1) / NGA;             // bundles per direction
+  const Membership mem = join_cluster<true>(xhead, G, (int)(2 * nb_dir), s_mem);
+  if (!mem.ok) return;
+  const int g = __builtin_amdgcn_readfirstlane(mem.g);
+  const int j = lane & 15, up = lane >> 4;                   // MFMA: sequence, unit within the row block
+  const int foff = j * HP2 + up * 16;                        // B fragment offset of this lane
+  const bool io_wave = wave >= 4;
+  const int s2 = (tid & 255) >> 4, uq = tid & 15;            // exchange / io thread <-> (sequence s2, unit quad uq)
+  const int iow = wave & 3;                                  // (scalar: LDS addresses of the copies stay in SGPRs)
+  constexpr unsigned OOR = 0x80000000u;
+
+  for (int round = 0;; ++round) {
+    const int64_t bundle = next_item<true>(xhead, mem, round, (int)(2 * nb_dir), nclusters, s_mem);
+    if (bundle >= 2 * nb_dir) {
+      if (bundle > 2 * nb_dir && tid == 0) atomicExch(err, 5);
+      break;
+    }
+    const int dir = (int)(bundle & 1);
+    const int64_t sg0 = (bundle >> 1) * NGA;                 // first sequence group of the bundle
+    // stationary weights -> registers
+    u32x4 wh[2][KS2], wl[2][KS2];
+    {
+      const u32x4* wp = wf + ((((int64_t)(dir * G + g) * 8 + wave) * 2) * KS2 * 2) * 64 + lane;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          wh[rb][ks] = wp[(int64_t)((rb * KS2 + ks) * 2 + 0) * 64];
+          wl[rb][ks] = wp[(int64_t)((rb * KS2 + ks) * 2 + 1) * 64];
+        }
+    }
+    float cst[NGA][2];
+#pragma unroll
+    for (int p = 0; p < NGA; ++p) cst[p][0] = cst[p][1] = 0.f;
+    const int64_t SN = layout ? 1 : T, ST = layout ? 32 : 1;
+    // The per-lane offsets and masks of the io arm are REBUILT in every phase from an opaque copy of the thread index
+    // (a dozen vector instructions): as loop invariants the compiler hoisted six masked offsets per group out of the
+    // step loop -- 24 registers it did not have -- and reloaded them from scratch in front of every store
+    // (`s_waitcnt vmcnt(0)`: the whole asynchronous io arm serialised).
+    auto seq0_of = [&](int p) { return (sg0 + p) * SQ; };
+    struct IoLane { unsigned goff0, coff, hoff; bool uok[4]; };
+    auto io_lane = [&](int p) __attribute__((always_inline)) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      const int s2v = (tv & 255) >> 4, uqv = tv & 15, uswv = uqv ^ s2v;
+      const unsigned lrv = (unsigned)(s2v * SN);
+      IoLane L;
+      const bool rok = seq0_of(p) + s2v < N;
+      const bool f4 = 64 * g + 4 * uqv + 4 <= H;
+      L.goff0 = (lrv * 2u * (unsigned)H + (unsigned)uswv) * 16u;
+      L.coff = (rok && f4) ? (lrv * 2u * (unsigned)H + 4u * (unsigned)uqv) * 4u : OOR;
+      L.hoff = (rok && f4) ? (lrv * (unsigned)ldo + 4u * (unsigned)uqv) * 4u : OOR;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L.uok[q] = rok && 64 * g + 16 * q + uswv < H;
+      return L;
+    };
+
+    // (group, step) of phase i of the loop iteration that starts at step `base`
+    auto grp_of = [](int i) { return i % NGA; };
+    auto stp_of = [](int64_t base, int i) { return base + i / NGA; };
+    auto srd_at = [&](const void* ptr) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);
+    };
+    auto gates_base = [&](int p, int64_t st) {
+      const int64_t t_ = dir ? T - 1 - st : st;
+      return reinterpret_cast<char*>(gates) + (((ROW(seq0_of(p), 0) + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16;
+    };
+    auto ring_of = [&](auto slot_tag) -> f32x4* {
+      constexpr int S = decltype(slot_tag)::value;
+      return S == 0 ? ring0 : S == 1 ? ring1 : S == 2 ? ring2 : ring3;
+    };
+    // asynchronous HBM -> LDS copy of the gate tile of (group p, step st) into ring slot S (four instructions)
+    auto io_dma = [&](auto slot_tag, int p, int64_t st) __attribute__((always_inline)) {
+      f32x4* rg = ring_of(slot_tag);
+      const char* gb = gates_base(p, st);
+      const IoLane L = io_lane(p);
+      // inline assembly, so that the compiler does not know that LDS is written: with the builtin it put a `vmcnt(0)` in
+      // front of every read of a gate tile -- also of the tiles that landed phases ago -- which waits for the copy just
+      // requested for two phases ahead.  The io waves wait explicitly (`vmcnt(4)` before the barrier that opens a
+      // phase).  Scalar base + 32-bit lane offset: no 64-bit per-lane addresses to keep (or spill).  (No immediate
+      // offset: the instruction adds it to the LDS address as well as to the global one.)
+#define DMA16(Q_, OFF_)                                                                                                    \
+      {                                                                                                                \
+        /* lanes outside N / H read the block's first bytes (a valid address) into cells nobody uses: the copy is     \
+           issued unconditionally, so that every phase queues exactly four copies and six stores (vmcnt arithmetic) */ \
+        const unsigned vo = L.uok[Q_] ? L.goff0 + (OFF_) : 0u;                                                         \
+        const int la = __builtin_amdgcn_readfirstlane(                                                                 \
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)&rg[((Q_) * 4 + iow) * 64]);                      \
+        if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"                         \
+                             :: "v"(vo), "s"(gb), "s"(la) : "memory");                                                 \
+        else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                               \
+                          :: "v"(vo), "s"(gb), "s"(la) : "memory");                                                    \
+      }
+      DMA16(0, 0) DMA16(1, 256) DMA16(2, 512) DMA16(3, 768)
+#undef DMA16
+    };
+    // flush of (group p, step st): c, h, then the activations of ring slot S (six stores)
+    auto io_flush = [&](auto slot_tag, int p, int64_t st) __attribute__((always_inline)) {
+      f32x4* rg = ring_of(slot_tag);
+      const int64_t t_ = dir ? T - 1 - st : st;
+      const int64_t row = ROW(seq0_of(p), 0) + t_ * ST;
+      const auto rc = srd_at(reinterpret_cast<char*>(cell) + ((row * 2 + dir) * (int64_t)H + 64 * g) * 4);
+      const auto rh = srd_at(reinterpret_cast<char*>(hout) + (row * ldo + dir * dstride + 64 * g) * 4);
+      const auto rs = srd_at(gates_base(p, st));
+      const IoLane L = io_lane(p);
+      const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s2 * PUBPITCH + 4 * uq);
+      const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s2 * PUBPITCH + 4 * uq);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cq), rc, (int)L.coff, 0, NT ? 2 : 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), rh, (int)L.hoff, 0, NT ? 2 : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = rg[(q * 4 + iow) * 64 + lane];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(L.uok[q] ? L.goff0 + q * 256 : OOR), 0, NT ? 2 : 0);
+      }
+    };
+    // exchange: payload of (group p): [slot 2][G][SQ][UPW] values as 8-byte granules of two
+    auto payload_srd = [&](int p) {
+      const int64_t item = ((sg0 + p) << 1) | dir;
+      return __builtin_amdgcn_make_buffer_rsrc(xpayload + item * 2 * G * SQ * UPW, 0, 2 * G * SQ * UPW * 4, 0x00020000);
+    };
+    u32x4 vg[5];
+    auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // h_{st-1} of group p
+      const auto prs = payload_srd(p);
+      const int slot = (int)((st - 1) & 1);
+#pragma unroll
+      for (int gs = 0; gs < 5; ++gs)
+        vg[gs] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1)
+                        : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto gather_finish = [&](int p, int64_t st) __attribute__((always_inline)) {
+      const auto prs = payload_srd(p);
+      const int slot = (int)((st - 1) & 1);
+      const unsigned want = tagbase | (unsigned)st;
+      int spins = 0;
+      bool fail = false;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs) ok = ok && (gs >= G || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
+        if (ok || (ONCHIP16_ABL & 16)) break;
+        if (++spins > SPIN_LIMIT) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int gs = 0; gs < 5; ++gs)
+          if (gs < G && !((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want))
+            vg[gs] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1);
+      }
+      if (fail) s_fail = 1;
+      char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2 * HP2;
+      char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2 * HP2;
+#pragma unroll
+      for (int gs = 0; gs < 5; ++gs) {
+        if (gs < G) {
+          const int k = 64 * gs + 4 * uq;
+          const u32x4 w = vg[gs];
+          unsigned h0, l0, h1, l1;
+          split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
+          split2(granule_a(w[2], w[3]), granule_b(w[3]), h1, l1);
+          *reinterpret_cast<u32x2*>(hh + 2 * k) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(hl + 2 * k) = u32x2{l0, l1};
+        }
+      }
+    };
+    auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
+      const auto prs = payload_srd(p);
+      const unsigned tag = tagbase | (unsigned)(st + 1);
+      const int slot = (int)(st & 1);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2 * PUBPITCH + 4 * uq);
+      const u32x2 ga = pack_granule(tag, pv[0], pv[1]), gb = pack_granule(tag, pv[2], pv[3]);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
+                                             (((slot * G + g) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC0);
+    };
+
+    // ---- one phase: ring slot S (static), group P (static), step st.  IO: the role of this wave -- the step loop
+    // exists once per role (below), so that neither the registers nor the compiler's wait-count bookkeeping of one
+    // role meet the other's at a join (a merged loop copied the prefetched gather registers behind the join, i.e.
+    // waited for the loads it had just issued)
+    auto phase = [&](auto io_tag, auto slot_tag, auto grp_tag, int64_t st, int64_t base) __attribute__((always_inline)) {
+      constexpr bool IO = decltype(io_tag)::value;
+      constexpr int S = decltype(slot_tag)::value, P = decltype(grp_tag)::value;
+      if (st >= T) return;                                     // (T tail of NGA < 4; uniform)
+      f32x4* rg = ring_of(slot_tag);
+      if constexpr (!IO) {
+        // (NGA = 4: this phase's h was decoded into the operand image behind the previous phase's publish -- below --
+        // so nothing stands between the exchange waves and the barrier)
+        if (NGA < 4 && st > 0 && !(ONCHIP16_ABL & 8)) gather_finish(P, st);
+      } else {
+        // the tile of this phase has landed: it was requested two phases ago, and exactly six stores + four copies
+        // (the previous phase's) were queued behind it -- those may still be in flight (a store acknowledgement
+        // takes longer than a phase under load: waiting for them paced the whole kernel)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      }
+      lds_barrier();
+      if (s_fail) return;
+      f32x4 acc[2];
+      acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (st > 0 && !(ONCHIP16_ABL & 1)) {
+        const char* hh = hs + (P * 2 + 0) * SQ * HP2 + foff;
+        const char* hl = hs + (P * 2 + 1) * SQ * HP2 + foff;
+        // fragments one k-step ahead, pinned: hoisting all twenty reads would cost 80 registers the kernel does not have
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(hh), bl = *reinterpret_cast<const bf16x8*>(hl);
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+          bf16x8 nh = bh, nl = bl;
+          if (ks + 1 < KS2) {
+            nh = *reinterpret_cast<const bf16x8*>(hh + (ks + 1) * 64);
+            nl = *reinterpret_cast<const bf16x8*>(hl + (ks + 1) * 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wl[rb][ks]), bh, acc[rb]);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bl, acc[rb]);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bh, acc[rb]);
+          __builtin_amdgcn_sched_barrier(0);
+          bh = nh; bl = nl;
+        }
+      }
+      // cell update: lane (sequence j, unit 8 wave + 4 rb + up), the four gates in acc[rb]
+      // (addresses rebuilt from an opaque copy of the lane index: hoisted out of the loop they were eight more
+      // registers -- one per ring slot and row block -- that ended up in scratch)
+      int lv = lane;
+      asm volatile("" : "+v"(lv));
+      const int jv = lv & 15, upv = lv >> 4;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int ul = 8 * wave + 4 * rb + upv;
+        f32x4* xp = &rg[(ul >> 4) * 256 + jv * 16 + ((ul & 15) ^ jv)];
+        const f32x4 gx = *xp;
+        const float a0 = acc[rb][0] + gx[0], a1 = acc[rb][1] + gx[1], a2 = acc[rb][2] + gx[2], a3 = acc[rb][3] + gx[3];
+        const bool fake = (ONCHIP16_ABL & 2) != 0;
+        const float ig = fake ? a0 : fast_sigmoid(a0), fg = fake ? a1 : fast_sigmoid(a1), gg = fake ? a2 : fast_tanh(a2), og = fake ? a3 : fast_sigmoid(a3);
+        const float cn = fg * cst[P][rb] + ig * gg;
+        cst[P][rb] = cn;
+        *xp = f32x4{ig, fg, gg, og};
+        pub[jv * PUBPITCH + ul] = (64 * g + ul < H) ? og * (fake ? cn : fast_tanh(cn)) : 0.f;
+        cellb[jv * PUBPITCH + ul] = cn;
+      }
+      lds_barrier();
+      // (group, step) of the next phase and of the phase after it
+      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
+      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
+      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
+      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
+      if constexpr (!IO) {
+        if (!(ONCHIP16_ABL & 8)) {
+          publish(P, st);
+          if (NGA < 4) {      // (two groups: the next phase wants the h published a phase ago -- decoding it here only spins)
+            if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+          } else {
+            // the NEXT phase's h (requested one phase ago) -> its operand image, while the io waves flush; then the
+            // request for the phase after that: two phases of latency budget per gather
+            if (st1 > 0 && st1 < T) gather_finish(P1, st1);
+            if (st2 > 0 && st2 < T) gather_issue(P2, st2);
+          }
+        }
+      } else if (!(ONCHIP16_ABL & 4)) {
+        io_flush(slot_tag, P, st);
+        if (st2 < T) io_dma(std::integral_constant<int, I2>{}, P2, st2);
+      }
+    };
+    auto run = [&](auto io_tag) __attribute__((always_inline)) {
+      constexpr bool IO = decltype(io_tag)::value;
+      if constexpr (IO) {      // prologue: the tiles of phases 0 and 1
+        io_dma(std::integral_constant<int, 0>{}, grp_of(0), stp_of(0, 0));
+        if (stp_of(0, 1) < T) io_dma(std::integral_constant<int, 1>{}, grp_of(1), stp_of(0, 1));
+      }
+      // the stationary weights have arrived before the loop (inputs of an empty asm: the compiler waits HERE, and its
+      // wait-count bookkeeping enters the loop with nothing pending -- otherwise the first MFMA of every phase carries
+      // a `vmcnt(0)` that drains the io arm)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) asm volatile("" :: "v"(wh[rb][ks]), "v"(wl[rb][ks]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int64_t base = 0; base < T; base += 4 / NGA) {
+        phase(io_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 0 % NGA>{}, base + 0 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 1 % NGA>{}, base + 1 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 % NGA>{}, base + 2 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 3 % NGA>{}, base + 3 / NGA, base);
+        if (s_fail) break;
+      }
+    };
+    if (io_wave) run(std::true_type{}); else run(std::false_type{});
+    if (s_fail) {
+      if (tid == 0) atomicExch(err, 3);
+      return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int tssep_lstm_onchip_supported(int H) { return H > 0 && H <= KP ? 1 : 0; }
@@ -980,5 +1353,62 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
     hipLaunchKernelGGL(blstm_onchip_bwd_kernel<false>, dim3(grid), dim3(512), 0, s, gates, cell, dhout,
                        ldo, dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N,
                        T, H, G, nc, layout & 1);
+  return tssep_launch_status();
+}
+
+// ---- interleaved forward (blstm_onchip16_fwd_kernel): own weight pack, own exchange layout (16-sequence items)
+extern "C" int64_t tssep_lstm_onchip16_pack_floats(int H) {
+  const int G = (H + UPW - 1) / UPW;
+  return (int64_t)2 * G * 8 * 2 * KS2 * 2 * 64 * 4;
+}
+extern "C" int tssep_lstm_pack_onchip16(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream) {
+  if (!w_hh_f || !w_hh_r || !wf) return TSSEP_E_NULL;
+  if (H <= 0 || H > KP2) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(wf)) return TSSEP_E_ALIGN;
+  const int G = (H + UPW - 1) / UPW;
+  const int64_t total = tssep_lstm_onchip16_pack_floats(H) / 4;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_onchip16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_hh_f, w_hh_r, H, G,
+                     (u32x4*)wf);
+  return tssep_launch_status();
+}
+extern "C" int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H) {
+  const int G = (H + UPW - 1) / UPW;
+  return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * G * SQ * UPW * 4;
+}
+// groups per cluster the launcher would use for N sequences (0: shape not supported -> use tssep_blstm_onchip_fwd):
+// the largest of 4 / 2 / 1 that divides the number of 16-sequence groups and still gives every cluster a bundle
+extern "C" int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs) {
+  const int G = (H + UPW - 1) / UPW;
+  if (N <= 0 || H <= 0 || H > KP2 || (H & 3) || G > 5 || max_wgs < 8 * G) return 0;
+  const int64_t ng16 = (N + SQ - 1) / SQ;
+  const int64_t ncl = 8 * ((max_wgs / 8) / G);
+  for (int nga = 4; nga >= 1; nga >>= 1)
+    if (ng16 % nga == 0 && (2 * ng16 / nga >= ncl || nga == 1)) return nga;
+  return 1;
+}
+extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+                                        const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
+                                        int max_wgs, int layout, int groups, void* stream) {
+  if (!gates || !cell || !hout || !wf || !xbuf || !err) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  const int G = (H + UPW - 1) / UPW;
+  const int nga = groups > 0 ? groups : tssep_blstm_onchip16_groups(N, H, max_wgs);
+  const int64_t ng16 = (N + SQ - 1) / SQ;
+  if (nga != 1 && nga != 2 && nga != 4) return TSSEP_E_UNSUPPORTED;
+  if (H > KP2 || (H & 3) || (ldo & 3) || (dstride & 3) || ng16 % nga || max_wgs < 8 * G) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(xbuf) || !aligned16(cell) || !aligned16(hout)) return TSSEP_E_ALIGN;
+  if (2 * ng16 >= 0xffff || T > 2046) return TSSEP_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16_xbuf_bytes(N, H), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
+  int nc;
+  const unsigned grid = onchip_grid(2 * ng16 / nga, G, max_wgs, true, &nc);
+  char* base = (char*)xbuf;
+  const int klayout = layout & 1;          // (the activation stream is always non-temporal here: used from 160 sequences up)
+#define L16(NGA_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, true>), dim3(grid), dim3(512), 0, s, gates, cell, hout, ldo, dstride, \
+                    (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, klayout)
+  if (nga == 4) L16(4); else if (nga == 2) L16(2); else L16(1);
+#undef L16
   return tssep_launch_status();
 }

@@ -82,7 +82,12 @@ class _RNNP(torch.autograd.Function):
         if kf == "cluster":
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
         elif kf == "onchip":
-            H.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf3, N, T, Hh)
+            g16 = H.onchip16_groups(N, Hh, dev) if (2 * Hp) % 4 == 0 and Hp % 4 == 0 else 0
+            if g16:      # interleaved 16-sequence groups (round 3)
+                wf16 = H.derived("pack_onchip16", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip16(w_hh, w_hh_r, Hh))
+                H.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16, N, T, Hh, g16)
+            else:
+                H.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf3, N, T, Hh)
         else:
             H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
         pk["whh_cb"] = cb if kb == "cluster" else None

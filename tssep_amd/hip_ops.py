@@ -568,6 +568,38 @@ def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
                                        _stream()), "blstm_onchip_fwd")
 
 
+# interleaved forward (16-sequence groups in rotation): TSSEP_ONCHIP16=0 switches it off (read per call)
+def onchip16_groups(N, H, device):
+    if _os.environ.get("TSSEP_ONCHIP16", "1") == "0":
+        return 0
+    forced = int(_os.environ.get("TSSEP_ONCHIP16_GROUPS", "0"))
+    g = int(_lib.lib().tssep_blstm_onchip16_groups(N, H, n_cus(device)))
+    if g and forced in (1, 2, 4) and ((N + 15) // 16) % forced == 0:
+        return forced
+    return g if N >= ONCHIP16_MIN_N else 0
+
+
+ONCHIP16_MIN_N = 160         # below: a few clusters, pure latency -- the 32-sequence kernel
+
+
+def lstm_pack_onchip16(w_hh_f, w_hh_r, H):
+    L = _lib.lib()
+    buf = torch.empty(int(L.tssep_lstm_onchip16_pack_floats(H)), device=w_hh_f.device, dtype=torch.float32)
+    a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
+    check(L.tssep_lstm_pack_onchip16(_p(a), _p(b), H, _p(buf), _stream()), "lstm_pack_onchip16")
+    return buf
+
+
+def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, layout=0):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_onchip16_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
+    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_onchip16_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf),
+                                         _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream()),
+              "blstm_onchip16_fwd")
+
+
 def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
     L = _lib.lib()
     cus = n_cus(gates.device)
