@@ -65,6 +65,22 @@ def test_onchip_workspace_sizes():
     assert int(L.tssep_lstm_onchip_pack_floats(300, 0)) > 0
 
 
+def test_interleaved_recurrence_group_choice():
+    """tssep_blstm_onchip16_groups: the largest of 4 / 2 / 1 groups of 16 sequences that divides the number of groups and
+    still gives each of the 48 XCD-local clusters (256 CUs, 5 workgroups each) a bundle; 0 where the kernel does not apply."""
+    L = _lib.lib()
+    assert L.tssep_blstm_onchip16_groups(3072, 300, 256) == 4          # 384 items / 4 = 96 bundles = 2 per cluster
+    assert L.tssep_blstm_onchip16_groups(768, 300, 256) == 2           # 96 items: 4 groups would leave half the clusters idle
+    assert L.tssep_blstm_onchip16_groups(1536, 300, 256) == 4
+    assert L.tssep_blstm_onchip16_groups(200, 300, 256) == 1           # 13 groups of 16: nothing else divides
+    assert L.tssep_blstm_onchip16_groups(768, 302, 256) == 0 and L.tssep_blstm_onchip16_groups(768, 400, 256) == 0
+    assert L.tssep_blstm_onchip16_groups(768, 300, 16) == 0            # not even one cluster per XCD
+    assert int(L.tssep_lstm_onchip16_xbuf_bytes(3072, 300)) == 1024 + 2 * 192 * 2 * 5 * 16 * 64 * 4
+    assert int(L.tssep_lstm_onchip16_pack_floats(300)) == 2 * 5 * 8 * 2 * 10 * 2 * 64 * 4
+    # argument validation of the launcher without a GPU
+    assert L.tssep_blstm_onchip16_fwd(None, None, None, 0, 0, None, None, None, 1, 1, 300, 256, 0, 0, None) < 0
+
+
 def test_abi_argument_validation_without_gpu():
     """Invalid arguments are rejected with a status before anything is launched."""
     L = _lib.lib()

@@ -15,8 +15,9 @@ Hh = 300
 torch.manual_seed(0)
 lstm = torch.nn.LSTM(64, Hh, bidirectional=True, batch_first=True).cuda()
 wf3, wb3 = h.lstm_pack_onchip(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
+wf16 = h.lstm_pack_onchip16(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 cf, cb = h.lstm_pack_cluster(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
-shapes = [(8, 5), (8, 40), (40, 17), (200, 30), (768, 12), (1600, 9)]
+shapes = [(8, 5), (8, 40), (40, 17), (200, 30), (768, 12), (1600, 9), (3072, 6)]
 state = {}
 for N, T in shapes:
     g0 = torch.randn(N * T, 8 * Hh, device="cuda") * 0.5
@@ -31,12 +32,18 @@ for it in range(iters):
         g = st["g0"].clone()
         cell = torch.empty(N, T, 2, Hh, device="cuda")
         hout = torch.zeros(N, T, 2 * Hh, device="cuda")
-        h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh)
+        # from 160 sequences up the interleaved forward (16-sequence groups in rotation), every third iteration the
+        # 32-sequence kernel: each kind must reproduce its own first launch
+        g16 = h.onchip16_groups(N, Hh, g.device) if it % 3 else 0
+        if g16:
+            h.blstm_onchip16_fwd(g, cell, hout, 2 * Hh, Hh, wf16, N, T, Hh, g16)
+        else:
+            h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh)
         if N <= 32 and it % 2:
             h.blstm_cluster_bwd(g, cell, st["dh"], 2 * Hh, Hh, cb, N, T, Hh)
         else:
             h.blstm_onchip_bwd(g, cell, st["dh"], 2 * Hh, Hh, wb3, N, T, Hh)
-        key = "ref_c" if (N <= 32 and it % 2) else "ref"
+        key = ("ref_c" if (N <= 32 and it % 2) else "ref") + ("16" if g16 else "")
         out = (hout.clone(), g.clone())
         if st.get(key) is None:
             st[key] = out
