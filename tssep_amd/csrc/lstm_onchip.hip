@@ -949,6 +949,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
   const int s2 = (tid & 255) >> 4, uq = tid & 15;            // exchange / io thread <-> (sequence s2, unit quad uq)
   const int iow = wave & 3;                                  // (scalar: LDS addresses of the copies stay in SGPRs)
   constexpr unsigned OOR = 0x80000000u;
+  // operand-image columns the gather never writes (k >= 64 G, when H <= 256) must be zero, not stale LDS: 0 x NaN
+  for (int i = tid; i < NGA * 2 * SQ * HP2 / 4; i += 512) reinterpret_cast<unsigned*>(hs)[i] = 0u;
 
   for (int round = 0;; ++round) {
     const int64_t bundle = next_item<true>(xhead, mem, round, (int)(2 * nb_dir), nclusters, s_mem);
@@ -1405,10 +1407,13 @@ extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, 
   int nc;
   const unsigned grid = onchip_grid(2 * ng16 / nga, G, max_wgs, true, &nc);
   char* base = (char*)xbuf;
-  const int klayout = layout & 1;          // (the activation stream is always non-temporal here: used from 160 sequences up)
-#define L16(NGA_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, true>), dim3(grid), dim3(512), 0, s, gates, cell, hout, ldo, dstride, \
+  const int klayout = layout & 1;
+  const bool nt = N >= 160 && !(layout & 32);          // non-temporal activation stream (as in the 32-sequence kernel)
+#define L16(NGA_) if (nt) L16B(NGA_, true); else L16B(NGA_, false)
+#define L16B(NGA_, NT_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, NT_>), dim3(grid), dim3(512), 0, s, gates, cell, hout, ldo, dstride, \
                     (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, klayout)
-  if (nga == 4) L16(4); else if (nga == 2) L16(2); else L16(1);
+  if (nga == 4) { L16(4); } else if (nga == 2) { L16(2); } else { L16(1); }
 #undef L16
+#undef L16B
   return tssep_launch_status();
 }

@@ -579,7 +579,7 @@ def onchip16_groups(N, H, device):
     return g if N >= ONCHIP16_MIN_N else 0
 
 
-ONCHIP16_MIN_N = 160         # below: a few clusters, pure latency -- the 32-sequence kernel
+ONCHIP16_MIN_N = int(_os.environ.get("TSSEP_ONCHIP16_MIN_N", "1"))     # (a one-group step is 3.5 us against 5.2: the latency regime gains too)
 
 
 def lstm_pack_onchip16(w_hh_f, w_hh_r, H):
