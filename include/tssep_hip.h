@@ -284,6 +284,17 @@ int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo
                              const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
                              int max_wgs, int layout, int groups, void* stream);
 
+/* Interleaved backward: the same rotation for the reduce-scatter of dh (exchange waves / io waves as in the forward, a
+ * ring of four LDS slots {gate activations, c_(t-1), dh} filled by asynchronous copies two phases ahead).  Own weight
+ * pack (W_hh^T as 16 x 16 x 32 MFMA fragments) and exchange layout; H = 257 .. 320 (five workgroups per cluster),
+ * H % 4 == 0; groups as for the forward (0 = the launcher's choice). */
+int64_t tssep_lstm_onchip16_bwd_pack_floats(int H);
+int tssep_lstm_pack_onchip16_bwd(const float* w_hh_f, const float* w_hh_r, int H, float* wb, void* stream);
+int64_t tssep_lstm_onchip16_bwd_xbuf_bytes(int64_t N, int H);
+int tssep_blstm_onchip16_bwd(float* gates, const float* cell, const float* dhout, int64_t ldo, int64_t dstride,
+                             const float* wb, void* xbuf, int* err, int64_t N, int64_t T, int H, int max_wgs,
+                             int layout, int groups, void* stream);
+
 /* ---------------------------------------------------------- elementwise ------*/
 /* d(pre-tanh) = dy * (1 - y^2) for the Tanh between post-net layers (tssep/train/net.py:623-625).
  * dz rows are (b,k,t) x P; combined_in != 0: dy and y live in the speaker-combined layout

@@ -1000,6 +1000,38 @@ def test_blstm_onchip_interleaved_forward(N, T, Hh, groups):
     close(gates, g_stream, rtol=1e-4, atol=1e-5, name="gate activations")
 
 
+@pytest.mark.parametrize("N,T,Hh,groups", [(64, 9, 300, 4), (64, 6, 300, 2), (32, 1, 300, 2), (96, 5, 300, 2), (128, 11, 300, 4),
+                                           (100, 7, 300, 1), (40, 12, 300, 1), (768, 3, 300, 2), (768, 5, 300, 4), (64, 8, 260, 4),
+                                           (3072, 3, 300, 4)])
+def test_blstm_onchip_interleaved_backward(N, T, Hh, groups):
+    """The interleaved backward recurrence (reduce-scatter of dh for groups of 16 sequences in rotation, 16x16x32 MFMAs,
+    exchange / io wave roles, ring of asynchronously filled LDS slots) against the exact-fp32 streaming backward on the
+    same saved activations: d(gates) in place; ragged last group, T tails, H < 300, two bundles per cluster."""
+    h = H()
+    I = 12
+    p, x = _lstm_case(N, T, I, Hh, 19)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    Hp = h.round_up(Hh, 4)
+    cell = torch.empty(N, T, 2, Hh, device="cuda"); hout = torch.zeros(N, T, 2 * Hp, device="cuda")
+    h.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)          # saved activations (exact fp32)
+    g_ref = gates.clone()
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = torch.randn(N, T, Hh, device="cuda"); dhd[..., Hp:Hp + Hh] = torch.randn(N, T, Hh, device="cuda")
+    if ((N + 15) // 16) % groups:
+        pytest.skip("group count must divide the number of 16-sequence groups")
+    wb16 = h.lstm_pack_onchip16_bwd(p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda(), Hh)
+    h.blstm_onchip16_bwd(gates, cell, dhd, 2 * Hp, Hp, wb16, N, T, Hh, groups)
+    h.check_cluster_errors()
+    h.blstm_bwd(g_ref, cell, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+    close(gates, g_ref, rtol=2e-4, atol=2e-6 + 2e-6 * float(g_ref.abs().max()), name="dgates")
+
+
 # ------------------------------------------------------------------ mask-based MVDR (TorchBF)
 def _bf_case(B, K, M, D, T, F, seed, mdt=torch.float32):
     g = torch.Generator().manual_seed(seed)

@@ -52,3 +52,33 @@ for N in [int(a) for a in sys.argv[1:]] or [768, 3072]:
         if k.endswith("_ms"):
             row[k.replace("_ms", "_us_per_step")] = round(row[k] * 1e3 / T / max(1, -(-N * 2 // (48 * (32 if k == "old_ms" else 16 * int(k[1]))))), 2)
     print(json.dumps(row), flush=True)
+
+# ---- backward: the 32-sequence kernel against the interleaved one (d(gates) in place on saved activations)
+wb16 = h.lstm_pack_onchip16_bwd(whh[0], whh[1], Hh)
+for N in [int(a) for a in sys.argv[1:]] or [768, 3072]:
+    g0 = torch.rand(N * T, 8 * Hh, device="cuda") * 0.8 + 0.1
+    gates = g0.clone()
+    cell = torch.randn(N, T, 2, Hh, device="cuda") * 0.5
+    dh = torch.randn(N, T, 2 * Hp, device="cuda") * 0.1
+    row = {"N": N, "direction": "backward"}
+
+    def cp():
+        gates.copy_(g0)
+
+    def oldb():
+        gates.copy_(g0); h.blstm_onchip_bwd(gates, cell, dh, 2 * Hp, Hp, wb, N, T, Hh)
+
+    t_cp = timeit(cp)
+    row["old_ms"] = round(timeit(oldb) - t_cp, 3)
+    ref = gates.clone()
+    for g in (1, 2, 4):
+        if ((N + 15) // 16) % g:
+            continue
+
+        def newb():
+            gates.copy_(g0); h.blstm_onchip16_bwd(gates, cell, dh, 2 * Hp, Hp, wb16, N, T, Hh, g)
+
+        row[f"g{g}_ms"] = round(timeit(newb) - t_cp, 3)
+        row[f"g{g}_maxdiff"] = float((gates - ref).abs().max())
+    h.check_cluster_errors()
+    print(json.dumps(row), flush=True)

@@ -1200,7 +1200,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         }
       } else if (!(ONCHIP16_ABL & 4)) {
         io_flush(slot_tag, P, st);
-        if (st2 < T) io_dma(std::integral_constant<int, I2>{}, P2, st2);
+        // (beyond the last step the copy is repeated for step T - 1 into a slot nobody reads any more: every phase
+        // queues exactly four copies, or `vmcnt(10)` above would not cover the tiles of the last phases)
+        io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
       }
     };
     auto run = [&](auto io_tag) __attribute__((always_inline)) {
@@ -1231,6 +1233,365 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  }
+}
+
+
+// =====================================================================================================
+// Backward recurrence, interleaved variant (round 3): the rotation of blstm_onchip16_fwd_kernel applied to the
+// reduce-scatter of dh, with the forward's division of labour -- waves 0-3 exchange, waves 4-7 move HBM data.
+//  * `v_mfma_f32_16x16x32_bf16`: A = 16 output units x 32 own gate columns, B = 32 gate columns x 16 sequences.  320
+//    output units = 20 tiles; wave w owns tiles 2w, 2w + 1 over all 8 k-steps and k-steps 4 (w & 1) .. + 3 of shared
+//    tile 16 + (w >> 1): 20 fragments x (hi, lo) = 160 registers, 60 MFMAs per wave and phase;
+//  * a ring of four LDS slots per phase {gate activations 16 KB, c_(t-1) 4 KB, dh 4 KB}, filled by asynchronous copies
+//    two phases ahead (inline assembly + `vmcnt(10)`, as in the forward); the cell backward (thread <-> sequence
+//    tid / 32, unit pair tid % 32) overwrites the gate tile with d(gates), which the io waves flush a phase later;
+//  * the exchange waves add the partial sums of the other workgroups (requested a phase ahead, compiler-visible loads)
+//    and the own partial (LDS, per group) into the dh tile before the barrier that opens the phase, and publish this
+//    phase's partial sums behind the MFMAs;
+//  * per-group state in registers: the dc chain and c_t of the two cells of a lane.
+// Three barriers per phase (dh complete | d(gates) image complete | partial sums complete).
+constexpr int DP2 = 256 * 2 + 16;            // 528 B per sequence row of the bf16 d(gates) image (conflict-free: 4 mod 64 dwords)
+constexpr int PP2 = 5 * UPW + 4;             // floats per row of partial dh
+constexpr int OWNP = UPW + 4;                // floats per row of the own slice
+
+__global__ void pack_onchip16_bwd_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G, u32x4* wb) {
+  // wb[dir][g][wave 8][frag 20][hl 2][lane 64]: frag f < 16: tile 2 wave + f / 8, k-step f % 8; f >= 16: shared tile
+  // 16 + (wave >> 1), k-step 4 (wave & 1) + f - 16.  Lane (i = lane % 16, kg = lane / 16): output unit 16 tile + i,
+  // own gate column c = 32 ks + 8 kg + j = 4 ul + gate of unit 64 g + ul
+  const int64_t n = (int64_t)2 * G * 8 * 20 * 2 * 64;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int hl = (int)(r & 1); r >>= 1;
+    const int f = (int)(r % 20); r /= 20;
+    const int wave = (int)(r & 7); r >>= 3;
+    const int g = (int)(r % G);
+    const int d = (int)(r / G);
+    const int tile = f < 16 ? 2 * wave + f / 8 : 16 + (wave >> 1);
+    const int ks = f < 16 ? f % 8 : 4 * (wave & 1) + f - 16;
+    const int i = lane & 15, kg = lane >> 4;
+    const int uo = 16 * tile + i;
+    const float* w = d ? w_hh_r : w_hh_f;
+    float x[8];
+    for (int j = 0; j < 8; ++j) {
+      const int c = 32 * ks + 8 * kg + j;
+      const int ui = 64 * g + (c >> 2), gate = c & 3;
+      x[j] = (ui < H && uo < H) ? w[(int64_t)(gate * H + ui) * H + uo] : 0.f;
+    }
+    unsigned h[4], l[4];
+    for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], h[j], l[j]);
+    wb[e] = hl ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{h[0], h[1], h[2], h[3]};
+  }
+}
+
+template <int NGA, bool NT>
+__global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
+    float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dhout, int64_t ldo,
+    int64_t dstride, const u32x4* __restrict__ wb, unsigned* __restrict__ xhead, float* __restrict__ xpayload,
+    int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters, int layout) {
+  const unsigned tagbase = tag16_base(err);
+  __shared__ f32x4 ringg[4][TILE4];                                          // gate activations -> d(gates)
+  __shared__ __attribute__((aligned(16))) float ringc[4][SQ * UPW];         // c_(t-1)  [seq][unit]
+  __shared__ __attribute__((aligned(16))) float ringd[4][SQ * UPW];         // dh (+ partial sums)
+  __shared__ __attribute__((aligned(16))) char dg_hi[SQ * DP2];
+  __shared__ __attribute__((aligned(16))) char dg_lo[SQ * DP2];
+  __shared__ __attribute__((aligned(16))) float psum[SQ * PP2];             // [seq][unit] partial dh (shared tiles: k half 0)
+  __shared__ __attribute__((aligned(16))) float psum2[SQ * OWNP];           // shared tiles, k half 1: [seq][unit - 256]
+  __shared__ __attribute__((aligned(16))) float pown[NGA * SQ * OWNP];      // own 64 units of every group
+  __shared__ int s_fail, s_mem[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) s_fail = 0;
+  layout &= 1;
+  const int64_t ng16 = (N + SQ - 1) / SQ;
+  const int64_t nb_dir = (ng16 + NGA - 1) / NGA;
+  const Membership mem = join_cluster<true>(xhead, G, (int)(2 * nb_dir), s_mem);
+  if (!mem.ok) return;
+  const int g = __builtin_amdgcn_readfirstlane(mem.g);
+  const int Hp = G * UPW;
+  const bool io_wave = wave >= 4;
+  const int iow = wave & 3;
+  constexpr unsigned OOR = 0x80000000u;
+
+  for (int round = 0;; ++round) {
+    const int64_t bundle = next_item<true>(xhead, mem, round, (int)(2 * nb_dir), nclusters, s_mem);
+    if (bundle >= 2 * nb_dir) {
+      if (bundle > 2 * nb_dir && tid == 0) atomicExch(err, 5);
+      break;
+    }
+    const int dir = (int)(bundle & 1);
+    const int64_t sg0 = (bundle >> 1) * NGA;
+    u32x4 wh[20], wl[20];
+    {
+      const u32x4* wp = wb + (((int64_t)(dir * G + g) * 8 + wave) * 20 * 2) * 64 + lane;
+#pragma unroll
+      for (int f = 0; f < 20; ++f) {
+        wh[f] = wp[(int64_t)(f * 2 + 0) * 64];
+        wl[f] = wp[(int64_t)(f * 2 + 1) * 64];
+      }
+    }
+    const int64_t SN = layout ? 1 : T, ST = layout ? 32 : 1;
+    auto seq0_of = [&](int p) { return (sg0 + p) * SQ; };
+    auto t_of = [&](int64_t st) { return dir ? st : T - 1 - st; };
+    auto rowb = [&](int p, int64_t t_) { return ROW(seq0_of(p), 0) + t_ * ST; };
+    auto srd_at = [&](const void* ptr) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, 0x7fffffff, 0x00020000);
+    };
+    auto payload_srd = [&](int p) {
+      const int64_t item = ((sg0 + p) << 1) | dir;
+      return __builtin_amdgcn_make_buffer_rsrc(xpayload + item * 2 * G * SQ * Hp, 0, 2 * G * SQ * Hp * 4, 0x00020000);
+    };
+    // carries of this lane's two cells (sequence tid / 32, units 2 (tid % 32), + 1) per group: dc chain and c_t
+    float dcr[NGA][2], ctc[NGA][2];
+#pragma unroll
+    for (int p = 0; p < NGA; ++p) {
+      dcr[p][0] = dcr[p][1] = 0.f;
+      const int s = tid >> 5, up = tid & 31;
+      const bool ok = seq0_of(p) + s < N && 64 * g + 2 * up < H;
+      const float2 c0 = ok ? *reinterpret_cast<const float2*>(cell + ((rowb(p, t_of(0)) + s * SN) * 2 + dir) * (int64_t)H + 64 * g + 2 * up)
+                           : make_float2(0.f, 0.f);
+      ctc[p][0] = c0.x; ctc[p][1] = c0.y;
+    }
+
+    // ---- io arm (waves 4-7): thread <-> (row s2, unit 16 q + (uq ^ s2)) for the gate tile, (row s2, units 4 uq ..) for c / dh
+    struct IoLane { unsigned goff0, coff, hoff; bool uok[4], rok, f4; };
+    auto io_lane = [&](int p) __attribute__((always_inline)) {
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+      const int s2v = (tv & 255) >> 4, uqv = tv & 15, uswv = uqv ^ s2v;
+      const unsigned lrv = (unsigned)(s2v * SN);
+      IoLane L;
+      L.rok = seq0_of(p) + s2v < N;
+      L.f4 = L.rok && 64 * g + 4 * uqv + 4 <= H;
+      L.goff0 = (lrv * 2u * (unsigned)H + (unsigned)uswv) * 16u;
+      L.coff = (lrv * 2u * (unsigned)H + 4u * (unsigned)uqv) * 4u;
+      L.hoff = (lrv * (unsigned)ldo + 4u * (unsigned)uqv) * 4u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) L.uok[q] = L.rok && 64 * g + 16 * q + uswv < H;
+      return L;
+    };
+    auto dma16 = [&](const char* base, unsigned voff, const void* ldsp) __attribute__((always_inline)) {
+      const int la = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)ldsp);
+      if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" :: "v"(voff), "s"(base), "s"(la) : "memory");
+      else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(base), "s"(la) : "memory");
+    };
+    // the three tiles of (group p, step st) -> ring slot S: six copies, issued unconditionally (lanes outside N / H
+    // copy the block's first bytes into cells nobody uses)
+    auto io_dma = [&](int S, int p, int64_t st) __attribute__((always_inline)) {
+      const IoLane L = io_lane(p);
+      const int64_t t_ = t_of(st);
+      const int64_t tp_ = st + 1 < T ? (dir ? t_ + 1 : t_ - 1) : t_;
+      const char* gb = reinterpret_cast<const char*>(gates) + ((rowb(p, t_) * 2 + dir) * (int64_t)H + 64 * g) * 16;
+      const char* cb = reinterpret_cast<const char*>(cell) + ((rowb(p, tp_) * 2 + dir) * (int64_t)H + 64 * g) * 4;
+      const char* hb = reinterpret_cast<const char*>(dhout) + (rowb(p, t_) * ldo + dir * dstride + 64 * g) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16(gb, L.uok[q] ? L.goff0 + q * 256 : 0u, &ringg[S][(q * 4 + iow) * 64]);
+      dma16(cb, L.f4 ? L.coff : 0u, &ringc[S][iow * 256]);
+      dma16(hb, L.f4 ? L.hoff : 0u, &ringd[S][iow * 256]);
+    };
+    // d(gates) of (group p, step st) from ring slot S -> HBM: four stores
+    auto io_flush = [&](int S, int p, int64_t st) __attribute__((always_inline)) {
+      const IoLane L = io_lane(p);
+      const auto rs = srd_at(reinterpret_cast<char*>(gates) + ((rowb(p, t_of(st)) * 2 + dir) * (int64_t)H + 64 * g) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int lvf = lane;
+        asm volatile("" : "+v"(lvf));
+        const f32x4 v = ringg[S][(q * 4 + iow) * 64 + lvf];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(L.uok[q] ? L.goff0 + q * 256 : OOR), 0, NT ? 2 : 0);
+      }
+    };
+
+    // ---- exchange arm (waves 0-3): thread <-> (sequence s2, own unit quad uq)
+    u32x4 vg[4];
+    int srcw[4];                   // the G - 1 other workgroups, ascending (G = 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) srcw[i] = i + (i >= g ? 1 : 0);
+    // (per-lane indices rebuilt from an opaque copy of the thread index in every use: see the forward kernel)
+#define EX_LANE() int tvx = tid; asm volatile("" : "+v"(tvx)); const int s2 = (tvx & 255) >> 4, uq = tvx & 15
+    auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // partial dh for step st of group p
+      const auto prs = payload_srd(p);
+      const int slot = (int)((st - 1) & 1);
+      EX_LANE();
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        vg[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + srcw[i]) * SQ + s2) * Hp + 64 * g + 4 * uq) * 4, 0, SC1);
+    };
+    auto gather_finish = [&](int S, int p, int64_t st) __attribute__((always_inline)) {
+      const auto prs = payload_srd(p);
+      const int slot = (int)((st - 1) & 1);
+      const unsigned want = tagbase | (unsigned)st;
+      EX_LANE();
+      int spins = 0;
+      bool fail = false;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ok = ok && (vg[i][0] & 0xffffu) == want && (vg[i][2] & 0xffffu) == want;
+        if (ok) break;
+        if (++spins > SPIN_LIMIT) { fail = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!((vg[i][0] & 0xffffu) == want && (vg[i][2] & 0xffffu) == want))
+            vg[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + srcw[i]) * SQ + s2) * Hp + 64 * g + 4 * uq) * 4, 0, SC1);
+      }
+      if (fail) s_fail = 1;
+      // fixed order: sources 0 .. G - 1 ascending, the own partial in its place (value selects between static elements)
+      f32x4 acc = *reinterpret_cast<const f32x4*>(&ringd[S][s2 * UPW + 4 * uq]);
+      const f32x4 own = *reinterpret_cast<const f32x4*>(pown + (p * SQ + s2) * OWNP + 4 * uq);
+#pragma unroll
+      for (int gs = 0; gs < 5; ++gs) {
+        const u32x4 wlo = vg[gs < 4 ? gs : 3], whi = vg[gs > 0 ? gs - 1 : 0];
+        const u32x4 w = gs < g ? wlo : whi;
+        const f32x4 pv = {granule_a(w[0], w[1]), granule_b(w[1]), granule_a(w[2], w[3]), granule_b(w[3])};
+        acc += gs == g ? own : pv;
+      }
+      *reinterpret_cast<f32x4*>(&ringd[S][s2 * UPW + 4 * uq]) = acc;
+    };
+    auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
+      const auto prs = payload_srd(p);
+      const unsigned tag = tagbase | (unsigned)(st + 1);
+      const int slot = (int)(st & 1);
+      EX_LANE();
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {           // unit block b = the 64 units of workgroup b
+        f32x4 v = *reinterpret_cast<const f32x4*>(psum + s2 * PP2 + 64 * b + 4 * uq);
+        if (b == 4) v += *reinterpret_cast<const f32x4*>(psum2 + s2 * OWNP + 4 * uq);
+        const u32x2 ga = pack_granule(tag, v[0], v[1]), gb = pack_granule(tag, v[2], v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
+                                               (int)(b != g ? (unsigned)((((slot * G + g) * SQ + s2) * Hp + 64 * b + 4 * uq) * 4) : OOR), 0, SC0);
+        if (b == g) *reinterpret_cast<f32x4*>(pown + (p * SQ + s2) * OWNP + 4 * uq) = v;
+      }
+    };
+
+    // ---- one phase: ring slot S = phase index (static), group P (static), step st
+    auto phase = [&](auto io_tag, auto slot_tag, auto grp_tag, int64_t st, int64_t base) __attribute__((always_inline)) {
+      constexpr bool IO = decltype(io_tag)::value;
+      constexpr int S = decltype(slot_tag)::value, P = decltype(grp_tag)::value;
+      if (st >= T) return;
+      const bool has_prev = st + 1 < T;
+      if constexpr (!IO) {
+        if (st > 0) gather_finish(S, P, st);
+      } else {
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // this phase's tiles have landed (four stores + six copies behind them)
+      }
+      lds_barrier();
+      if (s_fail) return;
+      // cell backward for this lane's two cells; d(gates) replaces the activations in the tile
+      {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
+        const int s = tv >> 5, up = tv & 31;
+        const bool valid = seq0_of(P) + s < N && 64 * g + 2 * up < H;
+        const float2 dh = *reinterpret_cast<const float2*>(&ringd[S][s * UPW + 2 * up]);
+        const float2 cpv = has_prev ? *reinterpret_cast<const float2*>(&ringc[S][s * UPW + 2 * up]) : make_float2(0.f, 0.f);
+        const float dhq[2] = {dh.x, dh.y}, cpq[2] = {cpv.x, cpv.y};
+        f32x4 d[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int u = 2 * up + q;
+          f32x4* xp = &ringg[S][(u >> 4) * 256 + s * 16 + ((u & 15) ^ s)];
+          d[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            const f32x4 gq = *xp;
+            const float tc = fast_tanh(ctc[P][q]);
+            const float d_o = dhq[q] * tc;
+            const float dc = dhq[q] * gq[3] * (1.f - tc * tc) + dcr[P][q];
+            dcr[P][q] = dc * gq[1];
+            d[q][0] = dc * gq[2] * gq[0] * (1.f - gq[0]);
+            d[q][1] = dc * cpq[q] * gq[1] * (1.f - gq[1]);
+            d[q][2] = dc * gq[0] * (1.f - gq[2] * gq[2]);
+            d[q][3] = d_o * gq[3] * (1.f - gq[3]);
+            *xp = d[q];
+          }
+          ctc[P][q] = cpq[q];
+        }
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        split2(d[0][0], d[0][1], h0, l0);
+        split2(d[0][2], d[0][3], h1, l1);
+        split2(d[1][0], d[1][1], h2, l2);
+        split2(d[1][2], d[1][3], h3, l3);
+        const int o = s * DP2 + 16 * up;                  // 8 gate columns = 16 bytes of bf16
+        *reinterpret_cast<u32x4*>(dg_hi + o) = u32x4{h0, h1, h2, h3};
+        *reinterpret_cast<u32x4*>(dg_lo + o) = u32x4{l0, l1, l2, l3};
+      }
+      lds_barrier();
+      if (has_prev) {
+        // partial dh_(t-1): two own tiles over 8 k-steps + 4 k-steps of a shared tile (three accumulator chains)
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
+        int lvm = lane;
+        asm volatile("" : "+v"(lvm));
+        const int foff = (lvm & 15) * DP2 + (lvm >> 4) * 16;       // B fragment offset (row = sequence, 16-byte k chunk)
+        // fragments one k-step ahead, pinned (all sixteen reads hoisted would cost 64 registers: W fragments spilled)
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff), bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          bf16x8 nh = bh, nl = bl;
+          if (ks + 1 < 8) {
+            nh = *reinterpret_cast<const bf16x8*>(dg_hi + foff + (ks + 1) * 64);
+            nl = *reinterpret_cast<const bf16x8*>(dg_lo + foff + (ks + 1) * 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = MFMA16_BF16(as_bf16x8(wl[ks]), bh, acc0);
+          acc1 = MFMA16_BF16(as_bf16x8(wl[8 + ks]), bh, acc1);
+          // (wave-uniform: this k-step also belongs to the wave's half of the shared tile)
+          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wl[16 + (ks & 3)]), bh, accs);
+          acc0 = MFMA16_BF16(as_bf16x8(wh[ks]), bl, acc0);
+          acc1 = MFMA16_BF16(as_bf16x8(wh[8 + ks]), bl, acc1);
+          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bl, accs);
+          acc0 = MFMA16_BF16(as_bf16x8(wh[ks]), bh, acc0);
+          acc1 = MFMA16_BF16(as_bf16x8(wh[8 + ks]), bh, acc1);
+          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bh, accs);
+          __builtin_amdgcn_sched_barrier(0);
+          bh = nh; bl = nl;
+        }
+        const int j = lvm & 15, r4 = 4 * (lvm >> 4);
+        *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
+        *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + 16 + r4) = acc1;
+        float* sh = (wave & 1) ? psum2 + j * OWNP : psum + j * PP2 + 256;
+        *reinterpret_cast<f32x4*>(sh + 16 * (wave >> 1) + r4) = accs;
+      }
+      lds_barrier();
+      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
+      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
+      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
+      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
+      if constexpr (!IO) {
+        if (has_prev) publish(P, st);
+        if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+      } else {
+        io_flush(S, P, st);
+        io_dma(I2, P2, st2 < T ? st2 : T - 1);
+      }
+    };
+    auto run = [&](auto io_tag) __attribute__((always_inline)) {
+      constexpr bool IO = decltype(io_tag)::value;
+      if constexpr (IO) {      // prologue: the tiles of phases 0 and 1
+        io_dma(0, 0 % NGA, 0);
+        io_dma(1, 1 % NGA, (1 / NGA) < T ? 1 / NGA : T - 1);
+      }
+#pragma unroll
+      for (int f = 0; f < 20; ++f) asm volatile("" :: "v"(wh[f]), "v"(wl[f]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int64_t base = 0; base < T; base += 4 / NGA) {
+        phase(io_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 0 % NGA>{}, base + 0 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 1 % NGA>{}, base + 1 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 % NGA>{}, base + 2 / NGA, base);
+        phase(io_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 3 % NGA>{}, base + 3 / NGA, base);
+        if (s_fail) break;
+      }
+      if constexpr (IO) {
+        // the d(gates) of the last phase of every group still sit in the ring... they were flushed in their own phase
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    if (io_wave) run(std::true_type{}); else run(std::false_type{});
+    if (s_fail) {
+      if (tid == 0) atomicExch(err, 4);
+      return;
+    }
     lds_barrier();
   }
 }
@@ -1415,5 +1776,54 @@ extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, 
   if (nga == 4) { L16(4); } else if (nga == 2) { L16(2); } else { L16(1); }
 #undef L16
 #undef L16B
+  return tssep_launch_status();
+}
+
+// ---- interleaved backward (blstm_onchip16_bwd_kernel)
+extern "C" int64_t tssep_lstm_onchip16_bwd_pack_floats(int H) {
+  const int G = (H + UPW - 1) / UPW;
+  return (int64_t)2 * G * 8 * 20 * 2 * 64 * 4;
+}
+extern "C" int tssep_lstm_pack_onchip16_bwd(const float* w_hh_f, const float* w_hh_r, int H, float* wb, void* stream) {
+  if (!w_hh_f || !w_hh_r || !wb) return TSSEP_E_NULL;
+  if (H <= 0 || H > KP2) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(wb)) return TSSEP_E_ALIGN;
+  const int G = (H + UPW - 1) / UPW;
+  const int64_t total = tssep_lstm_onchip16_bwd_pack_floats(H) / 4;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_onchip16_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_hh_f, w_hh_r, H,
+                     G, (u32x4*)wb);
+  return tssep_launch_status();
+}
+extern "C" int64_t tssep_lstm_onchip16_bwd_xbuf_bytes(int64_t N, int H) {
+  const int G = (H + UPW - 1) / UPW;
+  return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * G * SQ * (int64_t)(G * UPW) * 4;
+}
+extern "C" int tssep_blstm_onchip16_bwd(float* gates, const float* cell, const float* dhout, int64_t ldo, int64_t dstride,
+                                        const float* wb, void* xbuf, int* err, int64_t N, int64_t T, int H, int max_wgs,
+                                        int layout, int groups, void* stream) {
+  if (!gates || !cell || !dhout || !wb || !xbuf || !err) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  const int G = (H + UPW - 1) / UPW;
+  const int nga = groups > 0 ? groups : tssep_blstm_onchip16_groups(N, H, max_wgs);
+  const int64_t ng16 = (N + SQ - 1) / SQ;
+  if (nga != 1 && nga != 2 && nga != 4) return TSSEP_E_UNSUPPORTED;
+  // (five workgroups per cluster: the exchange arm gathers exactly four peers)
+  if (H > KP2 || (H & 3) || G != 5 || (ldo & 3) || (dstride & 3) || ng16 % nga || max_wgs < 8 * G) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(xbuf) || !aligned16(cell) || !aligned16(dhout)) return TSSEP_E_ALIGN;
+  if (2 * ng16 >= 0xffff || T > 2046) return TSSEP_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16_bwd_xbuf_bytes(N, H), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
+  int nc;
+  const unsigned grid = onchip_grid(2 * ng16 / nga, G, max_wgs, true, &nc);
+  char* base = (char*)xbuf;
+  const bool nt = N >= 160 && !(layout & 32);
+#define LB16(NGA_) if (nt) LB16B(NGA_, true); else LB16B(NGA_, false)
+#define LB16B(NGA_, NT_) hipLaunchKernelGGL((blstm_onchip16_bwd_kernel<NGA_, NT_>), dim3(grid), dim3(512), 0, s, gates, cell, dhout, ldo, \
+                     dstride, (const u32x4*)wb, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, layout & 1)
+  if (nga == 4) { LB16(4); } else if (nga == 2) { LB16(2); } else { LB16(1); }
+#undef LB16
+#undef LB16B
   return tssep_launch_status();
 }

@@ -181,7 +181,13 @@ class _RNNP(torch.autograd.Function):
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
         elif pk.get("whh_ob") is not None:
-            H.blstm_onchip_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_ob"], N, T, Hh)
+            g16 = H.onchip16_bwd_groups(N, Hh, gates.device) if Hp % 4 == 0 else 0
+            if g16:      # interleaved 16-sequence groups (round 3)
+                w_hh, w_hh_r = ctx.params[1], ctx.params[5]
+                wb16 = H.derived("pack_onchip16_bwd", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip16_bwd(w_hh, w_hh_r, Hh))
+                H.blstm_onchip16_bwd(gates, cell, dhout, 2 * Hp, Hp, wb16, N, T, Hh, g16)
+            else:
+                H.blstm_onchip_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_ob"], N, T, Hh)
         else:
             H.blstm_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
 

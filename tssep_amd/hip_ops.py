@@ -600,6 +600,33 @@ def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, l
               "blstm_onchip16_fwd")
 
 
+def onchip16_bwd_groups(N, H, device):
+    """group count of the interleaved backward (0: use the 32-sequence kernel); TSSEP_ONCHIP16_BWD=0 switches it off"""
+    if _os.environ.get("TSSEP_ONCHIP16_BWD", "1") == "0" or not (256 < H <= 320):
+        return 0
+    # (two groups at most: a backward phase is paced by its three barriers and the publish, 7.1 against 7.8 ms per launch
+    # at 3 072 sequences with four -- profiles/r3_onchip16_backward.jsonl)
+    return min(onchip16_groups(N, H, device), int(_os.environ.get("TSSEP_ONCHIP16_BWD_GROUPS", "2")))
+
+
+def lstm_pack_onchip16_bwd(w_hh_f, w_hh_r, H):
+    L = _lib.lib()
+    buf = torch.empty(int(L.tssep_lstm_onchip16_bwd_pack_floats(H)), device=w_hh_f.device, dtype=torch.float32)
+    a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
+    check(L.tssep_lstm_pack_onchip16_bwd(_p(a), _p(b), H, _p(buf), _stream()), "lstm_pack_onchip16_bwd")
+    return buf
+
+
+def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, layout=0):
+    L = _lib.lib()
+    cus = n_cus(gates.device)
+    xbuf = torch.empty(int(L.tssep_lstm_onchip16_bwd_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
+    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H):
+        check(L.tssep_blstm_onchip16_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(wb16), _p(xbuf),
+                                         _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream()),
+              "blstm_onchip16_bwd")
+
+
 def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
     L = _lib.lib()
     cus = n_cus(gates.device)
