@@ -11,7 +11,7 @@ for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16
          batch_sweep.jsonl ab_gemm_wide.jsonl ab_wgrad_products.jsonl bench_cfg4.json bench_cfg4_nograph.json bench_cfg5.json \
          bench_f32.json gemm_in_step_b768.jsonl step_clock.json ab_fusions.jsonl splitk_sweep.jsonl \
          ab_gemm_stream_shapes.jsonl ab_gemm_big_shapes.jsonl ab_wgrad_big_shapes.jsonl ab_gemm_kernels.jsonl ab_wgrad_tile.jsonl \
-         ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_forward.jsonl; do
+         ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_microbench.jsonl; do
   [ -s $F/$f ] && cp $F/$f ${P}_$f
 done
 python - <<PY

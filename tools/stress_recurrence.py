@@ -16,6 +16,7 @@ torch.manual_seed(0)
 lstm = torch.nn.LSTM(64, Hh, bidirectional=True, batch_first=True).cuda()
 wf3, wb3 = h.lstm_pack_onchip(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 wf16 = h.lstm_pack_onchip16(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
+wb16 = h.lstm_pack_onchip16_bwd(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 cf, cb = h.lstm_pack_cluster(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 shapes = [(8, 5), (8, 40), (40, 17), (200, 30), (768, 12), (1600, 9), (3072, 6)]
 state = {}
@@ -39,11 +40,15 @@ for it in range(iters):
             h.blstm_onchip16_fwd(g, cell, hout, 2 * Hh, Hh, wf16, N, T, Hh, g16)
         else:
             h.blstm_onchip_fwd(g, cell, hout, 2 * Hh, Hh, wf3, N, T, Hh)
+        b16 = h.onchip16_bwd_groups(N, Hh, g.device) if it % 3 else 0
         if N <= 32 and it % 2:
             h.blstm_cluster_bwd(g, cell, st["dh"], 2 * Hh, Hh, cb, N, T, Hh)
+            b16 = "c"
+        elif b16:
+            h.blstm_onchip16_bwd(g, cell, st["dh"], 2 * Hh, Hh, wb16, N, T, Hh, b16)
         else:
             h.blstm_onchip_bwd(g, cell, st["dh"], 2 * Hh, Hh, wb3, N, T, Hh)
-        key = ("ref_c" if (N <= 32 and it % 2) else "ref") + ("16" if g16 else "")
+        key = f"ref_f{g16}_b{b16}"
         out = (hout.clone(), g.clone())
         if st.get(key) is None:
             st[key] = out
