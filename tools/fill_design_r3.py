@@ -34,7 +34,7 @@ fam = {"big-tile": tot(lambda n: "big_kernel" in n and "tn_big" not in n), "stre
        "8-wave tiled": tot(lambda n: "tall_kernel<" in n and "tn_tall" not in n), "weight gradients big-tile": tot(lambda n: "tn_big" in n),
        "weight gradients 256 x 160 (dW_hh)": tot(lambda n: "tn_w160" in n), "weight gradients 256 x 128": tot(lambda n: "tn_tall" in n),
        "weight gradients 128 x 128": tot(lambda n: "tn_kernel" in n)}
-g = sum(fam.values()); rec_f = tot(lambda n: "onchip_fwd" in n); rec_b = tot(lambda n: "onchip_bwd" in n)
+g = sum(fam.values()); rec_f = tot(lambda n: "onchip_fwd" in n or "onchip16_fwd" in n); rec_b = tot(lambda n: "onchip_bwd" in n or "onchip16_bwd" in n)
 tail = tot(lambda n: "rfft_frames_kernel<true>" in n or "istft_kernel<true>" in n)
 s = s.replace("R3_SHARES", f"{allk:.1f} ms of kernel time per step: GEMMs {100 * g / allk:.1f} % ({g:.1f} ms: " +
               ", ".join(f"{k} {v:.1f}" for k, v in fam.items()) + f"), recurrences {100 * (rec_f + rec_b) / allk:.1f} % (forward {rec_f:.1f}, backward {rec_b:.1f} ms), "
