@@ -133,7 +133,9 @@ class _RNNP(torch.autograd.Function):
             if combine:   # layout change only: reuse tanh_bwd's gather with y = 0
                 dz = H.tanh_bwd(dy.contiguous(), torch.zeros_like(dy), R, hdim, K, T, True)
             else:
-                dz = _dense_rows(dy, hdim)
+                # (a strided [R, hdim] view of a padded buffer -- what the conditioning's backward hands the pre-net --
+                # goes to the GEMMs as it is: rows_view only copies what is not 16-byte-row addressable)
+                dz = dy if dy.dim() == 2 else dy.reshape(-1, hdim)
         dz, ld_dz = H.rows_view(dz)
         G = 8 * Hh
         params = ctx.params
