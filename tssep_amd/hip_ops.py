@@ -331,6 +331,10 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
         # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
         # smallest one -- 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
         return 8
+    if tiles <= 16 and ktiles >= 64 * 8:
+        # few tiles (the projection weight gradients: 320 x 601 = 15 tiles): one resident round of 512 workgroups --
+        # 32 splits 1.38 ms, the 56 of the general rule 1.51 (tools/sweep_wgrad_small.py)
+        return max(8, 512 // tiles // 8 * 8)
     s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
     if s > 1:        # multiples of the XCD count: split z runs on XCD z % 8 (gemm_common.h)
         s = min(round_up(s, 8), max(8, (ktiles // min_ktiles) // 8 * 8))
