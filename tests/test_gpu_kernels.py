@@ -164,6 +164,66 @@ def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(4096 + 255, 320, 600), (1100, 320, 2400), (2048, 160, 47), (3000, 470, 553), (1300, 300, 64)])
+def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
+    """The 256 x 160 row x row tile (csrc/gemm_bf16x3_nt_w160.hip: N = 320 pads to 2 x 160 instead of 3 x 128 columns)
+    against fp64 and bit for bit against the 128-wide tiles (TSSEP_GEMM_NT_W160=0): bias + tanh, accumulate, the folded
+    Tanh backward, the speaker-combination remap; K tails, ragged last row / column tiles.  (Plain stores go to the
+    streaming kernel first: switched off here so that every variant reaches the tile under test.)"""
+    import os
+    torch.manual_seed(6)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    os.environ["TSSEP_GEMM_STREAM"] = "0"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        ldy = ru(N, 4)
+        Y = torch.zeros(M, ldy); Y[:, :N] = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        Kc = 4 if (N % 4 == 0 and M % 4 == 0 and (M // 4) % 1 == 0) else 0
+        Tt = M // Kc // 1 if Kc else 0
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_NT_W160"] = mode
+            ldc = ru(N, 4)
+            C = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
+            C2 = torch.ones(M, N, device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+            C3 = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K, act=2, aux=(Yd, ldy))
+            C4 = torch.full((M, N), float("nan"), device="cuda")
+            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C4, N, M, N, K)
+            res = [C, C2, C3, C4]
+            if Kc and N % 4 == 0:      # rows (b, k, t) x N -> rows (b, t) x (k, N): the combining projection's store
+                Bb, Tq = 1, M // Kc
+                C5 = torch.full((Bb * Tq, Kc * N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C5, 0, M, N, K, bias=bd, act=1,
+                       remap=dict(T=Tq, K=Kc, sb=Tq * Kc * N, sk=N, st=Kc * N))
+                res.append(C5)
+            outs[mode] = res
+        s1 = outs["1"]
+        close(s1[0][:, :N], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="w160 nt+bias+tanh")
+        assert bool(torch.isnan(s1[0][:, N:]).all())
+        close(s1[1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="w160 accumulate")
+        close(s1[2], (ref - bias) * (1 - Y[:, :N] ** 2), rtol=2e-4, atol=2e-4, name="w160 (1 - y^2)")
+        close(s1[3], ref - bias, rtol=2e-4, atol=2e-4, name="w160 plain")
+        if len(s1) > 4:
+            want = torch.tanh(ref).view(1, Kc, M // Kc, N).permute(0, 2, 1, 3).reshape(M // Kc, Kc * N)
+            close(s1[4], want, rtol=2e-4, atol=2e-4, name="w160 remap")
+        for a, b in zip(outs["1"], outs["0"]):
+            assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+    finally:
+        os.environ.pop("TSSEP_GEMM_NT_W160", None)
+        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (4096 + 255, 320, 600),
                                    (3000, 129, 553), (1500, 2052, 31), (70000, 600, 64), (1280, 5, 2400)])
 def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):

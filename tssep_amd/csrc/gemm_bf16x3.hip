@@ -1209,6 +1209,16 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         if (rc != TSSEP_E_UNSUPPORTED) return rc;
       }
     }
+    // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (N = 320: the Tanh
+    // projections and d(input) of birnn1, which the two kernels above do not take).  TSSEP_GEMM_NT_W160 is read per call
+    {
+      const char* ue = getenv("TSSEP_GEMM_NT_W160");
+      const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
+      if ((!ue || ue[0] != '0') && n160 * 11 <= n128 * 10) {
+        const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, stream);
+        if (rc != TSSEP_E_UNSUPPORTED) return rc;
+      }
+    }
     // wide (256 x 256) tile where rounding N up to 256 wastes < 10 % of the columns (N = 2400, 1280 of the
     // step; not 513 / 320 / 600 / 2052)
     const char* wide_env = getenv("TSSEP_GEMM_WIDE");          // read per call: A/B runs toggle it in-process
