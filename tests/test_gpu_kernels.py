@@ -508,6 +508,57 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("R,M,N,S", [(6072, 320, 600, 8), (1000, 320, 600, 1), (2580, 300, 530, 3), (3111, 318, 389, 2),
+                                     (5000, 640, 257, 4), (40, 320, 600, 1), (2580, 320, 130, 3)])
+def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
+    """The 320 x 128 weight-gradient tile (csrc/gemm_bf16x3_tn_h160.hip: the projection weight gradients, M = 320 pads to
+    one 320-row tile instead of 3 x 128 rows) bit for bit against the 128 x 128 tn kernel (TSSEP_GEMM_TN_H160=0) and
+    against fp64: with and without the fused ones column, ragged row / column tiles (M = 300, 318; N = 530, 389),
+    splits with K tails, a K shorter than the pipeline, and (M = 640; fewer than four column tiles) shapes the dispatcher
+    leaves to the other tiles.  (The row counts put the split boundaries of the 16-row K tiles of this kernel on those
+    of the 32-row K tiles of the 128 x 128 kernel: partials are only comparable split by split when the splits agree.)"""
+    import os
+    torch.manual_seed(17)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        dz = torch.randn(R, h.round_up(M, 4), device="cuda")
+        x = torch.randn(R, h.round_up(N, 4), device="cuda") / R ** 0.5
+        for products in (None, "2"):
+            if products:
+                os.environ["TSSEP_WGRAD_PRODUCTS"] = products
+            for colsum in (True, False):
+                outs = {}
+                for mode in ("1", "0"):
+                    os.environ["TSSEP_GEMM_TN_H160"] = mode
+                    outs[mode] = h.wgrad(dz, dz.shape[1], x, x.shape[1], M, N, R, with_colsum=colsum, splitk=S)[0].clone()
+                Nc = N + 1 if colsum else N
+                ldp = outs["1"].numel() // (S * M)
+                a, b = outs["1"].view(S, M, ldp)[:, :, :Nc], outs["0"].view(S, M, ldp)[:, :, :Nc]
+                assert torch.equal(a, b), f"products {products} colsum {colsum}: {(a != b).sum().item()} differ"
+                if products is None:
+                    ref = dz[:, :M].double().t() @ x[:, :N].double()
+                    close(a.double().sum(0)[:, :N].float(), ref.float(), rtol=2e-4, atol=2e-4, name="h160")
+                    if colsum:
+                        close(a.double().sum(0)[:, N].float(), dz[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3,
+                              name="h160 column sums")
+        # accumulate into an existing gradient (one split, no partials)
+        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
+        acc = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_TN_H160"] = mode
+            C = torch.full((M, h.round_up(N, 4)), 0.5, device="cuda")
+            h.gemm(dz, dz.shape[1], x, x.shape[1], C, C.shape[1], M, N, R, a_kmajor=True, b_kmajor=True, accumulate=True)
+            acc[mode] = C
+        assert torch.equal(acc["1"], acc["0"])
+        assert bool((acc["1"][:, N:] == 0.5).all())
+    finally:
+        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
+        os.environ.pop("TSSEP_GEMM_TN_H160", None)
+        h.GEMM_PRECISION = old
+
+
 def test_gemm_wgrad_with_fused_column_sums():
     """Split-bf16 weight-gradient GEMM with the virtual all-ones column: column N of the partials
     is the column sum of dY (bias gradient), columns < N the weight gradient."""

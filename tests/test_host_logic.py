@@ -48,6 +48,9 @@ def test_splitk_choice():
         assert H.pick_splitk(2400, 554, 194304) == 8               # 25 tiles -> 1 slab (25 / 32)
         # dW_hh: not the big tile (M pads to 1536) but the 256 x 160 one: 10 tiles, two workgroups per CU -> 48 splits
         assert H.pick_splitk(1200, 300, 777216) == 48 and H.pick_splitk(1200, 300, 194304) == 48
+        # the projection weight gradients (M = 320): the 320 x 128 tile, 5 column tiles, two workgroups per CU
+        assert H.pick_splitk(320, 601, 777216) == H.H160_MAX_SPLITS and H.pick_splitk(320, 601, 25600) == 96
+        assert H.pick_splitk(640, 601, 777216) == 32              # (M = 640 fits the 128-row tiles: 25 tiles)
     finally:
         H.GEMM_PRECISION = old
 

@@ -60,6 +60,8 @@ for shape in (SHAPES if KIND == "nt" else TN_SHIFT if KIND == "shift" else TN_SH
                 h.TN_XC = v != "0"
             if var == "TSSEP_GEMM_TN_W160":
                 h.TN_W160 = v != "0"
+            if var == "TSSEP_GEMM_TN_H160":
+                h.TN_H160 = v != "0"
             f(); best[v] = min(best[v], timeit(f))
     for v in (va, vb):
         tot[v] += best[v]

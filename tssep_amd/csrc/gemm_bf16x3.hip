@@ -1284,6 +1284,16 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
           if (rc != TSSEP_E_UNSUPPORTED) return rc;
         }
       }
+      {   // 320 x 128 tile where 320-row tiles waste >= 10 % fewer rows than 128-row ones (the projection weight
+          // gradients: M = 320, N = 601: 1.18 vs 1.38 ms at each kernel's best split count), four column tiles or more
+          // (one column tile: 0.13 vs 0.08 ms, profiles/r3_wgrad_h160_sweep.jsonl).  TSSEP_GEMM_TN_H160 is read per call
+        const char* he = getenv("TSSEP_GEMM_TN_H160");
+        const int64_t m320 = (g->M + 319) / 320 * 320, m128 = (g->M + BM - 1) / BM * BM;
+        if ((!he || he[0] != '0') && !shift && m320 * 11 <= m128 * 10 && g->N > 3 * BN) {
+          const int rc = tssep_gemm_bf16x3_tn_h160_launch(g, sm, splitk, two ? 1 : 0, stream);
+          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        }
+      }
       const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
       const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
       // default 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones

@@ -376,5 +376,6 @@ int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::St
 int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
 // (gemm_bf16x3_tn_w160.hip)
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
+int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
 // (gemm_bf16x3_nt_w160.hip)
 int tssep_gemm_bf16x3_nt_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);

@@ -326,6 +326,13 @@ def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
         # one round of at most 512 (tools/sweep_wgrad_splits.py: 2.00 ms at S = 48, 2.30 at 40, 3.13 at 56)
         tiles = (round_up(M, 256) // 256) * (n160 // 160)
         return max(8, min(512 // tiles // 8 * 8, ktiles // 64 // 8 * 8))
+    m320 = round_up(M, 320)
+    if TN_H160 and GEMM_PRECISION == "bf16x3" and m320 * 11 <= round_up(M, 128) * 10 and N > 384 \
+            and ktiles >= 64 * 8:
+        # the 320 x 128 tile (csrc/gemm_bf16x3_tn_h160.hip; the projection weight gradients: M = 320, N = 601 -> 5 tiles):
+        # two workgroups per CU, one round of at most 512
+        tiles = (m320 // 320) * math.ceil(N / 128)
+        return max(8, min(512 // tiles // 8 * 8, H160_MAX_SPLITS, ktiles // 16 // 8 * 8))
     tiles = math.ceil(M / 128) * math.ceil(N / 128)
     if SPLITK_BIGK and K >= 400000 and tiles >= 48:
         # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
@@ -656,6 +663,8 @@ OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
 SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
 TN_W160 = _os.environ.get("TSSEP_GEMM_TN_W160", "1") != "0"
 TN_XC = _os.environ.get("TSSEP_GEMM_TN_XC", "1") != "0"
+TN_H160 = _os.environ.get("TSSEP_GEMM_TN_H160", "1") != "0"
+H160_MAX_SPLITS = int(_os.environ.get("TSSEP_GEMM_TN_H160_SPLITS", "96"))
 TN_BIG = _os.environ.get("TSSEP_GEMM_TN_BIG", "1") != "0"        # (the split rule follows the kernel the dispatcher picks)
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
