@@ -269,7 +269,7 @@ int tssep_blstm_onchip_bwd(float* gates, const float* cell, const float* dhout, 
                            int64_t dstride, const float* wb, void* xbuf, int* err, int64_t N,
                            int64_t T, int H, int max_wgs, int layout, void* stream);
 
-/* Interleaved forward of the same recurrence (round 3): `groups` (4, 2 or 1) independent groups of 16 sequences per
+/* Interleaved forward of the same recurrence (round 3): `groups` (2 or 1; 4 on request) independent groups of 16 sequences per
  * cluster share the stationary W_hh in rotation, so that a group's exchange of h overlaps the other groups' MFMAs and
  * cell updates (the kernel above walks one group of 32 sequences through a serial chain).  Same tensors, same
  * semantics, same err / concurrency contract; own weight pack (16 x 16 x 32 MFMA fragments) and own exchange

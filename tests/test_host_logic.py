@@ -69,12 +69,14 @@ def test_onchip_workspace_sizes():
 
 
 def test_interleaved_recurrence_group_choice():
-    """tssep_blstm_onchip16_groups: the largest of 4 / 2 / 1 groups of 16 sequences that divides the number of groups and
-    still gives each of the 48 XCD-local clusters (256 CUs, 5 workgroups each) a bundle; 0 where the kernel does not apply."""
+    """tssep_blstm_onchip16_groups: two groups of 16 sequences per cluster where that divides the number of groups and still
+    gives each of the 48 XCD-local clusters (256 CUs, 5 workgroups each) a bundle, else one; 0 where the kernel does not
+    apply.  (Four groups stay available through `groups`; two are faster since they request their operands early.)"""
     L = _lib.lib()
-    assert L.tssep_blstm_onchip16_groups(3072, 300, 256) == 4          # 384 items / 4 = 96 bundles = 2 per cluster
-    assert L.tssep_blstm_onchip16_groups(768, 300, 256) == 2           # 96 items: 4 groups would leave half the clusters idle
-    assert L.tssep_blstm_onchip16_groups(1536, 300, 256) == 4
+    assert L.tssep_blstm_onchip16_groups(3072, 300, 256) == 2          # 384 items / 2 = 192 bundles = 4 per cluster
+    assert L.tssep_blstm_onchip16_groups(768, 300, 256) == 2           # 96 items / 2 = 48 bundles: one per cluster
+    assert L.tssep_blstm_onchip16_groups(1536, 300, 256) == 2
+    assert L.tssep_blstm_onchip16_groups(384, 300, 256) == 1           # 48 items: two groups would leave half the clusters idle
     assert L.tssep_blstm_onchip16_groups(200, 300, 256) == 1           # 13 groups of 16: nothing else divides
     assert L.tssep_blstm_onchip16_groups(768, 302, 256) == 0 and L.tssep_blstm_onchip16_groups(768, 400, 256) == 0
     assert L.tssep_blstm_onchip16_groups(768, 300, 16) == 0            # not even one cluster per XCD

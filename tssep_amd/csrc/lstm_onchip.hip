@@ -923,6 +923,14 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 
 #define MFMA16_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Where the exchange waves request the next phase's h (two groups per cluster only; see ONCHIP16_BWD_GATHER below):
+// 0 = behind this phase's publish (the loads' round trip through L2 sits in front of the next phase's barrier),
+// 1 = behind the first barrier, k >= 2 = after k - 1 MFMA k-steps.  768 sequences 1.45 -> 1.36 ms, 1 536: 2.70 -> 2.50,
+// 3 072: 5.73 -> 5.43 (positions 1, 4, 7, 11 within noise of each other; profiles/r3_onchip16_fwd_gather.jsonl) --
+// two groups now beat four (2.63 / 5.65 ms, whose requests were two phases ahead already) at every size.
+#ifndef ONCHIP16_FWD_GATHER
+#define ONCHIP16_FWD_GATHER 4
+#endif
 template <int NGA, bool NT>
 __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
@@ -1135,6 +1143,15 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       }
       lds_barrier();
       if (s_fail) return;
+      // (group, step) of the next phase and of the phase after it
+      constexpr int FGAT = NGA == 2 ? ONCHIP16_FWD_GATHER : 0;
+      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
+      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
+      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
+      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
+      if constexpr (!IO && FGAT >= 1) {
+        if (st1 > 0 && st1 < T && (FGAT == 1 || st == 0) && !(ONCHIP16_ABL & 8)) gather_issue(P1, st1);
+      }
       f32x4 acc[2];
       acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (st > 0 && !(ONCHIP16_ABL & 1)) {
@@ -1158,6 +1175,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
           for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bh, acc[rb]);
           __builtin_amdgcn_sched_barrier(0);
           bh = nh; bl = nl;
+          if constexpr (!IO && FGAT >= 2) {
+            if (ks == FGAT - 2 && st1 > 0 && st1 < T && !(ONCHIP16_ABL & 8)) gather_issue(P1, st1);
+          }
         }
       }
       // cell update: lane (sequence j, unit 8 wave + 4 rb + up), the four gates in acc[rb]
@@ -1181,16 +1201,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         cellb[jv * PUBPITCH + ul] = cn;
       }
       lds_barrier();
-      // (group, step) of the next phase and of the phase after it
-      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
-      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
-      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
-      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
       if constexpr (!IO) {
         if (!(ONCHIP16_ABL & 8)) {
           publish(P, st);
           if (NGA < 4) {      // (two groups: the next phase wants the h published a phase ago -- decoding it here only spins)
-            if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+            if (FGAT == 0 && st1 > 0 && st1 < T) gather_issue(P1, st1);
           } else {
             // the NEXT phase's h (requested one phase ago) -> its operand image, while the io waves flush; then the
             // request for the phase after that: two phases of latency budget per gather
@@ -1252,6 +1267,15 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 //    phase's partial sums behind the MFMAs;
 //  * per-group state in registers: the dc chain and c_t of the two cells of a lane.
 // Three barriers per phase (dh complete | d(gates) image complete | partial sums complete).
+// Where the exchange waves request the partial sums of the NEXT phase: 0 = behind this phase's publish (the loads'
+// round trip through L2 then sits in front of the next phase's first barrier), 1 = behind the first barrier, 2 = behind
+// the second (in front of the MFMAs: the round trip hides behind them), k >= 3 = after k MFMA k-steps.  The peers
+// published those sums a phase earlier -- with ONE group per cluster they are this phase's own, so an early request only
+// finds stale tags and is repeated (7.8 -> 8.9 ms): position 0 there.  Two groups, 3 072 sequences: 7.1 -> 6.7 ms
+// (positions 2, 3, 5 equal; 1: 6.96), 768: 1.74 -> 1.56 (profiles/r3_onchip16_bwd_gather.jsonl).
+#ifndef ONCHIP16_BWD_GATHER
+#define ONCHIP16_BWD_GATHER 2
+#endif
 constexpr int DP2 = 256 * 2 + 16;            // 528 B per sequence row of the bf16 d(gates) image (conflict-free: 4 mod 64 dwords)
 constexpr int PP2 = 5 * UPW + 4;             // floats per row of partial dh
 constexpr int OWNP = UPW + 4;                // floats per row of the own slice
@@ -1479,6 +1503,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       }
       lds_barrier();
       if (s_fail) return;
+      constexpr int GAT = NGA == 1 ? 0 : ONCHIP16_BWD_GATHER;
+      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
+      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
+      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
+      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
+      if constexpr (!IO && GAT == 1) {
+        if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+      }
       // cell backward for this lane's two cells; d(gates) replaces the activations in the tile
       {
         int tv = tid;
@@ -1518,6 +1550,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         *reinterpret_cast<u32x4*>(dg_lo + o) = u32x4{l0, l1, l2, l3};
       }
       lds_barrier();
+      if constexpr (!IO && (GAT >= 2)) {
+        if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
+      }
       if (has_prev) {
         // partial dh_(t-1): two own tiles over 8 k-steps + 4 k-steps of a shared tile (three accumulator chains)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
@@ -1546,6 +1581,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bh, accs);
           __builtin_amdgcn_sched_barrier(0);
           bh = nh; bl = nl;
+          if constexpr (!IO && GAT >= 3) {
+            if (ks == GAT - 1 && st1 > 0 && st1 < T) gather_issue(P1, st1);
+          }
         }
         const int j = lvm & 15, r4 = 4 * (lvm >> 4);
         *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
@@ -1554,13 +1592,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         *reinterpret_cast<f32x4*>(sh + 16 * (wave >> 1) + r4) = accs;
       }
       lds_barrier();
-      constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
-      const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
-      constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
-      const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
       if constexpr (!IO) {
         if (has_prev) publish(P, st);
-        if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+        if constexpr (GAT == 0) {
+          if (st1 > 0 && st1 < T) gather_issue(P1, st1);
+        }
       } else {
         io_flush(S, P, st);
         io_dma(I2, P2, st2 < T ? st2 : T - 1);
@@ -1741,13 +1777,14 @@ extern "C" int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H) {
   return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * G * SQ * UPW * 4;
 }
 // groups per cluster the launcher would use for N sequences (0: shape not supported -> use tssep_blstm_onchip_fwd):
-// the largest of 4 / 2 / 1 that divides the number of 16-sequence groups and still gives every cluster a bundle
+// 2 where that divides the number of 16-sequence groups and still gives every cluster a bundle, else 1 (four groups
+// -- `groups` = 4 -- stay available: slower than two since the two-group kernel requests its operands early)
 extern "C" int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs) {
   const int G = (H + UPW - 1) / UPW;
   if (N <= 0 || H <= 0 || H > KP2 || (H & 3) || G > 5 || max_wgs < 8 * G) return 0;
   const int64_t ng16 = (N + SQ - 1) / SQ;
   const int64_t ncl = 8 * ((max_wgs / 8) / G);
-  for (int nga = 4; nga >= 1; nga >>= 1)
+  for (int nga = 2; nga >= 1; nga >>= 1)
     if (ng16 % nga == 0 && (2 * ng16 / nga >= ncl || nga == 1)) return nga;
   return 1;
 }
