@@ -709,6 +709,59 @@ def test_gemm_store_remaps(gemm_precision):
     close(C, ref, rtol=tol, atol=tol, name="logit remap")
 
 
+@pytest.mark.parametrize("B,T,K,F,P", [(5, 253, 4, 513, 40), (2, 70, 3, 9, 12), (3, 100, 4, 601, 64), (9, 64, 2, 5, 16), (2, 300, 4, 130, 320)])
+def test_gemm_wide_remapped_store(B, T, K, F, P):
+    """The 16-byte remapped store for column groups that are not multiples of four floats and / or permuted per utterance
+    (gemm_common.h: gemm_epilogue_rows_remap_wide -- the logit layer, net.py:629-666, 928-967: F = 513 bins per speaker)
+    bit for bit against the 4-byte-per-lane variant (TSSEP_GEMM_REMAP_WIDE=0) and against the permuted reference:
+    plain, accumulating, with the folded Tanh backward, and the speaker combination with an odd projection size."""
+    import os
+    torch.manual_seed(23)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        A = torch.randn(B * T, P, device="cuda"); W = torch.randn(K * F, P, device="cuda") / P ** 0.5
+        bias = torch.randn(K * F, device="cuda")
+        perm = torch.stack([torch.randperm(K) for _ in range(B)]).int().cuda()
+        Y = torch.tanh(torch.randn(B * T, K * F, device="cuda"))
+        raw = (A.double() @ W.double().t() + bias.double()).view(B, T, K, F).permute(0, 2, 1, 3)       # [B,K,T,F] by position
+        ref = torch.empty(B, K, T, F, device="cuda", dtype=torch.float64)
+        for b in range(B):
+            for k in range(K):
+                ref[b, perm[b, k]] = raw[b, k]
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["TSSEP_GEMM_REMAP_WIDE"] = mode
+            rm = dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=K)
+            C = torch.full((B, K, T, F), float("nan"), device="cuda")
+            h.gemm(A, P, W, P, C, 0, B * T, K * F, P, bias=bias, remap=rm)
+            C2 = C.clone()
+            h.gemm(A, P, W, P, C2, 0, B * T, K * F, P, bias=bias, remap=rm, accumulate=True)
+            # un-combine with the Tanh backward folded in, no permutation, odd group size
+            C3 = torch.full((B * K * T, F), float("nan"), device="cuda")
+            h.gemm(A, P, W, P, C3, 0, B * T, K * F, P, act=2, aux=(Y, K * F),
+                   remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F))
+            # speaker combination: rows (b, k, t) x F -> [B, T, K * F], one column group
+            A4 = torch.randn(B * K * T, P, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+            C4 = torch.full((B, T, K * F), float("nan"), device="cuda")
+            h.gemm(A4, P, W[:F], P, C4, 0, B * K * T, F, P, bias=bias[:F], act=1,
+                   remap=dict(T=T, K=K, sb=T * K * F, sk=F, st=K * F))
+            outs[mode] = (C, C2, C3, C4, A4)
+        for a, b in zip(outs["1"][:4], outs["0"][:4]):
+            assert torch.equal(a, b), f"{(a != b).sum().item()} differ"
+        C, C2, C3, C4, A4 = outs["1"]
+        close(C, ref.float(), rtol=2e-4, atol=2e-4, name="logit remap, wide store")
+        close(C2, 2 * ref.float(), rtol=2e-4, atol=4e-4, name="accumulate")
+        ref3 = ((A.double() @ W.double().t()) * (1 - Y.double() ** 2)).view(B, T, K, F).permute(0, 2, 1, 3).reshape(B * K * T, F)
+        close(C3, ref3.float(), rtol=2e-4, atol=2e-4, name="un-combine + tanh backward, wide store")
+        ref4 = torch.tanh(A4.double() @ W[:F].double().t() + bias[:F].double()).view(B, K, T, F).permute(0, 2, 1, 3).reshape(B, T, K * F)
+        close(C4, ref4.float(), rtol=2e-4, atol=2e-4, name="combine, wide store")
+    finally:
+        os.environ.pop("TSSEP_GEMM_REMAP_WIDE", None)
+        h.GEMM_PRECISION = old
+
+
 # odd lengths take the clamped 4-byte load path of the frame loader, N < one hop / one window and N just past a
 # chunk boundary of the rolling overlap-add (64 hops = 16 384 samples) exercise the ring's edges
 @pytest.mark.parametrize("rows,N", [(3, 4000), (2, 64000), (1, 1023), (2, 255), (1, 257), (3, 16385), (2, 16640),

@@ -258,7 +258,11 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (g->act < 0 || g->act > 2 || (g->act == 2 && !g->aux)) return TSSEP_E_SHAPE;
   if (g->a_kmajor && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
   if (g->kperiod > 0 && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
-  const StoreMap sm = make_store_map(g);
+  StoreMap sm = make_store_map(g);
+  if (sm.remap) {      // read per call (alternating A/B): 0 = the 4-byte-per-lane remapped store where the vector one does not apply
+    const char* we = getenv("TSSEP_GEMM_REMAP_WIDE");
+    if (we && we[0] == '0') sm.remap = 2;
+  }
   if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
   if (g->precision != 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);

@@ -376,6 +376,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_pipe_kernel(
     if (remap_vec_ok(sm, Cz))
       gemm_epilogue_rows_remap_vec(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane, bias,
                                    act, accumulate, sm);
+    else if (remap_wide_ok(sm))
+      gemm_epilogue_rows_remap_wide(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane,
+                                    splitk == 1 ? bias : nullptr, splitk == 1 ? act : 0, accumulate, sm);
     else
     gemm_epilogue_rows_remap(acc, stage, Cz, M, N, m0 + (int64_t)wm * 64, n0 + (int64_t)wn * 64, lane,
                              splitk == 1 ? bias : nullptr, splitk == 1 ? act : 0, accumulate, sm);
@@ -680,6 +683,9 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
       else if (remap_vec_ok(sm, C))
         gemm_epilogue_rows_remap_vec(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
                                      lane, bias, act, accumulate, sm);
+      else if (remap_wide_ok(sm))
+        gemm_epilogue_rows_remap_wide(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
+                                      lane, bias, act, accumulate, sm);
       else
         gemm_epilogue_rows_remap(a2, stage, C, M, N, m0 + (int64_t)wm * 128 + ih * 64, n0 + (int64_t)wn * 64,
                                  lane, bias, act, accumulate, sm);

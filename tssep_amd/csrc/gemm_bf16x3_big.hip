@@ -364,6 +364,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
         gemm_epilogue_rows(a2, stage, C, M, N, mr, nc, lane, bias, act, accumulate, sm.ldc, true, sm.aux, sm.ldaux);
       else if (remap_vec_ok(sm, C))
         gemm_epilogue_rows_remap_vec(a2, stage, C, M, N, mr, nc, lane, bias, act, accumulate, sm);
+      else if (remap_wide_ok(sm))
+        gemm_epilogue_rows_remap_wide(a2, stage, C, M, N, mr, nc, lane, bias, act, accumulate, sm);
       else
         gemm_epilogue_rows_remap(a2, stage, C, M, N, mr, nc, lane, bias, act, accumulate, sm);
     }

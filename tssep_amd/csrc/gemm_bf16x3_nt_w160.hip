@@ -167,6 +167,7 @@ __global__ __launch_bounds__(UNT, 2) void gemm_bf16x3_nt_w160_kernel(
     const int64_t mr = m0 + (int64_t)wave * 64, nc = n0 + jh * 64;
     if (!sm.remap) gemm_epilogue_rows(a2, stage, C, M, nlim, mr, nc, lane, bias, act, accumulate, sm.ldc, true, sm.aux, sm.ldaux);
     else if (remap_vec_ok(sm, C)) gemm_epilogue_rows_remap_vec(a2, stage, C, M, nlim, mr, nc, lane, bias, act, accumulate, sm);
+    else if (remap_wide_ok(sm)) gemm_epilogue_rows_remap_wide(a2, stage, C, M, nlim, mr, nc, lane, bias, act, accumulate, sm);
     else gemm_epilogue_rows_remap(a2, stage, C, M, nlim, mr, nc, lane, bias, act, accumulate, sm);
   }
 }

@@ -328,6 +328,100 @@ __device__ __forceinline__ void gemm_epilogue_rows_remap_vec(const f32x16 (&acc)
   }
 }
 
+// Wide variant of the remapped store for everything the vector variant above does not take -- column groups that are
+// not multiples of four floats and / or a permutation table (the logit layer: net.py:629-666, 928-967 -- 513 bins per
+// speaker, speakers un-permuted per utterance; K = 320, so the 4-byte-per-lane stores of the scalar variant were a third
+// of the kernel: 181 TFLOP/s).  Same 16-byte lanes as gemm_epilogue_rows: a lane's four consecutive columns go out as
+// ONE store wherever they lie in one column group -- at a 4-byte-aligned address (global memory takes unaligned
+// vectors) -- and one by one where they straddle two groups (one lane in cm / 4) or the matrix edge.  A 64-row block
+// spans at most two utterances (T >= 64): the column offsets of both are computed once per lane, rows follow from
+// the block's first row by carries.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// (StoreMap::remap == 2: the dispatcher's TSSEP_GEMM_REMAP_WIDE=0 -- the scalar variant, for alternating A/Bs)
+__device__ __forceinline__ bool remap_wide_ok(const StoreMap& sm) { return sm.remap == 1 && sm.T >= 64 && sm.cm >= 4; }
+__device__ __forceinline__ void gemm_epilogue_rows_remap_wide(const f32x16 (&acc)[2][2], float* __restrict__ stage,
+                                                              float* __restrict__ Cz, int64_t M, int64_t N,
+                                                              int64_t mrow0, int64_t ncol0, int lane,
+                                                              const float* __restrict__ bias, int act,
+                                                              int accumulate, const StoreMap& sm) {
+  const int col = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * EPITCH + j * 32 + col] = acc[i][j][e];
+  const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+  const int64_t n = ncol0 + c4;
+  if (n >= N || mrow0 >= M) return;
+  const int64_t cq0 = n / sm.cm;
+  const int cr0 = (int)(n - cq0 * sm.cm);
+  const bool one = n + 3 < N && cr0 + 3 < sm.cm;          // the four columns: inside the matrix and in one group
+  // wave-uniform decomposition of the block's first row; the utterance of its last row (at most one further)
+  const int64_t q0 = mrow0 / sm.T;
+  const int t0 = (int)(mrow0 - q0 * sm.T);
+  const int64_t b0 = q0 / sm.K;
+  const int k0 = (int)(q0 - b0 * sm.K);
+  const int64_t mlast = (mrow0 + 63 < M ? mrow0 + 63 : M - 1);
+  const int64_t b1 = mlast / sm.T / sm.K;
+  // column offsets of the lane's four columns for utterance b0 ([0]) and b1 ([1])
+  int64_t cof[2][4];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool wrap = cr0 + q >= sm.cm;
+    const int64_t cq = cq0 + (wrap ? 1 : 0);
+    const int64_t cr = cr0 + q - (wrap ? sm.cm : 0);
+    const bool in = n + q < N;
+    cof[0][q] = ((sm.perm && in) ? (int64_t)sm.perm[b0 * sm.perm_ld + cq] : cq) * sm.co + cr;
+    cof[1][q] = ((sm.perm && in) ? (int64_t)sm.perm[b1 * sm.perm_ld + cq] : cq) * sm.co + cr;
+    if (bias && in) bv[q] = bias[n + q];
+  }
+  const bool auxvec = one && ((sm.ldaux & 3) == 0) && ((((uintptr_t)sm.aux) & 15) == 0);
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int row = r * 4 + r0;
+    const int64_t m = mrow0 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * EPITCH + c4);
+    if (m >= M) continue;
+    int t = t0 + row, k = k0;
+    int64_t b = b0;
+    if (t >= sm.T) { t -= (int)sm.T; ++k; }
+    if (k >= sm.K) { k -= (int)sm.K; ++b; }
+    v += bv;
+    if (act == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+    }
+    if (act == 2) {
+      const float* ya = sm.aux + m * sm.ldaux + n;
+      if (auxvec) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(ya);
+        v *= 1.f - y * y;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (n + q < N) v[q] *= 1.f - ya[q] * ya[q];
+      }
+    }
+    float* rowp = Cz + b * sm.sb + k * sm.sk + t * sm.st;
+    const bool second = b != b0;
+    if (one) {
+      float* dst = rowp + (second ? cof[1][0] : cof[0][0]);
+      if (accumulate) v += *reinterpret_cast<const f32x4u*>(dst);
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4u*>(dst));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (n + q < N) {
+          float* dst = rowp + (second ? cof[1][q] : cof[0][q]);
+          *dst = accumulate ? *dst + v[q] : v[q];
+        }
+    }
+  }
+}
+
 // ---- pieces shared by the split-bf16 kernels (gemm_bf16x3.hip, gemm_bf16x3_stream.hip) -------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));

@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       constexpr bool IO = decltype(io_tag)::value;
       constexpr int S = decltype(slot_tag)::value, P = decltype(grp_tag)::value;
       if (st >= T) return;                                     // (T tail of NGA < 4; uniform)
+      constexpr int FGAT = NGA == 2 ? ONCHIP16_FWD_GATHER : 0;
       f32x4* rg = ring_of(slot_tag);
       if constexpr (!IO) {
         // (NGA = 4: this phase's h was decoded into the operand image behind the previous phase's publish -- below --
@@ -1144,7 +1145,6 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       lds_barrier();
       if (s_fail) return;
       // (group, step) of the next phase and of the phase after it
-      constexpr int FGAT = NGA == 2 ? ONCHIP16_FWD_GATHER : 0;
       constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
       const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
       constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
@@ -1204,7 +1204,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       if constexpr (!IO) {
         if (!(ONCHIP16_ABL & 8)) {
           publish(P, st);
-          if (NGA < 4) {      // (two groups: the next phase wants the h published a phase ago -- decoding it here only spins)
+          if (NGA < 4) {
+            // (two groups: the next phase's h is decoded in front of its barrier -- decoding it here, behind the publish,
+            // measured slower even with the early request: 1.42 -> 1.50 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
             if (FGAT == 0 && st1 > 0 && st1 < T) gather_issue(P1, st1);
           } else {
             // the NEXT phase's h (requested one phase ago) -> its operand image, while the io waves flush; then the
