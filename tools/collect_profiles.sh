@@ -24,7 +24,7 @@ for b in 8 32 64 128 256 384 512 768 1152 1536; do
   python bench.py --batch $b --steps 20 --warmup 4 $B 2>/dev/null | tail -1
 done > $O/batch_sweep.jsonl
 # round-3 kernel changes, each alternating off / on in this one job (the switches are read per call)
-for var in TSSEP_GEMM_STREAM TSSEP_GEMM_BIG TSSEP_GEMM_TN_BIG TSSEP_GEMM_TN_W160 TSSEP_GEMM_TN_XC TSSEP_ONCHIP16 TSSEP_ONCHIP16_BWD; do
+for var in TSSEP_GEMM_STREAM TSSEP_GEMM_BIG TSSEP_GEMM_NT_W160 TSSEP_GEMM_REMAP_WIDE TSSEP_GEMM_TN_BIG TSSEP_GEMM_TN_W160 TSSEP_GEMM_TN_H160 TSSEP_GEMM_TN_XC TSSEP_ONCHIP16 TSSEP_ONCHIP16_BWD; do
   for w in 0 1 0 1; do env $var=$w python bench.py --steps 15 --warmup 3 $B 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(dict(switch='$var', value=$w, frames_per_s=d['value'], ms_per_step=d['ms_per_step'], ms_per_step_median=d['ms_per_step_median'], gemm_tflops=d['roofline']['achieved'], mask_head_frac=d['roofline_mask_head']['frac'])))"; done
 done > $O/ab_gemm_kernels.jsonl
