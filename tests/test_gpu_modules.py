@@ -136,6 +136,66 @@ def test_model_end_to_end_against_oracle(res, loss_name, gemm_mode):
         close(v.grad, ref, rtol=1e-3, atol=1e-3 * scale + 1e-9, name="d" + k)
 
 
+@pytest.mark.parametrize("res,loss_name", [("tf", "LogMAE"), ("t", "VADSigmoidBCE")])
+def test_review_snapshot_branch(res, loss_name):
+    """``create_snapshot`` (model.py:692-752, loss.py:148-169): the summary carries the audios / images the reference
+    names -- estimates per batch entry, the observation, its STFT, the mask of the first example, the STFT estimate, one
+    image per loss target (and, for the VAD loss, the mask framed by the target activity) -- each the selected batch
+    entry as [freq-like, time]; the loss and its gradients are those of the step without the snapshot."""
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    from tssep_amd.data import DummyReader
+    from oracle import stft as ostft
+    B, K, N = 2, 3, 5000
+    obs, aux, tgt, vad = _example_batch(B, K, N)
+    T = ostft.num_frames(N)
+    Vad = vad.view(B, K, N)[..., ::256][..., :T]
+    Vad = torch.nn.functional.pad(Vad, (0, T - Vad.shape[-1]))
+    torch.manual_seed(0)
+    m = model.Model(
+        fe=fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"), reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=513, odim=513, units=12, projs=16, combination="mul",
+                                            aux_net_output_size=513, ts_vad=K, output_resolution=res),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE() if loss_name == "LogMAE" else loss.VADSigmoidBCE()).cuda()
+    results = {}
+    for snap in (False, True):
+        m.zero_grad()
+        m.create_snapshot = snap
+        ex = dict(observation=obs.cuda(), auxInput=aux.cuda(), reference_channel=0,
+                  speaker_reverberation_early_ch0=tgt.cuda(), Vad=Vad.cuda(), dataset=["v"] * B)
+        np.random.seed(3)
+        out = m(ex)
+        summary = m.review(ex, out)
+        summary["loss"].backward()
+        results[snap] = (summary, {k: v.grad.clone() for k, v in m.named_parameters() if v.grad is not None}, out)
+    plain, snap = results[False][0], results[True][0]
+    assert "audios" not in plain and "images" not in plain
+    close(snap["loss"], plain["loss"], rtol=1e-6, atol=1e-7, name="loss with snapshot")
+    for k, g in results[False][1].items():
+        close(results[True][1][k], g, rtol=1e-5, atol=1e-7 * float(g.abs().max()) + 1e-12, name="d" + k)
+    audios, images = snap["audios"], snap["images"]
+    assert set(audios) == {f"Masking_audio_est_{i}" for i in range(B)} | {"Masking_audio_observation"}
+    for a, sr in audios.values():
+        assert sr == 16000 and a.dim() == 1 and a.numel() == N and abs(float(a.abs().max()) - 0.95) < 1e-5
+    target_name = "Speaker_reverberation_early_ch0" if loss_name == "LogMAE" else "Vad"
+    want = {"Masking_Observation", "v_Masking_mask", "Masking_stft_estimate", f"Masking_target_{target_name}"}
+    if loss_name != "LogMAE":
+        want.add("Masking_mask")
+    assert set(images) == want, set(images)
+    out = results[True][2]
+    Fm = out.mask.shape[-1]
+    assert images["Masking_Observation"].shape == (513, T)
+    assert images["v_Masking_mask"].shape == (K * out.mask.shape[-3] * Fm, T)
+    assert images["Masking_stft_estimate"].shape == (K * 513, T)
+    assert images[f"Masking_target_{target_name}"].shape == (K * (513 if loss_name == "LogMAE" else 40), T)
+    if loss_name != "LogMAE":
+        assert images["Masking_mask"].shape == (K * out.mask.shape[-3] * (Fm + 80), T)
+    for im in images.values():
+        assert float(im.min()) >= 0.0 and float(im.max()) <= 1.0 + 1e-6
+    # the mask image is the first example's mask, frequency axis upwards
+    first = out.mask[0].detach().permute(2, 0, 1, 3).reshape(T, -1).t().flip(0).cpu()
+    close(images["v_Masking_mask"], first.clamp(0, 1), rtol=0, atol=0, name="mask image")
+
+
 def test_long_form_8_speakers_against_oracle():
     """BASELINE configs[4] sizes: 8 speakers, 30 s @ 16 kHz (T = 1878 frames), units 300 / projs 320,
     one utterance: the whole step (default split-bf16 GEMMs, on-chip recurrences at N = 8 and

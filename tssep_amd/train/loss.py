@@ -71,6 +71,14 @@ class LogitsSTFTDomain(ABC):
                 raise NotImplementedError(self.target)
         return self(estimate, ex[self.target])
 
+    def update_summary(self, summary, ex, out, model):   # loss.py:148-169: the mask image framed by the target activity
+        import einops
+        target_vad = einops.repeat(self.prepare_target(torch.as_tensor(ex[self.target])).to(out.mask.device, torch.float32),
+                                   "... spk time -> ... spk mask time freq", freq=40, mask=out.mask.shape[-3])
+        masks = torch.concat([target_vad, out.mask.detach(), target_vad], dim=-1)
+        summary.add_mask_image(f"{model.enhancer.name}_mask", masks,
+                               rearrange="... spk mask time freq -> ... time (spk mask freq)", batch_first=True)
+
 
 class VADSigmoidBCE(LogitsSTFTDomain):
     def __init__(self, target: str = "Vad", pit: bool = False, magnitude_threshold: float = 0.05):

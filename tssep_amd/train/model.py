@@ -1,5 +1,5 @@
-"""Model -- drop-in for tssep/train/model.py: ``forward`` (:465-536) and the loss part of
-``review`` (:653-690) on the HIP kernels; the dataset helpers follow :182-370 stage by stage on
+"""Model -- drop-in for tssep/train/model.py: ``forward`` (:465-536) and ``review`` (:653-752: the loss part on the
+HIP kernels, the snapshot branch as plain tensor glue); the dataset helpers follow :182-370 stage by stage on
 ``tssep_amd.dataset`` (lazy map / shuffle / batch / threaded prefetch, pinned asynchronous H2D)."""
 import dataclasses
 import functools
@@ -27,6 +27,42 @@ class ReviewSummary(dict):
     def add_histogram(self, name, values):
         self.setdefault("histograms", {}).setdefault(name, []).append(
             values.detach() if isinstance(values, torch.Tensor) else values)
+
+    # ---- snapshot members (model.py:692-752 calls them when ``create_snapshot`` is set).  padertorch is not in this
+    # image: the reference's versions render colour images for tensorboard; these keep the DATA such an image shows --
+    # the selected batch entry, rearranged as asked -- so that a writer can render it (parity of the rendering: unpinned)
+    @staticmethod
+    def _select(signal, batch_first):
+        signal = signal.detach() if isinstance(signal, torch.Tensor) else torch.as_tensor(np.asarray(signal))
+        if batch_first is True:
+            return signal[0]
+        if batch_first is False:
+            return signal[:, 0]
+        return signal
+
+    def add_audio(self, name, signal, sampling_rate=16000, batch_first=None, normalize=True):
+        audio = self._select(signal, batch_first).to(torch.float32).reshape(-1)
+        if normalize:
+            audio = audio * (0.95 / torch.clamp(audio.abs().max(), min=1e-30))
+        self.setdefault("audios", {})[name] = (audio.cpu(), sampling_rate)
+
+    def _image(self, name, signal, batch_first, rearrange):
+        signal = self._select(signal, batch_first)
+        if rearrange is not None:
+            import einops
+            signal = einops.rearrange(signal, rearrange)
+        assert signal.dim() == 2, (name, tuple(signal.shape))
+        self.setdefault("images", {})[name] = signal.transpose(0, 1).flip(0).cpu()      # [freq (top = high), time]
+
+    def add_stft_image(self, name, signal, batch_first=None, rearrange=None):
+        signal = signal.detach() if isinstance(signal, torch.Tensor) else torch.as_tensor(np.asarray(signal))
+        mag = signal.abs().to(torch.float32)
+        mag = torch.log10(torch.clamp(mag / torch.clamp(mag.max(), min=1e-30), min=1e-3)) / 3 + 1     # 60 dB below the peak -> [0, 1]
+        self._image(name, torch.clamp(mag, 0, 1), batch_first, rearrange)
+
+    def add_mask_image(self, name, mask, batch_first=None, rearrange=None):
+        mask = mask.detach() if isinstance(mask, torch.Tensor) else torch.as_tensor(np.asarray(mask))
+        self._image(name, torch.clamp(mask.to(torch.float32), 0, 1), batch_first, rearrange)
 
 
 class Model(Configurable, torch.nn.Module):
@@ -325,4 +361,33 @@ class Model(Configurable, torch.nn.Module):
                     summary.add_histogram(f"hist_{dataset_name}_{name}", lv)
             else:
                 raise NotImplementedError(loss_value.ndim, loss_value.shape)
+            has_batch_dim = loss_value.ndim == 1
+            if self.create_snapshot:                                      # model.py:692-752
+                enh = self.enhancer.name
+                if out.time_estimate is not None:
+                    for i, e in enumerate(out.time_estimate):
+                        summary.add_audio(f"{enh}_audio_est_{i}", e, sampling_rate=self.reader.sample_rate, batch_first=True)
+                if "observation" in ex:
+                    summary.add_audio(f"{enh}_audio_observation", ex["observation"][ex["reference_channel"]],
+                                      sampling_rate=self.reader.sample_rate, batch_first=True)
+                if "Observation" in ex:
+                    summary.add_stft_image(f"{enh}_Observation", ex["Observation"][ex["reference_channel"]], batch_first=True)
+                dataset_name = ex["dataset"][0] if has_batch_dim else ex["dataset"]
+                masks = out.mask                      # (materialises mask / stft_estimate: the snapshot looks at them)
+                summary.add_mask_image(f"{dataset_name}_{enh}_mask", masks[0] if has_batch_dim else masks,
+                                       rearrange="spk mask time freq -> time (spk mask freq)", batch_first=None)
+                if out.stft_estimate is not None:
+                    summary.add_stft_image(f"{enh}_stft_estimate", out.stft_estimate,
+                                           rearrange="... spk time freq -> ... time (spk freq)", batch_first=True)
+                for target_name in self.loss.targets(upper=True):
+                    if target_name == "Vad":
+                        import einops
+                        target = einops.repeat(torch.as_tensor(ex[target_name]), "... -> ... freq", freq=40)
+                    elif target_name in ex:
+                        target = ex[target_name]
+                    else:
+                        target = self.fe.stft(ex[target_name.lower()])
+                    summary.add_stft_image(f"{enh}_target_{target_name}", target,
+                                           rearrange="... spk time freq -> ... time (spk freq)", batch_first=True)
+                self.loss.update_summary(summary, ex, out, self)
         return summary
