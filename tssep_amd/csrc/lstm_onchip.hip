@@ -1275,6 +1275,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 // published those sums a phase earlier -- with ONE group per cluster they are this phase's own, so an early request only
 // finds stale tags and is repeated (7.8 -> 8.9 ms): position 0 there.  Two groups, 3 072 sequences: 7.1 -> 6.7 ms
 // (positions 2, 3, 5 equal; 1: 6.96), 768: 1.74 -> 1.56 (profiles/r3_onchip16_bwd_gather.jsonl).
+// 1: the partial sums of a wave's own two tiles are published straight from its accumulators behind its MFMAs (64-byte
+// runs per sequence); only the shared tiles (block 4) still go through LDS and the barrier
+#ifndef ONCHIP16_BWD_DIRECT
+#define ONCHIP16_BWD_DIRECT 1
+#endif
 #ifndef ONCHIP16_BWD_GATHER
 #define ONCHIP16_BWD_GATHER 2
 #endif
@@ -1482,7 +1487,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       const int slot = (int)(st & 1);
       EX_LANE();
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {           // unit block b = the 64 units of workgroup b
+      for (int b = ONCHIP16_BWD_DIRECT ? 4 : 0; b < 5; ++b) {           // unit block b = the 64 units of workgroup b
         f32x4 v = *reinterpret_cast<const f32x4*>(psum + s2 * PP2 + 64 * b + 4 * uq);
         if (b == 4) v += *reinterpret_cast<const f32x4*>(psum2 + s2 * OWNP + 4 * uq);
         const u32x2 ga = pack_granule(tag, v[0], v[1]), gb = pack_granule(tag, v[2], v[3]);
@@ -1501,7 +1506,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (!IO) {
         if (st > 0) gather_finish(S, P, st);
       } else {
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // this phase's tiles have landed (four stores + six copies behind them)
+        // this phase's tiles have landed (behind them: four stores + six copies, + the two direct publish stores)
+        if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
       lds_barrier();
       if (s_fail) return;
@@ -1588,10 +1594,32 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           }
         }
         const int j = lvm & 15, r4 = 4 * (lvm >> 4);
-        *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
-        *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + 16 + r4) = acc1;
+        if constexpr (ONCHIP16_BWD_DIRECT) {
+          // the wave's own two tiles (units 32 wave .. + 31 of block wave / 2) leave from the accumulators: a lane holds four
+          // consecutive units of one sequence = one 16-byte pair of granules; no LDS round trip, no barrier in front
+          const int bw = wave >> 1;
+          const auto prs = payload_srd(P);
+          const unsigned tag = tagbase | (unsigned)(st + 1);
+          const unsigned off = (unsigned)(((((int)(st & 1) * G + g) * SQ + j) * Hp + 32 * wave + r4) * 4);
+          const u32x2 a0 = pack_granule(tag, acc0[0], acc0[1]), a1 = pack_granule(tag, acc0[2], acc0[3]);
+          const u32x2 c0 = pack_granule(tag, acc1[0], acc1[1]), c1 = pack_granule(tag, acc1[2], acc1[3]);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], a1[0], a1[1]}, prs, (int)(bw != g ? off : OOR), 0, SC0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0[0], c0[1], c1[0], c1[1]}, prs, (int)(bw != g ? off + 64u : OOR), 0, SC0);
+          if (bw == g) {
+            *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + r4) = acc0;
+            *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + 16 + r4) = acc1;
+          }
+        } else {
+          *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
+          *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + 16 + r4) = acc1;
+        }
         float* sh = (wave & 1) ? psum2 + j * OWNP : psum + j * PP2 + 256;
         *reinterpret_cast<f32x4*>(sh + 16 * (wave >> 1) + r4) = accs;
+      } else if constexpr (IO && ONCHIP16_BWD_DIRECT) {
+        // (last step: the io waves' vector-memory count per phase must not depend on the step)
+        const auto prs = payload_srd(P);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, prs, (int)OOR, 0, SC0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, prs, (int)OOR, 0, SC0);
       }
       lds_barrier();
       if constexpr (!IO) {
