@@ -1328,7 +1328,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float ringd[4][SQ * UPW];         // dh (+ partial sums)
   __shared__ __attribute__((aligned(16))) char dg_hi[SQ * DP2];
   __shared__ __attribute__((aligned(16))) char dg_lo[SQ * DP2];
-  __shared__ __attribute__((aligned(16))) float psum[SQ * PP2];             // [seq][unit] partial dh (shared tiles: k half 0)
+  // [seq][unit] partial dh, k half 0 of the shared tiles (with the direct publish only those: units 256 .. 319)
+  constexpr int PSW = ONCHIP16_BWD_DIRECT ? OWNP : PP2, PSO = ONCHIP16_BWD_DIRECT ? 0 : 256;
+  __shared__ __attribute__((aligned(16))) float psum[SQ * PSW];
+  // the peers' + the own partial sums of this phase's dh, added to the dh tile by the cell backward.  (NOT added into the
+  // ring slot by the exchange waves: they run in front of the barrier that follows the io waves' `vmcnt` wait, i.e.
+  // nothing orders their read of the slot behind the asynchronous copy that fills it)
+  __shared__ __attribute__((aligned(16))) float dsum[SQ * UPW];
   __shared__ __attribute__((aligned(16))) float psum2[SQ * OWNP];           // shared tiles, k half 1: [seq][unit - 256]
   __shared__ __attribute__((aligned(16))) float pown[NGA * SQ * OWNP];      // own 64 units of every group
   __shared__ int s_fail, s_mem[4];
@@ -1470,7 +1476,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       }
       if (fail) s_fail = 1;
       // fixed order: sources 0 .. G - 1 ascending, the own partial in its place (value selects between static elements)
-      f32x4 acc = *reinterpret_cast<const f32x4*>(&ringd[S][s2 * UPW + 4 * uq]);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const f32x4 own = *reinterpret_cast<const f32x4*>(pown + (p * SQ + s2) * OWNP + 4 * uq);
 #pragma unroll
       for (int gs = 0; gs < 5; ++gs) {
@@ -1479,7 +1485,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         const f32x4 pv = {granule_a(w[0], w[1]), granule_b(w[1]), granule_a(w[2], w[3]), granule_b(w[3])};
         acc += gs == g ? own : pv;
       }
-      *reinterpret_cast<f32x4*>(&ringd[S][s2 * UPW + 4 * uq]) = acc;
+      *reinterpret_cast<f32x4*>(&dsum[s2 * UPW + 4 * uq]) = acc;
     };
     auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       EX_LANE();
 #pragma unroll
       for (int b = ONCHIP16_BWD_DIRECT ? 4 : 0; b < 5; ++b) {           // unit block b = the 64 units of workgroup b
-        f32x4 v = *reinterpret_cast<const f32x4*>(psum + s2 * PP2 + 64 * b + 4 * uq);
+        f32x4 v = *reinterpret_cast<const f32x4*>(psum + s2 * PSW + 64 * b - (ONCHIP16_BWD_DIRECT ? 256 : 0) + 4 * uq);
         if (b == 4) v += *reinterpret_cast<const f32x4*>(psum2 + s2 * OWNP + 4 * uq);
         const u32x2 ga = pack_granule(tag, v[0], v[1]), gb = pack_granule(tag, v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
@@ -1525,7 +1531,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         asm volatile("" : "+v"(tv));
         const int s = tv >> 5, up = tv & 31;
         const bool valid = seq0_of(P) + s < N && 64 * g + 2 * up < H;
-        const float2 dh = *reinterpret_cast<const float2*>(&ringd[S][s * UPW + 2 * up]);
+        float2 dh = *reinterpret_cast<const float2*>(&ringd[S][s * UPW + 2 * up]);
+        if (st > 0) {
+          const float2 ds = *reinterpret_cast<const float2*>(&dsum[s * UPW + 2 * up]);
+          dh.x += ds.x; dh.y += ds.y;
+        }
         const float2 cpv = has_prev ? *reinterpret_cast<const float2*>(&ringc[S][s * UPW + 2 * up]) : make_float2(0.f, 0.f);
         const float dhq[2] = {dh.x, dh.y}, cpq[2] = {cpv.x, cpv.y};
         f32x4 d[2];
@@ -1613,7 +1623,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
           *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + 16 + r4) = acc1;
         }
-        float* sh = (wave & 1) ? psum2 + j * OWNP : psum + j * PP2 + 256;
+        float* sh = (wave & 1) ? psum2 + j * OWNP : psum + j * PSW + PSO;
         *reinterpret_cast<f32x4*>(sh + 16 * (wave >> 1) + r4) = accs;
       } else if constexpr (IO && ONCHIP16_BWD_DIRECT) {
         // (last step: the io waves' vector-memory count per phase must not depend on the step)
