@@ -315,3 +315,31 @@ def test_stft_vad_is_a_sampling_of_the_activity_at_the_frame_centres(wl, sh, fad
     want = np.zeros((6, frames), dtype=bool)
     want[:, ok] = v[:, idx[ok]]
     np.testing.assert_array_equal(stft_vad(v, wl, sh, fading), want)
+
+
+def test_review_summary_snapshot_members():
+    """The snapshot members of ReviewSummary (model.py:692-752 calls them): the selected batch entry, rearranged as the
+    reference asks, as a [freq-like (top = high), time] array in [0, 1]; audios normalised to 0.95 peak."""
+    from tssep_amd.train.model import ReviewSummary
+    s = ReviewSummary()
+    x = torch.arange(2 * 3 * 5 * 4, dtype=torch.float32).reshape(2, 3, 5, 4) / 100       # [batch, spk, time, freq]
+    s.add_audio("a", torch.tensor([[0.1, -0.5, 0.25], [9.0, 9.0, 9.0]]), sampling_rate=8000, batch_first=True)
+    a, sr = s["audios"]["a"]
+    assert sr == 8000 and torch.allclose(a, torch.tensor([0.19, -0.95, 0.475]))
+    s.add_mask_image("m", x, rearrange="... spk time freq -> ... time (spk freq)", batch_first=True)
+    m = s["images"]["m"]
+    assert m.shape == (3 * 4, 5)
+    want = x[0].permute(1, 0, 2).reshape(5, 12).t().flip(0).clamp(0, 1)
+    assert torch.equal(m, want)
+    s.add_mask_image("m2", x[0], rearrange="spk time freq -> time (spk freq)", batch_first=None)
+    assert torch.equal(s["images"]["m2"], want)
+    X = torch.complex(torch.randn(2, 6, 7), torch.randn(2, 6, 7))                            # [batch, time, freq]
+    s.add_stft_image("S", X, batch_first=True)
+    im = s["images"]["S"]
+    assert im.shape == (7, 6) and float(im.min()) >= 0 and float(im.max()) <= 1
+    # 60 dB below the peak of the WHOLE signal -> 0, the peak -> 1; frequency axis upwards
+    mag = X.abs()
+    ref = (torch.log10(torch.clamp(mag / mag.max(), min=1e-3)) / 3 + 1).clamp(0, 1)[0].t().flip(0)
+    assert torch.allclose(im, ref, atol=1e-6)
+    s.add_scalar("x", 1.0)
+    assert set(s) == {"audios", "images", "scalars"}
