@@ -15,6 +15,7 @@
 // ds_read_b128 per 32 rows and 8 MFMA steps.  The [BK+4]-float row pitch makes
 // those reads bank-conflict free (pitch 80 B: 16-B slot index 5*row mod 16 is a
 // bijection over the 16 rows of a ds_read_b128 lane group).
+#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
     int64_t b_kshift, int64_t kperiod, const float* __restrict__ bias, int act, int accumulate,
-    StoreMap sm, int splitk, int64_t c_split_stride, int64_t n_begin, TileMap tmap) {
+    StoreMap sm, int splitk, int64_t c_split_stride, int64_t n_begin, TileMap tmap, int rows_epilogue) {
   __shared__ __attribute__((aligned(16))) float lds[2][2][OP_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int TM = NARROW ? 1 : 2, TN = NARROW ? 1 : 2, BNT = NARROW ? 32 : BN;
@@ -243,6 +244,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
   }
 
   float* Cz = C + (int64_t)zsplit * c_split_stride;
+  if constexpr (!NARROW) {
+    // the row-transposed store of the split-bf16 kernels (16 bytes per lane instead of 4: gemm_common.h), two waves at
+    // a time through the operand stages (4 x 64 x 68 floats do not fit the 40 KB of LDS at once); TSSEP_GEMM_F32_ROWS=0
+    // keeps the direct store
+    static_assert(2 * 64 * EPITCH <= 4 * OP_FLOATS, "two epilogue scratches must fit in the operand stages");
+    if (rows_epilogue) {
+      float* stage = &lds[0][0][0] + (wave & 1) * 64 * EPITCH;
+      const int64_t mr = m0 + (int64_t)wm * 64, nc = n0 + (int64_t)wn * 64;
+      const float* eb = splitk == 1 ? bias : nullptr;
+      const int ea = splitk == 1 ? act : 0;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if ((wave >> 1) == pass) {
+          if (!sm.remap) gemm_epilogue_rows(acc, stage, Cz, M, N, mr, nc, lane, eb, ea, accumulate, sm.ldc, splitk == 1, sm.aux, sm.ldaux);
+          else if (remap_vec_ok(sm, Cz)) gemm_epilogue_rows_remap_vec(acc, stage, Cz, M, N, mr, nc, lane, eb, ea, accumulate, sm);
+          else if (remap_wide_ok(sm)) gemm_epilogue_rows_remap_wide(acc, stage, Cz, M, N, mr, nc, lane, eb, ea, accumulate, sm);
+          else gemm_epilogue_rows_remap(acc, stage, Cz, M, N, mr, nc, lane, eb, ea, accumulate, sm);
+        }
+        if (pass == 0) __syncthreads();
+      }
+      return;
+    }
+  }
   gemm_epilogue<TM, TN>(acc, Cz, M, N, m0 + (int64_t)wm * TM * 32, n0 + (int64_t)wn * TN * 32, lane,
                         bias, act, accumulate, sm, splitk == 1);
 }
@@ -274,6 +298,8 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   // under-filled already, a second serialized launch would only add a tail
   if (rem > 96 || splitk > 1) n_main = g->N;
   const bool shift = g->kperiod > 0;
+  const char* re_ = getenv("TSSEP_GEMM_F32_ROWS");          // read per call (alternating A/B): 0 = the direct 4-byte-per-lane store
+  const int rows_epi = (re_ && re_[0] == '0') ? 0 : 1;
 #define LAUNCH(AK, BKM, SH, NARROW, GRIDX, NBEGIN)                                                 \
   do {                                                                                             \
     const TileMap tm_ = make_tile_map(mtiles, (GRIDX), splitk);                                    \
@@ -281,7 +307,7 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
                        dim3((unsigned)tile_map_blocks(tm_)), dim3(NTHREADS), 0, s, g->A, g->B,     \
                        g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift, g->kperiod, g->bias,   \
                        g->act, g->accumulate, sm, splitk, g->c_split_stride, (int64_t)(NBEGIN),    \
-                       tm_);                                                                       \
+                       tm_, rows_epi);                                                             \
   } while (0)
 #define DISPATCH(NARROW, GRIDX, NBEGIN)                                                            \
   do {                                                                                             \
