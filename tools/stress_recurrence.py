@@ -2,7 +2,7 @@
 buffers, small and large, with a weight-gradient-like GEMM stream running beside them; every launch must
 reproduce the first launch of its shape bit for bit and never raise the timeout flag.  Guards the granule
 tag scheme (5-bit launch epoch in 16-bit tags) against stale cache lines of earlier launches.
-usage: python tools/stress_recurrence.py [iterations]"""
+usage: python tools/stress_recurrence.py [iterations] [full]"""
 import json
 import os
 import sys
@@ -19,6 +19,8 @@ wf16 = h.lstm_pack_onchip16(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 wb16 = h.lstm_pack_onchip16_bwd(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 cf, cb = h.lstm_pack_cluster(lstm.weight_hh_l0, lstm.weight_hh_l0_reverse, Hh)
 shapes = [(8, 5), (8, 40), (40, 17), (200, 30), (768, 12), (1600, 9), (3072, 6)]
+if len(sys.argv) > 2 and sys.argv[2] == "full":        # the step's own shapes: 253 steps, full residency, HBM-bound side stream
+    shapes = [(3072, 253), (768, 253)]
 state = {}
 for N, T in shapes:
     g0 = torch.randn(N * T, 8 * Hh, device="cuda") * 0.5
