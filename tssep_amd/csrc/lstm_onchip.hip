@@ -1216,6 +1216,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
           }
         }
       } else if (!(ONCHIP16_ABL & 4)) {
+        // (storing the activations a phase later, beside the next phase's MFMAs -- what the backward does with its d(gates) --
+        // measured SLOWER here: 1.37 -> 1.49 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
         io_flush(slot_tag, P, st);
         // (beyond the last step the copy is repeated for step T - 1 into a slot nobody reads any more: every phase
         // queues exactly four copies, or `vmcnt(10)` above would not cover the tiles of the last phases)
@@ -1279,6 +1281,10 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 // runs per sequence); only the shared tiles (block 4) still go through LDS and the barrier
 #ifndef ONCHIP16_BWD_DIRECT
 #define ONCHIP16_BWD_DIRECT 1
+#endif
+// 1: the io waves store a phase's d(gates) during the NEXT phase's MFMA section instead of right behind its last barrier
+#ifndef ONCHIP16_BWD_DEFER_FLUSH
+#define ONCHIP16_BWD_DEFER_FLUSH 1
 #endif
 #ifndef ONCHIP16_BWD_GATHER
 #define ONCHIP16_BWD_GATHER 2
@@ -1428,7 +1434,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       dma16(hb, L.f4 ? L.hoff : 0u, &ringd[S][iow * 256]);
     };
     // d(gates) of (group p, step st) from ring slot S -> HBM: four stores
-    auto io_flush = [&](int S, int p, int64_t st) __attribute__((always_inline)) {
+    // (`live` = false: the same four stores out of range -- the vector-memory count per phase must not depend on the step)
+    auto io_flush = [&](int S, int p, int64_t st, bool live) __attribute__((always_inline)) {
       const IoLane L = io_lane(p);
       const auto rs = srd_at(reinterpret_cast<char*>(gates) + ((rowb(p, t_of(st)) * 2 + dir) * (int64_t)H + 64 * g) * 16);
 #pragma unroll
@@ -1436,7 +1443,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         int lvf = lane;
         asm volatile("" : "+v"(lvf));
         const f32x4 v = ringg[S][(q * 4 + iow) * 64 + lvf];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(L.uok[q] ? L.goff0 + q * 256 : OOR), 0, NT ? 2 : 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)((live && L.uok[q]) ? L.goff0 + q * 256 : OOR), 0, NT ? 2 : 0);
       }
     };
 
@@ -1571,6 +1578,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (!IO && (GAT >= 2)) {
         if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
       }
+      if constexpr (IO && ONCHIP16_BWD_DEFER_FLUSH) {
+        // the d(gates) of the PREVIOUS phase leave here, beside the MFMAs, not between two phases where the publish waits
+        // for issue slots (its ring slot is refilled a phase later)
+        constexpr int SP = (S + 3) & 3, PP = SP % NGA;
+        const int64_t stp = (SP == 3 ? base - 4 / NGA : base) + SP / NGA;
+        const bool livep = stp >= 0 && stp < T;
+        io_flush(SP, PP, livep ? stp : 0, livep);
+      }
       if (has_prev) {
         // partial dh_(t-1): two own tiles over 8 k-steps + 4 k-steps of a shared tile (three accumulator chains)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
@@ -1638,7 +1653,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           if (st1 > 0 && st1 < T) gather_issue(P1, st1);
         }
       } else {
-        io_flush(S, P, st);
+        if constexpr (!ONCHIP16_BWD_DEFER_FLUSH) io_flush(S, P, st, true);
         io_dma(I2, P2, st2 < T ? st2 : T - 1);
       }
     };
@@ -1659,7 +1674,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         if (s_fail) break;
       }
       if constexpr (IO) {
-        // the d(gates) of the last phase of every group still sit in the ring... they were flushed in their own phase
+        // (deferred flush: the last phase's d(gates) still sit in their ring slot)
+        if (ONCHIP16_BWD_DEFER_FLUSH && !s_fail) io_flush((int)((T * NGA - 1) & 3), NGA - 1, T - 1, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     };
