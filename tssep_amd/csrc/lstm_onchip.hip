@@ -1283,6 +1283,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 #define ONCHIP16_BWD_DIRECT 1
 #endif
 // 1: the io waves store a phase's d(gates) during the NEXT phase's MFMA section instead of right behind its last barrier
+// (two groups and more; with ONE group the publish chain is the critical path and the stores in front of the io waves'
+// MFMAs delay it: 0.74 -> 0.77 ms at 32 sequences)
 #ifndef ONCHIP16_BWD_DEFER_FLUSH
 #define ONCHIP16_BWD_DEFER_FLUSH 1
 #endif
@@ -1520,7 +1522,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         if (st > 0) gather_finish(S, P, st);
       } else {
         // this phase's tiles have landed (behind them: four stores + six copies, + the two direct publish stores)
-        if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
       lds_barrier();
       if (s_fail) return;
@@ -1578,13 +1581,15 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (!IO && (GAT >= 2)) {
         if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
       }
-      if constexpr (IO && ONCHIP16_BWD_DEFER_FLUSH) {
+      if constexpr (IO && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH) {
         // the d(gates) of the PREVIOUS phase leave here, beside the MFMAs, not between two phases where the publish waits
         // for issue slots (its ring slot is refilled a phase later)
         constexpr int SP = (S + 3) & 3, PP = SP % NGA;
         const int64_t stp = (SP == 3 ? base - 4 / NGA : base) + SP / NGA;
         const bool livep = stp >= 0 && stp < T;
         io_flush(SP, PP, livep ? stp : 0, livep);
+        // (requesting the tiles of phase + 2 here as well measured -5 % with ONE group at 768 / 3 072 sequences, +6 % at the 32
+        // sequences one group is used for, and +6 % with two groups: profiles/r3_onchip16_deferred_flush.jsonl -- not kept)
       }
       if (has_prev) {
         // partial dh_(t-1): two own tiles over 8 k-steps + 4 k-steps of a shared tile (three accumulator chains)
@@ -1653,7 +1658,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           if (st1 > 0 && st1 < T) gather_issue(P1, st1);
         }
       } else {
-        if constexpr (!ONCHIP16_BWD_DEFER_FLUSH) io_flush(S, P, st, true);
+        if constexpr (!(NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH)) io_flush(S, P, st, true);
         io_dma(I2, P2, st2 < T ? st2 : T - 1);
       }
     };
@@ -1675,7 +1680,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       }
       if constexpr (IO) {
         // (deferred flush: the last phase's d(gates) still sit in their ring slot)
-        if (ONCHIP16_BWD_DEFER_FLUSH && !s_fail) io_flush((int)((T * NGA - 1) & 3), NGA - 1, T - 1, true);
+        if (NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH && !s_fail) io_flush((int)((T * NGA - 1) & 3), NGA - 1, T - 1, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     };
