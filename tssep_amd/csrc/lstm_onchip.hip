@@ -928,6 +928,9 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 // 1 = behind the first barrier, k >= 2 = after k - 1 MFMA k-steps.  768 sequences 1.45 -> 1.36 ms, 1 536: 2.70 -> 2.50,
 // 3 072: 5.73 -> 5.43 (positions 1, 4, 7, 11 within noise of each other; profiles/r3_onchip16_fwd_gather.jsonl) --
 // two groups now beat four (2.63 / 5.65 ms, whose requests were two phases ahead already) at every size.
+#ifndef ONCHIP16_FWD_EARLY_DMA
+#define ONCHIP16_FWD_EARLY_DMA 1
+#endif
 #ifndef ONCHIP16_FWD_GATHER
 #define ONCHIP16_FWD_GATHER 4
 #endif
@@ -1140,7 +1143,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         // the tile of this phase has landed: it was requested two phases ago, and exactly six stores + four copies
         // (the previous phase's) were queued behind it -- those may still be in flight (a store acknowledgement
         // takes longer than a phase under load: waiting for them paced the whole kernel)
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        // (one group: the copies are requested at the START of a phase -- below -- so six more stores queue behind them)
+        if (NGA == 1 && ONCHIP16_FWD_EARLY_DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
       lds_barrier();
       if (s_fail) return;
@@ -1149,6 +1153,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       const int64_t b1 = I1 == 0 ? base + 4 / NGA : base, b2 = I2 < 2 ? base + 4 / NGA : base;
       constexpr int P1 = I1 % NGA, P2 = I2 % NGA;
       const int64_t st1 = b1 + I1 / NGA, st2 = b2 + I2 / NGA;
+      if constexpr (IO && NGA == 1 && ONCHIP16_FWD_EARLY_DMA) {
+        // ONE group per cluster (small batches): the exchange chain is the critical path and everything the io waves do
+        // between two phases delays the publish -> the tile of phase + 2 is requested here, beside the MFMAs (its slot was
+        // flushed two phases ago): 0.758 -> 0.724 ms at 32 sequences, 1.79 -> 1.52 at 768.  With two groups the same change
+        // costs 8-15 % (profiles/r3_onchip16_early_dma.jsonl)
+        if (!(ONCHIP16_ABL & 4)) io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
+      }
       if constexpr (!IO && FGAT >= 1) {
         if (st1 > 0 && st1 < T && (FGAT == 1 || st == 0) && !(ONCHIP16_ABL & 8)) gather_issue(P1, st1);
       }
@@ -1221,7 +1232,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         io_flush(slot_tag, P, st);
         // (beyond the last step the copy is repeated for step T - 1 into a slot nobody reads any more: every phase
         // queues exactly four copies, or `vmcnt(10)` above would not cover the tiles of the last phases)
-        io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
+        if constexpr (!(NGA == 1 && ONCHIP16_FWD_EARLY_DMA)) io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
       }
     };
     auto run = [&](auto io_tag) __attribute__((always_inline)) {
@@ -1287,6 +1298,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 // MFMAs delay it: 0.74 -> 0.77 ms at 32 sequences)
 #ifndef ONCHIP16_BWD_DEFER_FLUSH
 #define ONCHIP16_BWD_DEFER_FLUSH 1
+#endif
+// ONE group per cluster: the tiles of phase + 2 are requested in the MFMA section (see the forward): 0.88 -> 0.76 ms at 160
+// sequences, 1.80 -> 1.59 at 768, equal at 32; with two groups it costs 6 % (profiles/r3_onchip16_early_dma.jsonl)
+#ifndef ONCHIP16_BWD_EARLY_DMA_G1
+#define ONCHIP16_BWD_EARLY_DMA_G1 1
 #endif
 #ifndef ONCHIP16_BWD_GATHER
 #define ONCHIP16_BWD_GATHER 2
@@ -1522,7 +1538,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         if (st > 0) gather_finish(S, P, st);
       } else {
         // this phase's tiles have landed (behind them: four stores + six copies, + the two direct publish stores)
-        if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (ONCHIP16_BWD_DIRECT && NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
       lds_barrier();
@@ -1581,6 +1598,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (!IO && (GAT >= 2)) {
         if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
       }
+      if constexpr (IO && NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) io_dma(I2, P2, st2 < T ? st2 : T - 1);      // (one group: as in the forward)
       if constexpr (IO && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH) {
         // the d(gates) of the PREVIOUS phase leave here, beside the MFMAs, not between two phases where the publish waits
         // for issue slots (its ring slot is refilled a phase later)
@@ -1659,7 +1677,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         }
       } else {
         if constexpr (!(NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH)) io_flush(S, P, st, true);
-        io_dma(I2, P2, st2 < T ? st2 : T - 1);
+        if constexpr (!(NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1)) io_dma(I2, P2, st2 < T ? st2 : T - 1);
       }
     };
     auto run = [&](auto io_tag) __attribute__((always_inline)) {
