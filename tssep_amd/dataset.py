@@ -231,6 +231,8 @@ def _threaded(it, maps, num_workers, buffer_size, catch_filter):
         state["stop"] = True
         for _ in threads:
             slots.release()
+        for t in threads:                                    # (bounded: a map stage stuck in user code must not hang the exit)
+            t.join(timeout=2.0)
 
 
 class DeviceLoader:
@@ -362,5 +364,13 @@ class DeviceLoader:
                 self.stats["batches"] += 1
                 yield ex
         finally:
+            # stop the producer and WAIT for it (bounded): a daemon thread still inside a pinned-memory / HIP call when the
+            # interpreter finalises takes the process down (`terminate called without an active exception`)
             stop.set()
-            pool.shutdown(wait=False)
+            try:
+                while True:
+                    q.get_nowait()                      # (a producer blocked on the full queue sees the stop flag at once)
+            except queue.Empty:
+                pass
+            th.join(timeout=10.0)
+            pool.shutdown(wait=True)

@@ -135,3 +135,7 @@ def main(argv=None):
 if __name__ == "__main__":
     print(shlex.join(sys.argv))
     main()
+    # data pipelines left open anywhere: their generators' `finally` stops and joins the loader threads BEFORE the
+    # interpreter starts to tear the HIP runtime down (a daemon thread inside a HIP call at that point aborts the process)
+    import gc
+    gc.collect()

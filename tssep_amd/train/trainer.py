@@ -20,6 +20,22 @@ from .. import distributed as _dist
 from ..configurable import Configurable
 
 
+class _closing:
+    """contextlib.closing for iterators that may not have ``close`` (lists, tuples)."""
+
+    def __init__(self, it):
+        self.it = it
+
+    def __enter__(self):
+        return self.it
+
+    def __exit__(self, *exc):
+        close = getattr(self.it, "close", None)
+        if close is not None:
+            close()
+        return False
+
+
 class Trainer(Configurable):
     def __init__(self, model, storage_dir, optimizer, summary_trigger=(1, "epoch"),
                  checkpoint_trigger=(1, "epoch"), stop_trigger=(1, "epoch"),
@@ -175,28 +191,33 @@ class Trainer(Configurable):
                 else:
                     agree_per_step = True
             batches = iter(train_dataset)
-            while True:
-                ex = next(batches, None)
-                boundary = (self.iteration + 1) % self.virtual_minibatch_size == 0
-                if agree_per_step:
-                    if not _dist.same_on_all_ranks(0 if ex is None else 1) or ex is None:
-                        self.optimizer.zero_grad()       # an incomplete virtual minibatch is dropped everywhere
+            # (closed when the epoch ends early -- stop trigger, exception -- so that the loader's producer / prefetch
+            # threads stop NOW: a generator left open keeps daemon threads inside HIP calls until the interpreter tears the
+            # runtime down under them -- `terminate called without an active exception` at exit, one run in six of the toy
+            # experiments)
+            with _closing(batches):
+                while True:
+                    ex = next(batches, None)
+                    boundary = (self.iteration + 1) % self.virtual_minibatch_size == 0
+                    if agree_per_step:
+                        if not _dist.same_on_all_ranks(0 if ex is None else 1) or ex is None:
+                            self.optimizer.zero_grad()       # an incomplete virtual minibatch is dropped everywhere
+                            break
+                    elif ex is None:
                         break
-                elif ex is None:
-                    break
-                summary = self.model.review(ex, self.model(ex))
-                summary["loss"].backward()
-                self.iteration += 1
-                if boundary:
-                    self.optimizer.step()            # all-reduce(SUM) over ranks, clip, Adam
-                    self.optimizer.zero_grad()
-                if self._triggered(self.summary_trigger):
-                    self.history.append((self.iteration, float(summary["loss"])))     # host sync
-                    self.agree_on_failure()
-                if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None:
-                    self._chief_checkpoint(chief)
-                if self.iteration >= stop_n:
-                    break
+                    summary = self.model.review(ex, self.model(ex))
+                    summary["loss"].backward()
+                    self.iteration += 1
+                    if boundary:
+                        self.optimizer.step()            # all-reduce(SUM) over ranks, clip, Adam
+                        self.optimizer.zero_grad()
+                    if self._triggered(self.summary_trigger):
+                        self.history.append((self.iteration, float(summary["loss"])))     # host sync
+                        self.agree_on_failure()
+                    if self._triggered(self.checkpoint_trigger) and self.validation_dataset is not None:
+                        self._chief_checkpoint(chief)
+                    if self.iteration >= stop_n:
+                        break
             self.epoch += 1
         self.agree_on_failure()
         if self.validation_dataset is not None:
