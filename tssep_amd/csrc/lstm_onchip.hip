@@ -931,6 +931,10 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_EARLY_DMA
 #define ONCHIP16_FWD_EARLY_DMA 1
 #endif
+// one group per cluster: s_sleep units (64 cycles) between the publish and the first request of the peers' values
+#ifndef ONCHIP16_FWD_G1_DELAY
+#define ONCHIP16_FWD_G1_DELAY 14
+#endif
 #ifndef ONCHIP16_FWD_GATHER
 #define ONCHIP16_FWD_GATHER 4
 #endif
@@ -1218,7 +1222,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
           if (NGA < 4) {
             // (two groups: the next phase's h is decoded in front of its barrier -- decoding it here, behind the publish,
             // measured slower even with the early request: 1.42 -> 1.50 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
-            if (FGAT == 0 && st1 > 0 && st1 < T) gather_issue(P1, st1);
+            if (FGAT == 0 && st1 > 0 && st1 < T) {
+              // (one group: the peers publish these values at this very moment -- a request issued at once finds stale tags
+              // and pays a second round trip; 14 x 64 cycles later it usually finds them: 0.722 -> 0.685 ms at 32 sequences,
+              // 0.743 -> 0.70 at 160; 8: 0.70, 20: 0.72, 28: 0.78 -- profiles/r3_onchip16_g1_delay.jsonl)
+              if (NGA == 1 && ONCHIP16_FWD_G1_DELAY) __builtin_amdgcn_s_sleep(ONCHIP16_FWD_G1_DELAY);
+              gather_issue(P1, st1);
+            }
           } else {
             // the NEXT phase's h (requested one phase ago) -> its operand image, while the io waves flush; then the
             // request for the phase after that: two phases of latency budget per gather
@@ -1673,6 +1683,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (!IO) {
         if (has_prev) publish(P, st);
         if constexpr (GAT == 0) {
+          // (no pause in front of the request as in the forward: the direct publish is earlier here, a pause costs 1-9 %)
           if (st1 > 0 && st1 < T) gather_issue(P1, st1);
         }
       } else {
