@@ -41,7 +41,6 @@ K_SPK, N_SAMPLES = WORKLOADS["cfg3"]["K"], WORKLOADS["cfg3"]["N"]
 PEAK_F32_MFMA_TFLOPS = 157.3          # exact-fp32 MFMA (v_mfma_f32_32x32x2_f32 / 4x4x1_16b)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense bf16 MFMA; a bf16x3 GEMM issues 3 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0
-MEASURED_COPY_GBPS = 5300.0           # a plain copy of the mask head's bytes on this part (profiles/r1_maskhead_microbench.jsonl)
 
 
 def synth_batch(B, K, N, seed):
@@ -255,7 +254,7 @@ def main():
                     help="replay the step as a captured hipGraph (auto: small batches, where launches dominate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-f32", action="store_true",
-                    help="skip the secondary fp32-GEMM measurement")
+                    help="skip the secondary measurements (fp32 GEMMs, the fp32 end-to-end reference-width line, two-product weight gradients)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -325,7 +324,7 @@ def main():
         out = None
         for _ in range(warmup):
             out = step()
-        H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear()
+        H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear(); H.KERNEL_OWN_BYTES.clear()
         H.KERNEL_TIMING = gstep is None      # events cannot be read back out of a graph replay: see below
         opt.allreduce_events = [] if world > 1 else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -350,10 +349,11 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax), int(out.logit.shape[-2]), float(np.median(per_step))
 
-    def rooflines(dt, gemm_name):
+    def rooflines(dt, gemm_name, steps=None):
+        steps = steps or args.steps
         """Live HIP-event timings of this run -> (dominant MFMA kernel, mask head)."""
         T = H.stft_frames(N_s)          # frames per chunk (the timed runs report the same number)
-        traffic, mfma_busy, traffic_src, mfma_src = {}, None, None, None
+        traffic, traffic_x2, mfma_busy, traffic_src, mfma_src = {}, {}, None, None, None
         try:      # HBM bytes per launch from rocprofv3 PMC passes of this same command (separate --pmc runs)
             traffic_src = os.path.relpath(newest_profile("traffic_pmc.json"), ROOT)
             with open(newest_profile("traffic_pmc.json")) as f:
@@ -361,6 +361,7 @@ def main():
             c = tp["config"]
             if (c["batch_per_gpu"], c["gemm"], c.get("workload", "cfg3")) == (B, gemm_name, args.workload) and world == 1:
                 traffic = {k: v["bytes_raw"] for k, v in tp["dominant"].items()}
+                traffic_x2 = {k: v.get("bytes_fetch_x2") for k, v in tp["dominant"].items()}
         except (OSError, KeyError, ValueError, TypeError):
             pass
         try:      # MFMA-pipe busy share of the GEMM kernels from an SQ-counter pass of this same command
@@ -383,10 +384,21 @@ def main():
             ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
             split = name in ("gemm_bf16x3", "blstm_onchip_fwd", "blstm_onchip_bwd")
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            alg_bytes = H.KERNEL_BYTES.get(name, 0) // n_launch
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
-                            frac=round(ach / peak, 4), traffic=traffic.get(name), launches=n_launch,
+                            frac=round(ach / peak, 4), traffic=traffic.get(name),
+                            traffic_fetch_x2=traffic_x2.get(name),
+                            traffic_algorithmic=alg_bytes or None,
+                            traffic_over_algorithmic=(round(traffic_x2[name] / alg_bytes, 3)
+                                                      if traffic_x2.get(name) and alg_bytes else None),
+                            traffic_note="per launch, averaged over the family's launches: `traffic` = (FETCH_SIZE + WRITE_SIZE) as "
+                                         "reported, `traffic_fetch_x2` with the guide's gfx950 correction of the fetch side (x2 for "
+                                         "16-byte-per-lane streaming loads); `traffic_algorithmic` = 4 (M K + N K + M N) bytes "
+                                         "(+ the split-K partials of the weight gradients, + the read of an accumulating store): "
+                                         "a ratio well above 1 would be wasted re-reads",
+                            launches=n_launch,
                             avg_ms=round(avg_ms, 4), share_of_step=round(total_ms / (dt * 1e3), 3),
-                            tflop_per_step_launched=round(H.KERNEL_FLOPS[name] / max(args.steps if gstep is None else min(args.steps, 10), 1) / 1e12, 4),
+                            tflop_per_step_launched=round(H.KERNEL_FLOPS[name] / max(steps if gstep is None else min(steps, 10), 1) / 1e12, 4),
                             mfma_pipe_busy_frac_pmc=mfma_busy if name.startswith("gemm_") else None,
                             pmc_source=dict(
                                 traffic=traffic_src if traffic.get(name) is not None else None,
@@ -404,17 +416,31 @@ def main():
             ms = sum(v[1] for _, v in hb)
             by = sum(H.KERNEL_BYTES[k] for k, _ in hb)
             gbps = by / (ms * 1e-3) / 1e9
+            own = sum(H.KERNEL_OWN_BYTES.get(k, 0) for k, _ in hb)
+            phys_raw, phys_x2 = traffic.get("maskhead_fwd+bwd"), traffic_x2.get("maskhead_fwd+bwd")
+            per_launch_s = ms * 1e-3 / n_l
             mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
                              peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
-                             frac_of_copy_ceiling=round(gbps / MEASURED_COPY_GBPS, 4),
-                             traffic=traffic.get("maskhead_fwd+bwd"),
-                             pmc_source=traffic_src if traffic.get("maskhead_fwd+bwd") is not None else None,
+                             frac_is="EFFECTIVE: the unfused mask head's bytes (SURVEY 8d) over the fused kernels' time -- "
+                                     "not a bandwidth the kernels move; see frac_own_bytes / frac_physical",
+                             frac_own_bytes=round(own / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if own else None,
+                             own_bytes_per_launch=own // n_l if own else None,
+                             frac_physical=(dict(raw=round(phys_raw / per_launch_s / 1e9 / PEAK_HBM_GBPS, 4),
+                                                 fetch_x2=round(phys_x2 / per_launch_s / 1e9 / PEAK_HBM_GBPS, 4))
+                                            if phys_raw and phys_x2 else None),
+                             traffic=phys_raw, traffic_fetch_x2=phys_x2,
+                             pmc_source=traffic_src if phys_raw is not None else None,
                              launches=n_l,
                              avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l,
-                             note="bytes = (16 K F + 8 F) per frame and direction: the UNFUSED mask head of "
-                                  "net.py:983 + enhancer.py:98-100; the time is that of the FUSED kernels (mask "
-                                  "head + inverse STFT, iSTFT adjoint + mask-head backward), which also run the "
-                                  "FFTs: `chain` prices the same time against the unfused chain's bytes")
+                             note="`frac` prices the FUSED kernels' time (mask head + inverse STFT forward; iSTFT adjoint + "
+                                  "mask-head backward + LogMAE backward + logit un-map) against the bytes of the UNFUSED mask "
+                                  "head of net.py:983 + enhancer.py:98-100, (16 K F + 8 F) per frame and direction; "
+                                  "`frac_own_bytes` against what the fused kernels themselves must move (logit + observation "
+                                  "in, K x 256 samples out / estimate + target in, d(logit) out); `frac_physical` against the "
+                                  "PMC bytes of the committed counter pass (as reported / fetch side x2).  The fused kernels "
+                                  "run three FFT passes per frame and are VALU-bound (profiles/r3_sq_wave_states.jsonl), so "
+                                  "the own-bytes fraction is their honest distance from the HBM roofline; `chain` prices the "
+                                  "same time against the whole unfused chain's bytes")
             chain = by + n_l * B * T * 8 * K * FBINS + n_l * 4 * B * K * N_s      # + estimate (8 K F) + samples
             folded = ""
             if H.FOLD_TAIL and "maskhead_bwd" in ktimes:      # what else the backward kernel now does per launch
@@ -437,38 +463,60 @@ def main():
         g = ("split-bf16 (hi+lo) MFMA GEMMs, fp32 accumulate" if gemm_name == "bf16x3" else "exact fp32 MFMA GEMMs")
         return f"{g}; {rec}"
 
-    exact = None
+    exact = ref_width = None
     if args.gemm != "f32" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3":
-        # secondary line, first-class: the same step with every GEMM in exact fp32 (the reference's GEMM
-        # arithmetic), same steps / warm-up, its own roofline
+        # secondary line: the same step with every GEMM in exact fp32 (the reference's GEMM arithmetic) and the
+        # default split-bf16 recurrence, same steps / warm-up, its own roofline
         H.GEMM_PRECISION = "f32"
         dt_e, T_e, med_e = timed_run(args.steps, args.warmup)
         roof_e, mh_e = rooflines(dt_e, "f32")
+        rec_f32 = args.recurrence in ("stream", "cluster")
         exact = dict(value=round(B * T_e * args.steps / dt_e, 1), unit="frames/s",
                      ms_per_step=round(dt_e / args.steps * 1e3, 3), ms_per_step_median=round(med_e, 3),
-                     steps=args.steps, warmup=args.warmup, dtype="f32 GEMMs" + ("" if args.recurrence in ("stream", "cluster") else " + bf16x3 recurrence"),
+                     steps=args.steps, warmup=args.warmup, dtype="f32" if rec_f32 else "f32 GEMMs + bf16x3 recurrence",
                      arithmetic=arithmetic("f32"), roofline=roof_e, roofline_mask_head=mh_e)
+        if not rec_f32:
+            # the REFERENCE-WIDTH bookend (VERDICT r3 #5a): fp32 end to end as the reference computes
+            # (tssep/train/model.py:502-511) -- exact-fp32 MFMA GEMMs AND the exact-fp32 W-stationary recurrence
+            # (lstm_cluster.hip: fp32 MFMA 4x4x1, full 32-bit exchange granules), fewer steps (it is the slow line),
+            # its own roofline against the fp32 MFMA peak and its own parity run against the CPU oracle
+            old_rec, H.RECURRENCE = H.RECURRENCE, "cluster"
+            try:
+                st_r, wu_r = min(args.steps, 10), min(args.warmup, 2)
+                dt_r, T_r, med_r = timed_run(st_r, wu_r)
+                H.check_cluster_errors(dev)
+                roof_r, mh_r = rooflines(dt_r, "f32", st_r)
+                ref_width = dict(value=round(B * T_r * st_r / dt_r, 1), unit="frames/s",
+                                 ms_per_step=round(dt_r / st_r * 1e3, 3), ms_per_step_median=round(med_r, 3),
+                                 steps=st_r, warmup=wu_r, dtype="f32",
+                                 arithmetic="exact fp32 MFMA GEMMs; exact fp32 cluster recurrence (fp32 MFMA, 32-bit granules)",
+                                 roofline=roof_r, roofline_mask_head=mh_r,
+                                 parity_vs_cpu_oracle=None if args.no_cpu_baseline else cpu_baseline(model, opt, parity_only=True))
+            finally:
+                H.RECURRENCE = old_rec
         H.GEMM_PRECISION = args.gemm
     dt, T, med = timed_run(args.steps, args.warmup)
     H.check_cluster_errors(dev)
     roofline, mask_head = rooflines(dt, args.gemm)
     two_prod = None
-    if args.gemm == "bf16x3" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3" \
-            and not os.environ.get("TSSEP_WGRAD_PRODUCTS"):
-        # secondary line, opt-in arithmetic (TSSEP_WGRAD_PRODUCTS=2): the weight-gradient GEMMs drop the dY_lo x X_hi
+    if args.gemm == "bf16x3" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3" and gstep is None:
+        # secondary line, opt-in arithmetic (tssep_gemm_args.precision = 2): the weight-gradient GEMMs drop the dY_lo x X_hi
         # product -- d(gates) enters them as plain bf16, X keeps hi + lo.  The forward (masks, loss) is bit-identical;
         # every term of a weight-gradient sum carries up to 2^-9 instead of 2^-16 relative error, which averages over
         # 2e5 .. 8e5 rows: the gradient error against the CPU oracle is measured in this run and reported here.  NOT the
-        # headline `value`: the default keeps all three products.
-        os.environ["TSSEP_WGRAD_PRODUCTS"] = "2"
-        dt2, T2, med2 = timed_run(args.steps, args.warmup)
-        two_prod = dict(value=round(B * T2 * args.steps / dt2, 1), unit="frames/s", ms_per_step=round(dt2 / args.steps * 1e3, 3),
-                        ms_per_step_median=round(med2, 3), steps=args.steps, warmup=args.warmup,
-                        arithmetic="as the headline, weight-gradient GEMMs with two of the three split-bf16 products "
-                                   "(TSSEP_WGRAD_PRODUCTS=2)")
-        if not args.no_cpu_baseline:
-            two_prod["parity_vs_cpu_oracle"] = cpu_baseline(model, opt, parity_only=True)
-        os.environ.pop("TSSEP_WGRAD_PRODUCTS")
+        # headline `value`: the default keeps all three products.  (Not with a captured graph: a replay would run the
+        # three-product kernels it was captured with under this label -- ADVICE r3.)
+        H.WGRAD_PRODUCTS = 2
+        try:
+            dt2, T2, med2 = timed_run(args.steps, args.warmup)
+            two_prod = dict(value=round(B * T2 * args.steps / dt2, 1), unit="frames/s", ms_per_step=round(dt2 / args.steps * 1e3, 3),
+                            ms_per_step_median=round(med2, 3), steps=args.steps, warmup=args.warmup,
+                            arithmetic="as the headline, weight-gradient GEMMs with two of the three split-bf16 products "
+                                       "(tssep_gemm_args.precision = 2)")
+            if not args.no_cpu_baseline:
+                two_prod["parity_vs_cpu_oracle"] = cpu_baseline(model, opt, parity_only=True)
+        finally:
+            H.WGRAD_PRODUCTS = 3
     collective = None
     if world > 1:
         # what the first hardware run of the RCCL path should show at a glance: the collective's own time (HIP
@@ -515,7 +563,8 @@ def main():
                            recurrence_kernels=round(2 * 16 * UNITS * UNITS * (2 * K + 2) * B * T / 1e12, 4),
                            note="algorithmic, 2 flop per MAC, forward + backward (SURVEY 8d); the dW_hh weight "
                                 "gradients run as GEMMs, the h.W_hh products and their BPTT inside the recurrence kernels")},
-            "roofline": roofline, "roofline_mask_head": mask_head, "exact_f32": exact,
+            "roofline": roofline, "roofline_mask_head": mask_head,
+            "f32_gemms_bf16x3_recurrence": exact, "reference_width": ref_width,
             "two_product_wgrad": two_prod,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload == "cfg5")
             else cpu_baseline(model, opt),

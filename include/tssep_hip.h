@@ -9,7 +9,8 @@
  * Conventions
  *   - plain device pointers + explicit sizes/leading dimensions; no torch types
  *   - the CALLER owns every buffer (inputs, outputs, workspace); nothing is
- *     allocated, nothing global is mutated, no host synchronisation inside
+ *     allocated, nothing global is mutated, no host synchronisation inside, and the
+ *     library reads no environment variable: what runs is a function of the arguments
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*)
  *   - return value: 0 = ok, <0 = TSSEP_E_* (invalid shape / alignment / unsupported);
  *     never throws across the boundary
@@ -152,7 +153,9 @@ typedef struct tssep_gemm_args {
    * stored at C[b*c_sb + k*c_sk + t*c_st + q'*c_co + r], q' = c_perm ? c_perm[b*c_perm_ld+q] : q.
    * Covers 'spk time feature -> 1 time (spk feature)' (net.py:608-611) and
    * '1 time (spk mask freq) -> spk mask time freq' + the speaker un-permutation
-   * (net.py:637-641, 957-967) inside the producing GEMM's store. */
+   * (net.py:637-641, 957-967) inside the producing GEMM's store.
+   * c_remap = 2: the same map through the plain 4-byte-per-lane store only (the reference the 16-byte variants
+   * are tested against; same values). */
   int32_t c_remap;
   int64_t c_T, c_K, c_sb, c_sk, c_st, c_cm, c_co;
   const int32_t* c_perm; int64_t c_perm_ld;
@@ -162,7 +165,9 @@ typedef struct tssep_gemm_args {
   /* arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
    * 1 = split-bf16 "bf16x3": every fp32 operand is split on the fly into bf16 hi + bf16 lo and
    *     the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
-   *     (per-product relative error <= ~2^-16, i.e. fp32-class for the 1e-3 parity bar). */
+   *     (per-product relative error <= ~2^-16, i.e. fp32-class for the 1e-3 parity bar);
+   * 2 = weight gradients only (a_kmajor = b_kmajor = 1): as 1 with the A_lo * B_hi product dropped -- dY enters as
+   *     plain bf16, X keeps hi + lo (opt-in side line of bench.py, never the default). */
   int32_t precision;
   /* k-major B only, precision 1 only: column N-1 of B is VIRTUAL and reads as 1.0 for every valid
    * k, so column N-1 of C holds the column sums of A -- the bias gradient comes out of the
@@ -172,6 +177,36 @@ typedef struct tssep_gemm_args {
   const float* aux; int64_t ldaux;
 } tssep_gemm_args;
 int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
+
+/* The kernels behind tssep_gemm_f32.  The library picks one per request from the request alone (shape, layout,
+ * epilogue): no environment variable, no global state.  A caller that wants to know, or to decide itself
+ * (autotuning sweeps, A/B timing), uses the three calls below; every kernel of the split-bf16 family gives
+ * bit-identical results for the same request (same k order per output element, same epilogue arithmetic). */
+#define TSSEP_GEMM_AUTO 0        /* let the library choose                                                    */
+#define TSSEP_GEMM_F32 1         /* precision 0: exact-fp32 MFMA, 128 x 128 tiles                              */
+#define TSSEP_GEMM_PIPE 2        /* 128 x 128 x 32, every layout / epilogue                                    */
+#define TSSEP_GEMM_TALL2 3       /* row x row, 256 x 128, four waves                                           */
+#define TSSEP_GEMM_TALL4 4       /* row x row, 256 x 256, eight waves                                          */
+#define TSSEP_GEMM_TALL4_XCOL 5  /* ... N = 256 q + 1: the last column on the VALU                             */
+#define TSSEP_GEMM_BIG 6         /* row x row, 256 x 256, four waves of 128 x 128 (one per SIMD)               */
+#define TSSEP_GEMM_STREAM 7      /* row x row, persistent, plain stores hidden behind the next tile            */
+#define TSSEP_GEMM_NT_W160 8     /* row x row, 256 x 160                                                       */
+#define TSSEP_GEMM_TN 9          /* weight gradient (both operands k-major), 128 x 128                         */
+#define TSSEP_GEMM_TN_TALL 10    /* weight gradient, 256 x 128                                                 */
+#define TSSEP_GEMM_TN_BIG 11     /* weight gradient, 512 x 128, four waves of 128 x 128                        */
+#define TSSEP_GEMM_TN_W160 12    /* weight gradient, 256 x 160                                                 */
+#define TSSEP_GEMM_TN_H160 13    /* weight gradient, 320 x 128                                                 */
+#define TSSEP_GEMM_KERNEL_LAST 13
+/* As tssep_gemm_f32, on the kernel named (TSSEP_GEMM_AUTO = tssep_gemm_f32); TSSEP_E_UNSUPPORTED when that
+ * kernel does not cover the request. */
+int tssep_gemm_f32_on(const tssep_gemm_args* args, int32_t kernel, void* stream);
+/* *kernel = the kernel tssep_gemm_f32_on(args, force, .) would launch; nothing is launched, C may be NULL. */
+int tssep_gemm_plan(const tssep_gemm_args* args, int32_t force, int32_t* kernel);
+const char* tssep_gemm_kernel_name(int32_t kernel);
+/* Recommended splitk (>= 1; < 0 = TSSEP_E_*) for the weight gradient dW[M,N] = dY[K,M]^T X[K,N] described by
+ * `args` (a_kmajor = b_kmajor = 1; splitk, c_split_stride and C are ignored): follows the kernel the library
+ * picks for it. */
+int tssep_gemm_wgrad_splits(const tssep_gemm_args* args);
 
 /* column sums: out[n] (+)= sum_m A[m*lda+n]  (bias gradients) */
 int tssep_colsum_f32(const float* A, int64_t M, int64_t N, int64_t lda, float* out,

@@ -19,8 +19,34 @@ def test_build_and_symbols():
     exported = set(re.findall(r" T (tssep_\w+)", out))
     assert exported == set(protos), (exported ^ set(protos))
     L = _lib.lib()
-    assert L.tssep_abi_version() == 1
+    assert L.tssep_abi_version() == 2
     assert L.tssep_arch() == b"gfx950"
+
+
+def test_library_reads_no_environment_variable():
+    """VERDICT r3 #3 / header conventions: what runs is a function of the arguments.  The production library does not
+    even IMPORT getenv (the experiment build `make exp`, selected with TSSEP_HIP_LIB, is the one with switches)."""
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    assert not re.search(r"\b(secure_)?getenv\b", out), out
+    for f in sorted(os.listdir(os.path.join(ROOT, "tssep_amd", "csrc"))):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(ROOT, "tssep_amd", "csrc", f)).read()
+            # every getenv sits behind the experiment build's macro
+            depth, guarded = 0, []
+            for line in text.splitlines():
+                if line.startswith("#ifdef TSSEP_GEMM_EXP"):
+                    guarded.append(depth)
+                if line.startswith(("#if", "#ifdef", "#ifndef")):
+                    depth += 1
+                elif line.startswith("#endif"):
+                    depth -= 1
+                    if guarded and guarded[-1] == depth:
+                        guarded.pop()
+                elif line.startswith("#else") and guarded and guarded[-1] == depth - 1:
+                    guarded.pop()
+                if "getenv(" in line and not line.lstrip().startswith("//"):
+                    assert guarded, f"{f}: getenv outside TSSEP_GEMM_EXP: {line.strip()}"
 
 
 def test_host_side_helpers_match_oracle():

@@ -307,6 +307,7 @@ class _Sgd:
     """Stands in for the fused optimizer (which needs the GPU library): flat bucket + all-reduce + step count."""
     def __init__(self):
         self.steps = 0
+        self.micro = []
 
     def set_parameters(self, params):
         self.bucket = GradBucket(list(params))
@@ -320,6 +321,8 @@ class _Sgd:
     def step(self):
         self.bucket.all_reduce()
         self.steps += 1
+        # micro-batches in this step: d(loss)/d(bias) of _ToyModel is 2 rows per micro-batch and rank
+        self.micro.append(int(round(float(self.bucket.params[-1].grad.sum()) / (2 * dist.get_world_size()))))
 
 
 def _ragged_worker(rank, world, port, q, tmp):
@@ -333,15 +336,17 @@ def _ragged_worker(rank, world, port, q, tmp):
                 summary_trigger=(100, "iteration"), checkpoint_trigger=(100, "iteration"), virtual_minibatch_size=2)
     t.model.to = lambda *_a, **_k: t.model                    # CPU run of the loop (the product path is GPU only)
     t.train(_Ragged(5 if rank == 0 else 3), device="cpu")     # rank 1 runs out of batches two steps early
-    q.put((rank, t.iteration, t.epoch, t.optimizer.steps))
+    q.put((rank, t.iteration, t.epoch, t.optimizer.steps, t.optimizer.micro))
     dist.destroy_process_group()
 
 
 def test_ranks_with_different_batch_counts_end_the_epoch_together(tmp_path):
     """`equal_shard` equalises source examples only; a later stage that drops examples gives the ranks
     different batch counts and the one with more waits for ever in the all-reduce.  With an unknown length the
-    ranks agree per micro-step: both stop each epoch after rank 1's 3 batches (the half-filled virtual minibatch
-    of 2 is dropped), so both take the same number of optimizer steps and reach the stop trigger together."""
+    ranks agree per micro-step: both stop each epoch after rank 1's 3 batches, so both take the same number of
+    optimizer steps and reach the stop trigger together.  ADVICE r3: the half-filled virtual minibatch of 2 is
+    CARRIED over the epoch boundary (as on one GPU and in the reference), so 7 micro-steps are exactly 3 steps
+    and every step saw two micro-batches."""
     res = _spawn(_ragged_worker, 2, str(tmp_path))
     assert res[0][1:] == res[1][1:], res
-    assert res[0][1] == 7 and res[0][3] >= 3
+    assert res[0][1] == 7 and res[0][3] == 3 and res[0][4] == [2, 2, 2], res

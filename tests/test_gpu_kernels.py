@@ -123,8 +123,8 @@ def test_gemm_nt_bias_tanh(M, N, K, gemm_precision):
 def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
     """The 256 x 256 / 8-wave variant of the split-bf16 row x row GEMM (N >= 1024 whose padding to 256 stays
     under 10 %) against fp64, and bit for bit against the 256 x 128 tile (same K order, same MFMA sequence per
-    output element); bias + tanh, accumulate and the speaker-combination store remap."""
-    import os
+    output element); bias + tanh, accumulate and the speaker-combination store remap.  (Kernels are named through
+    hip_ops.prefer_gemm_kernels -> tssep_gemm_f32_on: the library has no environment switches.)"""
     torch.manual_seed(2)
     h = H()
     old = h.GEMM_PRECISION
@@ -137,12 +137,12 @@ def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
         Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
         ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
         outs = {}
-        for wide in ("1", "0"):
-            os.environ["TSSEP_GEMM_WIDE"] = wide
-            C = torch.full((M, N), float("nan"), device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
-            C2 = torch.ones(M, N, device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+        for wide, kern in (("1", "tall4"), ("0", "tall2")):
+            with h.prefer_gemm_kernels(kern):
+                C = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
+                C2 = torch.ones(M, N, device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
             outs[wide] = (C, C2)
         close(outs["1"][0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="wide nt+bias+tanh")
         close(outs["1"][1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="wide accumulate")
@@ -150,32 +150,29 @@ def test_gemm_wide_tile_is_bit_identical_to_the_tall_tile(M, N, K):
         # store remap (rows (b,k,t) -> [b, t, k*N + n]), as the projection in front of the combination layer
         Kspk, T = 4, M // 8
         R = 2 * Kspk * T
-        for wide in ("1", "0"):
-            os.environ["TSSEP_GEMM_WIDE"] = wide
+        for wide, kern in (("1", "tall4"), ("0", "tall2")):
             Y = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], Y, 0, R, N, K, bias=bd,
-                   remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+            with h.prefer_gemm_kernels(kern):
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], Y, 0, R, N, K, bias=bd,
+                       remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
             outs["r" + wide] = Y
         want = ref[:R].view(2, Kspk, T, N).permute(0, 2, 1, 3).reshape(2 * T, Kspk * N)
         close(outs["r1"], want, rtol=2e-4, atol=2e-4, name="wide remap")
         assert torch.equal(outs["r1"], outs["r0"])
     finally:
-        os.environ.pop("TSSEP_GEMM_WIDE", None)
         h.GEMM_PRECISION = old
 
 
 @pytest.mark.parametrize("M,N,K", [(4096 + 255, 320, 600), (1100, 320, 2400), (2048, 160, 47), (3000, 470, 553), (1300, 300, 64)])
 def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
     """The 256 x 160 row x row tile (csrc/gemm_bf16x3_nt_w160.hip: N = 320 pads to 2 x 160 instead of 3 x 128 columns)
-    against fp64 and bit for bit against the 128-wide tiles (TSSEP_GEMM_NT_W160=0): bias + tanh, accumulate, the folded
-    Tanh backward, the speaker-combination remap; K tails, ragged last row / column tiles.  (Plain stores go to the
-    streaming kernel first: switched off here so that every variant reaches the tile under test.)"""
-    import os
+    against fp64 and bit for bit against the 128-wide tiles ("tall2"): bias + tanh, accumulate, the folded
+    Tanh backward, the speaker-combination remap; K tails, ragged last row / column tiles.  (The kernel under test is
+    named, so that plain stores reach it too instead of the streaming kernel.)"""
     torch.manual_seed(6)
     h = H()
     old = h.GEMM_PRECISION
     h.GEMM_PRECISION = "bf16x3"
-    os.environ["TSSEP_GEMM_STREAM"] = "0"
     try:
         ru = h.round_up
         A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
@@ -188,8 +185,8 @@ def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
         Kc = 4 if (N % 4 == 0 and M % 4 == 0 and (M // 4) % 1 == 0) else 0
         Tt = M // Kc // 1 if Kc else 0
         outs = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_NT_W160"] = mode
+        for mode, kern in (("1", "nt_w160"), ("0", "tall2")):
+          with h.prefer_gemm_kernels(kern):
             ldc = ru(N, 4)
             C = torch.full((M, ldc), float("nan"), device="cuda")
             h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
@@ -219,8 +216,6 @@ def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
         for a, b in zip(outs["1"], outs["0"]):
             assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
     finally:
-        os.environ.pop("TSSEP_GEMM_NT_W160", None)
-        os.environ.pop("TSSEP_GEMM_STREAM", None)
         h.GEMM_PRECISION = old
 
 
@@ -229,10 +224,9 @@ def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
 def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
     """The persistent streaming kernel (csrc/gemm_bf16x3_stream.hip: 256 x 128 tiles walked by one workgroup per
     CU, two accumulator banks, C drained in paced 32 x 32 pieces while the next tile computes) against fp64, and bit
-    for bit against the tiled kernels it replaces (TSSEP_GEMM_STREAM=0): same K order and MFMA sequence per output
+    for bit against the tiled kernels it replaces ("tall2"): same K order and MFMA sequence per output
     element, same epilogue arithmetic -- bias, tanh, accumulate, the folded Tanh backward; K tails (K % 32 != 0),
     ragged last row / column tiles, more tiles than CUs (several tiles per workgroup) and fewer."""
-    import os
     torch.manual_seed(4)
     h = H()
     old = h.GEMM_PRECISION
@@ -247,8 +241,8 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
         ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
         outs = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_STREAM"] = mode
+        for mode, kern in (("1", "stream"), ("0", "tall2")):
+          with h.prefer_gemm_kernels(kern):     # (the streaming kernel takes plain stores only: the other calls fall to the library's choice)
             ldc = ru(N, 4)                      # padded rows: the pad columns must stay untouched
             C = torch.full((M, ldc), float("nan"), device="cuda")
             h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
@@ -268,7 +262,6 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         for a, b in zip(outs["1"], outs["0"]):
             assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
     finally:
-        os.environ.pop("TSSEP_GEMM_STREAM", None)
         h.GEMM_PRECISION = old
 
 
@@ -276,15 +269,13 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
                                    (70000, 1280, 64), (1500, 2400, 2400)])
 def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
     """The 256 x 256 tile with 128 x 128 wave tiles, one wave per SIMD (csrc/gemm_bf16x3_big.hip) against fp64, and
-    bit for bit against the 8-wave tiled kernels (TSSEP_GEMM_BIG=0, TSSEP_GEMM_STREAM=0): same K order and MFMA
+    bit for bit against the 8-wave tiled kernels ("tall4", "tall2"): same K order and MFMA
     sequence per output element, the shared epilogue -- bias + tanh, accumulate, the folded Tanh backward, the
     speaker-combination store remap; K tails (K % 32 != 0, K < 32), ragged last row / column tiles."""
-    import os
     torch.manual_seed(5)
     h = H()
     old = h.GEMM_PRECISION
     h.GEMM_PRECISION = "bf16x3"
-    os.environ["TSSEP_GEMM_STREAM"] = "0"
     try:
         ru = h.round_up
         A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
@@ -297,17 +288,20 @@ def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         Kspk, T = 4, M // 8
         R = 2 * Kspk * T
         outs = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_BIG"] = mode
-            C = torch.full((M, N), float("nan"), device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
-            C2 = torch.ones(M, N, device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
-            C3 = torch.full((M, N), float("nan"), device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K, act=2, aux=(Yd, ldy))
-            C4 = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
-            h.gemm(Ad, A.shape[1], Wd, W.shape[1], C4, 0, R, N, K, bias=bd,
-                   remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+        for mode, kern in (("1", ("big",)), ("0", ("tall4", "tall2"))):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(*kern):
+                C = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, N, M, N, K, bias=bd, act=1)
+                C2 = torch.ones(M, N, device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, accumulate=True)
+                C3 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K, act=2, aux=(Yd, ldy))
+                C4 = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C4, 0, R, N, K, bias=bd,
+                       remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+            h.GEMM_LOG = None
+            assert {k for k, *_ in log} <= set(kern), log          # the named kernels really ran
             outs[mode] = (C, C2, C3, C4)
         b = outs["1"]
         close(b[0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="big nt+bias+tanh")
@@ -318,22 +312,19 @@ def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         for x, y in zip(outs["1"], outs["0"]):
             assert torch.equal(x, y)
     finally:
-        os.environ.pop("TSSEP_GEMM_BIG", None)
-        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
 @pytest.mark.parametrize("M,N,K", [(3000, 513, 600), (1100, 769, 2400), (2048, 513, 448)])
 def test_gemm_big_tile_extra_column(M, N, K):
     """N = 256 q + 1 in the big-tile kernel: q MFMA tiles + column N - 1 on the VALU (exact fp32 products).  The
-    first N - 1 columns agree bit for bit with the 8-wave kernel's (TSSEP_GEMM_BIG=0), the last one with fp64;
+    first N - 1 columns agree bit for bit with the 8-wave kernel's ("tall4_xcol"), the last one with fp64;
     bias, the folded Tanh backward (aux), padded rows of C untouched."""
-    import os
     torch.manual_seed(8)
     h = H()
     old = h.GEMM_PRECISION
     h.GEMM_PRECISION = "bf16x3"
-    os.environ["TSSEP_GEMM_STREAM"] = "0"
     try:
         ru = h.round_up
         A = torch.randn(M, K); W = torch.randn(N, K) / K ** 0.5
@@ -343,12 +334,15 @@ def test_gemm_big_tile_extra_column(M, N, K):
         Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
         ref = A.double() @ W.double().t()
         outs = {}
-        for mode in ("2", "0"):
-            os.environ["TSSEP_GEMM_BIG"] = mode
-            C = torch.full((M, ldc), float("nan"), device="cuda")
-            h.gemm(Ad, K, Wd, K, C, ldc, M, N, K, bias=bd)
-            C2 = torch.full((M, ldc), float("nan"), device="cuda")
-            h.gemm(Ad, K, Wd, K, C2, ldc, M, N, K, act=2, aux=(Yd, ldc))
+        for mode, kern in (("2", "big"), ("0", "tall4_xcol")):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                C = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C, ldc, M, N, K, bias=bd)
+                C2 = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C2, ldc, M, N, K, act=2, aux=(Yd, ldc))
+            h.GEMM_LOG = None
+            assert {k for k, *_ in log} == {kern}, log
             outs[mode] = (C, C2)
         b = outs["2"]
         close(b[0][:, :N], (ref + bias.double()).float(), rtol=2e-4, atol=2e-4, name="big xcol + bias")
@@ -357,8 +351,7 @@ def test_gemm_big_tile_extra_column(M, N, K):
         for x, y in zip(outs["2"], outs["0"]):
             assert torch.equal(x[:, :N - 1], y[:, :N - 1])
     finally:
-        os.environ.pop("TSSEP_GEMM_BIG", None)
-        os.environ.pop("TSSEP_GEMM_STREAM", None)
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
@@ -367,9 +360,8 @@ def test_gemm_big_tile_extra_column(M, N, K):
 def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
     """The 512 x 128 weight-gradient tile with 128 x 128 wave tiles and three LDS stages
     (csrc/gemm_bf16x3_tn_big.hip) against fp64 and bit for bit against the 128 x 128 / 256 x 128 tn kernels
-    (TSSEP_GEMM_TN_BIG=0; the split-K boundaries of the two coincide for these R): ragged last row / column tiles,
-    the fused ones column (bias gradient), splits shorter than the three-stage pipeline."""
-    import os
+    (named through hip_ops.prefer_gemm_kernels; the split-K boundaries of the two coincide for these R): ragged last
+    row / column tiles, the fused ones column (bias gradient), splits shorter than the three-stage pipeline."""
     torch.manual_seed(11)
     h = H()
     old = h.GEMM_PRECISION
@@ -378,34 +370,34 @@ def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):
         dY = torch.randn(R, h.round_up(M, 4), device="cuda"); X = torch.full((R, h.round_up(N, 4)), 3.0, device="cuda")
         X[:, :N - 1] = torch.randn(R, N - 1, device="cuda")
         outs = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_TN_BIG"] = mode
-            part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
+        ntl = -(-N // 128)
+        ref_kernel = "tn_tall" if (ntl <= 3 or ntl >= 9) and M >= 1024 and (h.round_up(M, 256) - M) * 100 <= 8 * M else "tn"
+        for mode, kern in (("1", "tn_big"), ("0", ref_kernel)):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
+            h.GEMM_LOG = None
+            assert [k for k, *_ in log] == [kern], log
             outs[mode] = part.clone()
         ldp = h.round_up(N, 4)                  # (columns N .. ldp - 1 of the partials are never written)
         # N = 128 q + 1 | 2: the last columns are summed on the VALU in fp32 (exact products), not through the MFMAs
         nb = N - N % 128 if N > 128 and 1 <= N % 128 <= 2 else N
         assert torch.equal(outs["1"].view(S, M, ldp)[:, :, :nb], outs["0"].view(S, M, ldp)[:, :, :nb])
-        os.environ["TSSEP_GEMM_TN_XC"] = "0"     # ... unless switched off: then every column is bit-identical
-        part, _ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)
-        os.environ.pop("TSSEP_GEMM_TN_XC")
-        assert torch.equal(part.view(S, M, ldp)[:, :, :N], outs["0"].view(S, M, ldp)[:, :, :N])
         got = outs["1"].view(S, M, ldp).double().sum(0)
         ref = dY[:, :M].double().t() @ X[:, :N - 1].double()
         close(got[:, :N - 1].float(), ref.float(), rtol=2e-4, atol=3e-3, name="big wgrad")
         close(got[:, N - 1].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="big wgrad column sums")
         # the opt-in two-product arithmetic (dY as plain bf16): same kernel, a third of the MFMAs dropped
-        os.environ["TSSEP_WGRAD_PRODUCTS"] = "2"
+        h.WGRAD_PRODUCTS = 2
         two = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_TN_BIG"] = mode
-            two[mode] = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)[0].clone()
+        for mode, kern in (("1", "tn_big"), ("0", ref_kernel)):
+            with h.prefer_gemm_kernels(kern):
+                two[mode] = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N - 1, R, with_colsum=True, splitk=S)[0].clone()
         assert torch.equal(two["1"].view(S, M, ldp)[:, :, :nb], two["0"].view(S, M, ldp)[:, :, :nb])
         close(two["1"].view(S, M, ldp).double().sum(0)[:, :N - 1].float(), ref.float(), rtol=5e-3, atol=1.5, name="big wgrad, two products")
     finally:
-        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
-        os.environ.pop("TSSEP_GEMM_TN_BIG", None)
-        os.environ.pop("TSSEP_GEMM_TN_XC", None)
+        h.WGRAD_PRODUCTS = 3
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
@@ -457,10 +449,9 @@ def test_gemm_tn_time_shift(n, T, Mg, Hh, gemm_precision):
 @pytest.mark.parametrize("n,T,M,N,S", [(24, 253, 1200, 300, 8), (3, 70, 1200, 300, 1), (40, 33, 1100, 150, 3), (9, 253, 2300, 620, 2)])
 def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
     """The 256 x 160 weight-gradient tile (csrc/gemm_bf16x3_tn_w160.hip: the dW_hh shape M = 1200, N = 300 pads to
-    2 x 160 instead of 3 x 128 columns) bit for bit against the 256 x 128 / 128 x 128 tn kernels (TSSEP_GEMM_TN_W160=0)
+    2 x 160 instead of 3 x 128 columns) bit for bit against the 256 x 128 / 128 x 128 tn kernels ("tn_tall", "tn")
     and against fp64: time shifts -1 / +1 inside sequences of T, unshifted with the fused ones column, ragged row
     and column tiles, splits with K tails."""
-    import os
     torch.manual_seed(13)
     h = H()
     old = h.GEMM_PRECISION
@@ -471,12 +462,15 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
         hh = torch.randn(R, h.round_up(N, 4), device="cuda") / R ** 0.5
         for shift in (-1, 1, 0):
             outs = {}
-            for mode in ("1", "0"):
-                os.environ["TSSEP_GEMM_TN_W160"] = mode
-                if shift:
-                    part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=shift, kperiod=T, splitk=S)
-                else:
-                    part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, with_colsum=True, splitk=S)
+            for mode, kern in (("1", ("tn_w160",)), ("0", ("tn_tall", "tn"))):
+                log = h.GEMM_LOG = []
+                with h.prefer_gemm_kernels(*kern):
+                    if shift:
+                        part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=shift, kperiod=T, splitk=S)
+                    else:
+                        part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, with_colsum=True, splitk=S)
+                h.GEMM_LOG = None
+                assert log[0][0] in kern, log
                 outs[mode] = part.clone()
             Nc = N if shift else N + 1
             ldp = outs["1"].numel() // (S * M)
@@ -495,16 +489,16 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
             if not shift:
                 close(a.double().sum(0)[:, N].float(), dg[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="w160 column sums")
         # the opt-in two-product arithmetic through the same tile
-        os.environ["TSSEP_WGRAD_PRODUCTS"] = "2"
+        h.WGRAD_PRODUCTS = 2
         two = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_TN_W160"] = mode
-            two[mode] = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=-1, kperiod=T, splitk=S)[0].clone()
+        for mode, kern in (("1", ("tn_w160",)), ("0", ("tn_tall", "tn"))):
+            with h.prefer_gemm_kernels(*kern):
+                two[mode] = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, b_kshift=-1, kperiod=T, splitk=S)[0].clone()
         ldp = two["1"].numel() // (S * M)
         assert torch.equal(two["1"].view(S, M, ldp)[:, :, :N], two["0"].view(S, M, ldp)[:, :, :N])
     finally:
-        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
-        os.environ.pop("TSSEP_GEMM_TN_W160", None)
+        h.WGRAD_PRODUCTS = 3
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
@@ -512,12 +506,11 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
                                      (5000, 640, 257, 4), (40, 320, 600, 1), (2580, 320, 130, 3)])
 def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
     """The 320 x 128 weight-gradient tile (csrc/gemm_bf16x3_tn_h160.hip: the projection weight gradients, M = 320 pads to
-    one 320-row tile instead of 3 x 128 rows) bit for bit against the 128 x 128 tn kernel (TSSEP_GEMM_TN_H160=0) and
+    one 320-row tile instead of 3 x 128 rows) bit for bit against the 128 x 128 tn kernel ("tn") and
     against fp64: with and without the fused ones column, ragged row / column tiles (M = 300, 318; N = 530, 389),
     splits with K tails, a K shorter than the pipeline, and (M = 640; fewer than four column tiles) shapes the dispatcher
     leaves to the other tiles.  (The row counts put the split boundaries of the 16-row K tiles of this kernel on those
     of the 32-row K tiles of the 128 x 128 kernel: partials are only comparable split by split when the splits agree.)"""
-    import os
     torch.manual_seed(17)
     h = H()
     old = h.GEMM_PRECISION
@@ -527,12 +520,12 @@ def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
         x = torch.randn(R, h.round_up(N, 4), device="cuda") / R ** 0.5
         for products in (None, "2"):
             if products:
-                os.environ["TSSEP_WGRAD_PRODUCTS"] = products
+                h.WGRAD_PRODUCTS = int(products)
             for colsum in (True, False):
                 outs = {}
-                for mode in ("1", "0"):
-                    os.environ["TSSEP_GEMM_TN_H160"] = mode
-                    outs[mode] = h.wgrad(dz, dz.shape[1], x, x.shape[1], M, N, R, with_colsum=colsum, splitk=S)[0].clone()
+                for mode, kern in (("1", "tn_h160"), ("0", "tn")):
+                    with h.prefer_gemm_kernels(kern):
+                        outs[mode] = h.wgrad(dz, dz.shape[1], x, x.shape[1], M, N, R, with_colsum=colsum, splitk=S)[0].clone()
                 Nc = N + 1 if colsum else N
                 ldp = outs["1"].numel() // (S * M)
                 a, b = outs["1"].view(S, M, ldp)[:, :, :Nc], outs["0"].view(S, M, ldp)[:, :, :Nc]
@@ -544,18 +537,17 @@ def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
                         close(a.double().sum(0)[:, N].float(), dz[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3,
                               name="h160 column sums")
         # accumulate into an existing gradient (one split, no partials)
-        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
+        h.WGRAD_PRODUCTS = 3
         acc = {}
-        for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_TN_H160"] = mode
+        for mode, kern in (("1", "tn_h160"), ("0", "tn")):
             C = torch.full((M, h.round_up(N, 4)), 0.5, device="cuda")
-            h.gemm(dz, dz.shape[1], x, x.shape[1], C, C.shape[1], M, N, R, a_kmajor=True, b_kmajor=True, accumulate=True)
+            with h.prefer_gemm_kernels(kern):
+                h.gemm(dz, dz.shape[1], x, x.shape[1], C, C.shape[1], M, N, R, a_kmajor=True, b_kmajor=True, accumulate=True)
             acc[mode] = C
         assert torch.equal(acc["1"], acc["0"])
         assert bool((acc["1"][:, N:] == 0.5).all())
     finally:
-        os.environ.pop("TSSEP_WGRAD_PRODUCTS", None)
-        os.environ.pop("TSSEP_GEMM_TN_H160", None)
+        h.WGRAD_PRODUCTS = 3
         h.GEMM_PRECISION = old
 
 
@@ -582,9 +574,8 @@ def test_gemm_extra_column_instead_of_an_edge_tile():
     """N = 256 q + 1 (the 513 frequency bins: pre-net projection, d(input) of the first speaker BLSTM): the
     split-bf16 row x row kernel covers N - 1 columns with 256-wide tiles and computes the last column on the VALU
     from the A values it stages anyway, instead of a fifth 128-wide tile column.  Against fp64; the MFMA columns
-    bit for bit against the run with the extra tile column (TSSEP_GEMM_XCOL=0); the VALU column is exact fp32, so
+    bit for bit against the run with the extra tile column ("tall2"); the VALU column is exact fp32, so
     tighter than the split-bf16 ones.  bias + tanh, accumulate, store remap, K tail."""
-    import os
     h = H()
     old = h.GEMM_PRECISION
     h.GEMM_PRECISION = "bf16x3"
@@ -598,14 +589,14 @@ def test_gemm_extra_column_instead_of_an_edge_tile():
             R = 2 * Kspk * T
             want_r = ref[:R].view(2, Kspk, T, N).permute(0, 2, 1, 3).reshape(2 * T, Kspk * N)
             outs = {}
-            for x in ("1", "0"):
-                os.environ["TSSEP_GEMM_XCOL"] = x
-                C = torch.full((M, N), float("nan"), device="cuda")
-                h.gemm(Ad, K, Wd, K, C, N, M, N, K, bias=bd, act=1)
-                C2 = torch.ones(M, N, device="cuda")
-                h.gemm(Ad, K, Wd, K, C2, N, M, N, K, accumulate=True)
-                Y = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
-                h.gemm(Ad, K, Wd, K, Y, 0, R, N, K, bias=bd, remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
+            for x, kern in (("1", "tall4_xcol"), ("0", "tall2")):
+                with h.prefer_gemm_kernels(kern):
+                    C = torch.full((M, N), float("nan"), device="cuda")
+                    h.gemm(Ad, K, Wd, K, C, N, M, N, K, bias=bd, act=1)
+                    C2 = torch.ones(M, N, device="cuda")
+                    h.gemm(Ad, K, Wd, K, C2, N, M, N, K, accumulate=True)
+                    Y = torch.full((2 * T, Kspk * N), float("nan"), device="cuda")
+                    h.gemm(Ad, K, Wd, K, Y, 0, R, N, K, bias=bd, remap=dict(T=T, K=Kspk, sb=T * Kspk * N, sk=N, st=Kspk * N))
                 outs[x] = (C, C2, Y)
             close(outs["1"][0], torch.tanh(ref), rtol=2e-4, atol=2e-4, name=f"xcol nt+bias+tanh {M, N, K}")
             close(outs["1"][1], 1 + ref - bias, rtol=2e-4, atol=3e-4, name="xcol accumulate")
@@ -617,7 +608,6 @@ def test_gemm_extra_column_instead_of_an_edge_tile():
             y1, y0 = outs["1"][2].view(2 * T, Kspk, N), outs["0"][2].view(2 * T, Kspk, N)
             assert torch.equal(y1[..., :N - 1], y0[..., :N - 1])
     finally:
-        os.environ.pop("TSSEP_GEMM_XCOL", None)
         h.GEMM_PRECISION = old
 
 
@@ -625,9 +615,8 @@ def test_gemm_extra_column_instead_of_an_edge_tile():
                                          (2048, 1024, 128, 1), (1000, 2400, 130, 0)])
 def test_gemm_wgrad_tall_tile_against_the_128_tile(R, M, N, shift):
     """The 256 x 128 weight-gradient tile (M = 2400 / 1200: every LSTM weight gradient) against fp64 and against
-    the 128 x 128 kernel (TSSEP_GEMM_TN_TALL=0): same k order per output element, so bit-identical whenever both
+    the 128 x 128 kernel ("tn"): same k order per output element, so bit-identical whenever both
     split K at the same rows (K a multiple of 32 x splits)."""
-    import os
     h = H()
     old = h.GEMM_PRECISION
     h.GEMM_PRECISION = "bf16x3"
@@ -647,10 +636,13 @@ def test_gemm_wgrad_tall_tile_against_the_128_tile(R, M, N, shift):
             xs = sh.reshape(R, N)
         want = (dy[:, :M].double().t() @ xs.double()).float()
         got = {}
-        for tall in ("1", "0"):                   # 1: every eligible shape (the default, 2, is the shifted ones only)
-            os.environ["TSSEP_GEMM_TN_TALL"] = tall
-            part, S = h.wgrad(dy.cuda(), dy.shape[1], x.cuda(), x.shape[1], M, N, R, b_kshift=shift,
-                              kperiod=T if shift else 0, with_colsum=(shift == 0), splitk=8)
+        for tall, kern in (("1", "tn_tall"), ("0", "tn")):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                part, S = h.wgrad(dy.cuda(), dy.shape[1], x.cuda(), x.shape[1], M, N, R, b_kshift=shift,
+                                  kperiod=T if shift else 0, with_colsum=(shift == 0), splitk=8)
+            h.GEMM_LOG = None
+            assert [k for k, *_ in log] == [kern], log
             got[tall] = part.view(S, M, -1)
         close(got["1"].sum(0)[:, :N], want, rtol=2e-4, atol=2e-4 * float(want.abs().max()) + 1e-4, name="tall wgrad")
         if shift == 0:
@@ -658,7 +650,7 @@ def test_gemm_wgrad_tall_tile_against_the_128_tile(R, M, N, shift):
         if R % (32 * 8) == 0:
             assert torch.equal(got["1"][:, :, :N + (shift == 0)], got["0"][:, :, :N + (shift == 0)])
     finally:
-        os.environ.pop("TSSEP_GEMM_TN_TALL", None)
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
@@ -713,9 +705,8 @@ def test_gemm_store_remaps(gemm_precision):
 def test_gemm_wide_remapped_store(B, T, K, F, P):
     """The 16-byte remapped store for column groups that are not multiples of four floats and / or permuted per utterance
     (gemm_common.h: gemm_epilogue_rows_remap_wide -- the logit layer, net.py:629-666, 928-967: F = 513 bins per speaker)
-    bit for bit against the 4-byte-per-lane variant (TSSEP_GEMM_REMAP_WIDE=0) and against the permuted reference:
+    bit for bit against the 4-byte-per-lane variant (c_remap = 2 in the arguments) and against the permuted reference:
     plain, accumulating, with the folded Tanh backward, and the speaker combination with an odd projection size."""
-    import os
     torch.manual_seed(23)
     h = H()
     old = h.GEMM_PRECISION
@@ -732,8 +723,8 @@ def test_gemm_wide_remapped_store(B, T, K, F, P):
                 ref[b, perm[b, k]] = raw[b, k]
         outs = {}
         for mode in ("1", "0"):
-            os.environ["TSSEP_GEMM_REMAP_WIDE"] = mode
-            rm = dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=K)
+            nw = dict(narrow=True) if mode == "0" else {}
+            rm = dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=K, **nw)
             C = torch.full((B, K, T, F), float("nan"), device="cuda")
             h.gemm(A, P, W, P, C, 0, B * T, K * F, P, bias=bias, remap=rm)
             C2 = C.clone()
@@ -741,12 +732,12 @@ def test_gemm_wide_remapped_store(B, T, K, F, P):
             # un-combine with the Tanh backward folded in, no permutation, odd group size
             C3 = torch.full((B * K * T, F), float("nan"), device="cuda")
             h.gemm(A, P, W, P, C3, 0, B * T, K * F, P, act=2, aux=(Y, K * F),
-                   remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F))
+                   remap=dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, **nw))
             # speaker combination: rows (b, k, t) x F -> [B, T, K * F], one column group
             A4 = torch.randn(B * K * T, P, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
             C4 = torch.full((B, T, K * F), float("nan"), device="cuda")
             h.gemm(A4, P, W[:F], P, C4, 0, B * K * T, F, P, bias=bias[:F], act=1,
-                   remap=dict(T=T, K=K, sb=T * K * F, sk=F, st=K * F))
+                   remap=dict(T=T, K=K, sb=T * K * F, sk=F, st=K * F, **nw))
             outs[mode] = (C, C2, C3, C4, A4)
         for a, b in zip(outs["1"][:4], outs["0"][:4]):
             assert torch.equal(a, b), f"{(a != b).sum().item()} differ"
@@ -758,7 +749,6 @@ def test_gemm_wide_remapped_store(B, T, K, F, P):
         ref4 = torch.tanh(A4.double() @ W[:F].double().t() + bias[:F].double()).view(B, K, T, F).permute(0, 2, 1, 3).reshape(B, T, K * F)
         close(C4, ref4.float(), rtol=2e-4, atol=2e-4, name="combine, wide store")
     finally:
-        os.environ.pop("TSSEP_GEMM_REMAP_WIDE", None)
         h.GEMM_PRECISION = old
 
 

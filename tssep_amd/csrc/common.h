@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include "../../include/tssep_hip.h"
 
-#define TSSEP_ABI_VERSION 1
+#define TSSEP_ABI_VERSION 2
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

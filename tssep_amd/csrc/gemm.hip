@@ -15,7 +15,6 @@
 // ds_read_b128 per 32 rows and 8 MFMA steps.  The [BK+4]-float row pitch makes
 // those reads bank-conflict free (pitch 80 B: 16-B slot index 5*row mod 16 is a
 // bijection over the 16 rows of a ds_read_b128 lane group).
-#include <cstdlib>
 #include "gemm_common.h"
 
 namespace {
@@ -273,8 +272,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(
 
 }  // namespace
 
-extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
-  if (!g || !g->A || !g->B || !g->C) return TSSEP_E_NULL;
+// One entry for launch, forced launch and plan query (gemm_dispatch.h): `call` says which.
+static int gemm_dispatch(const tssep_gemm_args* g, GemmCall& call) {
+  if (!g || !g->A || !g->B || (!g->C && !call.dry)) return TSSEP_E_NULL;
   if (g->M <= 0 || g->N <= 0 || g->K <= 0) return TSSEP_E_SHAPE;
   if (!aligned16(g->A) || !aligned16(g->B) || (g->lda & 3) || (g->ldb & 3)) return TSSEP_E_ALIGN;
   const int splitk = g->splitk > 1 ? g->splitk : 1;
@@ -282,15 +282,16 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   if (g->act < 0 || g->act > 2 || (g->act == 2 && !g->aux)) return TSSEP_E_SHAPE;
   if (g->a_kmajor && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
   if (g->kperiod > 0 && !g->b_kmajor) return TSSEP_E_UNSUPPORTED;
+  const GemmSwitches sw = gemm_switches();
   StoreMap sm = make_store_map(g);
-  if (sm.remap) {      // read per call (alternating A/B): 0 = the 4-byte-per-lane remapped store where the vector one does not apply
-    const char* we = getenv("TSSEP_GEMM_REMAP_WIDE");
-    if (we && we[0] == '0') sm.remap = 2;
-  }
-  if (g->precision == 1) return tssep_gemm_bf16x3_launch(g, sm, splitk, stream);
+  if (sm.remap && !sw.remap_wide) sm.remap = 2;      // (experiment build: the 4-byte-per-lane remapped store)
+  if (g->precision == 1 || g->precision == 2) return tssep_gemm_bf16x3_launch(g, sm, splitk, call);
   if (g->precision != 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
+  if (call.force != TSSEP_GEMM_AUTO && call.force != TSSEP_GEMM_F32) return TSSEP_E_UNSUPPORTED;
+  call.chosen = TSSEP_GEMM_F32;
+  if (call.dry) return TSSEP_OK;
   const unsigned mtiles = (unsigned)((g->M + BM - 1) / BM);
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = (hipStream_t)call.stream;
   // columns [0, n_main) by 128-wide tiles; a remainder of <= 96 columns by 32-wide edge tiles
   int64_t n_main = (g->N / BN) * BN;
   const int64_t rem = g->N - n_main;
@@ -298,8 +299,7 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
   // under-filled already, a second serialized launch would only add a tail
   if (rem > 96 || splitk > 1) n_main = g->N;
   const bool shift = g->kperiod > 0;
-  const char* re_ = getenv("TSSEP_GEMM_F32_ROWS");          // read per call (alternating A/B): 0 = the direct 4-byte-per-lane store
-  const int rows_epi = (re_ && re_[0] == '0') ? 0 : 1;
+  const int rows_epi = sw.f32_rows ? 1 : 0;          // (0, experiment build: the direct 4-byte-per-lane store)
 #define LAUNCH(AK, BKM, SH, NARROW, GRIDX, NBEGIN)                                                 \
   do {                                                                                             \
     const TileMap tm_ = make_tile_map(mtiles, (GRIDX), splitk);                                    \
@@ -322,4 +322,119 @@ extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
 #undef DISPATCH
 #undef LAUNCH
   return tssep_launch_status();
+}
+
+// `accumulate` is a boolean in the ABI (include/tssep_hip.h): any non-zero value means C += result in EVERY epilogue
+// (the value 2 is a timing probe of the experiment build's kernels only)
+static tssep_gemm_args normalised(const tssep_gemm_args* g) {
+  tssep_gemm_args a = *g;
+  a.accumulate = a.accumulate ? 1 : 0;
+  return a;
+}
+
+extern "C" int tssep_gemm_f32(const tssep_gemm_args* g, void* stream) {
+  if (!g) return TSSEP_E_NULL;
+  const tssep_gemm_args a = normalised(g);
+  GemmCall call{stream, false, TSSEP_GEMM_AUTO, TSSEP_GEMM_AUTO};
+  return gemm_dispatch(&a, call);
+}
+
+extern "C" int tssep_gemm_f32_on(const tssep_gemm_args* g, int32_t kernel, void* stream) {
+  if (!g) return TSSEP_E_NULL;
+  if (kernel < TSSEP_GEMM_AUTO || kernel > TSSEP_GEMM_KERNEL_LAST) return TSSEP_E_SHAPE;
+  const tssep_gemm_args a = normalised(g);
+  GemmCall call{stream, false, kernel, TSSEP_GEMM_AUTO};
+  return gemm_dispatch(&a, call);
+}
+
+extern "C" int tssep_gemm_plan(const tssep_gemm_args* g, int32_t force, int32_t* kernel) {
+  if (!g || !kernel) return TSSEP_E_NULL;
+  if (force < TSSEP_GEMM_AUTO || force > TSSEP_GEMM_KERNEL_LAST) return TSSEP_E_SHAPE;
+  const tssep_gemm_args a = normalised(g);
+  GemmCall call{nullptr, true, force, TSSEP_GEMM_AUTO};
+  const int rc = gemm_dispatch(&a, call);
+  *kernel = rc == TSSEP_OK ? call.chosen : TSSEP_GEMM_AUTO;
+  return rc;
+}
+
+extern "C" const char* tssep_gemm_kernel_name(int32_t kernel) {
+  static const char* const names[] = {"auto", "f32", "pipe", "tall2", "tall4", "tall4_xcol", "big", "stream", "nt_w160",
+                                      "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160"};
+  return kernel >= 0 && kernel <= TSSEP_GEMM_KERNEL_LAST ? names[kernel] : "?";
+}
+
+// Split count of a weight gradient dW[M, N] = dY[K, M]^T X[K, N] (both operands k-major): `g` as for the launch,
+// splitk / c_split_stride / C ignored.  The rule follows the KERNEL the dispatcher picks (asked through the plan
+// query, never re-derived): tools/sweep_splitk.py, profiles/r2_splitk_sweep.jsonl, r3_wgrad_*_sweep.jsonl -- a model
+// that prices whole rounds of 512 resident workgroups predicts up to 20 % from other factors; measured, the large-K
+// shapes get SLOWER with more splits (the tiles of a K slab share it through one L2 only while they run together),
+// and these rules are within 0..5 % of the best S on every shape of the step.
+extern "C" int tssep_gemm_wgrad_splits(const tssep_gemm_args* g) {
+  if (!g) return TSSEP_E_NULL;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return TSSEP_E_SHAPE;
+  tssep_gemm_args a = normalised(g);
+  a.splitk = 8; a.c_split_stride = 0;
+  int32_t kid = TSSEP_GEMM_AUTO;
+  {
+    GemmCall call{nullptr, true, TSSEP_GEMM_AUTO, TSSEP_GEMM_AUTO};
+    const int rc = gemm_dispatch(&a, call);
+    if (rc != TSSEP_OK) return rc;
+    kid = call.chosen;
+  }
+  auto cdiv = [](int64_t x, int64_t y) { return (x + y - 1) / y; };
+  auto rup = [&](int64_t x, int64_t y) { return cdiv(x, y) * y; };
+  const int64_t M = g->M, N = g->N, K = g->K, ktiles = cdiv(K, 16);
+  const int min_ktiles = 8;
+  if (kid == TSSEP_GEMM_TN_BIG && K >= 16 * 64) {
+    // 512 x 128 tiles, ONE workgroup per CU, the tiles of a K slab on one XCD (32 CUs) -> as many slabs per XCD as fill
+    // its CUs best; multiples of 8 only (N = 128 q + 1 | 2: the last columns ride on the VALU of the q-th column tile)
+    const GemmSwitches sw = gemm_switches();
+    const int ones = g->b_ones_col ? 1 : 0;
+    const int64_t rem = N % 128;
+    const bool xc = sw.tn_xc && N > 128 && rem >= 1 && rem <= 2 && rem - ones <= 1;
+    const int64_t tiles = cdiv(M, 512) * (xc ? N / 128 : cdiv(N, 128));
+    int best = 8; double waste = 1e30;
+    for (int S = 8; S <= 32; S += 8) {
+      const int64_t wg = tiles * (S / 8);
+      const double w = (double)rup(wg, 32) / (double)wg;
+      if (w < waste) { waste = w; best = S; }
+    }
+    return best;
+  }
+  if (kid == TSSEP_GEMM_TN_W160 && ktiles >= 64 * 8) {
+    // 256 x 160 tile, two workgroups per CU, one round of at most 512 (tools/sweep_wgrad_splits.py: dW_hh 2.00 ms at
+    // S = 48, 2.30 at 40, 3.13 at 56)
+    const int64_t tiles = (rup(M, 256) / 256) * (rup(N, 160) / 160);
+    const int64_t a1 = 512 / tiles / 8 * 8, a2 = ktiles / 64 / 8 * 8;
+    const int64_t v = a1 < a2 ? a1 : a2;
+    return (int)(v > 8 ? v : 8);
+  }
+  if (kid == TSSEP_GEMM_TN_H160 && ktiles >= 64 * 8) {
+    // 320 x 128 tile, two workgroups per CU, one round of at most 512, at most 96 splits
+    const int64_t tiles = (rup(M, 320) / 320) * cdiv(N, 128);
+    int64_t v = 512 / tiles / 8 * 8;
+    if (v > 96) v = 96;
+    if (v > ktiles / 16 / 8 * 8) v = ktiles / 16 / 8 * 8;
+    return (int)(v > 8 ? v : 8);
+  }
+  const int64_t tiles = cdiv(M, 128) * cdiv(N, 128);
+  // the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the smallest one --
+  // 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
+  if (K >= 400000 && tiles >= 48) return 8;
+  const int64_t smax = ktiles / min_ktiles;          // every split keeps >= min_ktiles K tiles
+  if (tiles <= 16 && ktiles >= 64 * 8) {
+    // few tiles (a projection weight gradient off the 320-row tile): one resident round of 512 workgroups -- 32 splits
+    // 1.38 ms, the 56 of the general rule 1.51 (tools/sweep_wgrad_small.py); never more splits than K tiles allow
+    int64_t v = 512 / tiles / 8 * 8;
+    if (v > smax / 8 * 8) v = smax / 8 * 8;
+    return (int)(v > 8 ? v : 8);
+  }
+  int64_t sp = cdiv(768, tiles);
+  if (sp > smax) sp = smax;
+  if (sp < 1) sp = 1;
+  if (sp > 1) {        // multiples of the XCD count: split z runs on XCD z % 8 (gemm_common.h)
+    const int64_t cap = smax / 8 * 8 > 8 ? smax / 8 * 8 : 8;
+    sp = rup(sp, 8) < cap ? rup(sp, 8) : cap;
+  }
+  return (int)(sp < 64 ? sp : 64);
 }

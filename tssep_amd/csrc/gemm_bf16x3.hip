@@ -23,7 +23,6 @@
 // History (measured, profiles/r1_gemm_microbench_bf16x3.jsonl): a first version with one LDS
 // stage and two barriers per tile ran 113-267 TFLOP/s; BK = 64 and naive double buffering changed
 // nothing; the pipelined loop + row epilogue + tall tile run 190-320 TFLOP/s.
-#include <cstdlib>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -1184,61 +1183,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16x3_tn_tall_kernel(
 }  // namespace
 
 int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
-                             void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+                             gemm_detail::GemmCall& call) {
+  // The candidates in the order they are tried; `gemm_try(call, kernel, rule)`: in automatic mode the rule decides,
+  // a forced call (tssep_gemm_f32_on) tries exactly the kernel it names.  A candidate's own launcher checks what
+  // the kernel REQUIRES and returns TSSEP_E_UNSUPPORTED otherwise (the next candidate is tried in automatic mode).
+  // The rules are stated in quantities of the request (padding waste of a tile shape, K stages per tile, bytes of
+  // the C stream) -- profiles/r4_gemm_shape_sweep.jsonl holds, per shape of a sweep over units / projs / speakers,
+  // the time of every candidate next to the one the rules pick.
+  hipStream_t s = (hipStream_t)call.stream;
+  const GemmSwitches sw = gemm_switches();
   const bool shift = g->kperiod > 0;
+  const bool two = g->precision == 2;            // weight gradients only: the dY_lo * X_hi product dropped
   if (g->b_ones_col && (!g->b_kmajor || shift || g->N < 2)) return TSSEP_E_UNSUPPORTED;
-  static const bool tall = [] { const char* e = getenv("TSSEP_GEMM_TALL"); return !e || e[0] != '0'; }();
-  if (tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
-    // big-tile kernel (gemm_bf16x3_big.hip) where the wide tile applies (N >= 1024, < 10 % column padding).
-    // TSSEP_GEMM_BIG is read per call (alternating A/B runs toggle it)
-    {
-      const char* be = getenv("TSSEP_GEMM_BIG");
-      const int bmode = be ? atoi(be) : 1;
-      const int64_t n256b = (g->N + 255) / 256 * 256;
-      // (K < 448: a tile's life is mostly its C store there -- the streaming kernel, which hides it, measured
-      // 4.14 against 4.56 ms at K = 320, N = 2400; from K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280,
-      // 2.75 / 3.29 at K = 2400, N = 1280; bmode 2 = regardless of K)
-      const bool xcol_shape = g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0;      // N = 513: two tiles + a VALU column
-      if (bmode && (g->K >= 448 || bmode == 2) && ((g->N >= 1024 && n256b * 10 <= g->N * 11) || xcol_shape)) {
-        const int rc = tssep_gemm_bf16x3_big_launch(g, sm, stream);
-        if (rc != TSSEP_E_UNSUPPORTED) return rc;
-      }
+  if (two && !(g->a_kmajor && g->b_kmajor)) return TSSEP_E_UNSUPPORTED;
+#define TAKEN(KID_) do { call.chosen = (KID_); if (call.dry) return TSSEP_OK; } while (0)
+  if (sw.tall && !g->a_kmajor && !g->b_kmajor && splitk == 1 && g->M >= 4 * TBM) {
+    const int64_t n256 = (g->N + 255) / 256 * 256;
+    const bool xcol_shape = g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0;      // N = 256 q + 1: q tiles + a VALU column
+    const bool pads_to_256 = g->N >= 1024 && n256 * 10 <= g->N * 11;               // < 10 % column padding
+    // big-tile kernel (gemm_bf16x3_big.hip) where the 256-wide tile applies.  (K < 448: a tile's life is mostly its
+    // C store there -- the streaming kernel, which hides it, measured 4.14 against 4.56 ms at K = 320, N = 2400; from
+    // K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280, 2.75 / 3.29 at K = 2400, N = 1280; sw.big 2 =
+    // regardless of K)
+    if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (g->K >= 448 || sw.big == 2) && (pads_to_256 || xcol_shape))) {
+      const int rc = tssep_gemm_bf16x3_big_launch(g, sm, call);
+      if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG; return rc; }
     }
     // persistent streaming kernel (gemm_bf16x3_stream.hip): plain row-major stores; the N = 256 q + 1 shapes keep
-    // the wide tile with its VALU column.  TSSEP_GEMM_STREAM is read per call (alternating A/B runs toggle it)
-    {
-      const char* se = getenv("TSSEP_GEMM_STREAM");
-      const int smode = se ? atoi(se) : 1;
-      if (smode && !sm.remap && !(g->N > 256 && g->N % 256 == 1)) {
-        const int rc = tssep_gemm_bf16x3_stream_launch(g, sm, stream);
-        if (rc != TSSEP_E_UNSUPPORTED) return rc;
-      }
+    // the wide tile with its VALU column
+    if (gemm_try(call, TSSEP_GEMM_STREAM, sw.stream && !sm.remap && !(g->N > 256 && g->N % 256 == 1))) {
+      const int rc = tssep_gemm_bf16x3_stream_launch(g, sm, call);
+      if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_STREAM; return rc; }
     }
     // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (N = 320: the Tanh
-    // projections and d(input) of birnn1, which the two kernels above do not take).  TSSEP_GEMM_NT_W160 is read per call
+    // projections and d(input) of birnn1, which the two kernels above do not take)
     {
-      const char* ue = getenv("TSSEP_GEMM_NT_W160");
       const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-      if ((!ue || ue[0] != '0') && n160 * 11 <= n128 * 10) {
-        const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, stream);
-        if (rc != TSSEP_E_UNSUPPORTED) return rc;
+      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && n160 * 11 <= n128 * 10)) {
+        const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, call);
+        if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_NT_W160; return rc; }
       }
     }
-    // wide (256 x 256) tile where rounding N up to 256 wastes < 10 % of the columns (N = 2400, 1280 of the
-    // step; not 513 / 320 / 600 / 2052)
-    const char* wide_env = getenv("TSSEP_GEMM_WIDE");          // read per call: A/B runs toggle it in-process
-    const int wide = wide_env ? atoi(wide_env) : 1;
-    const int64_t n256 = (g->N + 255) / 256 * 256;
-    if (wide && g->N >= 1024 && n256 * 10 <= g->N * 11) {
+    // wide (256 x 256) eight-wave tile where rounding N up to 256 wastes < 10 % of the columns
+    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256)) {
+      TAKEN(TSSEP_GEMM_TALL4);
       const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
 #ifdef TSSEP_GEMM_EXP
       {
-        const char* he = getenv("TSSEP_GEMM_HACK");
-        const int hack = he ? atoi(he) : 0;
 #define HK(H_) case H_: hipLaunchKernelGGL((gemm_bf16x3_tall_kernel<4, false, H_>), dim3((unsigned)tile_map_blocks(tm4)), dim3(512), 0, s, \
                          g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tm4); return tssep_launch_status();
-        switch (hack) { HK(1) HK(2) HK(3) HK(4) HK(6) HK(8) HK(10) HK(12) HK(14) HK(16) HK(18) HK(32) HK(64) default: break; }
+        switch (sw.hack) { HK(1) HK(2) HK(3) HK(4) HK(6) HK(8) HK(10) HK(12) HK(14) HK(16) HK(18) HK(32) HK(64) default: break; }
 #undef HK
       }
 #endif
@@ -1247,71 +1241,67 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
                          g->accumulate, sm, tm4);
       return tssep_launch_status();
     }
-    const char* xc_env = getenv("TSSEP_GEMM_XCOL");            // read per call (alternating A/B)
-    if ((!xc_env || xc_env[0] != '0') && g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0) {
+    if (xcol_shape && gemm_try(call, TSSEP_GEMM_TALL4_XCOL, sw.xcol != 0)) {
+      TAKEN(TSSEP_GEMM_TALL4_XCOL);
       const TileMap tmx = make_tile_map((g->M + TBM - 1) / TBM, (g->N - 1) / 256, 1);
       hipLaunchKernelGGL((gemm_bf16x3_tall_kernel<4, true>), dim3((unsigned)tile_map_blocks(tmx)), dim3(512), 0, s,
                          g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
                          g->accumulate, sm, tmx);
       return tssep_launch_status();
     }
-    const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
-    hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<2>, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
-                       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
-                       g->accumulate, sm, tm2);
-    return tssep_launch_status();
+    if (gemm_try(call, TSSEP_GEMM_TALL2, true)) {
+      TAKEN(TSSEP_GEMM_TALL2);
+      const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
+      hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<2>, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
+                         g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act,
+                         g->accumulate, sm, tm2);
+      return tssep_launch_status();
+    }
   }
   const TileMap tmap = make_tile_map((g->M + BM - 1) / BM, (g->N + BN - 1) / BN, splitk);
   dim3 grid((unsigned)tile_map_blocks(tmap));
   {
     // weight gradients: both operands k-major, plain store, 16-byte rows (see gemm_bf16x3_tn_kernel)
-    static const bool tn = [] { const char* e = getenv("TSSEP_GEMM_TN"); return !e || e[0] != '0'; }();
     const int64_t nreal = g->N - (g->b_ones_col ? 1 : 0);
     const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
-    if (tn && g->a_kmajor && g->b_kmajor && !sm.remap && !g->bias && g->act == 0 && (g->lda & 3) == 0 &&
+    if (sw.tn && g->a_kmajor && g->b_kmajor && !sm.remap && !g->bias && g->act == 0 && (g->lda & 3) == 0 &&
         (g->ldb & 3) == 0 && aligned16(g->A) && aligned16(g->B) && ((g->M + 3) & ~(int64_t)3) <= g->lda &&
         nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
-      const char* pe = getenv("TSSEP_WGRAD_PRODUCTS");           // opt-in: 2 = drop the dY_lo * X_hi product
-      const bool two = pe && pe[0] == '2';
-      {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by < 10 % (the four dW_ih GEMMs: M = 2400)
-        const char* tbe = getenv("TSSEP_GEMM_TN_BIG");            // read per call (alternating A/B)
-        const int tbig = tbe ? atoi(tbe) : 1;
+      {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by < 10 % (the dW_ih GEMMs: M = 8 units)
         const int64_t m512 = (g->M + 511) / 512 * 512;
-        if (tbig && !shift && g->M >= 1024 && m512 * 10 <= g->M * 11) {
-          const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, two ? 1 : 0, stream);
-          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        if (gemm_try(call, TSSEP_GEMM_TN_BIG, sw.tn_big && !shift && g->M >= 1024 && m512 * 10 <= g->M * 11)) {
+          const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, two ? 1 : 0, call);
+          if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_BIG; return rc; }
         }
       }
-      {   // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (dW_hh: N = 300)
-        const char* we = getenv("TSSEP_GEMM_TN_W160");            // read per call (alternating A/B)
+      {   // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (dW_hh: N = units = 300)
         const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-        if ((!we || we[0] != '0') && n160 * 11 <= n128 * 10) {
-          const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, stream);
-          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && n160 * 11 <= n128 * 10)) {
+          const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
+          if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
         }
       }
       {   // 320 x 128 tile where 320-row tiles waste >= 10 % fewer rows than 128-row ones (the projection weight
-          // gradients: M = 320, N = 601: 1.18 vs 1.38 ms at each kernel's best split count), four column tiles or more
-          // (one column tile: 0.13 vs 0.08 ms, profiles/r3_wgrad_h160_sweep.jsonl).  TSSEP_GEMM_TN_H160 is read per call
-        const char* he = getenv("TSSEP_GEMM_TN_H160");
+          // gradients: M = projs = 320, N = 2 units + 1: 1.18 vs 1.38 ms at each kernel's best split count), four column
+          // tiles or more (one column tile: 0.13 vs 0.08 ms, profiles/r3_wgrad_h160_sweep.jsonl)
         const int64_t m320 = (g->M + 319) / 320 * 320, m128 = (g->M + BM - 1) / BM * BM;
-        if ((!he || he[0] != '0') && !shift && m320 * 11 <= m128 * 10 && g->N > 3 * BN) {
-          const int rc = tssep_gemm_bf16x3_tn_h160_launch(g, sm, splitk, two ? 1 : 0, stream);
-          if (rc != TSSEP_E_UNSUPPORTED) return rc;
+        if (gemm_try(call, TSSEP_GEMM_TN_H160, sw.tn_h160 && !shift && m320 * 11 <= m128 * 10 && g->N > 3 * BN)) {
+          const int rc = tssep_gemm_bf16x3_tn_h160_launch(g, sm, splitk, two ? 1 : 0, call);
+          if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_H160; return rc; }
         }
       }
-      const char* te = getenv("TSSEP_GEMM_TN_TALL");             // read per call (alternating A/B)
       const int64_t m256 = (g->M + TTM - 1) / TTM * TTM;
-      // default 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones
+      // rule 4: the time-shifted dW_hh GEMMs (-2.3 ms per step, alternating A/B) and, round 3, the unshifted ones
       // with at most 3 or at least 9 column tiles (dW_ih of birnn1: N = 321, birnn2: N = 1281 -- 4.89 vs 5.27 ms and
-      // 4.28 vs 4.55 ms with the split counts hip_ops.pick_splitk gives them, profiles/r3_wgrad_tile_sweep.jsonl);
+      // 4.28 vs 4.55 ms with the split counts tssep_gemm_wgrad_splits gives them, profiles/r3_wgrad_tile_sweep.jsonl);
       // the 5-column-tile shapes (N = 514 / 554) stay on the 128 x 128 tile: there the larger tile measured equal or
       // slower at every split count.  (1: all eligible, 2: shifted only, 3: unshifted only, 0: off)
-      const int tmode = te ? atoi(te) : 4;
+      const int tmode = sw.tn_tall;
       const int64_t ntl = (g->N + BN - 1) / BN;
       const bool want = tmode == 1 || (tmode == 2 && shift) || (tmode == 3 && !shift) ||
                         (tmode == 4 && (shift || ntl <= 3 || ntl >= 9));
-      if (want && g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16)) {
+      if (g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16) && gemm_try(call, TSSEP_GEMM_TN_TALL, want)) {
+        TAKEN(TSSEP_GEMM_TN_TALL);
         const TileMap tmt = make_tile_map(m256 / TTM, (g->N + BN - 1) / BN, splitk);
         dim3 gridt((unsigned)tile_map_blocks(tmt));
 #define TT_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_tall_kernel<SH, TW>), gridt, dim3(NTHREADS), 0, s, \
@@ -1321,22 +1311,27 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
 #undef TT_LAUNCH
         return tssep_launch_status();
       }
+      if (gemm_try(call, TSSEP_GEMM_TN, true)) {
+        TAKEN(TSSEP_GEMM_TN);
 #define TN_LAUNCH(SH, TW, ...) hipLaunchKernelGGL((gemm_bf16x3_tn_kernel<SH, TW>), grid, dim3(NTHREADS), 0, s, __VA_ARGS__)
-      if (shift) {
-        if (two) TN_LAUNCH(true, true, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift,
-                           (int)g->kperiod, g->accumulate, sm.ldc, splitk, g->c_split_stride, tmap, 0);
-        else TN_LAUNCH(true, false, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift,
-                       (int)g->kperiod, g->accumulate, sm.ldc, splitk, g->c_split_stride, tmap, 0);
-      } else {
-        if (two) TN_LAUNCH(false, true, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, 0, 1, g->accumulate,
-                           sm.ldc, splitk, g->c_split_stride, tmap, g->b_ones_col);
-        else TN_LAUNCH(false, false, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, 0, 1, g->accumulate,
-                       sm.ldc, splitk, g->c_split_stride, tmap, g->b_ones_col);
-      }
+        if (shift) {
+          if (two) TN_LAUNCH(true, true, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift,
+                             (int)g->kperiod, g->accumulate, sm.ldc, splitk, g->c_split_stride, tmap, 0);
+          else TN_LAUNCH(true, false, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift,
+                         (int)g->kperiod, g->accumulate, sm.ldc, splitk, g->c_split_stride, tmap, 0);
+        } else {
+          if (two) TN_LAUNCH(false, true, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, 0, 1, g->accumulate,
+                             sm.ldc, splitk, g->c_split_stride, tmap, g->b_ones_col);
+          else TN_LAUNCH(false, false, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, 0, 1, g->accumulate,
+                         sm.ldc, splitk, g->c_split_stride, tmap, g->b_ones_col);
+        }
 #undef TN_LAUNCH
-      return tssep_launch_status();
+        return tssep_launch_status();
+      }
     }
   }
+  if (two || !gemm_try(call, TSSEP_GEMM_PIPE, true)) return TSSEP_E_UNSUPPORTED;
+  TAKEN(TSSEP_GEMM_PIPE);
 #define LAUNCH(AK, BKM, SH)                                                                      \
   hipLaunchKernelGGL((gemm_bf16x3_pipe_kernel<32, AK, BKM, SH>), grid, dim3(NTHREADS), 0, s,     \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->b_kshift,            \
@@ -1349,5 +1344,6 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
   else if (shift) { if (fast) LAUNCH(true, true, 2); else LAUNCH(true, true, 1); }
   else LAUNCH(true, true, 0);
 #undef LAUNCH
+#undef TAKEN
   return tssep_launch_status();
 }

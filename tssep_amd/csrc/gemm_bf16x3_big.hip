@@ -373,8 +373,9 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
 
 }  // namespace
 
-int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream) {
+int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call) {
   using namespace gemm_detail;
+  void* const stream = call.stream;
   if (g->a_kmajor || g->b_kmajor || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B)) return TSSEP_E_UNSUPPORTED;
   if (g->M < 4 * GM || g->K < 1) return TSSEP_E_UNSUPPORTED;
@@ -384,11 +385,13 @@ int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::St
   const TileMap tm = make_tile_map((g->M + GM - 1) / GM, (g->N + GN - 1) / GN, 1);
   if (g->N > 256 && g->N % 256 == 1) {        // 256 q + 1 columns: q tiles + one VALU column
     if (g->K & 3) return TSSEP_E_UNSUPPORTED;
+    if (call.dry) return TSSEP_OK;
     const TileMap tmx = make_tile_map((g->M + GM - 1) / GM, (g->N - 1) / GN, 1);
     hipLaunchKernelGGL((gemm_bf16x3_big_kernel<0, true>), dim3((unsigned)tile_map_blocks(tmx)), dim3(GNT), 0, (hipStream_t)stream,
                        g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tmx);
     return tssep_launch_status();
   }
+  if (call.dry) return TSSEP_OK;
 #define GLAUNCH(P_) hipLaunchKernelGGL((gemm_bf16x3_big_kernel<P_, false>), dim3((unsigned)tile_map_blocks(tm)), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tm)
 #ifdef TSSEP_GEMM_EXP

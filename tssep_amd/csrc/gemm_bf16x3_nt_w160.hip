@@ -175,13 +175,15 @@ __global__ __launch_bounds__(UNT, 2) void gemm_bf16x3_nt_w160_kernel(
 }  // namespace
 
 // Returns TSSEP_E_UNSUPPORTED where the geometry does not apply (the caller falls back to the 128-wide tiles).
-int tssep_gemm_bf16x3_nt_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream) {
+int tssep_gemm_bf16x3_nt_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call) {
   using namespace gemm_detail;
+  void* const stream = call.stream;
   if (g->a_kmajor || g->b_kmajor || g->M < 1024 || g->K < 48 || (g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B))
     return TSSEP_E_UNSUPPORTED;
   // 32-bit buffer offsets inside a row tile
   if ((int64_t)UM * g->lda * 4 + g->K * 4 >= ((int64_t)1 << 31) || (int64_t)UN * g->ldb * 4 + g->K * 4 >= ((int64_t)1 << 31))
     return TSSEP_E_UNSUPPORTED;
+  if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + UM - 1) / UM, (g->N + UN - 1) / UN, 1);
   hipLaunchKernelGGL(gemm_bf16x3_nt_w160_kernel, dim3((unsigned)tile_map_blocks(tm)), dim3(UNT), 0, (hipStream_t)stream, g->A, g->B,
                      g->C, g->M, g->N, g->K, g->lda, g->ldb, g->bias, g->act, g->accumulate, sm, tm);

@@ -343,8 +343,9 @@ __global__ __launch_bounds__(SNT, 2) void gemm_bf16x3_stream_kernel(
 }
 }  // namespace
 
-int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream) {
+int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call) {
   using namespace gemm_detail;
+  void* const stream = call.stream;
   if (g->a_kmajor || g->b_kmajor || sm.remap || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   // plain stores + bias only (the GEMMs with a Tanh / its backward / an accumulate in the store keep the tiled kernels:
   // their extra loads would sit in the drain's way), 16-byte rows of C
@@ -355,6 +356,7 @@ int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail:
   // 32-bit buffer offsets: one tile's rows and the whole K extent must stay below 2 GB
   if ((int64_t)SM * g->lda * 4 + g->K * 4 >= (int64_t)1 << 31 || (int64_t)SN * g->ldb * 4 + g->K * 4 >= (int64_t)1 << 31)
     return TSSEP_E_UNSUPPORTED;
+  if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + SM - 1) / SM, (g->N + SN - 1) / SN, 1);
   const int64_t nids = tile_map_blocks(tm);
   static const int ncu = [] {

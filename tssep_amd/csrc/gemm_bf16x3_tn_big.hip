@@ -330,8 +330,10 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
 
 }  // namespace
 
-int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream) {
+int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two,
+                                    const gemm_detail::GemmCall& call) {
   using namespace gemm_detail;
+  void* const stream = call.stream;
   if (!g->a_kmajor || !g->b_kmajor || sm.remap || g->bias || g->act || g->kperiod > 0) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B) || (g->M & 3) || (g->K % WBK)) return TSSEP_E_UNSUPPORTED;
   const int64_t nreal = g->N - (g->b_ones_col ? 1 : 0);
@@ -341,10 +343,10 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
   if ((per + 4) * WBK * (g->lda > g->ldb ? g->lda : g->ldb) * 4 >= (int64_t)1 << 31) return TSSEP_E_UNSUPPORTED;
   // N = 128 q + 1 or + 2 (q >= 1): the last one / two columns on the VALU instead of a column tile of their own
   // (one real column at most; the ones column of b_ones_col is the last column)
-  const char* xe = getenv("TSSEP_GEMM_TN_XC");
+  if (call.dry) return TSSEP_OK;
   const int rem = (int)(g->N % WN), ones = g->b_ones_col ? 1 : 0;
   int xc = 0;
-  if ((!xe || xe[0] != '0') && g->N > WN && rem >= 1 && rem <= 2 && rem - ones <= 1)
+  if (gemm_switches().tn_xc && g->N > WN && rem >= 1 && rem <= 2 && rem - ones <= 1)
     xc = 10 * (rem - ones) + ones;
   const TileMap tm = make_tile_map((g->M + WM - 1) / WM, xc ? g->N / WN : (g->N + WN - 1) / WN, splitk);
 #define TNB_LAUNCH(TW, XC_) hipLaunchKernelGGL((gemm_bf16x3_tn_big_kernel<TW, XC_>), dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, \

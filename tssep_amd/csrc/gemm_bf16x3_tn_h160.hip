@@ -249,13 +249,15 @@ __global__ __launch_bounds__(HNT, 2) void gemm_bf16x3_tn_h160_kernel(
 // Returns TSSEP_E_UNSUPPORTED where the geometry does not apply: the caller (gemm_bf16x3.hip) has already checked the
 // operand layout of the tn kernels (k-major operands, 16-byte rows, no bias / activation / remapped store, no shift).
 int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two,
-                                     void* stream) {
+                                     const gemm_detail::GemmCall& call) {
+  void* const stream = call.stream;
   using namespace gemm_detail;
   if (g->kperiod > 0 || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
   // 32-bit buffer offsets inside a split
   const int64_t ktiles = (g->K + HBK - 1) / HBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
   if ((per + 4) * HBK * ldmax * 4 >= ((int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
+  if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + HM - 1) / HM, (g->N + HN - 1) / HN, splitk);
   const dim3 grid((unsigned)tile_map_blocks(tm));
 #define H_LAUNCH(TW) hipLaunchKernelGGL((gemm_bf16x3_tn_h160_kernel<TW>), grid, dim3(HNT), 0, (hipStream_t)stream, g->A, g->B, g->C, \

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
 // Returns TSSEP_E_UNSUPPORTED where the geometry does not apply: the caller (gemm_bf16x3.hip) has already checked the
 // operand layout of the tn kernels (k-major operands, 16-byte rows, no bias / activation / remapped store).
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two,
-                                     void* stream) {
+                                     const gemm_detail::GemmCall& call) {
+  void* const stream = call.stream;
   const bool shift = g->kperiod > 0;
   const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
   const int64_t m256 = (g->M + VM - 1) / VM * VM;
@@ -287,6 +288,7 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
   if ((per + 4) * VBK * ldmax * 4 >= ((int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
+  if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map(m256 / VM, (g->N + VN - 1) / VN, splitk);
   const dim3 grid((unsigned)tile_map_blocks(tm));
 #define V_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_w160_kernel<SH, TW>), grid, dim3(VNT), 0, (hipStream_t)stream, \

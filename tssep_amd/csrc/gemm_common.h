@@ -1,6 +1,7 @@
 // Shared pieces of the two GEMM kernels (exact fp32 and split-bf16): output mapping + epilogue.
 #pragma once
 #include "common.h"
+#include "gemm_dispatch.h"
 
 namespace gemm_detail {
 
@@ -186,9 +187,14 @@ __device__ __forceinline__ void gemm_epilogue_rows(const f32x16 (&acc)[2][2], fl
     }
     float* dst = Cz + m * ldc + n;
     if (vec) {
+#ifdef TSSEP_GEMM_EXP
       if (accumulate == 1) v += *reinterpret_cast<const f32x4*>(dst);
-      if (accumulate == 2) *reinterpret_cast<f32x4*>(dst) = v;      // (experiment builds: temporal stores)
+      if (accumulate == 2) *reinterpret_cast<f32x4*>(dst) = v;      // (timing probe HACK & 64: temporal stores)
       else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);    // a boolean, as in every other epilogue
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -457,19 +463,18 @@ __device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned
 
 }  // namespace gemm_detail
 
-// split-bf16 (bf16x3) variant, defined in gemm_bf16x3.hip
-int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk,
-                             void* stream);
-// persistent streaming variant (row x row, plain store), defined in gemm_bf16x3_stream.hip: returns
-// TSSEP_E_UNSUPPORTED when the arguments are outside what it covers
-int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
+// split-bf16 (bf16x3) family, defined in gemm_bf16x3*.hip.  Every launcher checks what its kernel REQUIRES and returns
+// TSSEP_E_UNSUPPORTED otherwise; with call.dry it stops in front of the launch (plan query).  gemm_dispatch.h.
+int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, gemm_detail::GemmCall& call);
+// persistent streaming variant (row x row, plain store), gemm_bf16x3_stream.hip
+int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);
 // 256 x 256 tile with 128 x 128 wave tiles, one wave per SIMD (gemm_bf16x3_big.hip); every epilogue option
-int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
+int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);
 // weight gradients (both operands k-major, no time shift): 512 x 128 tile, 128 x 128 wave tiles, three LDS stages
 // (gemm_bf16x3_tn_big.hip)
-int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
-// (gemm_bf16x3_tn_w160.hip)
-int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
-int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, void* stream);
+int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
+// (gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_h160.hip)
+int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
+int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 // (gemm_bf16x3_nt_w160.hip)
-int tssep_gemm_bf16x3_nt_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, void* stream);
+int tssep_gemm_bf16x3_nt_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);

@@ -96,7 +96,42 @@ def init_from_env(backend=None):
         import datetime
         timeout = datetime.timedelta(seconds=float(os.environ.get("TSSEP_DIST_TIMEOUT_S", 4 * 3600)))
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout, **kw)
+        _make_control_group(backend, timeout)
     return rank, world, local_rank
+
+
+# Control plane: the small integers the ranks agree on per micro-step (has-data flags, failure codes) travel
+# over a HOST-side gloo group next to the RCCL data plane.  On the nccl group the same 16-byte all-reduce is a
+# GPU collective queued behind the previous step's kernels and read back with a host sync: the host would lose
+# its launch-ahead on every micro-step.  Without the group (creation failed / TSSEP_DIST_CONTROL=0)
+# the exchanges fall back to the default group, correct but synchronising.
+_CONTROL = None
+
+
+def _make_control_group(backend, timeout):
+    global _CONTROL
+    import os
+    _CONTROL = None
+    if backend != "nccl" or os.environ.get("TSSEP_DIST_CONTROL", "1") == "0":
+        return
+    try:
+        _CONTROL = dist.new_group(backend="gloo", timeout=timeout)
+    except Exception as e:                                   # noqa: BLE001 -- every rank fails alike or none does
+        import warnings
+        warnings.warn(f"tssep_amd.distributed: no host-side control group ({e}); control exchanges will "
+                      "synchronise with the GPU stream")
+        _CONTROL = None
+
+
+def _control_tensor(values, device=None):
+    """(tensor, group) for a control exchange: host memory on the gloo control / default group, device memory
+    only when the one group there is, is RCCL."""
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+    if _CONTROL is not None:
+        return t, _CONTROL
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+    return t, None
 
 
 def agree_on_failure(code, device=None):
@@ -106,10 +141,8 @@ def agree_on_failure(code, device=None):
     if world_size() == 1:
         return int(code), (0 if code else -1)
     rank = get_rank()
-    t = torch.tensor([int(code), (rank + 1) if code else 0], dtype=torch.int64)
-    if dist.get_backend() == "nccl":
-        t = t.to(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t, group = _control_tensor([code, (rank + 1) if code else 0], device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     worst, who = (int(v) for v in t.cpu())
     return worst, who - 1
 
@@ -118,10 +151,8 @@ def same_on_all_ranks(value):
     """Collective: True when the integer `value` is the same on every rank."""
     if world_size() == 1:
         return True
-    t = torch.tensor([int(value), -int(value)], dtype=torch.int64)
-    if dist.get_backend() == "nccl":
-        t = t.to(torch.device("cuda", torch.cuda.current_device()))
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t, group = _control_tensor([value, -int(value)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     hi, neg_lo = (int(v) for v in t.cpu())
     return hi == -neg_lo
 

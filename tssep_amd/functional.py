@@ -24,11 +24,11 @@ def _pad4(n):
 _ZERO = {}
 
 
-def _dummy_grad(like):
+def _dummy_grad(like, shape=None):
     z = _ZERO.get(like.device)
     if z is None:
         z = _ZERO[like.device] = torch.zeros(1, device=like.device, dtype=torch.float32)
-    return z.expand(like.shape)
+    return z.expand(tuple(like.shape if shape is None else shape))
 
 
 def _is_dummy(g):
@@ -47,6 +47,13 @@ class _Link:
         p, self.payload = self.payload, None
         return p
 
+    def observed(self):
+        """True when somebody watches the gradient of the tensor this link hangs on (``register_hook``,
+        ``retain_grad``): a fold that never forms that gradient must not be taken then."""
+        ref = getattr(self, "out", None)
+        t = ref() if ref is not None else None
+        return t is not None and (bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "retains_grad", False)))
+
 
 # ------------------------------------------------------------------------------ RNNP
 class _RNNP(torch.autograd.Function):
@@ -58,7 +65,7 @@ class _RNNP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj,
-                N, T, act, combine, in_tanh=0, dz_given=False):
+                N, T, act, combine, in_tanh=0, in_link=None, out_link=None):
         dev = x.device
         Hh = w_hh.shape[1]
         I = w_ih.shape[1]
@@ -108,8 +115,10 @@ class _RNNP(torch.autograd.Function):
         ctx.params = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, w_proj, b_proj)
         ctx.pk = pk
         ctx.meta = (N, T, I, Hh, Hp, hdim, ld_x, ld_y, act, combine)
-        ctx.fold = (int(in_tanh), bool(dz_given))
-        assert not dz_given or act == 1, "dz_given: only behind the fused Tanh"
+        # Tanh-backward fold (see rnnp_layer): in_link = the link my producer hung on x, out_link = the one my
+        # consumer may answer on.  Both are decided again in backward, when it is known who else uses the tensors.
+        ctx.fold = (int(in_tanh) if in_link is not None else 0, in_link, out_link)
+        assert out_link is None or act == 1, "out_link: only behind the fused Tanh"
         ctx.x_shape = x.shape
         return y if combine else y[:, :hdim]
 
@@ -122,9 +131,17 @@ class _RNNP(torch.autograd.Function):
         R = N * T
         K = combine if combine else 1
         # d(pre-activation) of the projection, rows (n,t) x hdim, contiguous
-        in_tanh, dz_given = ctx.fold
-        if dz_given:      # the consumer's d(input) GEMM already applied 1 - y^2 and wrote dense rows (n,t) x hdim
-            dz = dy.contiguous().view(R, hdim)
+        in_tanh, in_link, out_link = ctx.fold
+        folded = out_link.take() if out_link is not None else None
+        if folded is not None:
+            # the consumer's d(input) GEMM already applied 1 - y^2 and wrote dense rows (n,t) x hdim; `dy` is the
+            # dummy it returned -- unless y has ANOTHER consumer (auxiliary loss): autograd then summed that
+            # consumer's plain d(y) onto the dummy's zeros, and it goes through the Tanh backward here
+            dz = folded.view(R, hdim)
+            if not _is_dummy(dy):
+                dyc = dy.contiguous() if combine else _dense_rows(dy, hdim)
+                yc = y if combine else _dense_rows(y[:, :hdim], hdim)
+                dz = dz + H.tanh_bwd(dyc, yc, R, hdim, K, T, bool(combine))
         elif act:
             dyc = dy.contiguous() if combine else _dense_rows(dy, hdim)
             yc = y if combine else _dense_rows(y[:, :hdim], hdim)
@@ -236,7 +253,9 @@ class _RNNP(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wihT, ld_t = H.derived("wih_T", [params[0], params[4]],
                                    lambda: H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I))
-            if in_tanh:       # my input is a Tanh output: its backward rides on this GEMM's store
+            if in_tanh and not in_link.observed():
+                # my input is a Tanh output: its backward rides on this GEMM's store and the result travels on
+                # the link; x receives a dummy (its true gradient is never formed -- hence not when it is watched)
                 Kc = in_tanh
                 assert I % 4 == 0 and I % Kc == 0 and ld_x == I, (I, Kc, ld_x)
                 dxb = torch.empty(R, I, device=dev, dtype=torch.float32)
@@ -245,14 +264,15 @@ class _RNNP(torch.autograd.Function):
                     hd = I // Kc
                     remap = dict(T=T, K=1, sb=Kc * T * hd, sk=0, st=hd, cm=hd, co=T * hd)
                 H.gemm(gates, G, wihT, ld_t, dxb, 0 if remap else I, R, I, G, act=2, aux=(xv, ld_x), remap=remap)
-                dx = dxb.view(ctx.x_shape)
+                in_link.payload = dxb
+                dx = _dummy_grad(xv, ctx.x_shape)
             else:
                 dxb, ld_dx = H.padded(R, I, dev, zero=True)
                 H.gemm(gates, G, wihT, ld_t, dxb, ld_dx, R, I, G)
                 dx = dxb[:, :I]
                 if tuple(ctx.x_shape) != tuple(dx.shape):
                     dx = dx.reshape(ctx.x_shape)
-        return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None, None, None)
+        return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None, None, None, None)
 
 
 def _grad_sink(p):
@@ -288,14 +308,26 @@ def _proj_unlayout(dwp, Hh, Hp):
 def rnnp_layer(x, lstm, linear, N, T, act=0, combine=0, in_tanh=0, dz_given=False):
     """x rows (n,t); lstm = torch.nn.LSTM parameter container, linear = nn.Linear container.
     The Tanh between two layers (net.py:623-625) runs forward in the producer's projection epilogue (act = 1);
-    its BACKWARD runs in the store of the consumer's d(input) GEMM: the consumer is called with in_tanh
-    (1: same row layout; K > 1: its input is the producer's speaker-combined tensor [B T, K hdim] and the
-    gradient is stored back as rows (b,k,t) x hdim) and the producer with dz_given -- what reaches it is already
-    d(pre-activation) in dense rows, shaped like its output only for autograd's shape check."""
-    return _RNNP.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
-                       lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,
-                       lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse,
-                       linear.weight, linear.bias, N, T, act, combine, in_tanh, dz_given)
+    its BACKWARD may run in the store of the consumer's d(input) GEMM: the producer is called with dz_given and
+    hangs a _Link on its output, the consumer with in_tanh (1: same row layout; K > 1: its input is the
+    producer's speaker-combined tensor [B T, K hdim] and the gradient is stored back as rows (b,k,t) x hdim).
+    In backward the consumer leaves d(pre-activation) on the link and returns a dummy for its input; the
+    producer adds the Tanh backward of whatever ELSE arrived for its output (a second consumer), and when the
+    output is watched (hook / retain_grad) or the consumer never ran, nothing is folded and `tssep_tanh_bwd`
+    runs as without the fold -- correct either way (VERDICT r3 #8)."""
+    import weakref
+    in_link = getattr(x, "_tssep_tanh_link", None) if in_tanh else None
+    if in_link is not None and not (x.requires_grad and torch.is_grad_enabled()):
+        in_link = None
+    out_link = _Link() if (dz_given and act == 1 and torch.is_grad_enabled()) else None
+    out = _RNNP.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                      lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse,
+                      lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse,
+                      linear.weight, linear.bias, N, T, act, combine, in_tanh, in_link, out_link)
+    if out_link is not None and out.requires_grad:
+        out_link.out = weakref.ref(out)
+        out._tssep_tanh_link = out_link
+    return out
 
 
 # ---------------------------------------------------------------------- conditioning

@@ -40,6 +40,14 @@ class _timed:
             KERNEL_BYTES[self.name] = KERNEL_BYTES.get(self.name, 0) + self.nbytes
 
 
+KERNEL_OWN_BYTES = {}   # name -> bytes the kernel that actually runs must move (fused kernels: not the unfused chain's)
+
+
+def _own_bytes(name, nbytes):
+    if KERNEL_TIMING:
+        KERNEL_OWN_BYTES[name] = KERNEL_OWN_BYTES.get(name, 0) + nbytes
+
+
 def kernel_time_summary():
     torch.cuda.synchronize()
     return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in KERNEL_TIMERS.items()}
@@ -185,7 +193,9 @@ def mask_istft_fwd(logit, obs, wsyn, N, size=1024, shift=256, fading=True, tgt=N
     if tgt is not None:
         part = torch.empty(B * K, int(L.tssep_istft_chunks(N)), device=logit.device, dtype=torch.float32)
         tgt = _f32(tgt).contiguous()
-    # roofline bookkeeping: the UNFUSED mask head's algorithmic bytes, whatever is moved
+    # roofline bookkeeping: the UNFUSED mask head's algorithmic bytes, whatever is moved; the fused kernel's OWN
+    # bytes (logit + observation in, samples out, target in when the loss sums ride along) are kept beside them
+    _own_bytes("maskhead_fwd", B * T * (4 * K * F + 8 * F) + 4 * B * K * N * (2 if tgt is not None else 1))
     with _timed("maskhead_fwd", 0, B * T * (16 * K * F + 8 * F)):
         check(L.tssep_mask_istft_fwd(_p(logit), _p(obs_r), B, K, T, size, shift, int(fading), _p(wsyn),
                                      _p(fft_tables(size, logit.device)), _p(y), N, _p(tgt), _p(part),
@@ -202,6 +212,7 @@ def mask_istft_bwd(dy, logit, obs, wsyn, size=1024, shift=256, fading=True, loss
     B, K, T, F = logit.shape
     obs_r = torch.view_as_real(obs.contiguous())
     dlogit = torch.empty(B * T, K * F, device=logit.device, dtype=torch.float32) if bt_major else torch.empty_like(logit)
+    _own_bytes("maskhead_bwd", B * T * (8 * K * F + 8 * F) + 4 * B * K * (dy.shape[-1] if loss is None else 2 * loss[0].shape[-1]))
     with _timed("maskhead_bwd", 0, B * T * (16 * K * F + 8 * F)):
         if loss is None and not bt_major:
             dy = _f32(dy).contiguous()
@@ -267,7 +278,7 @@ def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, 
     g.bias = bias.data_ptr() if bias is not None else None
     g.act, g.accumulate = act, int(accumulate)
     if remap is not None:
-        g.c_remap = 1
+        g.c_remap = 2 if remap.get("narrow") else 1      # (2: the 4-byte-per-lane store, the reference of the tests)
         g.c_T, g.c_K = remap["T"], remap.get("K", 1)
         g.c_sb, g.c_sk, g.c_st = remap["sb"], remap.get("sk", 0), remap["st"]
         g.c_cm, g.c_co = remap.get("cm", 0), remap.get("co", 0)
@@ -283,13 +294,60 @@ def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, 
     return g
 
 
+# Kernel ids of include/tssep_hip.h (TSSEP_GEMM_*).  The library chooses by itself; tests, the shape sweep and the
+# A/B tools may name kernels to be tried first: GEMM_PREFER = ("stream", "tall2") launches the first one of them that
+# covers the request (asked through tssep_gemm_plan) and the library's own choice when none does.
+GEMM_KERNELS = {"auto": 0, "f32": 1, "pipe": 2, "tall2": 3, "tall4": 4, "tall4_xcol": 5, "big": 6, "stream": 7,
+                "nt_w160": 8, "tn": 9, "tn_tall": 10, "tn_big": 11, "tn_w160": 12, "tn_h160": 13}
+GEMM_KERNEL_NAMES = {v: k for k, v in GEMM_KERNELS.items()}
+GEMM_PREFER = ()
+GEMM_LOG = None          # a list: (kernel name, M, N, K) of every launch is appended (tests)
+
+
+class prefer_gemm_kernels:
+    """``with prefer_gemm_kernels("big"): ...`` -- see GEMM_PREFER."""
+
+    def __init__(self, *names):
+        self.names = tuple(n for n in names if n)
+
+    def __enter__(self):
+        global GEMM_PREFER
+        self.old, GEMM_PREFER = GEMM_PREFER, self.names
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_PREFER
+        GEMM_PREFER = self.old
+        return False
+
+
+def gemm_plan(g, force="auto"):
+    """-> name of the kernel tssep_gemm_f32_on(g, force) would launch, or None when `force` does not cover g."""
+    kid = ctypes.c_int32(0)
+    rc = _lib.lib().tssep_gemm_plan(ctypes.byref(g), GEMM_KERNELS[force], ctypes.byref(kid))
+    return GEMM_KERNEL_NAMES[kid.value] if rc == 0 else None
+
+
+def _launch_gemm(g):
+    kid = 0
+    for name in GEMM_PREFER:
+        if gemm_plan(g, name) is not None:
+            kid = GEMM_KERNELS[name]
+            break
+    if GEMM_LOG is not None:
+        GEMM_LOG.append((gemm_plan(g, GEMM_KERNEL_NAMES[kid]), g.M, g.N, g.K))
+    L = _lib.lib()
+    check(L.tssep_gemm_f32_on(ctypes.byref(g), kid, _stream()) if kid else L.tssep_gemm_f32(ctypes.byref(g), _stream()),
+          "gemm_f32")
+
+
 def gemm(A, lda, B, ldb, C, ldc, M, N, K, **kw):
     """C = epilogue(op(A) x op(B)); see include/tssep_hip.h.  A, B, C: tensors (or (tensor,
     float_offset) tuples) whose data pointers are used as given.  Keywords: a_kmajor, b_kmajor, bias, act,
     accumulate, b_kshift, kperiod, remap, splitk, split_stride, b_ones_col, aux."""
     g = _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, **kw)
-    with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K):
-        check(_lib.lib().tssep_gemm_f32(ctypes.byref(g), _stream()), "gemm_f32")
+    with _timed("gemm_" + GEMM_PRECISION, 2 * M * N * K, 4 * (M * K + N * K + M * N * (2 if kw.get("accumulate") else 1))):
+        _launch_gemm(g)
 
 
 def transposed(w, rows, cols):
@@ -304,61 +362,50 @@ def transposed(w, rows, cols):
     return out, ld
 
 
-def pick_splitk(M, N, K, target_blocks=768, min_ktiles=8):
-    # (tools/sweep_splitk.py, profiles/r2_splitk_sweep.jsonl: a model that prices whole rounds of 512 resident
-    # workgroups predicts up to 20 % from other factors; measured, the large-K shapes get SLOWER with more splits
-    # -- the tiles of a K slab share it through one L2 only while they run together -- and this rule is within
-    # 0..5 % of the best S on every shape of the step)
-    if TN_BIG and GEMM_PRECISION == "bf16x3" and M >= 1024 and M % 4 == 0 and K % 16 == 0 \
-            and round_up(M, 512) * 10 <= M * 11 and K >= 16 * 64:
-        # the big-tile weight-gradient kernel (csrc/gemm_bf16x3_tn_big.hip): 512 x 128 tiles, ONE workgroup per CU, the
-        # tiles of a K slab on one XCD (32 CUs) -> as many slabs per XCD as fill its CUs best; multiples of 8 only
-        # (N = 128 q + 1 | 2: the last columns ride on the VALU of the q-th column tile, no tile of their own)
-        ntile = N // 128 if TN_XC and N > 128 and 1 <= N % 128 <= 2 else math.ceil(N / 128)
-        tiles = math.ceil(M / 512) * ntile
-        best = min((8, 16, 24, 32), key=lambda S: (math.ceil(tiles * (S // 8) / 32) * 32) / (tiles * (S // 8)))
-        return best
-    ktiles = math.ceil(K / 16)
-    n160, n128 = round_up(N, 160), round_up(N, 128)
-    if TN_W160 and GEMM_PRECISION == "bf16x3" and M >= 1024 and (round_up(M, 256) - M) * 100 <= 8 * M \
-            and n160 * 11 <= n128 * 10 and ktiles >= 64 * 8:
-        # the 256 x 160 tile (csrc/gemm_bf16x3_tn_w160.hip; dW_hh: M = 1200, N = 300 -> 10 tiles): two workgroups per CU,
-        # one round of at most 512 (tools/sweep_wgrad_splits.py: 2.00 ms at S = 48, 2.30 at 40, 3.13 at 56)
-        tiles = (round_up(M, 256) // 256) * (n160 // 160)
-        return max(8, min(512 // tiles // 8 * 8, ktiles // 64 // 8 * 8))
-    m320 = round_up(M, 320)
-    if TN_H160 and GEMM_PRECISION == "bf16x3" and m320 * 11 <= round_up(M, 128) * 10 and N > 384 \
-            and ktiles >= 64 * 8:
-        # the 320 x 128 tile (csrc/gemm_bf16x3_tn_h160.hip; the projection weight gradients: M = 320, N = 601 -> 5 tiles):
-        # two workgroups per CU, one round of at most 512
-        tiles = (m320 // 320) * math.ceil(N / 128)
-        return max(8, min(512 // tiles // 8 * 8, H160_MAX_SPLITS, ktiles // 16 // 8 * 8))
-    tiles = math.ceil(M / 128) * math.ceil(N / 128)
-    if SPLITK_BIGK and K >= 400000 and tiles >= 48:
-        # the two largest dW_ih GEMMs of the step (K = 777 216 rows, 95 / 57 tiles): the sweep's best S is the
-        # smallest one -- 8.37 vs 8.65 ms and 5.16 vs 5.24 ms standalone, -0.5 ms per step in an alternating A/B x3
-        return 8
-    if tiles <= 16 and ktiles >= 64 * 8:
-        # few tiles (the projection weight gradients: 320 x 601 = 15 tiles): one resident round of 512 workgroups --
-        # 32 splits 1.38 ms, the 56 of the general rule 1.51 (tools/sweep_wgrad_small.py)
-        return max(8, 512 // tiles // 8 * 8)
-    s = max(1, min(math.ceil(target_blocks / tiles), ktiles // min_ktiles))
-    if s > 1:        # multiples of the XCD count: split z runs on XCD z % 8 (gemm_common.h)
-        s = min(round_up(s, 8), max(8, (ktiles // min_ktiles) // 8 * 8))
-    return min(s, 64)
+def pick_splitk(M, N, K, shifted=False, ones_col=False):
+    """Split count the library recommends for the weight gradient dW[M,N] = dY[K,M]^T X[K,N] (host-only query on
+    a description of the request: tools and tests; `wgrad` asks with the real arguments)."""
+    g = GemmArgs()
+    g.A = g.B = 0x1000
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = round_up(M, 4), round_up(N, 4), round_up(N, 4)
+    g.a_kmajor = g.b_kmajor = 1
+    if shifted:
+        g.b_kshift, g.kperiod = -1, 253
+    g.b_ones_col = int(ones_col)
+    g.precision = _PREC[GEMM_PRECISION]
+    S = int(_lib.lib().tssep_gemm_wgrad_splits(ctypes.byref(g)))
+    if S < 1:
+        check(S, "gemm_wgrad_splits")
+    return S
+
+
+# Opt-in arithmetic of the weight gradients (bench.py's `two_product_wgrad` side line): 2 = the dY_lo * X_hi product is
+# dropped (tssep_gemm_args.precision = 2); an argument of the call, not an environment variable of the library.
+WGRAD_PRODUCTS = 3
 
 
 def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False, splitk=None):
     """dW[M,N] = dY[R,M]^T X[R,N] by split-K partials -> (partials [S, M*N], S).
     with_colsum (split-bf16 GEMM only): partials are [S, M, round_up(N+1, 4)] and column N holds
-    the column sums of dY (the bias gradient), from a virtual all-ones column of X."""
+    the column sums of dY (the bias gradient), from a virtual all-ones column of X.
+    The split count is the library's (tssep_gemm_wgrad_splits: it follows the kernel the library picks)."""
     Nc = N + 1 if with_colsum else N
     ldp = round_up(Nc, 4) if with_colsum else N      # 16-byte rows keep the vector epilogue
-    S = splitk or pick_splitk(M, Nc, R)
+    g = _gemm_args(dY, ld_dy, X, ld_x, X, ldp, M, Nc, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
+                   kperiod=kperiod, splitk=8, split_stride=M * ldp, b_ones_col=with_colsum)
+    if WGRAD_PRODUCTS == 2 and GEMM_PRECISION == "bf16x3":
+        g.precision = 2
+    S = splitk
+    if not S:
+        S = int(_lib.lib().tssep_gemm_wgrad_splits(ctypes.byref(g)))
+        if S < 1:
+            check(S, "gemm_wgrad_splits")
     dev = dY[0].device if isinstance(dY, tuple) else dY.device
     part = torch.empty(S, M * ldp, device=dev, dtype=torch.float32)
-    gemm(dY, ld_dy, X, ld_x, part, ldp, M, Nc, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
-         kperiod=kperiod, splitk=S, split_stride=M * ldp, b_ones_col=with_colsum)
+    g.C, g.splitk = part.data_ptr(), S
+    with _timed("gemm_" + GEMM_PRECISION, 2 * M * Nc * R, 4 * (M * R + N * R + S * M * ldp)):
+        _launch_gemm(g)
     return part, S
 
 
@@ -660,12 +707,6 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 # second HIP stream, overlapping the T-sequential recurrences of the layers still to come.
 _SIDE = {}
 OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
-SPLITK_BIGK = _os.environ.get("TSSEP_SPLITK_BIGK", "1") != "0"
-TN_W160 = _os.environ.get("TSSEP_GEMM_TN_W160", "1") != "0"
-TN_XC = _os.environ.get("TSSEP_GEMM_TN_XC", "1") != "0"
-TN_H160 = _os.environ.get("TSSEP_GEMM_TN_H160", "1") != "0"
-H160_MAX_SPLITS = int(_os.environ.get("TSSEP_GEMM_TN_H160_SPLITS", "96"))
-TN_BIG = _os.environ.get("TSSEP_GEMM_TN_BIG", "1") != "0"        # (the split rule follows the kernel the dispatcher picks)
 FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
 FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
 

@@ -176,7 +176,10 @@ class Trainer(Configurable):
             # that rank alone in an all-reduce, for ever.  `Dataset.shard` equalises the SOURCE examples; when
             # the length of the prepared dataset is known it is compared once per epoch, when a stage may drop
             # examples (`catch`) the ranks agree before every micro-step on whether all of them still have data
-            # (one 16-byte all-reduce) and end the epoch together at the first one that has not.
+            # (one 16-byte all-reduce on the host-side control group, distributed.py: no GPU sync, the launch-ahead
+            # of the host survives) and end the epoch together at the first one that has not.  All ranks leave at
+            # the same `iteration`, so a half-filled virtual minibatch is CARRIED into the next epoch (consistent
+            # partial sums on every rank), exactly as on one GPU and in the reference's trainer.
             agree_per_step = False
             if world > 1:
                 try:
@@ -201,7 +204,6 @@ class Trainer(Configurable):
                     boundary = (self.iteration + 1) % self.virtual_minibatch_size == 0
                     if agree_per_step:
                         if not _dist.same_on_all_ranks(0 if ex is None else 1) or ex is None:
-                            self.optimizer.zero_grad()       # an incomplete virtual minibatch is dropped everywhere
                             break
                     elif ex is None:
                         break
