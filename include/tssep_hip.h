@@ -116,14 +116,17 @@ int tssep_mask_istft_bwd_loss(const float* est, const float* tgt, const float* s
  *   X     [B, T, F] complex64 (reference channel already selected)
  *   fb    [F, n_mels], dct [n_mels, n_mfcc]    (fp32, row major)
  *   out   [B, T, ld_out] : cols [0,n_mfcc) = MFCC, [n_mfcc, n_mfcc+F) = log1p feature
- *   ws    workspace, tssep_feat_workspace_bytes(B,T,n_mels) bytes
+ *   ws    workspace, tssep_feat_workspace_bytes(B,T,n_mels,F,stat_axis) bytes
  * n_mfcc == 0 skips the MFCC block (plain Log1pMaxNormAbsSTFT).
+ * stat_axis: the maximum the log1p feature is normalised by, Log1pMaxNormAbsSTFT's `statistics_axis`
+ * (feature_extractor.py:239-242): 0 = 'tf' one per utterance (every shipped config), 1 = 't' one per
+ * (utterance, frequency) over the frames, 2 = 'f' one per frame over the frequencies.
  * The dB floor (top_db) is taken over the WHOLE batch, as torchaudio's
  * AmplitudeToDB does for the 3-D input the reference passes. */
-int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels);
+int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels, int F, int stat_axis);
 int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F,
                    const float* fb, const float* dct, int n_mels, int n_mfcc,
-                   float top_db, float* out, int64_t ld_out, void* ws, void* stream);
+                   float top_db, int stat_axis, float* out, int64_t ld_out, void* ws, void* stream);
 
 /* ------------------------------------------------------------------- GEMM ----
  * Exact-fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32): C = epilogue(A x B).
@@ -293,6 +296,11 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
  * contract as stated for the cluster kernels above.  max_wgs: number of CUs the launch may occupy.
  * H <= 304. */
 int tssep_lstm_onchip_supported(int H);
+/* Longest sequence (frames) one launch takes for `seqs_per_item` sequences per work item (32: the kernels
+ * declared here; 16: the interleaved tssep_blstm_onchip16_* below): 32-bit lane offsets into the gate tensor,
+ * ((1 << 31) - 8192) / ((seqs - 1) 2H 16) -- 14 913 / 7 215 frames at H = 300.  Longer: TSSEP_E_SHAPE (the
+ * streaming kernels tssep_blstm_fwd/bwd have no limit, like tssep/train/rnnp.py:111-173). */
+int64_t tssep_lstm_onchip_max_steps(int H, int seqs_per_item);
 int64_t tssep_lstm_onchip_pack_floats(int H, int which /* 0: forward, 1: backward */);
 int tssep_lstm_pack_onchip(const float* w_hh_f, const float* w_hh_r, int H, float* wf, float* wb,
                            void* stream);

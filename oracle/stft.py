@@ -14,13 +14,24 @@ import torch
 from scipy.signal import get_window
 
 
+def fade_widths(window_length, shift, fading):
+    """(zeros in front, zeros behind) of paderbox stft's ``fading``: True / 'full' = window_length - shift on both
+    sides; 'half' = half of that in front, the other half (the odd sample) behind; None / False = none.
+    ('half' is restated from the published paderbox 0.0.8 and pinned only through the frame counts of
+    oracle/stft_vad.py -- no reference test transforms with it: parity unpinned for that option.)"""
+    if fading in (None, False):
+        return 0, 0
+    p = window_length - shift
+    if fading == "half":
+        return p // 2, p - p // 2
+    return p, p
+
+
 def num_frames(num_samples, size=1024, shift=256, window_length=None,
                pad=True, fading=True):
     """Frame count (tssep/train/model.py:480: 80000 -> 316)."""
     window_length = size if window_length is None else window_length
-    n = num_samples
-    if fading:
-        n += 2 * (window_length - shift)
+    n = num_samples + sum(fade_widths(window_length, shift, fading))
     if pad:
         return max(int(math.ceil((n - window_length) / shift)), 0) + 1
     return (n - window_length) // shift + 1
@@ -50,9 +61,9 @@ def stft(x, size=1024, shift=256, window="hann", window_length=None,
     is_np = isinstance(x, np.ndarray)
     xt = torch.as_tensor(x)
     window_length = size if window_length is None else window_length
-    if fading:
-        p = window_length - shift
-        xt = torch.nn.functional.pad(xt, (p, p))
+    lead, tail = fade_widths(window_length, shift, fading)
+    if lead or tail:
+        xt = torch.nn.functional.pad(xt, (lead, tail))
     n = xt.shape[-1]
     if pad:
         frames = max(int(math.ceil((n - window_length) / shift)), 0) + 1
@@ -86,9 +97,8 @@ def istft(X, size=1024, shift=256, window="hann", window_length=None,
     out = torch.nn.functional.fold(
         cols, output_size=(1, length), kernel_size=(1, window_length),
         stride=(1, shift)).reshape(*lead, length)
-    if fading:
-        p = window_length - shift
-        out = out[..., p:length - p]
+    lead, tail = fade_widths(window_length, shift, fading)
+    out = out[..., lead:length - tail]
     if num_samples is not None:
         out = out[..., :num_samples]
     return out.numpy() if is_np else out

@@ -783,6 +783,95 @@ def test_stft_istft(rows, N):
     close(xr, x, rtol=1e-4, atol=2e-5, name="round trip")
 
 
+@pytest.mark.parametrize("window_length", [1024, 768, 512])
+@pytest.mark.parametrize("fading", [True, "full", "half", False, None])
+@pytest.mark.parametrize("pad", [True, False])
+def test_stft_options_of_the_reference_configs(window_length, fading, pad):
+    """the `fe` slot accepts every STFT option the reference's configs may set
+    (tssep/exp/init_cfg_common.yaml:33-43, padertorch STFT on paderbox stft / istft): window_length <= size, pad,
+    fading in {True / 'full', 'half', False / None}.  The drop-in class against oracle/stft.py: frame count, stft,
+    istft, the gradient of istft (autograd of the oracle), and the masked inverse (sigmoid -> Masking -> istft)
+    through `masked_istft` (the fused kernels for the shipped configuration, mask head + istft otherwise)."""
+    from tssep_amd.train.feature_extractor import STFT
+    torch.manual_seed(31)
+    N = 5000
+    fe = STFT(size=1024, shift=256, window_length=window_length, pad=pad, fading=fading, window="hann")
+    kw = dict(size=1024, shift=256, window="hann", window_length=window_length)
+    x = torch.randn(2, 3, N)
+    Xref = ostft.stft(x, pad=pad, fading=fading, **kw)
+    X = fe.stft(x.cuda())
+    assert tuple(X.shape) == tuple(Xref.shape) and X.shape[-2] == fe.frames(N) == ostft.num_frames(N, 1024, 256, window_length, pad, fading)
+    close(X, Xref, rtol=1e-4, atol=2e-4 * float(Xref.abs().max()) / 50, name="stft")
+    T = X.shape[-2]
+    Y = torch.randn(2, 3, T, 513, dtype=torch.complex64).requires_grad_()
+    yref = ostft.istft(Y, fading=fading, num_samples=N, **kw)
+    dy = torch.randn_like(yref)
+    (yref * dy).sum().backward()
+    Yd = Y.detach().cuda().requires_grad_()
+    y = fe.istft(Yd, num_samples=N)
+    assert tuple(y.shape) == tuple(yref.shape)
+    close(y, yref, rtol=1e-4, atol=2e-5, name="istft")
+    (y * dy.cuda()).sum().backward()
+    close(Yd.grad, Y.grad, rtol=1e-4, atol=2e-6, name="istft gradient")
+    # round trip where the frames cover the signal (paderbox's biorthogonal window)
+    xr = fe.istft(X, num_samples=N)
+    lo = 0 if fading in (True, "full") else window_length
+    hi = xr.shape[-1] if (fading in (True, "full") and pad) else xr.shape[-1] - window_length
+    close(xr[..., lo:hi], x[..., lo:hi], rtol=1e-4, atol=3e-5, name="round trip")
+    # the masked inverse: logit [B,K,T,F], observation [B,T,F]
+    logit = torch.randn(2, 3, T, 513).requires_grad_()
+    obs = torch.randn(2, T, 513, dtype=torch.complex64)
+    te_ref = ostft.istft(obs[:, None] * torch.sigmoid(logit), fading=fading, num_samples=N, **kw)
+    g = torch.randn_like(te_ref)
+    (te_ref * g).sum().backward()
+    ld = logit.detach().cuda().requires_grad_()
+    te = fe.masked_istft(ld, obs.cuda(), num_samples=N)
+    close(te, te_ref, rtol=1e-4, atol=3e-5, name="masked istft")
+    (te * g.cuda()).sum().backward()
+    close(ld.grad, logit.grad, rtol=1e-3, atol=2e-6, name="masked istft gradient")
+
+
+def test_stft_rejects_what_paderbox_rejects():
+    from tssep_amd.train.feature_extractor import STFT
+    with pytest.raises(ValueError):
+        STFT(size=1024, shift=256, window_length=2048)
+    with pytest.raises(ValueError):
+        STFT(size=1024, shift=256, fading="quarter")
+    fe = STFT(size=1024, shift=256, window_length=700, window="hann")          # stft: fine; istft: wl % shift != 0
+    X = fe.stft(torch.randn(1, 4000).cuda())
+    assert X.shape[-2] == ostft.num_frames(4000, 1024, 256, 700)
+    with pytest.raises(ValueError):
+        fe.istft(X)
+    with pytest.raises(ValueError):
+        STFT(size=1024, shift=256, pad=False, fading=False, window="hann").stft(torch.randn(1, 500).cuda())
+    with pytest.raises(RuntimeError, match="unsupported"):                      # another FFT plan: named by the library
+        STFT(size=512, shift=128, window="hann").stft(torch.randn(1, 4000).cuda())
+
+
+@pytest.mark.parametrize("axis", ["tf", "t", "f"])
+@pytest.mark.parametrize("mfcc", [False, True])
+def test_log1p_max_norm_statistics_axis(axis, mfcc):
+    """Log1pMaxNormAbsSTFT's statistics_axis (feature_extractor.py:239-242): the maximum per utterance ('tf'), per
+    utterance and frequency over the frames ('t'), per frame over the frequencies ('f') -- alone and as the second
+    half of ConcaternatedSTFTFeatures, against oracle/features.py."""
+    from tssep_amd.train import feature_extractor as fe
+    torch.manual_seed(33)
+    B, T = 3, 70
+    X = torch.randn(B, T, 513, dtype=torch.complex64) * torch.rand(B, 1, 1) * 10 * (1 + torch.rand(1, T, 1)) * (1 + torch.rand(1, 1, 513))
+    l1p = fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann", statistics_axis=axis)
+    ref = ofeat.log1p_max_norm_abs(X, axis)
+    if not mfcc:
+        close(l1p.stft_to_feature(X.cuda()), ref, rtol=1e-5, atol=1e-6, name=f"log1p {axis}")
+        close(l1p.stft_to_feature(X[0].cuda()), ofeat.log1p_max_norm_abs(X[0], axis), rtol=1e-5, atol=1e-6, name=f"log1p {axis}, one utterance")
+        return
+    cat = fe.ConcaternatedSTFTFeatures(fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40), l1p,
+                                       size=1024, shift=256, window="hann").cuda()
+    out = cat.stft_to_feature(X.cuda())
+    fb, dct = ofeat.mfcc_tables(1024)
+    close(out[..., :40], ofeat.torch_mfcc(X, fb, dct), rtol=1e-4, atol=2e-3, name="mfcc")
+    close(out[..., 40:553], ref, rtol=1e-5, atol=1e-6, name=f"log1p {axis} in the concatenation")
+
+
 @pytest.mark.parametrize("B,K,N", [(1, 3, 2000), (2, 4, 64000), (3, 8, 9300), (1, 1, 300), (2, 2, 16385), (1, 5, 7777)])
 def test_mask_istft_fused_against_oracle_and_unfused_chain(B, K, N):
     """tssep_mask_istft_fwd / _bwd: sigmoid (net.py:983) -> Masking (enhancer.py:98-100) -> istft
@@ -1184,6 +1273,76 @@ def test_blstm_onchip_interleaved_backward(N, T, Hh, groups):
     h.check_cluster_errors()
     h.blstm_bwd(g_ref, cell, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
     close(gates, g_ref, rtol=2e-4, atol=2e-6 + 2e-6 * float(g_ref.abs().max()), name="dgates")
+
+
+@pytest.mark.parametrize("N,T,Hh,groups", [(16, 4096, 300, 1), (32, 10000, 300, 2), (32, 4096, 256, 0)])
+def test_blstm_onchip_long_sequences(N, T, Hh, groups):
+    """tssep/train/rnnp.py:111-173 has no length limit; rounds 1-3 refused T > 2046 frames on the
+    W-stationary kernels (11-bit step field in the exchange tags) and dropped to the 3x slower streaming kernel without
+    a word.  The step field wraps now: forward against the CPU oracle (torch LSTM arithmetic, rnnp.py:146-153) and the
+    exact-fp32 streaming kernel, backward against the streaming backward on the same saved activations, at 4 096 and
+    10 000 frames (groups 0 = the 32-sequence kernels, which serve H <= 256 backward)."""
+    h = H()
+    I = 12
+    p, x = _lstm_case(N, T, I, Hh, 23)
+    assert h.recurrence_kernel(N, Hh, False, T, torch.device("cuda", 0)) == "onchip" or not groups
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    g_stream = gates.clone()
+    Hp = h.round_up(Hh, 4)
+    cell = torch.full((N, T, 2, Hh), float("nan"), device="cuda")
+    hout = torch.zeros(N, T, 2 * Hp, device="cuda")
+    whf, whr = p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda()
+    if groups:
+        h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, h.lstm_pack_onchip16(whf, whr, Hh), N, T, Hh, groups)
+    else:
+        wf, wb = h.lstm_pack_onchip(whf, whr, Hh)
+        h.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf, N, T, Hh)
+    h.check_cluster_errors()
+    cell2 = torch.empty_like(cell); hout2 = torch.zeros_like(hout)
+    h.blstm_fwd(g_stream, cell2, hout2, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+    # (the 1e-3 bar of the north star: 10^4 steps of split-bf16 products against fp32 ones)
+    close(hout, hout2, rtol=1e-3, atol=1e-4, name="h vs streaming fp32")
+    close(cell, cell2, rtol=1e-3, atol=1e-4, name="cell vs streaming fp32")
+    with torch.no_grad():
+        ref = ornnp.blstm(x, p, "")
+    got = torch.cat([hout[..., :Hh], hout[..., Hp:Hp + Hh]], -1)
+    close(got, ref, rtol=1e-3, atol=1e-4, name="h vs oracle")
+    # the last frames saw every step of the forward direction, the first ones every step of the reverse one
+    close(got[:, -3:], ref[:, -3:], rtol=1e-3, atol=1e-4, name="h, last frames")
+    close(got[:, :3], ref[:, :3], rtol=1e-3, atol=1e-4, name="h, first frames")
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = torch.randn(N, T, Hh, device="cuda"); dhd[..., Hp:Hp + Hh] = torch.randn(N, T, Hh, device="cuda")
+    g_ref = g_stream.clone()
+    if groups:
+        h.blstm_onchip16_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, h.lstm_pack_onchip16_bwd(whf, whr, Hh), N, T, Hh, groups)
+    else:
+        h.blstm_onchip_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, wb, N, T, Hh)
+    h.check_cluster_errors()
+    h.blstm_bwd(g_ref, cell2, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+    close(g_stream, g_ref, rtol=1e-3, atol=2e-5 + 1e-4 * float(g_ref.abs().max()), name="dgates")
+
+
+def test_recurrence_falls_back_loudly_beyond_the_offset_limit():
+    """Beyond the 32-bit lane offsets of the W-stationary kernels (14 913 frames at H = 300) the streaming kernels run --
+    announced by a warning, and with the right result (RNNP over 15 000 frames against the CPU oracle)."""
+    from tssep_amd.train.rnnp import RNNP_packed
+    from tssep_amd import hip_ops
+    torch.manual_seed(29)
+    hip_ops._WARNED.clear()
+    m = RNNP_packed(8, 1, 300, 8, 0).cuda()
+    x = torch.randn(1, 15000, 8, device="cuda")
+    with pytest.warns(RuntimeWarning, match="streaming fp32 kernel runs instead"):
+        y = m(x)
+    lstm, lin = m.net[0], m.net[1]
+    with torch.no_grad():
+        ref = lin.cpu()(lstm.cpu()(x.cpu())[0])
+    close(y, ref, rtol=1e-3, atol=1e-4, name="rnnp, 15 000 frames")
 
 
 # ------------------------------------------------------------------ mask-based MVDR (TorchBF)

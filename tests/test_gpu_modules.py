@@ -971,3 +971,26 @@ def test_bench_two_ranks_on_one_gpu():
     c = d["config"]["collective"]
     assert c["process_group_world_size"] == 2 and c["replicas_agree"] is True and c["launches"] == 2
     assert c["allreduce_ms"] > 0 and c["bytes"] > 4e7
+
+
+@pytest.mark.parametrize("units,projs,K", [(300, 320, 4), (128, 256, 8), (512, 320, 4), (256, 256, 4)])
+def test_gemm_shape_sweep_parity_and_interchangeable_kernels(units, projs, K):
+    """another `units` / `projs` / speaker count (net.py:504-509) goes through the same dispatcher.  Per
+    model size: the real model against the CPU oracle (masks, loss, gradients), then every GEMM request of a step
+    replayed on the library's choice AND on every other kernel that covers it (tssep_gemm_f32_on) -- bit-identical
+    results for single-pass requests; TFLOP/s per request are recorded (tools/sweep_gemm_shapes.py writes
+    profiles/r4_gemm_shape_sweep.jsonl with the bench's batch)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sweep_gemm_shapes as sw
+    from tssep_amd import hip_ops
+    old = hip_ops.GEMM_PRECISION
+    hip_ops.GEMM_PRECISION = "bf16x3"
+    try:
+        lines = sw.sweep([(units, projs, K)], B=24, reps=1)
+    finally:
+        hip_ops.GEMM_PRECISION = old
+    assert len(lines) >= 20
+    kernels = {l["choice"] for l in lines}
+    assert kernels <= set(hip_ops.GEMM_KERNELS) - {"auto", "f32"} and len(kernels) >= 4, kernels
+    for l in lines:
+        assert l["tflops_choice"] > 0 and l["parity_vs_oracle"]["max_abs_mask_err"] < 1e-3

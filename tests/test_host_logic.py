@@ -17,7 +17,15 @@ def test_recurrence_policy():
         assert H.recurrence_kernel(1536, 300, False) == "onchip"
         assert H.recurrence_kernel(8, 300, True) == "onchip"
         assert H.recurrence_kernel(32, 300, True) == "onchip"
-        assert H.recurrence_kernel(32, 300, True, T=1878) == "onchip" and H.recurrence_kernel(32, 300, True, T=4000) == "stream"
+        # no cliff at 2 046 frames any more (the step field of the exchange tags wraps); the limit is the
+        # 32-bit lane offset into the gate tensor -- 14 913 frames for the 16-sequence kernels, 7 215 for the 32-sequence
+        # ones (what this GPU-less process assumes) -- and a fallback beyond it is announced
+        assert H.recurrence_kernel(32, 300, True, T=1878) == "onchip" and H.recurrence_kernel(32, 300, True, T=4000) == "onchip"
+        L = _lib.lib()
+        assert L.tssep_lstm_onchip_max_steps(300, 16) == 14913 and L.tssep_lstm_onchip_max_steps(300, 32) == 7215
+        import pytest
+        with pytest.warns(RuntimeWarning, match="streaming fp32 kernel runs instead"):
+            assert H.recurrence_kernel(32, 300, True, T=20000) == "stream"
         assert H.recurrence_kernel(33, 300, True) == "onchip"
         assert H.recurrence_kernel(768, 300, True) == "onchip"
         # small or unsupported hidden sizes fall back to the streaming kernels

@@ -1,0 +1,265 @@
+"""Shape sweep of the GEMM dispatcher (GPU box): what does another `units` / `projs` / speaker count cost?
+
+  python tools/sweep_gemm_shapes.py [--batch 768] [--reps 5] [--out profiles/r4_gemm_shape_sweep.jsonl] [--quick]
+
+For every model size of units x projs x speakers (tssep/train/net.py:504-509):
+  1. PARITY: one forward + backward of the real model (tssep_amd.train.*) on 2 utterances against the CPU oracle with the
+     same weights -- masks, loss, every parameter gradient (the bars of bench.py / smoke()).
+  2. one step at `--batch` utterances with the GEMM log on: every request the step makes of tssep_gemm_f32 (shape, layouts,
+     epilogue, split count), de-duplicated;
+  3. every request is replayed on fresh buffers on EVERY kernel that covers it (tssep_gemm_plan / tssep_gemm_f32_on) and on
+     the library's own choice: one JSON line per request with the TFLOP/s of the choice, of each candidate, and the ratio
+     choice / best.  A candidate's result is also compared bit for bit with the choice's (same k order, same epilogue
+     arithmetic: the family's contract) wherever the split boundaries can agree (single-pass requests).
+Lines with `tflops_choice` < 200 carry a `reason` field (few tiles / short K / store-bound ...), written by rule below.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from tssep_amd import _lib, hip_ops as H  # noqa: E402
+
+F = 513
+
+
+def build(units, projs, K):
+    from tssep_amd.data import DummyReader
+    from tssep_amd.train import enhancer, feature_extractor as fe, loss, model, net
+    torch.manual_seed(0)
+    return model.Model(
+        fe=fe.ConcaternatedSTFTFeatures(
+            fe.TorchMFCC(size=1024, shift=256, window="hann", output_size=40),
+            fe.Log1pMaxNormAbsSTFT(size=1024, shift=256, window="hann"),
+            size=1024, shift=256, window="hann"),
+        reader=DummyReader(),
+        mask_estimator=net.MaskEstimator_v2(idim=553, odim=F, units=units, projs=projs, combination="mul",
+                                            aux_net_output_size=F, ts_vad=K, output_resolution="tf",
+                                            random_speaker_order=True, num_averaged_permutations=1),
+        enhancer=enhancer.Masking(), loss=loss.LogMAE()).cuda()
+
+
+def batch(B, K, N, seed):
+    rng = np.random.RandomState(seed)
+    tgt = (rng.randn(B, K, N) * 0.1).astype(np.float32)
+    obs = tgt.sum(1, keepdims=True) + 0.05 * rng.rand(B, 1, N).astype(np.float32)
+    aux = rng.rand(B, K, F).astype(np.float32)
+    return obs, aux, tgt
+
+
+def example(obs, aux, tgt):
+    return dict(observation=torch.as_tensor(obs).cuda(), auxInput=torch.as_tensor(aux).cuda(),
+                speaker_reverberation_early_ch0=torch.as_tensor(tgt).cuda(), reference_channel=0,
+                dataset=["sweep"] * obs.shape[0])
+
+
+def parity(m, units, projs, K, N=16000):
+    """The real model against the CPU oracle, same weights, same permutation stream -> dict of errors (asserted)."""
+    from oracle import model as omodel
+    obs, aux, tgt = batch(2, K, N, 7)
+    ex = example(obs, aux, tgt)
+    for p in m.parameters():
+        p.grad = None
+    np.random.seed(11)
+    out = m(ex)
+    loss = m.review(ex, out)["loss"]
+    loss.backward()
+    H.join_side_stream(torch.device("cuda", torch.cuda.current_device()))
+    torch.cuda.synchronize()
+    p = {"mask_estimator." + k: v.detach().cpu().clone().requires_grad_() for k, v in m.mask_estimator.state_dict().items()}
+    np.random.seed(11)
+    o = omodel.forward_loss(p, torch.as_tensor(obs), torch.as_tensor(aux), torch.as_tensor(tgt),
+                            cfg=dict(odim=F, combination="mul", ts_vad=K, output_resolution="tf"), fast=True)
+    o["loss"].sum().backward()
+    merr = float((out.mask.detach().cpu() - o["mask"]).abs().max())
+    lrel = abs(float(loss) - float(o["loss"].sum())) / max(abs(float(o["loss"].sum())), 1e-12)
+    gerr = max(float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max() / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
+               for k, v in m.mask_estimator.named_parameters())
+    res = dict(max_abs_mask_err=merr, rel_loss_err=lrel, max_rel_grad_err=gerr)
+    assert merr < 1e-3 and lrel < 1e-3 and gerr < 1e-2, (units, projs, K, res)      # north star: 1e-3 on the outputs
+    for q in m.parameters():
+        q.grad = None
+    return res
+
+
+def requests_of_a_step(m, K, B, N=64000):
+    """-> de-duplicated list of (descriptor, count) of one forward + backward at batch B."""
+    obs, aux, tgt = batch(B, K, N, 3)
+    ex = example(obs, aux, tgt)
+    np.random.seed(5)
+    log = H.GEMM_LOG = []
+    try:
+        out = m(ex)
+        m.review(ex, out)["loss"].backward()
+        H.join_side_stream(torch.device("cuda", torch.cuda.current_device()))
+        torch.cuda.synchronize()
+    finally:
+        H.GEMM_LOG = None
+    for q in m.parameters():
+        q.grad = None
+    uniq = {}
+    for _name, _M, _N, _K, d in log:
+        key = json.dumps(d, sort_keys=True)
+        uniq[key] = (d, uniq.get(key, (d, 0))[1] + 1)
+    return list(uniq.values())
+
+
+class Replay:
+    """Fresh operands for a logged request."""
+
+    def __init__(self, d):
+        self.d = d
+        M, N, K = d["M"], d["N"], d["K"]
+        g = torch.Generator(device="cuda").manual_seed(1)
+        ra = (K + 64) if d["a_kmajor"] else M          # (+64 rows: a time-shifted B reads past row K - 1 by design, masked)
+        rb = (K + 64) if d["b_kmajor"] else N
+        self.A = torch.randn(ra, d["lda"], device="cuda", generator=g)
+        self.B = torch.randn(rb, d["ldb"], device="cuda", generator=g) / max(K, 1) ** 0.5
+        S = max(d["splitk"], 1)
+        if S > 1:
+            celems = S * d["c_split_stride"]
+        elif d["c_remap"]:
+            nb = -(-M // (max(d["c_T"], 1) * max(d["c_K"], 1)))
+            celems = nb * d["c_sb"] + 4096
+        else:
+            celems = M * d["ldc"]
+        self.celems = celems
+        self.bias = torch.randn(N, device="cuda", generator=g) if d["bias"] else None
+        self.aux = torch.tanh(torch.randn(M, d["ldaux"], device="cuda", generator=g)) if d["has_aux"] else None
+        self.perm = None
+        if d["perm"]:
+            nb = -(-M // (max(d["c_T"], 1) * max(d["c_K"], 1)))
+            q = -(-N // max(d["c_cm"], 1))
+            self.perm = torch.stack([torch.randperm(q, device="cuda") for _ in range(nb)]).int()
+            assert d["c_perm_ld"] == q, (d["c_perm_ld"], q)
+
+    def args(self, C):
+        d = self.d
+        g = _lib.GemmArgs()
+        for f, _ in _lib.GemmArgs._fields_:
+            if f in d:
+                setattr(g, f, d[f])
+        g.A, g.B, g.C = self.A.data_ptr(), self.B.data_ptr(), C.data_ptr()
+        g.bias = self.bias.data_ptr() if self.bias is not None else None
+        g.aux = self.aux.data_ptr() if self.aux is not None else None
+        g.c_perm = self.perm.data_ptr() if self.perm is not None else None
+        return g
+
+    def run(self, kernel, reps):
+        """-> (ms, C) of `kernel` ('auto' = tssep_gemm_f32), None when the kernel does not cover the request."""
+        L = _lib.lib()
+        C = torch.zeros(self.celems, device="cuda")
+        g = self.args(C)
+        if H.gemm_plan(g, kernel) is None:
+            return None
+        kid = H.GEMM_KERNELS[kernel]
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        call = (lambda: L.tssep_gemm_f32_on(ctypes.byref(g), kid, st)) if kid else (lambda: L.tssep_gemm_f32(ctypes.byref(g), st))
+        assert call() == 0
+        torch.cuda.synchronize()
+        first = C.clone() if not self.d["accumulate"] else None
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            call()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / reps, first
+
+
+def why_slow(d, tfl):
+    """One written reason for a request below 200 TFLOP/s (the sweep's acceptance rule)."""
+    M, N, K = d["M"], d["N"], d["K"]
+    if d["precision"] == 0:
+        return "exact-fp32 MFMA: peak 157 TFLOP/s"
+    if d["a_kmajor"]:
+        tiles = -(-M // 128) * -(-N // 128)
+        if tiles <= 25:
+            return f"weight gradient with {tiles} 128 x 128 output tiles: split-K partials + their reduction dominate"
+        return "weight gradient: transposed staging of both operands (4-byte LDS writes) + split-K partial stores"
+    if K < 448:
+        return f"K = {K}: {4 * (M * N) / 1e9:.1f} GB of C for {2 * M * N * K / 1e12:.1f} TFLOP -- bound by the C store, not the MFMAs"
+    if N < 512:
+        return f"N = {N}: one or two column tiles, every A tile is used for few MFMAs per byte staged"
+    if d["c_remap"]:
+        return "remapped store (rows of an odd number of floats start on 4-byte boundaries)"
+    return "see DESIGN 4.1"
+
+
+def sweep(configs, B, reps, out=None, check_bits=True):
+    lines = []
+    nt_family = ("pipe", "tall2", "tall4", "tall4_xcol", "big", "stream", "nt_w160")
+    tn_family = ("pipe", "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160")
+    for units, projs, K in configs:
+        m = build(units, projs, K)
+        par = parity(m, units, projs, K)
+        reqs = requests_of_a_step(m, K, B)
+        del m
+        torch.cuda.empty_cache()
+        for d, count in reqs:
+            r = Replay(d)
+            got = r.run("auto", reps)
+            assert got is not None, d
+            ms_auto, c_auto = got
+            choice = H.gemm_plan(r.args(torch.zeros(1, device="cuda")), "auto")
+            fl = 2 * d["M"] * d["N"] * d["K"]
+            cand = {}
+            fam = ("f32",) if d["precision"] == 0 else (tn_family if d["a_kmajor"] else nt_family)
+            for k in fam:
+                if k == choice:
+                    continue
+                res = r.run(k, reps)
+                if res is None:
+                    continue
+                cand[k] = round(fl / res[0] / 1e9, 1)
+                if check_bits and c_auto is not None and max(d["splitk"], 1) == 1 and d["precision"] == 1 \
+                        and not (d["N"] % 256 == 1 or {k, choice} & {"tall4_xcol"}):
+                    assert torch.equal(torch.nan_to_num(res[1]), torch.nan_to_num(c_auto)), (k, choice, d)
+            tfl = round(fl / ms_auto / 1e9, 1)
+            best = max([tfl] + list(cand.values()))
+            line = dict(units=units, projs=projs, speakers=K, batch=B, calls_per_step=count,
+                        M=d["M"], N=d["N"], K=d["K"],
+                        layout=("tn" if d["a_kmajor"] else "nn" if d["b_kmajor"] else "nt") + ("+shift" if d["kperiod"] else ""),
+                        epilogue="+".join(x for x, on in (("bias", d["bias"]), ("tanh", d["act"] == 1), ("dtanh", d["act"] == 2),
+                                                           ("acc", d["accumulate"]), ("remap", d["c_remap"]), ("ones", d["b_ones_col"])) if on) or "plain",
+                        splitk=max(d["splitk"], 1), choice=choice, ms=round(ms_auto, 4), tflops_choice=tfl,
+                        candidates=cand, choice_over_best=round(tfl / best, 3), parity_vs_oracle=par)
+            if tfl < 200:
+                line["reason"] = why_slow(d, tfl)
+            lines.append(line)
+            if out is not None:
+                out.write(json.dumps(line) + "\n")
+                out.flush()
+            del r
+            torch.cuda.empty_cache()
+    return lines
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=768)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--quick", action="store_true", help="the default size and one other only")
+    ap.add_argument("--precision", default="bf16x3")
+    a = ap.parse_args()
+    H.GEMM_PRECISION = a.precision
+    if a.quick:
+        configs = [(300, 320, 4), (256, 256, 8)]
+    else:
+        configs = [(u, p, k) for k in (4, 8) for u in (128, 256, 300, 512) for p in (256, 320)]
+    out = open(a.out, "w") if a.out else sys.stdout
+    lines = sweep(configs, a.batch, a.reps, out)
+    worst = min(lines, key=lambda l: l["choice_over_best"])
+    slow = [l for l in lines if l["tflops_choice"] < 200]
+    sys.stderr.write(f"{len(lines)} requests; worst choice/best = {worst['choice_over_best']} ({worst['choice']} at "
+                     f"{worst['M']}x{worst['N']}x{worst['K']} {worst['layout']}); {len(slow)} below 200 TFLOP/s\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,8 @@
 //           -> dB, global max (AmplitudeToDB's top_db floor is over the whole batch) and the
 //           per-utterance max |X| (atomicMax on the ordered bit pattern: exact, order free)
 //   pass 2: dB floor, 40x40 DCT, log1p(|X| (e-1)/max) -> out[B,T, n_mfcc + F]
+// The maximum of Log1pMaxNormAbsSTFT follows its `statistics_axis` (feature_extractor.py:239-242): 'tf' = one per
+// utterance (every shipped config), 't' = one per utterance and frequency (over the frames), 'f' = one per frame.
 #include <math.h>
 #include "common.h"
 
@@ -26,12 +28,14 @@ constexpr int GSLOTS = 64;   // the batch-global dB maximum is collected in 64 s
 
 struct FeatWs {            // layout of the caller's workspace
   unsigned* gmax;          // [GSLOTS] ordered bits of max dB (a single address serialised 97 k atomics: 1 ms)
-  unsigned* umax;          // [B]   ordered bits of max |X| per utterance
+  unsigned* umax;          // [nmax] ordered bits of max |X|: per utterance (nmax = B), per (utterance, bin) (B F), unused (per frame)
   int* range;              // [2*n_mels]
   float* fbT;              // [n_mels][MAXF]  filterbank transposed (a filter's support contiguous)
   float* db;               // [B*T*n_mels]
 };
-__host__ __device__ inline FeatWs feat_ws(void* ws, int64_t B, int n_mels) {
+constexpr int STAT_TF = 0, STAT_T = 1, STAT_F = 2;
+__host__ __device__ inline int64_t feat_nmax(int64_t B, int F, int stat) { return stat == STAT_T ? B * F : B; }
+__host__ __device__ inline FeatWs feat_ws(void* ws, int64_t B /* = feat_nmax(...) */, int n_mels) {
   FeatWs w;
   char* p = (char*)ws;
   w.gmax = (unsigned*)p;
@@ -50,10 +54,8 @@ __global__ __launch_bounds__(64) void feat_init_kernel(void* ws, int64_t B, cons
                                                        int F, int n_mels) {
   FeatWs w = feat_ws(ws, B, n_mels);
   const int lane = threadIdx.x, m = blockIdx.x;
-  if (m == 0) {
-    w.gmax[lane] = 0u;            // GSLOTS == 64 == wave size
-    for (int64_t b = lane; b < B; b += 64) w.umax[b] = 0u;
-  }
+  if (m == 0) w.gmax[lane] = 0u;  // GSLOTS == 64 == wave size
+  for (int64_t b = (int64_t)m * 64 + lane; b < B; b += (int64_t)gridDim.x * 64) w.umax[b] = 0u;
   if (m >= n_mels) return;
   float lo = (float)F, hi = 0.f;
   for (int f = lane; f < F; f += 64) {
@@ -81,12 +83,12 @@ constexpr int LMELS = 128;        // filters whose table fits in LDS (40 in ever
 __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restrict__ X, int64_t B,
                                                          int64_t T, int F,
                                                          const float* __restrict__ fb, int n_mels,
-                                                         int n_mfcc, void* ws) {
+                                                         int n_mfcc, void* ws, int stat) {
   __shared__ float pw[4][MAXF];
   __shared__ float cw[CWMAX];
   __shared__ int clo[LMELS], chi[LMELS], coff[LMELS + 1];
   __shared__ int s_packed;
-  FeatWs w = feat_ws(ws, B, n_mels);
+  FeatWs w = feat_ws(ws, feat_nmax(B, F, stat), n_mels);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- filterbank -> LDS
   if (n_mfcc > 0) {
@@ -133,6 +135,11 @@ __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restric
         const float p = xv[r].x * xv[r].x + xv[r].y * xv[r].y;
         pw[wave][f] = p;
         amax = fmaxf(amax, sqrtf(p));
+        if (stat == STAT_T) {      // per (utterance, bin) maximum over the frames: most frames do not raise it
+          unsigned* slot = w.umax + (frame / T) * F + f;
+          const unsigned o_ = ord(sqrtf(p));
+          if (o_ > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, o_);
+        }
       }
     }
     // pw[wave] is private to the wave: LDS operations of one wave execute in order, a wave-level fence
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     amax = wave_max(amax);
-    if (lane == 0) atomicMax(w.umax + frame / T, ord(amax));
+    if (lane == 0 && stat == STAT_TF) atomicMax(w.umax + frame / T, ord(amax));
     if (n_mfcc > 0) {
       // one lane per filter walks its own band front to back (<= 64 bins for the widest filters): ~3 instructions per
       // bin on 40 lanes.  (Rounds 1-2: all 64 lanes shared each band and a butterfly summed them -- ~25 instructions
@@ -191,9 +198,9 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
                                                          const float* __restrict__ dct, int n_mels,
                                                          int n_mfcc, float top_db,
                                                          float* __restrict__ out, int64_t ld_out,
-                                                         const void* ws) {
+                                                         const void* ws, int stat) {
   __shared__ float dbl[4][64];
-  FeatWs w = feat_ws(const_cast<void*>(ws), B, n_mels);
+  FeatWs w = feat_ws(const_cast<void*>(ws), feat_nmax(B, F, stat), n_mels);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t frame = (int64_t)blockIdx.x * 4 + wave;
   const bool valid = frame < B * T;
@@ -216,8 +223,6 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
     }
   }
   if (!valid) return;
-  const float norm = unord(w.umax[frame / T]);
-  const float scale = (float)(M_E - 1.0) / norm;
   const float2* x = X + frame * F;
   float2 xv[17];                      // all loads of the frame first (F <= 1025), then the arithmetic
 #pragma unroll
@@ -225,37 +230,61 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
     const int f = lane + 64 * r;
     xv[r] = f < F ? x[f] : make_float2(0.f, 0.f);
   }
+  if (stat == STAT_TF) {
+    const float scale = (float)(M_E - 1.0) / unord(w.umax[frame / T]);
+#pragma unroll
+    for (int r = 0; r < 17; ++r) {
+      const int f = lane + 64 * r;
+      if (f < F) o[n_mfcc + f] = log1pf(sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y) * scale);
+    }
+    return;
+  }
+  // statistics_axis 'f': the frame's own maximum; 't': the (utterance, bin) maximum collected by pass 1
+  float fmx = 0.f;
+  if (stat == STAT_F) {
+#pragma unroll
+    for (int r = 0; r < 17; ++r)
+      if (lane + 64 * r < F) fmx = fmaxf(fmx, sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y));
+    fmx = wave_max(fmx);
+  }
 #pragma unroll
   for (int r = 0; r < 17; ++r) {
     const int f = lane + 64 * r;
-    if (f < F) o[n_mfcc + f] = log1pf(sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y) * scale);
+    if (f < F) {
+      const float norm = stat == STAT_F ? fmx : unord(w.umax[(frame / T) * F + f]);
+      o[n_mfcc + f] = log1pf(sqrtf(xv[r].x * xv[r].x + xv[r].y * xv[r].y) * ((float)(M_E - 1.0) / norm));
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels) {
-  FeatWs w = feat_ws(nullptr, B, n_mels);
+extern "C" int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels, int F, int stat_axis) {
+  if (stat_axis < 0 || stat_axis > 2 || F <= 0) return 0;
+  FeatWs w = feat_ws(nullptr, feat_nmax(B, F, stat_axis), n_mels);
   return (int64_t)((char*)w.db - (char*)nullptr) + B * T * (int64_t)n_mels * 4 + 16;       // incl. fbT
 }
 
 extern "C" int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F, const float* fb,
-                              const float* dct, int n_mels, int n_mfcc, float top_db, float* out,
-                              int64_t ld_out, void* ws, void* stream) {
+                              const float* dct, int n_mels, int n_mfcc, float top_db, int stat_axis,
+                              float* out, int64_t ld_out, void* ws, void* stream) {
   if (!X || !out || !ws) return TSSEP_E_NULL;
   if (n_mfcc > 0 && (!fb || !dct)) return TSSEP_E_NULL;
   if (B <= 0 || T <= 0 || F <= 0 || F > MAXF || ld_out < n_mfcc + F) return TSSEP_E_SHAPE;
   if (n_mfcc > 0 && (n_mels <= 0 || n_mels > 1024)) return TSSEP_E_SHAPE;
   if (n_mfcc == 0) n_mels = 0;
+  if (stat_axis < 0 || stat_axis > 2) return TSSEP_E_SHAPE;
   if ((((uintptr_t)X) & 7u) || (((uintptr_t)ws) & 15u)) return TSSEP_E_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   const int nm = n_mels > 0 ? n_mels : 1;
-  hipLaunchKernelGGL(feat_init_kernel, dim3((unsigned)nm), dim3(64), 0, s, ws, B, fb, F, n_mels);
+  const int64_t nmax = feat_nmax(B, F, stat_axis);
+  const int64_t nb0 = (nmax + 64 * 16 - 1) / (64 * 16);                  // (the maxima are zeroed by the same launch)
+  hipLaunchKernelGGL(feat_init_kernel, dim3((unsigned)(nb0 > nm ? (nb0 > 4096 ? 4096 : nb0) : nm)), dim3(64), 0, s, ws, nmax, fb, F, n_mels);
   const unsigned blocks = (unsigned)((B * T + 3) / 4);
   const unsigned blocks1 = (unsigned)((B * T + 4 * FPW - 1) / (4 * FPW));
   hipLaunchKernelGGL(feat_pass1_kernel, dim3(blocks1), dim3(256), 0, s, (const float2*)X, B, T, F,
-                     fb, n_mels, n_mfcc, ws);
+                     fb, n_mels, n_mfcc, ws, stat_axis);
   hipLaunchKernelGGL(feat_pass2_kernel, dim3(blocks), dim3(256), 0, s, (const float2*)X, B, T, F,
-                     dct, n_mels, n_mfcc, top_db, out, ld_out, ws);
+                     dct, n_mels, n_mfcc, top_db, out, ld_out, ws, stat_axis);
   return tssep_launch_status();
 }

@@ -80,7 +80,11 @@ __device__ __forceinline__ float fast_tanh(float x) {
 //     word0 = tag16 | a24[15:0] << 16,   word1 = a24[23:16] | b24 << 8,
 // a24 / b24 = the fp32 value rounded to its upper 24 bits (sign, exponent, 15 mantissa bits: 2^-16
 // relative -- what the split-bf16 MFMA operand keeps of it anyway: hi 8 + lo 8 significant bits).
-// tag16 = {launch epoch 1..31} << 11 | step + 1 (T <= 2046).  Against the {32-bit tag, fp32 value}
+// tag16 = {launch epoch 1..127} << 9 | (step + 1) mod 512.  (Round 4: rounds 1-3 spent 11 bits on the step and refused
+// T > 2046.  A poll only has to tell step t from what the SAME slot held before -- step t - 2, or the zeros of the
+// reset kernel -- and a slot is rewritten every second step, so the step may wrap; the epoch never is 0, so a tag never
+// equals the zeroed buffer's.  The seven epoch bits exclude a stale granule of the previous 126 launches.)
+// Against the {32-bit tag, fp32 value}
 // granule of round 1 this halves every byte of the exchange: the forward gather moves 41 instead of
 // 82 KB per workgroup and step (both sequence halves now fit into ONE round trip of ten 16-byte
 // loads), and the backward's exchange working set per XCD drops from 4.9 MB -- more than the 4-MB L2:
@@ -88,7 +92,10 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // launch for 4.7 GB of d(gates)) -- to 2.5 MB.
 __device__ __forceinline__ unsigned tag16_base(const int* err) {
   const unsigned e = (unsigned)__hip_atomic_load(err + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return (unsigned)__builtin_amdgcn_readfirstlane((int)(((e % 31u) + 1u) << 11));
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(((e % 127u) + 1u) << 9));
+}
+__device__ __forceinline__ unsigned mk_tag(unsigned tagbase, int64_t step_plus_1) {
+  return tagbase | ((unsigned)step_plus_1 & 0x1ffu);
 }
 __device__ __forceinline__ u32x2 pack_granule(unsigned tag16, float a, float b) {
   const unsigned ua = __float_as_uint(a) + 0x80u, ub = __float_as_uint(b) + 0x80u;   // round to 24 bits
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
         // (source workgroup, sequence); then into the bf16 hi+lo operand image
         if (!io_wave) {
           const int slot = (int)((step - 1) & 1);
-          const unsigned want = tagbase | (unsigned)step;
+          const unsigned want = mk_tag(tagbase, step);
           u32x4 v[10];
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_fwd_kernel(
       if (!io_wave) {
         // ---- publish h_t: 2 granules = 4 units per 16-byte store, 256-byte runs per sequence row
         // (write-through; no drain, no flag -- the tag is the flag)
-        const unsigned tag = tagbase | (unsigned)(step + 1);
+        const unsigned tag = mk_tag(tagbase, step + 1);
         const int slot = (int)(step & 1);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
       // spills 16 registers)
       if (step > 0) {
         const int slot = (int)((step - 1) & 1);
-        const unsigned want = tagbase | (unsigned)step;
+        const unsigned want = mk_tag(tagbase, step);
         u32x4 v[5];
         // this workgroup's own partial never leaves the CU: it is still in psum (rewritten only
         // after this step's barrier) -- 1/G less exchange traffic, same summation order.  One 16-byte
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
         }
         __syncthreads();
         // ---- (5) publish: 2 granules per lane and store, 1 KB contiguous per wave instruction
-        const unsigned tag = tagbase | (unsigned)(step + 1);
+        const unsigned tag = mk_tag(tagbase, step + 1);
         const int slot = (int)(step & 1);
         // quad index qd = tid + 512 i walks the [seq][Hp/4] array linearly: a wave instruction writes
         // 1 KB contiguous (4 x 256-byte runs per instruction measured 3x slower under load); one
@@ -1088,7 +1095,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     auto gather_finish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
-      const unsigned want = tagbase | (unsigned)st;
+      const unsigned want = mk_tag(tagbase, st);
       int spins = 0;
       bool fail = false;
       for (;;) {
@@ -1121,7 +1128,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     };
     auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
-      const unsigned tag = tagbase | (unsigned)(st + 1);
+      const unsigned tag = mk_tag(tagbase, st + 1);
       const int slot = (int)(st & 1);
       const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2 * PUBPITCH + 4 * uq);
       const u32x2 ga = pack_granule(tag, pv[0], pv[1]), gb = pack_granule(tag, pv[2], pv[3]);
@@ -1493,7 +1500,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     auto gather_finish = [&](int S, int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
-      const unsigned want = tagbase | (unsigned)st;
+      const unsigned want = mk_tag(tagbase, st);
       EX_LANE();
       int spins = 0;
       bool fail = false;
@@ -1524,7 +1531,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     };
     auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
-      const unsigned tag = tagbase | (unsigned)(st + 1);
+      const unsigned tag = mk_tag(tagbase, st + 1);
       const int slot = (int)(st & 1);
       EX_LANE();
 #pragma unroll
@@ -1657,7 +1664,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           // consecutive units of one sequence = one 16-byte pair of granules; no LDS round trip, no barrier in front
           const int bw = wave >> 1;
           const auto prs = payload_srd(P);
-          const unsigned tag = tagbase | (unsigned)(st + 1);
+          const unsigned tag = mk_tag(tagbase, st + 1);
           const unsigned off = (unsigned)(((((int)(st & 1) * G + g) * SQ + j) * Hp + 32 * wave + r4) * 4);
           const u32x2 a0 = pack_granule(tag, acc0[0], acc0[1]), a1 = pack_granule(tag, acc0[2], acc0[3]);
           const u32x2 c0 = pack_granule(tag, acc1[0], acc1[1]), c1 = pack_granule(tag, acc1[2], acc1[3]);
@@ -1760,6 +1767,15 @@ extern "C" int64_t tssep_lstm_onchip_xbuf_bytes(int64_t N, int H, int backward) 
 
 // (granule tags carry a per-launch epoch kept in device memory: common.h; tag16_base above)
 
+// Longest sequence a W-stationary launch takes: a lane addresses its sequence's rows of gates / cell / hout with a 32-bit
+// byte offset from the work item's base -- (seqs - 1) T 2H 16 bytes for the gate tensor must stay below 2^31.  (The step
+// field of the exchange tags wraps: no limit from there any more.)  H = 300: 14 913 frames (238 s) for the 16-sequence
+// kernels, 7 215 for the 32-sequence ones; tssep/train/rnnp.py:111-173 has no limit -- beyond, the streaming kernels run.
+extern "C" int64_t tssep_lstm_onchip_max_steps(int H, int seqs_per_item) {
+  if (H <= 0 || seqs_per_item < 2) return 0;
+  return (((int64_t)1 << 31) - 8192) / ((int64_t)(seqs_per_item - 1) * 2 * H * 16);
+}
+
 // grid: cross-XCD mode -> exactly the clusters wanted; XCD-local mode -> whole clusters per XCD
 // (workgroup b is observed on XCD b % 8; a cluster needs G workgroups of ONE XCD) plus one spare
 // workgroup per XCD for uneven dispatch.  Leftover workgroups exit (join_cluster).
@@ -1789,7 +1805,7 @@ extern "C" int tssep_blstm_onchip_fwd(float* gates, float* cell, float* hout, in
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, UPW, &items, &pb);
-  if (items >= 0xffff || T > 2046) return TSSEP_E_SHAPE;     // the step shares 16 tag bits with the epoch
+  if (items >= 0xffff || T > tssep_lstm_onchip_max_steps(H, SEQS)) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
@@ -1824,7 +1840,7 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
   if (max_wgs < G) return TSSEP_E_SHAPE;
   int64_t items, pb;
   xbuf_layout(N, G, G * UPW, &items, &pb);
-  if (items >= 0xffff || T > 2046) return TSSEP_E_SHAPE;     // the step shares 16 tag bits with the epoch
+  if (items >= 0xffff || T > tssep_lstm_onchip_max_steps(H, SEQS)) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)(HDR_BYTES + pb), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   // XCD-local clusters (48 on MI355X) unless asked otherwise -- or unless the cross-XCD packing
@@ -1889,7 +1905,7 @@ extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, 
   if (nga != 1 && nga != 2 && nga != 4) return TSSEP_E_UNSUPPORTED;
   if (H > KP2 || (H & 3) || (ldo & 3) || (dstride & 3) || ng16 % nga || max_wgs < 8 * G) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf) || !aligned16(cell) || !aligned16(hout)) return TSSEP_E_ALIGN;
-  if (2 * ng16 >= 0xffff || T > 2046) return TSSEP_E_SHAPE;
+  if (2 * ng16 >= 0xffff || T > tssep_lstm_onchip_max_steps(H, SQ)) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16_xbuf_bytes(N, H), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   int nc;
@@ -1939,7 +1955,7 @@ extern "C" int tssep_blstm_onchip16_bwd(float* gates, const float* cell, const f
   // (five workgroups per cluster: the exchange arm gathers exactly four peers)
   if (H > KP2 || (H & 3) || G != 5 || (ldo & 3) || (dstride & 3) || ng16 % nga || max_wgs < 8 * G) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf) || !aligned16(cell) || !aligned16(dhout)) return TSSEP_E_ALIGN;
-  if (2 * ng16 >= 0xffff || T > 2046) return TSSEP_E_SHAPE;
+  if (2 * ng16 >= 0xffff || T > tssep_lstm_onchip_max_steps(H, SQ)) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16_bwd_xbuf_bytes(N, H), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   int nc;

@@ -80,7 +80,7 @@ class _RNNP(torch.autograd.Function):
         Hp = _pad4(Hh)
         cell = torch.empty(N, T, 2, Hh, device=dev, dtype=torch.float32)
         hout = (torch.zeros if Hp != Hh else torch.empty)(R, 2 * Hp, device=dev, dtype=torch.float32)
-        kf, kb = H.recurrence_kernel(N, Hh, False, T), H.recurrence_kernel(N, Hh, True, T)
+        kf, kb = H.recurrence_kernel(N, Hh, False, T, dev), H.recurrence_kernel(N, Hh, True, T, dev)
         cf = cb = wf3 = wb3 = None
         if "cluster" in (kf, kb):
             cf, cb = H.derived("pack_cluster", [w_hh, w_hh_r], lambda: H.lstm_pack_cluster(w_hh, w_hh_r, Hh))
@@ -488,19 +488,27 @@ def sigmoid(logit):
 _WINDOWS = {}
 
 
-def windows(window, size, shift, device):
+def windows(window, size, shift, device, window_length=None):
+    """(analysis window, biorthogonal synthesis window), both [size] fp32 on `device`.  window_length < size
+    (paderbox stft / istft: the window covers the first window_length samples of a frame, the transform is
+    zero-padded to size): both windows are zero beyond window_length, so the kernels -- which always move `size`
+    samples per frame -- compute exactly irfft(X)[..., :window_length] * w_syn."""
     from scipy.signal import get_window
-    key = (window, size, shift, str(device))
+    wl = size if window_length is None else int(window_length)
+    key = (window, size, shift, str(device), wl)
     if key not in _WINDOWS:
-        w = get_window(window, size, fftbins=True).astype(np.float64)
-        denom = np.zeros(size)
-        for i in range(-(size // shift) - 1, size // shift + 2):
+        w = get_window(window, wl, fftbins=True).astype(np.float64)
+        denom = np.zeros(wl)
+        for i in range(-(wl // shift) - 1, wl // shift + 2):
             off = i * shift
-            lo, hi = max(0, off), min(size, size + off)
+            lo, hi = max(0, off), min(wl, wl + off)
             if lo < hi:
                 denom[lo:hi] += (w ** 2)[lo - off:hi - off]
-        _WINDOWS[key] = (torch.as_tensor(w, dtype=torch.float32).to(device),
-                         torch.as_tensor(w / denom, dtype=torch.float32).to(device))
+        wa, ws = np.zeros(size), np.zeros(size)
+        wa[:wl] = w
+        ws[:wl] = w / denom
+        _WINDOWS[key] = (torch.as_tensor(wa, dtype=torch.float32).to(device),
+                         torch.as_tensor(ws, dtype=torch.float32).to(device))
     return _WINDOWS[key]
 
 

@@ -142,12 +142,15 @@ def stft_frames(N, size=1024, shift=256, window_length=None, pad=True, fading=Tr
                                             int(fading)))
 
 
-def stft_fwd(x, window, size=1024, shift=256, fading=True):
-    """x [rows, N] -> complex64 [rows, T, size//2+1]"""
+def stft_fwd(x, window, size=1024, shift=256, fading=True, T=None):
+    """x [rows, N] -> complex64 [rows, T, size//2+1].  fading: size - shift zeros in front (True) or none (False);
+    T: frame count when it is not the padded, full-window one (pad=False, window_length < size: the caller's
+    feature extractor computes it; frames that reach past the signal read zeros)."""
     L = _lib.lib()
     x = _f32(x).contiguous()
     rows, N = x.shape
-    T = stft_frames(N, size, shift, None, True, fading)
+    if T is None:
+        T = stft_frames(N, size, shift, None, True, fading)
     X = torch.empty(rows, T, size // 2 + 1, 2, device=x.device, dtype=torch.float32)
     check(L.tssep_stft_fwd(_p(x), rows, N, size, shift, int(fading), _p(window),
                            _p(fft_tables(size, x.device)), _p(X), T, _stream()), "stft_fwd")
@@ -233,7 +236,10 @@ def mask_istft_bwd(dy, logit, obs, wsyn, size=1024, shift=256, fading=True, loss
 
 
 # --------------------------------------------------------------------------- features
-def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
+STAT_AXES = {"tf": 0, "t": 1, "f": 2}
+
+
+def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0, statistics_axis="tf"):
     """X complex64 [B,T,F] -> (view [B,T,n_mfcc+F], ld)."""
     L = _lib.lib()
     Xr = torch.view_as_real(X.contiguous())
@@ -246,10 +252,11 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0):
     out = torch.empty(B, T, ld, device=X.device, dtype=torch.float32)
     if ld != D:
         out[..., D:].zero_()
-    ws = torch.empty(int(L.tssep_feat_workspace_bytes(B, T, max(n_mels, 1))) // 4 + 4,
+    stat = STAT_AXES[statistics_axis]
+    ws = torch.empty(int(L.tssep_feat_workspace_bytes(B, T, max(n_mels, 1), F, stat)) // 4 + 4,
                      device=X.device, dtype=torch.float32)
     check(L.tssep_feat_fwd(_p(Xr), B, T, F, _p(fb) if n_mfcc else None,
-                           _p(dct) if n_mfcc else None, n_mels, n_mfcc, float(top_db), _p(out),
+                           _p(dct) if n_mfcc else None, n_mels, n_mfcc, float(top_db), stat, _p(out),
                            ld, _p(ws), _stream()), "feat_fwd")
     return out[..., :D], ld
 
@@ -328,6 +335,13 @@ def gemm_plan(g, force="auto"):
     return GEMM_KERNEL_NAMES[kid.value] if rc == 0 else None
 
 
+def gemm_descriptor(g):
+    """The request without its pointers (what the dispatcher's choice depends on): tools/sweep_gemm_shapes.py replays it."""
+    d = {f: getattr(g, f) for f, _ in GemmArgs._fields_ if f not in ("A", "B", "C", "bias", "c_perm", "aux")}
+    d.update(bias=bool(g.bias), perm=bool(g.c_perm), has_aux=bool(g.aux))
+    return d
+
+
 def _launch_gemm(g):
     kid = 0
     for name in GEMM_PREFER:
@@ -335,7 +349,7 @@ def _launch_gemm(g):
             kid = GEMM_KERNELS[name]
             break
     if GEMM_LOG is not None:
-        GEMM_LOG.append((gemm_plan(g, GEMM_KERNEL_NAMES[kid]), g.M, g.N, g.K))
+        GEMM_LOG.append((gemm_plan(g, GEMM_KERNEL_NAMES[kid]), g.M, g.N, g.K, gemm_descriptor(g)))
     L = _lib.lib()
     check(L.tssep_gemm_f32_on(ctypes.byref(g), kid, _stream()) if kid else L.tssep_gemm_f32(ctypes.byref(g), _stream()),
           "gemm_f32")
@@ -545,10 +559,29 @@ def n_cus(device):
     return torch.cuda.get_device_properties(device).multi_processor_count
 
 
-ONCHIP_MAX_T = 2046       # the on-chip kernels' 16-bit granule tag holds the step in 11 bits
+_WARNED = set()
 
 
-def recurrence_kernel(N, H, backward, T=0):
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def onchip_max_steps(N, H, backward, device=None):
+    """Longest sequence (frames) the W-stationary split-bf16 recurrence takes for this launch: the 16-sequence
+    kernels address (seqs - 1) T 2H 16 bytes of gates from a work item's base with 32 bits -- 14 913 frames at
+    H = 300 (7 215 for the 32-sequence kernels that serve the shapes the interleaved ones do not).  Rounds 1-3
+    stopped at 2 046 (an 11-bit step field in the exchange tags; it wraps now, lstm_onchip.hip)."""
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    g16 = 0
+    if dev is not None and H % 4 == 0:
+        g16 = onchip16_bwd_groups(N, H, dev) if backward else onchip16_groups(N, H, dev)
+    return int(_lib.lib().tssep_lstm_onchip_max_steps(H, 16 if g16 else 32))
+
+
+def recurrence_kernel(N, H, backward, T=0, device=None):
     """-> 'stream' | 'cluster' | 'onchip' for a BLSTM over N sequences (ms per launch on MI355X at H=300,
     T=253, profiles/r2_recurrence_microbench.jsonl, forward / backward):
       on-chip bf16x3 (compact granules)  1.34 / 1.32 (8 sequences), 1.58 / 1.53 (32), 1.85 / 1.74 (256),
@@ -556,12 +589,17 @@ def recurrence_kernel(N, H, backward, T=0):
                                          32 sequences x 1 direction), 4.3 / 4.1 (1536), 8.4 / 8.1 (3072)
       fp32 cluster                       1.50 / 1.34 (8), 1.50 / 1.57 (32), 7.8 / 21.5 (768)
       streaming fp32                     4.75 / 6.0 (<= 512), 5.3 / 6.2 (768), 17.0 / 18.7 (3072)
-    Policy: the on-chip kernels for every N where they exist (H >= 128, T <= 2046); round 1 sent backward
-    launches of <= 32 sequences to the fp32 cluster kernel, which the compact granules overtook.  The fp32
-    W-stationary (cluster) and streaming kernels remain selectable (RECURRENCE) as the exact-fp32
-    recurrences, and streaming is the path for H the W-stationary kernels do not support."""
+    Policy: the on-chip kernels for every N where they exist (H >= 128, T up to `onchip_max_steps`: 14 913 frames
+    = 238 s at H = 300); round 1 sent backward launches of <= 32 sequences to the fp32 cluster kernel, which the
+    compact granules overtook.  The fp32 W-stationary (cluster) and streaming kernels remain selectable
+    (RECURRENCE) as the exact-fp32 recurrences, and streaming is the path for H the W-stationary kernels do not
+    support -- a fallback for a SUPPORTED H (sequence too long) is announced, never silent."""
     L = _lib.lib()
-    onchip_ok = bool(L.tssep_lstm_onchip_supported(H)) and T <= ONCHIP_MAX_T
+    h_ok = bool(L.tssep_lstm_onchip_supported(H))
+    onchip_ok = h_ok and (T <= 2046 or T <= onchip_max_steps(N, H, backward, device))
+    if h_ok and not onchip_ok and RECURRENCE in ("auto", "onchip") and H >= 128:
+        _warn_once(("onchip_T", H, backward), f"tssep_amd: {T} frames per sequence exceed the W-stationary recurrence's "
+                   f"{onchip_max_steps(N, H, backward, device)} at H = {H}: the streaming fp32 kernel runs instead (about 3x slower)")
     if RECURRENCE in ("stream", "cluster", "onchip"):
         ok = {"stream": True, "cluster": bool(L.tssep_lstm_cluster_supported(H)), "onchip": onchip_ok}[RECURRENCE]
         return RECURRENCE if ok else "stream"

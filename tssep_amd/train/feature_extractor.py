@@ -25,12 +25,20 @@ def _cuda_f32(x):
 
 
 class STFT(Configurable):
+    """padertorch.contrib.cb.feature_extractor.STFT on paderbox.transform.module_stft (star-imported at
+    feature_extractor.py:8): every option the reference's configs may set (init_cfg_common.yaml:33-43) --
+    ``window_length <= size`` (the transform is zero-padded), ``pad`` (False: only full frames), ``fading`` in
+    {True / 'full', 'half', False / None}.  The FFT plan is 1024 / 256 (any other: TSSEP_E_UNSUPPORTED from
+    the library, naming the plan)."""
+
     def __init__(self, size=1024, shift=256, window_length=None, pad=True, fading=True,
                  output_size=None, window="blackman"):
         if window_length is None:
             window_length = size
-        if window_length != size:
-            raise NotImplementedError("window_length != size")
+        if not 0 < window_length <= size:
+            raise ValueError(f"window_length = {window_length} must lie in (0, size = {size}]")
+        if fading not in (None, False, True, "full", "half"):
+            raise ValueError(f"fading = {fading!r}: None, False, True, 'full' or 'half' (paderbox stft)")
         self.size, self.shift, self.window_length = size, shift, window_length
         self.pad, self.fading, self.window = pad, fading, window
         self.output_size = self._get_output_size(output_size)
@@ -45,36 +53,90 @@ class STFT(Configurable):
         return output_size
 
     def _windows(self, device):
-        return Fn.windows(self.window, self.size, self.shift, device)
+        return Fn.windows(self.window, self.size, self.shift, device, self.window_length)
+
+    def _fade(self):
+        """(zeros in front, zeros behind) that `fading` adds to a signal (paderbox stft): 'full' = window_length -
+        shift on both sides, 'half' = half of that (the odd sample behind)."""
+        if self.fading in (None, False):
+            return 0, 0
+        p = self.window_length - self.shift
+        if self.fading == "half":
+            return p // 2, p - p // 2
+        return p, p
+
+    def _plain(self):
+        """The configuration the fused kernels are built for: full fading with a full-size window."""
+        return self.window_length == self.size and self.fading in (True, "full")
+
+    def _check_plan(self):
+        if (self.size, self.shift) != (1024, 256):
+            raise RuntimeError(f"unsupported FFT plan size={self.size}, shift={self.shift}: libtssep_hip.so builds the "
+                               "1024 / 256 plan of the reference's configs (TSSEP_E_UNSUPPORTED)")
+
+    def frames(self, num_samples):
+        lead, tail = self._fade()
+        n = num_samples + lead + tail
+        if self.pad:
+            return max(-(-(n - self.window_length) // self.shift), 0) + 1
+        if n < self.window_length:
+            raise ValueError(f"pad=False: {num_samples} samples (+ fading) are shorter than one window")
+        return (n - self.window_length) // self.shift + 1
 
     def stft(self, signal):
         """[..., N] -> complex64 [..., T, F]  (fe.stft, model.py:503-504)"""
+        self._check_plan()
         x = _cuda_f32(signal)
-        if not self.pad:
-            raise NotImplementedError("pad=False")
         w, _ = self._windows(x.device)
-        X = H.stft_fwd(x.reshape(-1, x.shape[-1]), w, self.size, self.shift, self.fading)
+        x2 = x.reshape(-1, x.shape[-1])
+        T = self.frames(x.shape[-1])
+        if self._plain():
+            X = H.stft_fwd(x2, w, self.size, self.shift, True, T=T)
+        else:
+            # the kernel knows "size - shift zeros in front" or none: any other fade is laid out here (zero padding is
+            # layout, the transform stays the library's); frames reaching past the signal read zeros (pad=True) or
+            # do not exist (pad=False: T is smaller)
+            lead, tail = self._fade()
+            if lead or tail:
+                x2 = torch.nn.functional.pad(x2, (lead, tail))
+            X = H.stft_fwd(x2, w, self.size, self.shift, False, T=T)
         return X.reshape(*x.shape[:-1], X.shape[-2], X.shape[-1])
+
+    def _num_samples(self, T, num_samples):
+        lead, tail = self._fade()
+        full = (T - 1) * self.shift + self.window_length - lead - tail
+        return full if num_samples is None else min(num_samples, full)
 
     def istft(self, signal, num_samples=None):
         """complex [..., T, F] -> [..., N]  (fe.istft, model.py:661-664); differentiable."""
+        self._check_plan()
+        if self.window_length % self.shift:
+            raise ValueError("istft: window_length must be a multiple of shift (paderbox's biorthogonal window)")
         T = signal.shape[-2]
-        full = (T - 1) * self.shift + self.size - (2 * (self.size - self.shift) if self.fading else 0)
-        N = full if num_samples is None else min(num_samples, full)
+        N = self._num_samples(T, num_samples)
         _, wsyn = self._windows(signal.device)
-        return Fn.istft(signal, wsyn, N, self.size, self.shift, self.fading)
+        lead, _ = self._fade()
+        lead0 = self.size - self.shift                 # what the kernel drops in front
+        if lead == lead0:
+            return Fn.istft(signal, wsyn, N, self.size, self.shift, True)
+        # another fade: k empty frames in front move the overlap-add by k hops, d more samples are computed and cut
+        # (layout only; autograd takes pad and slice back)
+        k = -(-(lead0 - lead) // self.shift)
+        d = lead - lead0 + k * self.shift
+        Xp = torch.nn.functional.pad(torch.view_as_real(signal), (0, 0, 0, 0, k, 0))
+        y = Fn.istft(torch.view_as_complex(Xp), wsyn, N + d, self.size, self.shift, True)
+        return y[..., d:]
 
     def masked_istft(self, logit, observation, num_samples=None, target=None):
         """istft(sigmoid(logit) * observation) as one fused kernel each way (functional.mask_istft):
         logit [B,K,T,F], observation complex [B,T,F] -> [B,K,N]; ``target`` [B,K,N] (optional) lets the
         forward accumulate the |estimate - target| sums a LogMAE / MAE loss needs."""
-        T = logit.shape[-2]
-        full = (T - 1) * self.shift + self.size - (2 * (self.size - self.shift) if self.fading else 0)
-        N = full if num_samples is None else min(num_samples, full)
-        if not self.fading:
-            raise NotImplementedError("fading=False")
+        if not self._plain():         # the fused tail is built for the shipped STFT; any other: mask head, then istft
+            _, est = Fn.mask_head(logit, observation)
+            return self.istft(est, num_samples=num_samples)
+        N = self._num_samples(logit.shape[-2], num_samples)
         _, wsyn = self._windows(logit.device)
-        return Fn.mask_istft(logit, observation, wsyn, N, self.size, self.shift, self.fading, tgt=target)
+        return Fn.mask_istft(logit, observation, wsyn, N, self.size, self.shift, True, tgt=target)
 
     def stft_to_feature(self, stft_signals):
         raise NotImplementedError(type(self))
@@ -93,14 +155,15 @@ class Log1pMaxNormAbsSTFT(STFT):
                  output_size=None, window="blackman", statistics_axis="tf"):
         super().__init__(size=size, shift=shift, window_length=window_length, pad=pad,
                          fading=fading, output_size=output_size, window=window)
-        if statistics_axis != "tf":
-            raise NotImplementedError("statistics_axis != 'tf' (the shipped configs use 'tf')")
+        if statistics_axis not in H.STAT_AXES:
+            raise ValueError(f"statistics_axis = {statistics_axis!r}: 'tf', 't' or 'f' (feature_extractor.py:239-242)")
         self.statistics_axis = statistics_axis
 
     def stft_to_feature(self, stft_signals):
         X = stft_signals
         lead = X.shape[:-2]
-        out, _ = H.feat_fwd(X.reshape(-1, X.shape[-2], X.shape[-1]).contiguous(), None, None, 0)
+        out, _ = H.feat_fwd(X.reshape(-1, X.shape[-2], X.shape[-1]).contiguous(), None, None, 0,
+                            statistics_axis=self.statistics_axis)
         return out.reshape(*lead, X.shape[-2], X.shape[-1])
 
 
@@ -220,6 +283,7 @@ class ConcaternatedSTFTFeatures(STFT, torch.nn.Module):
         if isinstance(self.fe1, TorchMFCC) and isinstance(self.fe2, Log1pMaxNormAbsSTFT) \
                 and X.dim() == 3:
             # one fused pass pair writes [mfcc | log1p] side by side (feature_extractor.py:352-360)
-            out, _ = H.feat_fwd(X, self.fe1.fb, self.fe1.dct_mat, self.fe1.n_mfcc, self.fe1.top_db)
+            out, _ = H.feat_fwd(X, self.fe1.fb, self.fe1.dct_mat, self.fe1.n_mfcc, self.fe1.top_db,
+                                statistics_axis=self.fe2.statistics_axis)
             return out
         return torch.concat([self.fe1.stft_to_feature(X), self.fe2.stft_to_feature(X)], dim=-1)
