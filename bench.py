@@ -477,10 +477,13 @@ def main():
                      arithmetic=arithmetic("f32"), roofline=roof_e, roofline_mask_head=mh_e)
         if not rec_f32:
             # the REFERENCE-WIDTH bookend (VERDICT r3 #5a): fp32 end to end as the reference computes
-            # (tssep/train/model.py:502-511) -- exact-fp32 MFMA GEMMs AND the exact-fp32 W-stationary recurrence
-            # (lstm_cluster.hip: fp32 MFMA 4x4x1, full 32-bit exchange granules), fewer steps (it is the slow line),
-            # its own roofline against the fp32 MFMA peak and its own parity run against the CPU oracle
-            old_rec, H.RECURRENCE = H.RECURRENCE, "cluster"
+            # (tssep/train/model.py:502-511) -- exact-fp32 MFMA GEMMs AND an exact-fp32 recurrence: the sequence-parallel
+            # streaming kernel (lstm.hip: fp32 FMAs, no exchange) at large batches, the W-stationary cluster kernel
+            # (lstm_cluster.hip: fp32 MFMA 4x4x1, full 32-bit exchange granules) at small ones -- r4: 524 ms per step with
+            # the cluster kernel at batch 768.  Fewer steps (it is the slow line), its own roofline against the fp32 MFMA
+            # peak and its own parity run against the CPU oracle
+            ref_rec = "stream" if B * K >= 256 else "cluster"
+            old_rec, H.RECURRENCE = H.RECURRENCE, ref_rec
             try:
                 st_r, wu_r = min(args.steps, 10), min(args.warmup, 2)
                 dt_r, T_r, med_r = timed_run(st_r, wu_r)
@@ -489,7 +492,7 @@ def main():
                 ref_width = dict(value=round(B * T_r * st_r / dt_r, 1), unit="frames/s",
                                  ms_per_step=round(dt_r / st_r * 1e3, 3), ms_per_step_median=round(med_r, 3),
                                  steps=st_r, warmup=wu_r, dtype="f32",
-                                 arithmetic="exact fp32 MFMA GEMMs; exact fp32 cluster recurrence (fp32 MFMA, 32-bit granules)",
+                                 arithmetic=arithmetic("f32").split(";")[0] + f"; exact fp32 {ref_rec} recurrence",
                                  roofline=roof_r, roofline_mask_head=mh_r,
                                  parity_vs_cpu_oracle=None if args.no_cpu_baseline else cpu_baseline(model, opt, parity_only=True))
             finally:

@@ -47,6 +47,13 @@ int tssep_probe_xcc(int* out, int nblocks, void* stream);
 /* Shader clock under load: out[2b] = s_memtime ticks, out[2b+1] = 100 MHz reference ticks spent by
  * block b in `iters` x 8 bf16 MFMAs per wave (heavy != 0) or as many s_sleep (heavy == 0). */
 int tssep_probe_clock(int64_t* out, int nblocks, int iters, int heavy, void* stream);
+/* Store-flavour probe: every one of `nblocks` workgroups rewrites its own bytes_per_wg (multiple of 4096) of buf
+ * `reps` times with 16-byte stores of one flavour (0 plain, 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt) and streams `pressure`
+ * bytes (0: none) of stream_src [stream_bytes] through the L2 between two rewrites.  Under rocprofv3 --pmc
+ * WRITE_SIZE it tells whether rewritten lines reach the memory side once or every time (the exchange granules
+ * of the W-stationary recurrences: DESIGN 4.2). */
+int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, const float* stream_src,
+                        int64_t stream_bytes, int pressure, float* sink, void* stream);
 
 /* ------------------------------------------------------------------- STFT ----
  * paderbox-semantics STFT (fading + end padding + periodic window + rfft, no
@@ -238,7 +245,8 @@ int tssep_lstm_pack(const float* w_ih_f, const float* w_hh_f, const float* b_ih_
                     const float* b_ih_r, const float* b_hh_r, int H, int I, int64_t ld_i,
                     float* wih_p, float* bias_p, float* whh_f, float* whh_b, void* stream);
 /* gates [N,T,2,H,4]: in = pre-activations from the input GEMM; out = activated gates
- * (kept for backward).  cell [N,T,2,H]; hout [N,T,ldo] (cols d*dstride+u).  H <= 320. */
+ * (kept for backward).  cell [N,T,2,H]; hout [N,T,ldo] (cols d*dstride+u).  H <= 512 (round 4; the
+ * W-stationary families below cover H <= 320 / 304, which is where the reference's configs live). */
 int tssep_blstm_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
                     const float* whh_f, int64_t N, int64_t T, int H, void* stream);
 /* dhout [N,T,ldo] -> gates is overwritten with d(pre-activation) in the same layout. */

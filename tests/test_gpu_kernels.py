@@ -220,7 +220,10 @@ def test_gemm_160_wide_row_tile_is_bit_identical_to_the_128_wide_tiles(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (4096 + 255, 320, 600),
-                                   (3000, 129, 553), (1500, 2052, 31), (70000, 600, 64), (1280, 5, 2400)])
+                                   (3000, 129, 553), (1500, 2052, 31), (70000, 600, 64), (1280, 5, 2400),
+                                   # several tiles per workgroup with a K loop long enough for the paced drain (round 4: the
+                                   # shapes above never had both -- the drain's store hazard corrupted ~100 of 50 M elements)
+                                   (24288, 2048, 512), (24288, 2400, 513), (70000, 600, 320), (40000, 1280, 130)])
 def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
     """The persistent streaming kernel (csrc/gemm_bf16x3_stream.hip: 256 x 128 tiles walked by one workgroup per
     CU, two accumulator banks, C drained in paced 32 x 32 pieces while the next tile computes) against fp64, and bit
@@ -261,7 +264,18 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         close(s1[3], ref - bias, rtol=2e-4, atol=2e-4, name="stream plain")
         for a, b in zip(outs["1"], outs["0"]):
             assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        # the plain store again, five times (the store-data hazard of round 3's drain was timing dependent)
+        log = h.GEMM_LOG = []
+        for _ in range(5):
+            C5 = torch.full((M, N), float("nan"), device="cuda")
+            with h.prefer_gemm_kernels("stream"):
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C5, N, M, N, K)
+            assert torch.equal(C5, outs["0"][3])
+        h.GEMM_LOG = None
+        if M >= 1024 and K > 96 and N % 4 == 0:
+            assert {k for k, *_ in log} == {"stream"}, log
     finally:
+        h.GEMM_LOG = None
         h.GEMM_PRECISION = old
 
 
@@ -470,6 +484,8 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
                     else:
                         part, S_ = h.wgrad(dg, dg.shape[1], hh, hh.shape[1], M, N, R, with_colsum=True, splitk=S)
                 h.GEMM_LOG = None
+                if mode == "1" and log[0][0] not in kern:
+                    pytest.skip("the 256 x 160 tile does not cover this request (M pads to 256 by more than 8 %): nothing to compare")
                 assert log[0][0] in kern, log
                 outs[mode] = part.clone()
             Nc = N if shift else N + 1
@@ -529,7 +545,12 @@ def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
                 Nc = N + 1 if colsum else N
                 ldp = outs["1"].numel() // (S * M)
                 a, b = outs["1"].view(S, M, ldp)[:, :, :Nc], outs["0"].view(S, M, ldp)[:, :, :Nc]
-                assert torch.equal(a, b), f"products {products} colsum {colsum}: {(a != b).sum().item()} differ"
+                # split boundaries: this kernel cuts K in 16-row tiles, the 128 x 128 one in 32-row tiles
+                per16, per32 = -(-(-(-R // 16)) // S) * 16, -(-(-(-R // 32)) // S) * 32
+                if S == 1 or per16 == per32:
+                    assert torch.equal(a, b), f"products {products} colsum {colsum}: {(a != b).sum().item()} differ"
+                else:       # (a shape the dispatcher leaves to the other tiles: named here, the splits differ -> sums agree)
+                    close(a.double().sum(0).float(), b.double().sum(0).float(), rtol=1e-4, atol=1e-4 * float(b.double().sum(0).abs().max()), name="h160 vs tn, sums")
                 if products is None:
                     ref = dz[:, :M].double().t() @ x[:, :N].double()
                     close(a.double().sum(0)[:, :N].float(), ref.float(), rtol=2e-4, atol=2e-4, name="h160")
@@ -951,7 +972,7 @@ def _lstm_case(N, T, I, Hh, seed):
 
 
 @pytest.mark.parametrize("N,T,I,Hh", [(3, 6, 7, 5), (8, 9, 20, 40), (11, 5, 33, 300), (16, 12, 64, 64),
-                                      (2, 4, 9, 130)])
+                                      (2, 4, 9, 130), (9, 7, 12, 512), (5, 6, 8, 400), (3, 5, 8, 336)])
 def test_blstm_forward_backward(N, T, I, Hh):
     h = H()
     p, x = _lstm_case(N, T, I, Hh, 7)

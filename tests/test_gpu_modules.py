@@ -936,7 +936,7 @@ def test_bench_default_flags_print_one_json_line():
     assert d["roofline_mask_head"]["bound"] == "hbm" and "chain" in d["roofline_mask_head"]
     mh = d["roofline_mask_head"]
     assert "frac_of_copy_ceiling" not in mh and 0 < mh["frac_own_bytes"] < 1 and mh["own_bytes_per_launch"] < mh["algorithmic_bytes_per_launch"]
-    assert d["roofline"]["traffic_algorithmic"] > 0
+    assert d["roofline"]["traffic_algorithmic"] > 0          # (at batch 8 the dominant MFMA kernel is a recurrence: 40 / 44 B per cell)
     e = d["f32_gemms_bf16x3_recurrence"]
     assert e is not None and e["roofline"]["peak"] == pytest.approx(157.3) and e["dtype"] == "f32 GEMMs + bf16x3 recurrence"
     # the fp32 end-to-end bookend: exact-fp32 GEMMs AND the exact-fp32 recurrence (VERDICT r3 #5a)

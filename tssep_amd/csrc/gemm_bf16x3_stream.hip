@@ -207,8 +207,13 @@ __global__ __launch_bounds__(SNT, 2) void gemm_bf16x3_stream_kernel(
 #define DW(e) if constexpr (DQ >= 0) scr[(((e) & 3) + 8 * ((e) >> 2) + 4 * (lane >> 5)) * DPF + (lane & 31)] = acc[1 - BANK][DI][DJ][e]
 #define DBIAS if constexpr (DQ >= 0) { const int64_t n_ = p_n0 + wn * 64 + DJ * 32 + (lane & 7) * 4; dbv = *reinterpret_cast<const f32x4*>(bias_s + (n_ < SBIAS - 3 ? n_ : 0)); }
 #define DR(it) if constexpr (DQ >= 0) dv[(it) & 1] = *reinterpret_cast<const f32x4*>(scr + ((it) * 8 + (lane >> 3)) * DPF + (lane & 7) * 4)
+// (the row-group offset goes into the per-lane offset, soffset stays the immediate 0: for a store of more than 64 bits
+// whose soffset is an SGPR the compiler inserts NO wait state in front of a VALU write of the data registers -- LLVM's
+// hazard recognizer exempts that form -- and on gfx950 the store was seen to read data the next instruction had already
+// overwritten: the integer offset of the next operand load reached C as a denormal in lanes 12-15 of every 16, ~100
+// elements of 50 M, only where a workgroup walks several tiles -- round 4, tools/scan_store_hazard.py guards the build)
 #define DS(it) if constexpr (DQ >= 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dv[(it) & 1] + dbv), csrd, \
-                   (int)((dm + (it) * 8 < M) ? dvo : OOR), (int)((it) * 8 * ldc * 4), 2)
+                   (int)((dm + (it) * 8 < M) ? dvo + (unsigned)((it) * 8 * ldc * 4) : OOR), 0, 2)
 #define SB __builtin_amdgcn_sched_barrier(0)
 #define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * SROWB + (fo))
 #define MM(x, y, i, j) if (PROBE & 16) acc[BANK][i][j][0] += (float)x[i][0] + (float)y[j][1]; else acc[BANK][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[i], y[j], acc[BANK][i][j], 0, 0, 0)
@@ -268,8 +273,8 @@ __global__ __launch_bounds__(SNT, 2) void gemm_bf16x3_stream_kernel(
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {       // (not unrolled: the loop around it is at the register ceiling)
       const f32x4 v = *reinterpret_cast<const f32x4*>(scr + (it * 8 + r0) * DPF + c4) + bv;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd, (int)((mb + it * 8 + r0 < M) ? vo : OOR),
-                                             (int)(it * 8 * ldc * 4), 2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd,
+                                             (int)((mb + it * 8 + r0 < M) ? vo + (unsigned)(it * 8 * ldc * 4) : OOR), 0, 2);
     }
   };
   auto drain_one = [&](auto bank_tag) __attribute__((always_inline)) {         // the next pending sub-tile of bank BANK (register indices static)

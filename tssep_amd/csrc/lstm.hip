@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void blstm_bwd_kernel(
 extern "C" int tssep_lstm_pack_sizes(int H, int I, int64_t ld_i, tssep_lstm_sizes* out) {
   if (!out) return TSSEP_E_NULL;
   if (H <= 0 || I <= 0 || ld_i < I || (ld_i & 3)) return TSSEP_E_SHAPE;
-  if (lstm_nb(H) > 5) return TSSEP_E_UNSUPPORTED;
+  if (lstm_nb(H) > 8) return TSSEP_E_UNSUPPORTED;      // H <= 512
   out->wih_p = (int64_t)8 * H * ld_i;
   out->bias_p = (int64_t)8 * H;
   out->whh_f = (int64_t)2 * 4 * lstm_kq3(H) * lstm_nb(H) * 256;
@@ -414,7 +414,7 @@ extern "C" int tssep_blstm_fwd(float* gates, float* cell, float* hout, int64_t l
   if (N <= 0 || T <= 0 || H <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!aligned16(gates) || !aligned16(whh_f)) return TSSEP_E_ALIGN;
   const int NB = lstm_nb(H), KQ3 = lstm_kq3(H);
-  if (NB > 5) return TSSEP_E_UNSUPPORTED;
+  if (NB > 8) return TSSEP_E_UNSUPPORTED;
   dim3 grid((unsigned)((N + 7) / 8), 2);
   const size_t lds = (size_t)2 * 8 * (4 * KQ3 + 12) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
@@ -426,7 +426,10 @@ extern "C" int tssep_blstm_fwd(float* gates, float* cell, float* hout, int64_t l
     case 2: L(2); break;
     case 3: L(3); break;
     case 4: L(4); break;
-    default: L(5); break;
+    case 5: L(5); break;
+    case 6: L(6); break;
+    case 7: L(7); break;
+    default: L(8); break;
   }
 #undef L
   return tssep_launch_status();
@@ -439,7 +442,7 @@ extern "C" int tssep_blstm_bwd(float* gates, const float* cell, const float* dho
   if (N <= 0 || T <= 0 || H <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
   if (!aligned16(gates) || !aligned16(whh_b)) return TSSEP_E_ALIGN;
   const int NB = lstm_nb(H), NBB = lstm_nbb(H), KQ3 = lstm_kq3(H);
-  if (NB > 5) return TSSEP_E_UNSUPPORTED;
+  if (NB > 8) return TSSEP_E_UNSUPPORTED;
   dim3 grid((unsigned)((N + 7) / 8), 2);
   const size_t lds = (size_t)(4 * 8 * (4 * KQ3 + 12) + 4 * 8 * (NBB * 64 + 4)) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
@@ -451,7 +454,10 @@ extern "C" int tssep_blstm_bwd(float* gates, const float* cell, const float* dho
   else if (NB == 2) L(2, 2);
   else if (NB == 3) L(3, 3);
   else if (NB == 4) L(4, 4);
-  else L(5, 5);
+  else if (NB == 5) L(5, 5);
+  else if (NB == 6) L(6, 6);
+  else if (NB == 7) L(7, 7);
+  else L(8, 8);
 #undef L
   return tssep_launch_status();
 }

@@ -87,5 +87,51 @@ extern "C" int tssep_probe_clock(int64_t* out_, int nblocks, int iters, int heav
   return tssep_launch_status();
 }
 
+// Store-flavour probe (round 4): does a line that is REWRITTEN while it sits in the XCD's L2 reach the
+// memory side once or every time?  Every workgroup rewrites its own `bytes_per_wg` region `reps` times with 16-byte
+// stores of one flavour (0 plain, 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt -- the exchange granules of the W-stationary
+// recurrences are sc0 stores) and, with `pressure` > 0, streams `pressure` bytes of a read-only buffer through the
+// L2 between two rewrites (the recurrences' activation stream).  Read with rocprofv3 --pmc WRITE_SIZE:
+// tools/probe_rewrite.py, profiles/r4_store_flavour_probe.json.
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+template <int AUX>
+__global__ __launch_bounds__(256) void probe_rewrite_kernel(float* buf, int bytes_per_wg, int reps, const float* stream_src,
+                                                            long long stream_bytes, int pressure, float* sink) {
+  char* mine = reinterpret_cast<char*>(buf) + (size_t)blockIdx.x * bytes_per_wg;
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, bytes_per_wg, 0x00020000);
+  float acc = 0.f;
+  const long long per_wg = pressure;
+  for (int r = 0; r < reps; ++r) {
+    const pu32x4 v = {(unsigned)r, threadIdx.x, blockIdx.x, 0x5eedu};
+    for (int off = threadIdx.x * 16; off < bytes_per_wg; off += 256 * 16)
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, AUX);
+    if (pressure > 0) {
+      const long long base = (((long long)blockIdx.x * reps + r) * per_wg) % (stream_bytes - per_wg);
+      const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stream_src) + (base & ~15ll));
+      for (long long i = threadIdx.x; i < per_wg / 16; i += 256) { const f32x4 q = __builtin_nontemporal_load(src + i); acc += q[0] + q[3]; }
+    }
+    __syncthreads();
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+extern "C" int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, const float* stream_src,
+                                   int64_t stream_bytes, int pressure, float* sink, void* stream) {
+  if (!buf || !sink || (pressure > 0 && !stream_src)) return TSSEP_E_NULL;
+  if (nblocks <= 0 || bytes_per_wg < 4096 || (bytes_per_wg & 4095) || reps <= 0 || flavour < 0 || flavour > 4 ||
+      (pressure > 0 && ((pressure & 4095) || stream_bytes < 2 * (int64_t)pressure)))
+    return TSSEP_E_SHAPE;
+#define PR(AUX_) hipLaunchKernelGGL(probe_rewrite_kernel<AUX_>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, buf, \
+                                   bytes_per_wg, reps, stream_src, (long long)stream_bytes, pressure, sink)
+  switch (flavour) {
+    case 0: PR(0); break;
+    case 1: PR(1); break;
+    case 2: PR(16); break;
+    case 3: PR(17); break;
+    default: PR(2); break;
+  }
+#undef PR
+  return tssep_launch_status();
+}
+
 extern "C" int tssep_abi_version(void) { return TSSEP_ABI_VERSION; }
 extern "C" const char* tssep_arch(void) { return "gfx950"; }

@@ -658,7 +658,7 @@ def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 0)) // 8 + 2, device=gates.device,
                        dtype=torch.int64)
-    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H):
+    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 40):      # gates in / activations out 16 + 16, c 4, h 4 B per cell
         check(L.tssep_blstm_onchip_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf), _p(xbuf),
                                        _p(_err_flag(gates.device)), N, T, H, cus, layout,
                                        _stream()), "blstm_onchip_fwd")
@@ -690,7 +690,7 @@ def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, l
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
-    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H):
+    with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 40):      # gates in / activations out 16 + 16, c 4, h 4 B per cell
         check(L.tssep_blstm_onchip16_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf),
                                          _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream()),
               "blstm_onchip16_fwd")
@@ -717,7 +717,7 @@ def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, 
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_bwd_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
-    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H):
+    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 44):      # activations 16, c 4 + 4, dh 4 in, d(gates) 16 out
         check(L.tssep_blstm_onchip16_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(wb16), _p(xbuf),
                                          _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream()),
               "blstm_onchip16_bwd")
@@ -728,7 +728,7 @@ def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 1)) // 8 + 2, device=gates.device,
                        dtype=torch.int64)
-    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H):
+    with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 44):      # activations 16, c 4 + 4, dh 4 in, d(gates) 16 out
         check(L.tssep_blstm_onchip_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(wb), _p(xbuf),
                                        _p(_err_flag(gates.device)), N, T, H, cus, layout,
                                        _stream()), "blstm_onchip_bwd")
