@@ -48,12 +48,14 @@ int tssep_probe_xcc(int* out, int nblocks, void* stream);
  * block b in `iters` x 8 bf16 MFMAs per wave (heavy != 0) or as many s_sleep (heavy == 0). */
 int tssep_probe_clock(int64_t* out, int nblocks, int iters, int heavy, void* stream);
 /* Store-flavour probe: every one of `nblocks` workgroups rewrites its own bytes_per_wg (multiple of 4096) of buf
- * `reps` times with 16-byte stores of one flavour (0 plain, 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt) and streams `pressure`
- * bytes (0: none) of stream_src [stream_bytes] through the L2 between two rewrites.  Under rocprofv3 --pmc
- * WRITE_SIZE it tells whether rewritten lines reach the memory side once or every time (the exchange granules
- * of the W-stationary recurrences: DESIGN 4.2). */
-int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, const float* stream_src,
-                        int64_t stream_bytes, int pressure, float* sink, void* stream);
+ * `reps` times with 16-byte stores of one flavour (0 plain, 1 sc0, 2 sc1, 3 sc0 sc1, 4 nt), streams `pressure`
+ * bytes (0: none) of stream_src [2 x stream_bytes: the upper half receives 2/3 x pressure bytes of non-temporal
+ * stores per rewrite] through the L2 between two rewrites, and -- read_flavour != 0 -- reads
+ * the region of the workgroup 8 blocks on (same XCD) with 16-byte loads (1 sc1, 2 nt, 3 sc0 sc1, 4 sc0) after every
+ * rewrite.  Under rocprofv3 --pmc WRITE_SIZE it tells whether rewritten lines reach the memory side once or every
+ * time, and whether a peer's read forces them out (the exchange granules of the W-stationary recurrences: DESIGN 4.2). */
+int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, int read_flavour,
+                        const float* stream_src, int64_t stream_bytes, int pressure, float* sink, void* stream);
 
 /* ------------------------------------------------------------------- STFT ----
  * paderbox-semantics STFT (fading + end padding + periodic window + rfft, no

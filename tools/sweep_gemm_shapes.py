@@ -198,7 +198,8 @@ def sweep(configs, B, reps, out=None, check_bits=True):
     for units, projs, K in configs:
         m = build(units, projs, K)
         par = parity(m, units, projs, K)
-        reqs = requests_of_a_step(m, K, B)
+        Bk = B if K <= 4 else max(B // 2, 1)          # (8 speakers: half the utterances = the same number of speaker rows)
+        reqs = requests_of_a_step(m, K, Bk)
         del m
         torch.cuda.empty_cache()
         for d, count in reqs:
@@ -222,7 +223,7 @@ def sweep(configs, B, reps, out=None, check_bits=True):
                     assert torch.equal(torch.nan_to_num(res[1]), torch.nan_to_num(c_auto)), (k, choice, d)
             tfl = round(fl / ms_auto / 1e9, 1)
             best = max([tfl] + list(cand.values()))
-            line = dict(units=units, projs=projs, speakers=K, batch=B, calls_per_step=count,
+            line = dict(units=units, projs=projs, speakers=K, batch=Bk, calls_per_step=count,
                         M=d["M"], N=d["N"], K=d["K"],
                         layout=("tn" if d["a_kmajor"] else "nn" if d["b_kmajor"] else "nt") + ("+shift" if d["kperiod"] else ""),
                         epilogue="+".join(x for x, on in (("bias", d["bias"]), ("tanh", d["act"] == 1), ("dtanh", d["act"] == 2),

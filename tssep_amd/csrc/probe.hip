@@ -94,11 +94,16 @@ extern "C" int tssep_probe_clock(int64_t* out_, int nblocks, int iters, int heav
 // L2 between two rewrites (the recurrences' activation stream).  Read with rocprofv3 --pmc WRITE_SIZE:
 // tools/probe_rewrite.py, profiles/r4_store_flavour_probe.json.
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
-template <int AUX>
+// RD: how a PEER workgroup of the same XCD (block b + 8) reads the region after every rewrite -- the gather of the
+// recurrences' exchange: 0 = nobody reads, else the aux bits of the 16-byte buffer loads (16 = sc1, 2 = nt, 17 = sc0 sc1,
+// 1 = sc0).  Does a peer's L1-bypassing read make the L2 write the dirty line back?
+template <int AUX, int RD>
 __global__ __launch_bounds__(256) void probe_rewrite_kernel(float* buf, int bytes_per_wg, int reps, const float* stream_src,
                                                             long long stream_bytes, int pressure, float* sink) {
   char* mine = reinterpret_cast<char*>(buf) + (size_t)blockIdx.x * bytes_per_wg;
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, bytes_per_wg, 0x00020000);
+  const unsigned peer = (blockIdx.x + 8u) % gridDim.x;
+  const auto rp = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(buf) + (size_t)peer * bytes_per_wg, 0, bytes_per_wg, 0x00020000);
   float acc = 0.f;
   const long long per_wg = pressure;
   for (int r = 0; r < reps; ++r) {
@@ -109,26 +114,39 @@ __global__ __launch_bounds__(256) void probe_rewrite_kernel(float* buf, int byte
       const long long base = (((long long)blockIdx.x * reps + r) * per_wg) % (stream_bytes - per_wg);
       const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(stream_src) + (base & ~15ll));
       for (long long i = threadIdx.x; i < per_wg / 16; i += 256) { const f32x4 q = __builtin_nontemporal_load(src + i); acc += q[0] + q[3]; }
+      // ... and writes two thirds as much back non-temporally (the d(gates) stream of the backward recurrence), into the
+      // upper half of stream_src
+      f32x4* dst = reinterpret_cast<f32x4*>(const_cast<char*>(reinterpret_cast<const char*>(stream_src)) + stream_bytes + (base & ~15ll));
+      for (long long i = threadIdx.x; i < per_wg / 24; i += 256) __builtin_nontemporal_store(f32x4{acc, 1.f, 2.f, 3.f}, dst + i);
+    }
+    if (RD) {
+      for (int off = threadIdx.x * 16; off < bytes_per_wg; off += 256 * 16) {
+        const pu32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, RD);
+        acc += (float)(q[0] & 1u);
+      }
     }
     __syncthreads();
   }
   if (acc == 12345.678f) sink[0] = acc;
 }
-extern "C" int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, const float* stream_src,
-                                   int64_t stream_bytes, int pressure, float* sink, void* stream) {
+extern "C" int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int flavour, int read_flavour,
+                                   const float* stream_src, int64_t stream_bytes, int pressure, float* sink, void* stream) {
   if (!buf || !sink || (pressure > 0 && !stream_src)) return TSSEP_E_NULL;
   if (nblocks <= 0 || bytes_per_wg < 4096 || (bytes_per_wg & 4095) || reps <= 0 || flavour < 0 || flavour > 4 ||
-      (pressure > 0 && ((pressure & 4095) || stream_bytes < 2 * (int64_t)pressure)))
+      read_flavour < 0 || read_flavour > 4 || (pressure > 0 && ((pressure & 4095) || stream_bytes < 2 * (int64_t)pressure)))
     return TSSEP_E_SHAPE;
-#define PR(AUX_) hipLaunchKernelGGL(probe_rewrite_kernel<AUX_>, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, buf, \
-                                   bytes_per_wg, reps, stream_src, (long long)stream_bytes, pressure, sink)
+#define PR(AUX_, RD_) hipLaunchKernelGGL((probe_rewrite_kernel<AUX_, RD_>), dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, buf, \
+                                         bytes_per_wg, reps, stream_src, (long long)stream_bytes, pressure, sink)
+#define PRR(AUX_) switch (read_flavour) { case 0: PR(AUX_, 0); break; case 1: PR(AUX_, 16); break; case 2: PR(AUX_, 2); break; \
+                                          case 3: PR(AUX_, 17); break; default: PR(AUX_, 1); break; }
   switch (flavour) {
-    case 0: PR(0); break;
-    case 1: PR(1); break;
-    case 2: PR(16); break;
-    case 3: PR(17); break;
-    default: PR(2); break;
+    case 0: PRR(0); break;
+    case 1: PRR(1); break;
+    case 2: PRR(16); break;
+    case 3: PRR(17); break;
+    default: PRR(2); break;
   }
+#undef PRR
 #undef PR
   return tssep_launch_status();
 }
