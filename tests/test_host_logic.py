@@ -104,6 +104,13 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     assert plan(320, 601, 4 * R, wgrad=True, ones=True) == "tn_h160"
     assert plan(513, 601, R, wgrad=True, ones=True) == "tn"
     assert plan(100, 50, 30) == "pipe" and plan(100, 50, 30, prec=0) == "f32"
+    # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the
+    # 160-wide tile, its weight gradient (M = 2052) and the 8-speaker one (4104) on the big weight-gradient tile, one /
+    # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
+    assert plan(R, 2052, 320, remap=True) == "nt_w160" and plan(2052, 320, R, wgrad=True) == "tn_big"
+    assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
+    assert plan(4 * R, 256, 1024, act=1) == "big" and plan(4 * R, 256, 256, act=1) == "tall2"
+    assert plan(R // 2, 4104, 256, remap=True) == "tall2"
     # naming a kernel: honoured when it covers the request, refused (None) when it does not
     assert plan(4 * R, 2400, 320, force="big") == "big" and plan(4 * R, 2400, 320, force="tall4") == "tall4"
     assert plan(4 * R, 320, 600, act=1, force="stream") is None                      # no Tanh in the streaming kernel

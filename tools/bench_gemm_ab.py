@@ -6,6 +6,11 @@ import torch
 from tssep_amd import hip_ops as h
 
 var, va, vb = sys.argv[1], sys.argv[2], sys.argv[3]
+# round 4: the production library reads no environment variable; the TSSEP_GEMM_* switches live in the experiment
+# build (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so), where they are read per call
+from tssep_amd import _lib
+assert not var.startswith(("TSSEP_GEMM_", "TSSEP_BIG_", "TSSEP_STREAM_")) or "exp" in os.path.basename(_lib.LIB_PATH), \
+    f"{var} is a switch of the experiment build: set TSSEP_HIP_LIB=.../libtssep_hip_exp.so"
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 768
 KIND = sys.argv[5] if len(sys.argv) > 5 else "nt"          # "nt": forward / d(input) shapes, "tn": weight gradients
 h.GEMM_PRECISION = "bf16x3"
@@ -56,12 +61,6 @@ for shape in (SHAPES if KIND == "nt" else TN_SHIFT if KIND == "shift" else TN_SH
     for _ in range(3):
         for v in (va, vb):
             os.environ[var] = v
-            if var == "TSSEP_GEMM_TN_XC":          # (the split rule follows the tile count of the kernel)
-                h.TN_XC = v != "0"
-            if var == "TSSEP_GEMM_TN_W160":
-                h.TN_W160 = v != "0"
-            if var == "TSSEP_GEMM_TN_H160":
-                h.TN_H160 = v != "0"
             f(); best[v] = min(best[v], timeit(f))
     for v in (va, vb):
         tot[v] += best[v]

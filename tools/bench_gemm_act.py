@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 """Alternating A/B of a GEMM switch on the row x row shapes of the step whose store carries a Tanh (act 1) or the folded
 Tanh backward (act 2) -- the ones the streaming / big-tile kernels do not take (GPU box):
    python tools/bench_gemm_act.py TSSEP_GEMM_NT_W160 1 0 [batch]"""

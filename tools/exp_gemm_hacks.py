@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 """Experiment (GPU box, TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so): where does the life of a 256 x 256 tile of the
 row x row split-bf16 GEMM go?  TIMING probes -- the hacked variants compute garbage (csrc/gemm_bf16x3.hip, HACK)."""
 import json, os, sys

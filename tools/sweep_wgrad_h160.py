@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 """Split sweep of the 320 x 128 weight-gradient tile (csrc/gemm_bf16x3_tn_h160.hip) against the 128 x 128 tile at its
 own best split, alternating, on the M = 320 shapes of the step; checks that the two agree bit for bit."""
 import os, sys, json
@@ -17,10 +19,10 @@ for (M, N, K) in [(320, 600, 777216), (320, 600, 194304), (320, 100, 194304), (3
     def run(S):
         part, s = h.wgrad(A, A.shape[1], W, W.shape[1], M, N, K, with_colsum=True, splitk=S)
         return part
-    os.environ["TSSEP_GEMM_TN_H160"] = "0"; h.TN_H160 = False
+    os.environ["TSSEP_GEMM_TN_H160"] = "0"; 
     s0 = h.pick_splitk(M, N + 1, K)
     ref = run(s0).view(s0, -1).sum(0)
-    os.environ["TSSEP_GEMM_TN_H160"] = "1"; h.TN_H160 = True
+    os.environ["TSSEP_GEMM_TN_H160"] = "1"; 
     s1 = h.pick_splitk(M, N + 1, K)
     same = bool((run(s0) == 0).sum() >= 0)
     os.environ["TSSEP_GEMM_TN_H160"] = "0"; p0 = run(32).clone()

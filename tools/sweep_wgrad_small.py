@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 import os, sys, json
 sys.path.insert(0, "/root/repo")
 import torch

@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 """Split-count sweep of the weight-gradient GEMMs under an environment switch (GPU box):
    python tools/sweep_wgrad_splits.py [VAR a b]     (default: TSSEP_GEMM_TN_XC 1 0)"""
 import os, sys, json

@@ -1,3 +1,5 @@
+# HISTORICAL (round 3): toggles TSSEP_GEMM_* switches, which since round 4 exist only in the experiment build
+# (make -C tssep_amd/csrc exp; TSSEP_HIP_LIB=tssep_amd/libtssep_hip_exp.so).  The numbers it produced are under profiles/r3_*.
 """Sweep (GPU box): the 256 x 128 weight-gradient tile (TSSEP_GEMM_TN_TALL=1) against the 128 x 128 one (=2, default
 for the unshifted shapes) over split-K counts, on the dW_ih shapes of the step."""
 import json, os, sys

@@ -1201,11 +1201,18 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     const int64_t n256 = (g->N + 255) / 256 * 256;
     const bool xcol_shape = g->N > 256 && g->N % 256 == 1 && (g->K & 3) == 0;      // N = 256 q + 1: q tiles + a VALU column
     const bool pads_to_256 = g->N >= 1024 && n256 * 10 <= g->N * 11;               // < 10 % column padding
+    const bool pads_to_256_any = g->N >= 256 && n256 * 10 <= g->N * 11;            // ... also one or two column tiles (projs = 256)
+    const bool short_k = g->K < 448;               // a tile's life is mostly its C store below this
     // big-tile kernel (gemm_bf16x3_big.hip) where the 256-wide tile applies.  (K < 448: a tile's life is mostly its
     // C store there -- the streaming kernel, which hides it, measured 4.14 against 4.56 ms at K = 320, N = 2400; from
     // K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280, 2.75 / 3.29 at K = 2400, N = 1280; sw.big 2 =
     // regardless of K)
-    if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (g->K >= 448 || sw.big == 2) && (pads_to_256 || xcol_shape))) {
+    // Round 4 (profiles/r4_gemm_shape_sweep.jsonl, units x projs x speakers): N = 256 / 512 (projs = 256) belong here too
+    // (302 against 244 TFLOP/s at 777 216 x 256 x 1024 with the Tanh store); the folded Tanh backward with the
+    // un-combining remap reads its aux operand in the unhidden epilogue -- below K = 1536 the eight-wave tiles win
+    // (280 against 230 at 194 304 x 1280 x 1024; at K = 2400, the default size, this kernel leads 338 to 300)
+    const bool aux_remap_short = g->act == 2 && sm.remap && g->K < 1536;
+    if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (!short_k || sw.big == 2) && (pads_to_256_any || xcol_shape) && !aux_remap_short)) {
       const int rc = tssep_gemm_bf16x3_big_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG; return rc; }
     }
@@ -1218,14 +1225,18 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (N = 320: the Tanh
     // projections and d(input) of birnn1, which the two kernels above do not take)
     {
+      // (short K, where the C store dominates: 4 % fewer columns already pay -- the logit layer, N = 4 x 513 = 2052, K = projs:
+      // 207 against 175 TFLOP/s on the 128-wide tiles)
       const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && n160 * 11 <= n128 * 10)) {
+      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && (n160 * 11 <= n128 * 10 || (short_k && n160 * 26 <= n128 * 25)))) {
         const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, call);
         if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_NT_W160; return rc; }
       }
     }
     // wide (256 x 256) eight-wave tile where rounding N up to 256 wastes < 10 % of the columns
-    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256)) {
+    // (not below K = 448: 145 against 207 TFLOP/s on the four-wave tile for the 8-speaker logit layer, 97 152 x 4104 x 256;
+    // from K = 448 up the big-tile kernel above has taken the request unless it cannot address it)
+    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256 && !short_k)) {
       TAKEN(TSSEP_GEMM_TALL4);
       const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
 #ifdef TSSEP_GEMM_EXP
@@ -1267,9 +1278,11 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     if (sw.tn && g->a_kmajor && g->b_kmajor && !sm.remap && !g->bias && g->act == 0 && (g->lda & 3) == 0 &&
         (g->ldb & 3) == 0 && aligned16(g->A) && aligned16(g->B) && ((g->M + 3) & ~(int64_t)3) <= g->lda &&
         nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
-      {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by < 10 % (the dW_ih GEMMs: M = 8 units)
+      {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by at most a quarter (the dW_ih GEMMs: M = 8 units; round 4:
+          // the logit layer's M = speakers x 513 = 2052 / 4104 too -- 297 against 232 and 278 against 211 TFLOP/s on the tiles
+          // the 10 % rule of round 3 left them, profiles/r4_gemm_shape_sweep.jsonl)
         const int64_t m512 = (g->M + 511) / 512 * 512;
-        if (gemm_try(call, TSSEP_GEMM_TN_BIG, sw.tn_big && !shift && g->M >= 1024 && m512 * 10 <= g->M * 11)) {
+        if (gemm_try(call, TSSEP_GEMM_TN_BIG, sw.tn_big && !shift && g->M >= 1024 && m512 * 4 <= g->M * 5)) {
           const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_BIG; return rc; }
         }
