@@ -29,7 +29,7 @@ for gemm, rec, products in [(g, r, "3") for g in ("f32", "bf16x3") for r in ("st
         [("bf16x3", "onchip", "2")]:
     if True:
         H.GEMM_PRECISION, H.RECURRENCE = gemm, rec
-        os.environ["TSSEP_WGRAD_PRODUCTS"] = products
+        H.WGRAD_PRODUCTS = int(products)
         model.zero_grad(set_to_none=True)
         np.random.seed(5)
         out = model(ex)

@@ -3,7 +3,7 @@
 # usage: bash tools/install_profiles.sh [round] [batch] [gemm]      then re-run `python bench.py` on the GPU box
 # for the default line with the PMC fields filled (profiles/r<round>_bench_default.json).
 set -e
-R=${1:-3}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
+R=${1:-4}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
 python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G cfg3 > ${P}_traffic_pmc.json
 python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G cfg3 > ${P}_mfma_pmc.json
 for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16x3.jsonl gemm_microbench_bf16x3_wide0.jsonl \
@@ -11,7 +11,8 @@ for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16
          batch_sweep.jsonl ab_gemm_wide.jsonl ab_wgrad_products.jsonl bench_cfg4.json bench_cfg4_nograph.json bench_cfg5.json \
          bench_f32.json gemm_in_step_b768.jsonl step_clock.json ab_fusions.jsonl splitk_sweep.jsonl \
          ab_gemm_stream_shapes.jsonl ab_gemm_big_shapes.jsonl ab_wgrad_big_shapes.jsonl ab_gemm_kernels.jsonl ab_wgrad_tile.jsonl \
-         ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_microbench.jsonl; do
+         ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_microbench.jsonl \
+         bench_default.json store_flavour_probe_16384.json store_flavour_probe_81920.json; do
   [ -s $F/$f ] && cp $F/$f ${P}_$f
 done
 python - <<PY

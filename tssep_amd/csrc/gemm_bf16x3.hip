@@ -23,6 +23,7 @@
 // History (measured, profiles/r1_gemm_microbench_bf16x3.jsonl): a first version with one LDS
 // stage and two barriers per tile ran 113-267 TFLOP/s; BK = 64 and naive double buffering changed
 // nothing; the pipelined loop + row epilogue + tall tile run 190-320 TFLOP/s.
+#include <algorithm>
 #include <type_traits>
 #include "gemm_common.h"
 
@@ -1203,6 +1204,12 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     const bool pads_to_256 = g->N >= 1024 && n256 * 10 <= g->N * 11;               // < 10 % column padding
     const bool pads_to_256_any = g->N >= 256 && n256 * 10 <= g->N * 11;            // ... also one or two column tiles (projs = 256)
     const bool short_k = g->K < 448;               // a tile's life is mostly its C store below this
+    // Occupancy (round 4, the 8-utterance shard of the 8-GPU configuration: M = 2024 / 8096 rows): a kernel whose tiles do
+    // not fill three quarters of the CUs once leaves the chip idle -- 128 x 128 tiles on two workgroups per CU then run up
+    // to 2.7 x faster (profiles/r4_gemm_shape_sweep_b8.jsonl: 168 against 70 TFLOP/s at 8096 x 320 x 2400).  The
+    // persistent streaming kernel balances its own tile list: half the CUs suffice there.
+    const int64_t mt256 = (g->M + 255) / 256;
+    auto fills = [&](int64_t col_tiles, int64_t need) { return mt256 * col_tiles >= need; };
     // big-tile kernel (gemm_bf16x3_big.hip) where the 256-wide tile applies.  (K < 448: a tile's life is mostly its
     // C store there -- the streaming kernel, which hides it, measured 4.14 against 4.56 ms at K = 320, N = 2400; from
     // K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280, 2.75 / 3.29 at K = 2400, N = 1280; sw.big 2 =
@@ -1212,13 +1219,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // un-combining remap reads its aux operand in the unhidden epilogue -- below K = 1536 the eight-wave tiles win
     // (280 against 230 at 194 304 x 1280 x 1024; at K = 2400, the default size, this kernel leads 338 to 300)
     const bool aux_remap_short = g->act == 2 && sm.remap && g->K < 1536;
-    if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (!short_k || sw.big == 2) && (pads_to_256_any || xcol_shape) && !aux_remap_short)) {
+    if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (!short_k || sw.big == 2) && (pads_to_256_any || xcol_shape) && !aux_remap_short &&
+                                       fills(xcol_shape ? (g->N - 1) / 256 : n256 / 256, 192))) {
       const int rc = tssep_gemm_bf16x3_big_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG; return rc; }
     }
     // persistent streaming kernel (gemm_bf16x3_stream.hip): plain row-major stores; the N = 256 q + 1 shapes keep
     // the wide tile with its VALU column
-    if (gemm_try(call, TSSEP_GEMM_STREAM, sw.stream && !sm.remap && !(g->N > 256 && g->N % 256 == 1))) {
+    if (gemm_try(call, TSSEP_GEMM_STREAM, sw.stream && !sm.remap && !(g->N > 256 && g->N % 256 == 1) && fills((g->N + 127) / 128, 128))) {
       const int rc = tssep_gemm_bf16x3_stream_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_STREAM; return rc; }
     }
@@ -1228,7 +1236,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       // (short K, where the C store dominates: 4 % fewer columns already pay -- the logit layer, N = 4 x 513 = 2052, K = projs:
       // 207 against 175 TFLOP/s on the 128-wide tiles)
       const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && (n160 * 11 <= n128 * 10 || (short_k && n160 * 26 <= n128 * 25)))) {
+      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && (n160 * 11 <= n128 * 10 || (short_k && n160 * 26 <= n128 * 25)) &&
+                                                fills(n160 / 160, 192))) {
         const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, call);
         if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_NT_W160; return rc; }
       }
@@ -1236,7 +1245,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // wide (256 x 256) eight-wave tile where rounding N up to 256 wastes < 10 % of the columns
     // (not below K = 448: 145 against 207 TFLOP/s on the four-wave tile for the 8-speaker logit layer, 97 152 x 4104 x 256;
     // from K = 448 up the big-tile kernel above has taken the request unless it cannot address it)
-    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256 && !short_k)) {
+    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256 && !short_k && fills(n256 / 256, 192))) {
       TAKEN(TSSEP_GEMM_TALL4);
       const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
 #ifdef TSSEP_GEMM_EXP
@@ -1252,7 +1261,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
                          g->accumulate, sm, tm4);
       return tssep_launch_status();
     }
-    if (xcol_shape && gemm_try(call, TSSEP_GEMM_TALL4_XCOL, sw.xcol != 0)) {
+    if (xcol_shape && gemm_try(call, TSSEP_GEMM_TALL4_XCOL, sw.xcol != 0 && fills((g->N - 1) / 256, 192))) {
       TAKEN(TSSEP_GEMM_TALL4_XCOL);
       const TileMap tmx = make_tile_map((g->M + TBM - 1) / TBM, (g->N - 1) / 256, 1);
       hipLaunchKernelGGL((gemm_bf16x3_tall_kernel<4, true>), dim3((unsigned)tile_map_blocks(tmx)), dim3(512), 0, s,
@@ -1260,7 +1269,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
                          g->accumulate, sm, tmx);
       return tssep_launch_status();
     }
-    if (gemm_try(call, TSSEP_GEMM_TALL2, true)) {
+    if (gemm_try(call, TSSEP_GEMM_TALL2, fills((g->N + BN - 1) / BN, 192))) {
       TAKEN(TSSEP_GEMM_TALL2);
       const TileMap tm2 = make_tile_map((g->M + TBM - 1) / TBM, (g->N + BN - 1) / BN, 1);
       hipLaunchKernelGGL(gemm_bf16x3_tall_kernel<2>, dim3((unsigned)tile_map_blocks(tm2)), dim3(NTHREADS), 0, s,
@@ -1278,18 +1287,24 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     if (sw.tn && g->a_kmajor && g->b_kmajor && !sm.remap && !g->bias && g->act == 0 && (g->lda & 3) == 0 &&
         (g->ldb & 3) == 0 && aligned16(g->A) && aligned16(g->B) && ((g->M + 3) & ~(int64_t)3) <= g->lda &&
         nreal >= 1 && ((nreal + 3) & ~(int64_t)3) <= g->ldb && g->M >= 4 && (!shift || (ks <= 32 && ks < g->K))) {
+      // Occupancy of a weight gradient: its tiles times the splits its K allows (>= 8 K tiles of 16 rows per split, <= 64
+      // splits) must fill three quarters of the CUs, else the next smaller tile is tried (the 8-utterance shard: K = 2024
+      // rows -> 15 splits; the 256 x 160 tile of dW_hh then has 150 workgroups at most: 54 against 89 TFLOP/s on 128 x 128)
+      const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, ((g->K + 15) / 16) / 8));
+      auto tn_fills = [&](int64_t tiles) { return tiles * max_splits >= 192; };
       {   // big-tile weight-gradient kernel: unshifted, M padded to 512 by at most a quarter (the dW_ih GEMMs: M = 8 units; round 4:
           // the logit layer's M = speakers x 513 = 2052 / 4104 too -- 297 against 232 and 278 against 211 TFLOP/s on the tiles
           // the 10 % rule of round 3 left them, profiles/r4_gemm_shape_sweep.jsonl)
         const int64_t m512 = (g->M + 511) / 512 * 512;
-        if (gemm_try(call, TSSEP_GEMM_TN_BIG, sw.tn_big && !shift && g->M >= 1024 && m512 * 4 <= g->M * 5)) {
+        if (gemm_try(call, TSSEP_GEMM_TN_BIG, sw.tn_big && !shift && g->M >= 1024 && m512 * 4 <= g->M * 5 &&
+                                                  tn_fills((m512 / 512) * ((g->N + 127) / 128)))) {
           const int rc = tssep_gemm_bf16x3_tn_big_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_BIG; return rc; }
         }
       }
       {   // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (dW_hh: N = units = 300)
         const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && n160 * 11 <= n128 * 10)) {
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && n160 * 11 <= n128 * 10 && tn_fills(((g->M + 255) / 256) * (n160 / 160)))) {
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
         }
@@ -1298,7 +1313,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
           // gradients: M = projs = 320, N = 2 units + 1: 1.18 vs 1.38 ms at each kernel's best split count), four column
           // tiles or more (one column tile: 0.13 vs 0.08 ms, profiles/r3_wgrad_h160_sweep.jsonl)
         const int64_t m320 = (g->M + 319) / 320 * 320, m128 = (g->M + BM - 1) / BM * BM;
-        if (gemm_try(call, TSSEP_GEMM_TN_H160, sw.tn_h160 && !shift && m320 * 11 <= m128 * 10 && g->N > 3 * BN)) {
+        if (gemm_try(call, TSSEP_GEMM_TN_H160, sw.tn_h160 && !shift && m320 * 11 <= m128 * 10 && g->N > 3 * BN &&
+                                                   tn_fills((m320 / 320) * ((g->N + 127) / 128)))) {
           const int rc = tssep_gemm_bf16x3_tn_h160_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_H160; return rc; }
         }
@@ -1313,7 +1329,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       const int64_t ntl = (g->N + BN - 1) / BN;
       const bool want = tmode == 1 || (tmode == 2 && shift) || (tmode == 3 && !shift) ||
                         (tmode == 4 && (shift || ntl <= 3 || ntl >= 9));
-      if (g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16) && gemm_try(call, TSSEP_GEMM_TN_TALL, want)) {
+      if (g->M >= 1024 && (m256 - g->M) * 100 <= 8 * g->M && (!shift || ks <= 16) &&
+          gemm_try(call, TSSEP_GEMM_TN_TALL, want && tn_fills((m256 / TTM) * ntl))) {
         TAKEN(TSSEP_GEMM_TN_TALL);
         const TileMap tmt = make_tile_map(m256 / TTM, (g->N + BN - 1) / BN, splitk);
         dim3 gridt((unsigned)tile_map_blocks(tmt));
