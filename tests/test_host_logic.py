@@ -107,10 +107,14 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the
     # 160-wide tile, its weight gradient (M = 2052) and the 8-speaker one (4104) on the big weight-gradient tile, one /
     # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
-    assert plan(R, 2052, 320, remap=True) == "nt_w160" and plan(2052, 320, R, wgrad=True) == "tn_big"
+    assert plan(R, 2052, 320, remap=True) == "tall2" and plan(2052, 320, R, wgrad=True) == "tn_big"
     assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
     assert plan(4 * R, 256, 1024, act=1) == "big" and plan(4 * R, 256, 256, act=1) == "tall2"
     assert plan(R // 2, 4104, 256, remap=True) == "tall2"
+    # occupancy: the 8-utterance shard of the 8-GPU configuration (2024 / 8096 rows) takes the 128 x 128 tiles where the big
+    # tiles cannot fill the chip; 380 big tiles (1.48 resident rounds) go to the persistent kernel
+    assert plan(8096, 320, 2400, act=1) == "pipe" and plan(2024, 2400, 1280) == "stream" and plan(2024, 513, 600) == "pipe"
+    assert plan(1200, 300, 2024, wgrad=True, shifted=True) in ("tn", "tn_tall") and plan(R // 2, 256, 512) == "stream"
     # naming a kernel: honoured when it covers the request, refused (None) when it does not
     assert plan(4 * R, 2400, 320, force="big") == "big" and plan(4 * R, 2400, 320, force="tall4") == "tall4"
     assert plan(4 * R, 320, 600, act=1, force="stream") is None                      # no Tanh in the streaming kernel

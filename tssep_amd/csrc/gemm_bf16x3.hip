@@ -1210,6 +1210,9 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // persistent streaming kernel balances its own tile list: half the CUs suffice there.
     const int64_t mt256 = (g->M + 255) / 256;
     auto fills = [&](int64_t col_tiles, int64_t need) { return mt256 * col_tiles >= need; };
+    // ... and a one-workgroup-per-CU kernel whose last resident round is mostly empty loses it whole: 380 tiles = 1.48
+    // rounds of 256 run at 74 % (the 8-speaker pre-net, 97 152 x 256 x 512: 261 against 312 TFLOP/s on the persistent kernel)
+    auto rounds_ok = [&](int64_t col_tiles) { const int64_t t = mt256 * col_tiles; return t * 5 >= (t + 255) / 256 * 256 * 4; };
     // big-tile kernel (gemm_bf16x3_big.hip) where the 256-wide tile applies.  (K < 448: a tile's life is mostly its
     // C store there -- the streaming kernel, which hides it, measured 4.14 against 4.56 ms at K = 320, N = 2400; from
     // K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280, 2.75 / 3.29 at K = 2400, N = 1280; sw.big 2 =
@@ -1220,7 +1223,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // (280 against 230 at 194 304 x 1280 x 1024; at K = 2400, the default size, this kernel leads 338 to 300)
     const bool aux_remap_short = g->act == 2 && sm.remap && g->K < 1536;
     if (gemm_try(call, TSSEP_GEMM_BIG, sw.big && (!short_k || sw.big == 2) && (pads_to_256_any || xcol_shape) && !aux_remap_short &&
-                                       fills(xcol_shape ? (g->N - 1) / 256 : n256 / 256, 192))) {
+                                       fills(xcol_shape ? (g->N - 1) / 256 : n256 / 256, 192) &&
+                                       rounds_ok(xcol_shape ? (g->N - 1) / 256 : n256 / 256))) {
       const int rc = tssep_gemm_bf16x3_big_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG; return rc; }
     }
@@ -1233,11 +1237,10 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // 256 x 160 tile where 160-wide column tiles waste >= 10 % fewer columns than 128-wide ones (N = 320: the Tanh
     // projections and d(input) of birnn1, which the two kernels above do not take)
     {
-      // (short K, where the C store dominates: 4 % fewer columns already pay -- the logit layer, N = 4 x 513 = 2052, K = projs:
-      // 207 against 175 TFLOP/s on the 128-wide tiles)
+      // (a looser rule -- 4 % fewer columns at short K, for the logit layer's N = 2052 -- looked 19 % better in the first,
+      // incumbent-first sweep and measured equal to slower in the interleaved one: not adopted)
       const int64_t n160 = (g->N + 159) / 160 * 160, n128 = (g->N + BN - 1) / BN * BN;
-      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && (n160 * 11 <= n128 * 10 || (short_k && n160 * 26 <= n128 * 25)) &&
-                                                fills(n160 / 160, 192))) {
+      if (gemm_try(call, TSSEP_GEMM_NT_W160, sw.nt_w160 && n160 * 11 <= n128 * 10 && fills(n160 / 160, 192))) {
         const int rc = tssep_gemm_bf16x3_nt_w160_launch(g, sm, call);
         if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_NT_W160; return rc; }
       }
@@ -1245,7 +1248,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // wide (256 x 256) eight-wave tile where rounding N up to 256 wastes < 10 % of the columns
     // (not below K = 448: 145 against 207 TFLOP/s on the four-wave tile for the 8-speaker logit layer, 97 152 x 4104 x 256;
     // from K = 448 up the big-tile kernel above has taken the request unless it cannot address it)
-    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256 && !short_k && fills(n256 / 256, 192))) {
+    if (gemm_try(call, TSSEP_GEMM_TALL4, sw.wide && pads_to_256 && !short_k && !aux_remap_short && fills(n256 / 256, 192))) {
       TAKEN(TSSEP_GEMM_TALL4);
       const TileMap tm4 = make_tile_map((g->M + TBM - 1) / TBM, n256 / 256, 1);
 #ifdef TSSEP_GEMM_EXP
