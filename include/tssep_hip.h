@@ -208,7 +208,8 @@ int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 #define TSSEP_GEMM_TN_BIG 11     /* weight gradient, 512 x 128, four waves of 128 x 128                        */
 #define TSSEP_GEMM_TN_W160 12    /* weight gradient, 256 x 160                                                 */
 #define TSSEP_GEMM_TN_H160 13    /* weight gradient, 320 x 128                                                 */
-#define TSSEP_GEMM_KERNEL_LAST 13
+#define TSSEP_GEMM_BIG_P 14      /* row x row, 256 x 256 persistent: plain / bias / Tanh store hidden behind tiles */
+#define TSSEP_GEMM_KERNEL_LAST 14
 /* As tssep_gemm_f32, on the kernel named (TSSEP_GEMM_AUTO = tssep_gemm_f32); TSSEP_E_UNSUPPORTED when that
  * kernel does not cover the request. */
 int tssep_gemm_f32_on(const tssep_gemm_args* args, int32_t kernel, void* stream);

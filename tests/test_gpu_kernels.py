@@ -279,6 +279,60 @@ def test_gemm_streaming_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 64), (4096 + 255, 320, 600),
+                                   (3000, 132, 553), (70000, 600, 65), (66000, 256, 96),
+                                   # several tiles per workgroup (the loader crosses tile boundaries, the store of a tile runs
+                                   # beside the next tile's first stages)
+                                   (24288, 2048, 512), (24288, 2400, 513), (70000, 600, 320), (40000, 1280, 130)])
+def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K):
+    """The persistent big-tile kernel (csrc/gemm_bf16x3_bigp.hip: 256 x 256 tiles walked by one workgroup per CU, the
+    operand loads two K stages ahead across tile boundaries, MFMA operands swapped so that the accumulators leave
+    through LDS in 16-byte pieces) against fp64, and bit for bit against the tiled kernel ("tall2"): plain, bias and
+    bias + Tanh stores into padded rows; K tails, K = 64 (two stages: the loader's lead), ragged last row / column
+    tiles, more tiles than CUs and fewer, 264 ids for 258 tiles (workgroups whose second id is empty)."""
+    torch.manual_seed(6)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        outs = {}
+        for mode, kern in (("1", "big_p"), ("0", "tall2")):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                ldc = ru(N, 4) + 8                  # padded rows: the pad columns must stay untouched
+                C = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
+                C2 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, bias=bd)
+                C3 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K)
+            h.GEMM_LOG = None
+            assert {k for k, *_ in log} == {kern}, log          # the named kernel really ran
+            outs[mode] = (C, C2, C3)
+        p1 = outs["1"]
+        close(p1[0][:, :N], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="big_p nt+bias+tanh")
+        assert bool(torch.isnan(p1[0][:, N:]).all())
+        close(p1[1], ref, rtol=2e-4, atol=2e-4, name="big_p bias")
+        close(p1[2], ref - bias, rtol=2e-4, atol=2e-4, name="big_p plain")
+        for a, b in zip(outs["1"], outs["0"]):
+            assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        # the plain store again, five times (a store whose data registers were overwritten too early would be timing dependent)
+        for _ in range(5):
+            C5 = torch.full((M, N), float("nan"), device="cuda")
+            with h.prefer_gemm_kernels("big_p"):
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C5, N, M, N, K)
+            assert torch.equal(C5, outs["0"][2])
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (3000, 2052, 31),
                                    (70000, 1280, 64), (1500, 2400, 2400)])
 def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):

@@ -94,11 +94,13 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
         return H.gemm_plan(g, force)
 
     R = 768 * 253
-    assert plan(R, 2400, 556) == "big" and plan(4 * R, 2400, 516) == "big"          # input projections, K >= 448
-    assert plan(4 * R, 2400, 320) == "stream"                                        # birnn1: short K, C-store bound
+    # input projections: the persistent big tile (plain / bias / Tanh store) since round 4's second half, any K
+    assert plan(R, 2400, 556) == "big_p" and plan(4 * R, 2400, 516) == "big_p" and plan(4 * R, 2400, 320) == "big_p"
+    assert plan(R, 1280, 2400, remap=True) == "big"                                  # ... a remapped store keeps the tiled kernel
     assert plan(R, 513, 600) == "big"                                                # pre-net projection: 2 tiles + a VALU column
     assert plan(4 * R, 320, 600, act=1) == "nt_w160" and plan(4 * R, 320, 600, act=1, remap=True) == "nt_w160"
-    assert plan(4 * R, 600, 320) == "stream"                                         # dgrad proj dh
+    assert plan(4 * R, 600, 320) == "big_p" and plan(4 * R, 1000, 320) == "big_p"    # dgrad proj dh: 768 columns computed for 600
+    assert plan(4 * R, 780, 320) == "stream"                                         # ... 1024 for 780 is too many
     assert plan(2400, 557, R, wgrad=True, ones=True) == "tn_big"
     assert plan(1200, 300, 4 * R, wgrad=True, shifted=True) == "tn_w160"
     assert plan(320, 601, 4 * R, wgrad=True, ones=True) == "tn_h160"
@@ -109,7 +111,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
     assert plan(R, 2052, 320, remap=True) == "tall2" and plan(2052, 320, R, wgrad=True) == "tn_big"
     assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
-    assert plan(4 * R, 256, 1024, act=1) == "big" and plan(4 * R, 256, 256, act=1) == "tall2"
+    assert plan(4 * R, 256, 1024, act=1) == "big_p" and plan(4 * R, 256, 256, act=1) == "big_p"
     assert plan(R // 2, 4104, 256, remap=True) == "tall2"
     # occupancy: the 8-utterance shard of the 8-GPU configuration (2024 / 8096 rows) takes the 128 x 128 tiles where the big
     # tiles cannot fill the chip; 380 big tiles (1.48 resident rounds) go to the persistent kernel
@@ -120,7 +122,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     assert plan(4 * R, 320, 600, act=1, force="stream") is None                      # no Tanh in the streaming kernel
     assert plan(100, 50, 30, force="big") is None and plan(100, 50, 30, prec=0, force="pipe") is None
     L = _lib.lib()
-    assert L.tssep_gemm_kernel_name(6) == b"big" and L.tssep_gemm_kernel_name(99) == b"?"
+    assert L.tssep_gemm_kernel_name(6) == b"big" and L.tssep_gemm_kernel_name(14) == b"big_p" and L.tssep_gemm_kernel_name(99) == b"?"
 
 
 def test_onchip_workspace_sizes():

@@ -1,0 +1,61 @@
+"""Persistent big-tile GEMM kernel (csrc/gemm_bf16x3_bigp.hip) against the kernels it competes with, on the row x row
+shapes of the step whose store is plain / bias / bias + Tanh: interleaved timing (tools/sweep_gemm_shapes.time_calls),
+bit comparison of the results.  `python tools/ab_big_p.py [batch] > profiles/rN_ab_gemm_big_p.jsonl`"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tssep_amd.hip_ops as H  # noqa: E402
+from sweep_gemm_shapes import time_calls  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 768
+    R1, R4 = B * 253, B * 4 * 253
+    shapes = [("pre_net in", R1, 2400, 553, 0), ("birnn0 in", R4, 2400, 513, 0), ("birnn1 in", R4, 2400, 320, 0),
+              ("birnn2 in", R1, 2400, 1280, 0), ("dgrad proj dh", R4, 600, 320, 0), ("dgrad proj dh (pre)", R1, 600, 513, 0),
+              ("proj 600->256 tanh", R4, 256, 600, 1), ("proj 1200->512 tanh", R1, 512, 600, 1)]
+    H.GEMM_PRECISION = "bf16x3"
+    tot = {}
+    for name, M, N, K, act in shapes:
+        A = torch.randn(M, H.round_up(K, 4), device="cuda")
+        W = torch.randn(N, H.round_up(K, 4), device="cuda") / K ** 0.5
+        bias = torch.randn(N, device="cuda")
+        outs, calls = {}, {}
+        probes = [p for p in os.environ.get("AB_BIGP_PROBES", "").split(",") if p]      # (experiment build, TSSEP_HIP_LIB)
+        for kern in ["big_p"] + ["big_p@" + p for p in probes] + ["big", "stream", "tall4", "tall2"]:
+            C = torch.empty(M, N, device="cuda")
+            kname, _, probe = kern.partition("@")
+
+            def call(kname=kname, probe=probe, C=C):
+                os.environ["TSSEP_BIGP_PROBE"] = probe or "0"      # "big_p@24": timing probe 24 (experiment build only)
+                with H.prefer_gemm_kernels(kname):
+                    H.gemm(A, A.shape[1], W, W.shape[1], C, N, M, N, K, bias=bias, act=act)
+
+            log = H.GEMM_LOG = []
+            call()
+            H.GEMM_LOG = None
+            if log[0][0] != kname:
+                continue
+            outs[kern], calls[kern] = C, call
+        torch.cuda.synchronize()
+        ms = time_calls(calls, 5)
+        ref = outs.get("tall2", outs.get("tall4"))
+        rec = dict(name=name, M=M, N=N, K=K, act=act)
+        for k, v in ms.items():
+            rec[k + "_ms"] = round(v, 4)
+            rec[k + "_tflops"] = round(2 * M * N * K / v / 1e9, 1)
+            rec[k + "_bit_identical"] = bool(torch.equal(outs[k], ref))
+            tot[k] = tot.get(k, 0) + v
+        print(json.dumps(rec), flush=True)
+        del A, W, outs, calls
+        torch.cuda.empty_cache()
+    print(json.dumps({"total_ms": {k: round(v, 3) for k, v in tot.items()}}))
+
+
+if __name__ == "__main__":
+    main()

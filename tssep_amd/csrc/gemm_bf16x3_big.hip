@@ -164,105 +164,9 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
 #define SB3(i) if (!(PROBE & 4)) { *reinterpret_cast<u32x2*>(nxt + 2 * GARR + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
                *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                if (!(PROBE & 2)) rb[i] = bload4(bsrd, boffs[i] | tmask, so)
-    // k-step 0
-    FRAG(al, GARR + aoff, 0, fo0); FRAG(bh, boff, 0, fo0); FRAG(bh, boff, 1, fo0); FRAG(bh, boff, 2, fo0); FRAG(bh, boff, 3, fo0);
-    FRAG(al, GARR + aoff, 1, fo0); FRAG(al, GARR + aoff, 2, fo0); FRAG(al, GARR + aoff, 3, fo0); SB;
-    MM(al, bh, 0, 0); FRAG(ah, aoff, 0, fo0); SB;
-    MM(al, bh, 0, 1); FRAG(bl, GARR + boff, 0, fo0); SB;
-    MM(al, bh, 0, 2); FRAG(bl, GARR + boff, 1, fo0); SB;
-    MM(al, bh, 0, 3); FRAG(bl, GARR + boff, 2, fo0); SB;
-    MM(al, bh, 1, 0); FRAG(bl, GARR + boff, 3, fo0); SB;
-    MM(al, bh, 1, 1); FRAG(ah, aoff, 1, fo0); SB;
-    MM(al, bh, 1, 2); FRAG(ah, aoff, 2, fo0); SB;
-    MM(al, bh, 1, 3); FRAG(ah, aoff, 3, fo0); SB;
-    MM(al, bh, 2, 0); SA1(0); SB;
-    MM(al, bh, 2, 1); SA2(0); SB;
-    MM(al, bh, 2, 2); SB;
-    MM(al, bh, 2, 3); SA3(0); SB;
-    MM(al, bh, 3, 0); SA1(1); SB;
-    MM(al, bh, 3, 1); SB;
-    MM(al, bh, 3, 2); SA2(1); SB;
-    MM(al, bh, 3, 3); SA3(1); SB;
-    MM(ah, bl, 0, 0); FRAG(al1, GARR + aoff, 0, fo1); SB;
-    MM(ah, bl, 0, 1); FRAG(bh1, boff, 0, fo1); SB;
-    MM(ah, bl, 0, 2); FRAG(bh1, boff, 1, fo1); SB;
-    MM(ah, bl, 0, 3); FRAG(bh1, boff, 2, fo1); SB;
-    MM(ah, bl, 1, 0); FRAG(bh1, boff, 3, fo1); SB;
-    MM(ah, bl, 1, 1); FRAG(al1, GARR + aoff, 1, fo1); SB;
-    MM(ah, bl, 1, 2); FRAG(al1, GARR + aoff, 2, fo1); SB;
-    MM(ah, bl, 1, 3); FRAG(al1, GARR + aoff, 3, fo1); SB;
-    MM(ah, bl, 2, 0); SB;
-    MM(ah, bl, 2, 1); SA1(2); SB;
-    MM(ah, bl, 2, 2); SA2(2); SB;
-    MM(ah, bl, 2, 3); SB;
-    MM(ah, bl, 3, 0); SA3(2); SB;
-    MM(ah, bl, 3, 1); SA1(3); SB;
-    MM(ah, bl, 3, 2); SB;
-    MM(ah, bl, 3, 3); SA2(3); SB;
-    MM(ah, bh, 0, 0); FRAG(ah1, aoff, 0, fo1); SB;
-    MM(ah, bh, 0, 1); FRAG(bl1, GARR + boff, 0, fo1); SB;
-    MM(ah, bh, 0, 2); FRAG(bl1, GARR + boff, 1, fo1); SB;
-    MM(ah, bh, 0, 3); FRAG(bl1, GARR + boff, 2, fo1); SB;
-    MM(ah, bh, 1, 0); FRAG(bl1, GARR + boff, 3, fo1); SB;
-    MM(ah, bh, 1, 1); FRAG(ah1, aoff, 1, fo1); SB;
-    MM(ah, bh, 1, 2); FRAG(ah1, aoff, 2, fo1); SB;
-    MM(ah, bh, 1, 3); FRAG(ah1, aoff, 3, fo1); SB;
-    MM(ah, bh, 2, 0); SA3(3); SB;
-    MM(ah, bh, 2, 1); SB;
-    MM(ah, bh, 2, 2); SA1(4); SB;
-    MM(ah, bh, 2, 3); SA2(4); SB;
-    MM(ah, bh, 3, 0); SB;
-    MM(ah, bh, 3, 1); SA3(4); SB;
-    MM(ah, bh, 3, 2); SA1(5); SB;
-    MM(ah, bh, 3, 3); SB;
-    MM(al1, bh1, 0, 0); SA2(5); SB;
-    MM(al1, bh1, 0, 1); SA3(5); SB;
-    MM(al1, bh1, 0, 2); SB;
-    MM(al1, bh1, 0, 3); SA1(6); SB;
-    MM(al1, bh1, 1, 0); SA2(6); SB;
-    MM(al1, bh1, 1, 1); SB;
-    MM(al1, bh1, 1, 2); SA3(6); SB;
-    MM(al1, bh1, 1, 3); SA1(7); SB;
-    MM(al1, bh1, 2, 0); SB;
-    MM(al1, bh1, 2, 1); SA2(7); SB;
-    MM(al1, bh1, 2, 2); SA3(7); SB;
-    MM(al1, bh1, 2, 3); SB;
-    MM(al1, bh1, 3, 0); SB1(0); SB;
-    MM(al1, bh1, 3, 1); SB2(0); SB;
-    MM(al1, bh1, 3, 2); SB;
-    MM(al1, bh1, 3, 3); SB3(0); SB;
-    MM(ah1, bl1, 0, 0); SB1(1); SB;
-    MM(ah1, bl1, 0, 1); SB;
-    MM(ah1, bl1, 0, 2); SB2(1); SB;
-    MM(ah1, bl1, 0, 3); SB3(1); SB;
-    MM(ah1, bl1, 1, 0); SB;
-    MM(ah1, bl1, 1, 1); SB1(2); SB;
-    MM(ah1, bl1, 1, 2); SB2(2); SB;
-    MM(ah1, bl1, 1, 3); SB;
-    MM(ah1, bl1, 2, 0); SB3(2); SB;
-    MM(ah1, bl1, 2, 1); SB1(3); SB;
-    MM(ah1, bl1, 2, 2); SB;
-    MM(ah1, bl1, 2, 3); SB2(3); SB;
-    MM(ah1, bl1, 3, 0); SB3(3); SB;
-    MM(ah1, bl1, 3, 1); SB;
-    MM(ah1, bl1, 3, 2); SB1(4); SB;
-    MM(ah1, bl1, 3, 3); SB2(4); SB;
-    MM(ah1, bh1, 0, 0); SB;
-    MM(ah1, bh1, 0, 1); SB3(4); SB;
-    MM(ah1, bh1, 0, 2); SB1(5); SB;
-    MM(ah1, bh1, 0, 3); SB;
-    MM(ah1, bh1, 1, 0); SB2(5); SB;
-    MM(ah1, bh1, 1, 1); SB3(5); SB;
-    MM(ah1, bh1, 1, 2); SB;
-    MM(ah1, bh1, 1, 3); SB1(6); SB;
-    MM(ah1, bh1, 2, 0); SB2(6); SB;
-    MM(ah1, bh1, 2, 1); SB;
-    MM(ah1, bh1, 2, 2); SB3(6); SB;
-    MM(ah1, bh1, 2, 3); SB1(7); SB;
-    MM(ah1, bh1, 3, 0); SB;
-    MM(ah1, bh1, 3, 1); SB2(7); SB;
-    MM(ah1, bh1, 3, 2); SB3(7); SB;
-    MM(ah1, bh1, 3, 3); SB;
+#define MMZ(x, y, i, j) MM(x, y, i, j)
+#include "gemm_bf16x3_big_schedule.inc"
+#undef MMZ
     if constexpr (XCOL) rx = rxn;
 #undef SPL
 #undef SB3

@@ -1,0 +1,378 @@
+// Persistent variant of the big-tile split-bf16 GEMM (gemm_bf16x3_big.hip) for row-major x row-major operands whose
+// store is a plain row-major C: the LSTM input projections (N = 2400, K = 320 / 513 / 553 / 1280) and the other wide
+// nn.Linear GEMMs (tssep/train/rnnp.py:88-96,146-161).
+//
+// Why: the 256 x 256 tile's life in gemm_bf16x3_big.hip has a FIXED part of ~22 us next to its K stages (2.3 us per
+// 32 k): fitted over K = 553 / 1280 at N = 2400, and the "no epilogue" probe of profiles/r3_gemm_big_probes.jsonl
+// alone is 16 us per tile -- half of a K = 320 tile, a third of a K = 513 one.  Nothing of that is bandwidth (256 KB
+// per CU and tile): it is the LDS transposition in 64 four-byte writes per 32 x 32 tile, the wait of `s_endpgm` for
+// the last store's acknowledgement with the CU's registers and LDS held, the next workgroup's dispatch and its
+// prologue's load latency.  This kernel removes the three:
+//  * persistent grid (one workgroup per CU) walking the XCD-aware tile list in ONE software pipeline over (tile,
+//    K stage): the operand loads run two stages ahead ACROSS tile boundaries, so a tile ends with the next tile's
+//    stage 0 in LDS and its stage 1 in flight -- no drain, no dispatch, no prologue;
+//  * the MFMA operands swapped (weights as the A operand, activations as B): a lane's four consecutive accumulator
+//    registers are then four consecutive COLUMNS of one row, and the transposition through LDS is 16 `ds_write_b128`
+//    + 16 `ds_read_b128` per 32 x 128 block (XOR-swizzled 16-byte chunks, conflict-free both ways) instead of 64
+//    `ds_write_b32`; the same dot products in the same k order: bit-identical to the other split-bf16 kernels;
+//  * stores as buffer stores (scalar base, one 32-bit lane offset, no 64-bit address arithmetic per row; soffset 0:
+//    see tools/scan_store_hazard.py), two rows x 512 B per wave instruction; the bias from LDS (a global load would
+//    sit behind the prefetched operand tiles in the in-order memory counter);
+//  * a tile's accumulators start from the C operand 0 of its first products (no zeroing pass).
+// Everything else -- 128 x 128 wave tiles, one wave per SIMD, the slot schedule of a stage -- is the big-tile kernel's
+// (gemm_bf16x3_big_schedule.inc).
+#include <cstdlib>
+#include <type_traits>
+#include "gemm_common.h"
+
+namespace {
+
+using namespace gemm_detail;
+
+constexpr int GM = 256, GN = 256, GBK = 32, GNT = 256;
+constexpr int GROWB = 64;                                   // bytes per LDS row: 32 bf16
+constexpr int GARR = GM * GROWB;                            // 16 384 B per plane
+constexpr int GSTAGE = 4 * GARR;                            // A hi, A lo, B hi, B lo = 65 536 B
+constexpr unsigned GOOR = 0x80000000u;                      // buffer offset beyond the range: loads return 0, stores are dropped
+constexpr int PBIAS = 4096;                                 // floats of bias kept in LDS (N beyond that: the tiled kernel)
+
+// PROBE (experiment builds only, TIMING probes): 24 = no epilogue at all (garbage results), 32 = plain instead of
+// non-temporal stores, 64 = sc1 stores (results stay right); profiles/r4_gemm_big_p_probes.jsonl
+// Tile list of one workgroup without divisions: position (n-group ng, m-tile rm of this XCD, n-tile rn of the group) of
+// id = 8 l + xcd in the map of gemm_common.h (l = (ng MTx + rm) NG + rn), advanced by `step` = gridDim.x / 8 ids of the
+// same XCD at a time (dq = step / NG, dr = step % NG from the host).  Scalar registers only.
+struct TileWalk { int step, dq, dr; };
+
+template <int PROBE, int ACT>
+__global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N, int64_t K,
+    int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * GSTAGE];
+  // the bias, read by the store from LDS: a global load would sit behind the prefetched operand tiles in the in-order
+  // memory counter
+  __shared__ __attribute__((aligned(16))) float bias_s[PBIAS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int KT = (int)((K + GBK - 1) / GBK);
+  const bool ktail = (K % GBK) != 0;
+  for (int i = tid; i < PBIAS; i += GNT) bias_s[i] = (bias && i < N) ? bias[i] : 0.f;      // (visible after the prologue's barrier)
+
+  // ---- tile list of this workgroup (see TileWalk); `first`: the position of id = blockIdx.x itself is tried as it is
+  const int xcd = (int)(blockIdx.x % NXCD);
+  int w_ng, w_rm, w_rn;
+  {
+    const int l = (int)(blockIdx.x / NXCD), per_group = tmap.MTx * tmap.NG;
+    w_ng = l / per_group;
+    const int r = l - w_ng * per_group;
+    w_rm = r / tmap.NG;
+    w_rn = r - w_rm * tmap.NG;
+  }
+  int mt = 0, nt = 0;
+  bool w_first = true;
+  auto next_tile = [&]() __attribute__((always_inline)) -> bool {
+    for (;;) {
+      if (!w_first) {
+        if (walk.step == 0) return false;                     // fewer ids than CUs: one tile per workgroup
+        w_rn += walk.dr;
+        w_rm += walk.dq;
+        if (w_rn >= tmap.NG) { w_rn -= tmap.NG; ++w_rm; }
+        while (w_rm >= tmap.MTx) { w_rm -= tmap.MTx; ++w_ng; }
+      }
+      w_first = false;
+      if (w_ng >= tmap.NGc) return false;
+      mt = w_rm * NXCD + xcd;
+      nt = w_ng * tmap.NG + w_rn;
+      if (mt < tmap.MT && nt < tmap.NT) return true;
+    }
+  };
+  if (!next_tile()) return;
+
+  // ---- loads: lane <-> (row tid / 8 + 32 i, 16-byte chunk tid % 8 of the row's 128-byte K slice)
+  const int lrow = tid >> 3, lch = tid & 7;
+  srd_t asrd = make_srd(A), bsrd = make_srd(B);
+  unsigned aoffs[8], boffs[8];
+  auto set_tile_loads = [&](bool valid) __attribute__((always_inline)) {
+    const int64_t m0 = (int64_t)mt * GM, n0 = (int64_t)nt * GN;
+    asrd = make_srd(A + m0 * lda);
+    bsrd = make_srd(B + n0 * ldb);
+    // rows beyond M / N repeat the last row (their products land in rows / columns the store drops)
+    const int mlim = (int)(M - 1 - m0 < GM - 1 ? M - 1 - m0 : GM - 1), nlim = (int)(N - 1 - n0 < GN - 1 ? N - 1 - n0 : GN - 1);
+    const unsigned la4 = (unsigned)lda * 4u, lb4 = (unsigned)ldb * 4u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ra_ = lrow + 32 * i < mlim ? lrow + 32 * i : mlim, rb_ = lrow + 32 * i < nlim ? lrow + 32 * i : nlim;
+      aoffs[i] = valid ? (unsigned)ra_ * la4 + (unsigned)(lch * 16) : GOOR;
+      boffs[i] = valid ? (unsigned)rb_ * lb4 + (unsigned)(lch * 16) : GOOR;
+    }
+  };
+  set_tile_loads(true);
+  int64_t c_m0 = (int64_t)mt * GM, c_n0 = (int64_t)nt * GN;      // the tile being computed
+  // chunks at or beyond K in the last, partial K stage read offset GOOR = zero; a chunk that straddles K is fixed up
+  // in LDS after it was staged (fix_tail)
+  const int ktail_k0 = (KT - 1) * GBK + lch * 4;
+  const bool tail_out = ktail && ktail_k0 >= K;
+  const int tail_keep = (ktail && ktail_k0 < K && ktail_k0 + 4 > K) ? (int)(K - ktail_k0) : 4;
+  auto load_mask = [&](int kt) __attribute__((always_inline)) -> unsigned { return (tail_out && kt == KT - 1) ? GOOR : 0u; };
+  f32x4 ra[8], rb[8];
+  // ---- staging: 4 consecutive k of one row = 8 bytes of bf16, chunk (k / 8) ^ ((row >> 2) & 3) of the row
+  const int soff = lrow * GROWB + (((lch >> 1) ^ ((tid >> 5) & 3)) << 4) + ((lch & 1) << 3);
+  auto stage_ab = [&](char* st, int i) __attribute__((always_inline)) {
+    unsigned h0, l0, h1, l1;
+    split2n(ra[i][0], ra[i][1], h0, l0);
+    split2n(ra[i][2], ra[i][3], h1, l1);
+    *reinterpret_cast<u32x2*>(st + soff + i * 32 * GROWB) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(st + GARR + soff + i * 32 * GROWB) = u32x2{l0, l1};
+    split2n(rb[i][0], rb[i][1], h0, l0);
+    split2n(rb[i][2], rb[i][3], h1, l1);
+    *reinterpret_cast<u32x2*>(st + 2 * GARR + soff + i * 32 * GROWB) = u32x2{h0, h1};
+    *reinterpret_cast<u32x2*>(st + 3 * GARR + soff + i * 32 * GROWB) = u32x2{l0, l1};
+  };
+  auto fix_tail = [&](char* st) __attribute__((always_inline)) {
+    if (tail_keep < 4) {
+#pragma unroll
+      for (int e = 1; e < 4; ++e) {
+        if (e >= tail_keep) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              *reinterpret_cast<unsigned short*>(st + p * GARR + soff + i * 32 * GROWB + 2 * e) = 0;
+        }
+      }
+    }
+  };
+
+  // ---- fragments: lane = row (lane & 31), 8 consecutive k = chunk 2 ks + (lane >> 5), swizzled as above
+  const int fsw = ((lane >> 5) ^ ((lane >> 2) & 3)) << 4;            // k-step 0; k-step 1 = fsw ^ 32
+  const int aoff = (wm * 128 + (lane & 31)) * GROWB, boff = 2 * GARR + (wn * 128 + (lane & 31)) * GROWB;
+  // acc[i][j]: SWAPPED operands (B rows as the MFMA's A operand): lane holds row m = 32 i + lane % 32 of the wave tile
+  // and columns n = 32 j + 8 (e / 4) + 4 (lane / 32) + e % 4
+  f32x16 acc[4][4];
+
+  // One stage = two k-steps x three products x 16 accumulator tiles = 96 MFMAs per wave, in the slot schedule of the tiled
+  // kernel (gemm_bf16x3_big_schedule.inc).  FIRST: the stage starts the tile's accumulators (C operand 0 in its first
+  // product).  (Two generated schedules -- one staging sub-step per MFMA gap; the same with a stage's last product moved
+  // behind the next stage's barrier -- measured 1.3 % slower: profiles/r4_ab_gemm_big_p_schedules_rejected.jsonl.)
+  auto body = [&](auto first_tag, const char* cur, char* nxt, int kt_load) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    bf16x8 al[4], bh[4], ah[4], bl[4], al1[4], bh1[4], ah1[4], bl1[4];
+    const int fo0 = fsw, fo1 = fsw ^ 32;
+    const int so = kt_load * GBK * 4;
+    const unsigned tmask = load_mask(kt_load);
+#define SB __builtin_amdgcn_sched_barrier(0)
+#define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
+#define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
+#define MMZ(x, y, i, j) if constexpr (FIRST) { const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                                               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); } else MM(x, y, i, j)
+    // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
+    unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
+#define SA1(i) split2n(ra[i][0], ra[i][1], sh0, sl0)
+#define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
+               *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               ra[i] = bload4(asrd, aoffs[i] | tmask, so)
+#define SB1(i) split2n(rb[i][0], rb[i][1], sh0, sl0)
+#define SB2(i) split2n(rb[i][2], rb[i][3], sh1, sl1)
+#define SB3(i) { *reinterpret_cast<u32x2*>(nxt + 2 * GARR + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
+               *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               rb[i] = bload4(bsrd, boffs[i] | tmask, so)
+#include "gemm_bf16x3_big_schedule.inc"
+#undef SB3
+#undef SB2
+#undef SB1
+#undef SA3
+#undef SA2
+#undef SA1
+#undef MMZ
+#undef MM
+#undef FRAG
+#undef SB
+  };
+
+  // ---- epilogue of the tile at (m0, n0): per wave four blocks of 32 rows x 128 columns through a 16-KB scratch in
+  // the stage that was consumed last.  Scratch row = 512 B = 32 chunks of 16 B, chunk c of row r at c ^ (r & 15).
+  auto epilogue = [&](int64_t m0, int64_t n0, char* scr_base, bool live) __attribute__((always_inline)) {
+    if (PROBE == 24) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sacc += acc[i][j][0] + acc[i][j][7];
+      if (sacc == 123.456f) C[tid] = sacc;
+      return;
+    }
+    char* scr = scr_base + wave * 16384;
+    // (from an opaque copy of the lane index: as loop invariants of the tile loop the sixteen swizzled write addresses and
+    // the store offsets would be hoisted out of it -- registers the stage body does not have)
+    int lv = lane;
+    asm volatile("" : "+v"(lv));
+    const int h = lv >> 5, ml = lv & 31;
+    const int64_t mrow0 = m0 + (int64_t)wm * 128, ncol0 = n0 + (int64_t)wn * 128;
+    const int64_t n = ncol0 + 4 * ml;                         // this lane's four columns in the read-back
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (n < PBIAS - 3 ? n : 0));
+    const srd_t csrd = make_srd(C + mrow0 * ldc + ncol0);
+    const bool ncol_ok = live && n + 3 < N;
+    const int mleft = (int)(M - mrow0 < 128 ? M - mrow0 : 128);      // valid rows of the wave tile
+    // byte offset of (row h, columns 4 ml ..) from the wave tile's first element; + 2 rows per store
+    unsigned voff = ((unsigned)h * (unsigned)ldc + 4u * (unsigned)ml) * 4u;
+    const unsigned vstep = (unsigned)ldc * 8u;
+    char* wp = scr + ml * 512;
+    const int wsw = ml & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = j * 8 + 2 * q + h;
+          *reinterpret_cast<f32x4*>(wp + ((c ^ wsw) << 4)) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+      // (one wave writes and reads its own scratch: LDS operations of a wave complete in order)
+      const char* rp = scr + h * 512;
+      int row = i * 32 + h;
+      auto store_rows = [&](int r) __attribute__((always_inline)) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(rp + r * 1024 + ((ml ^ ((2 * r + h) & 15)) << 4));
+        v += bv;
+        if constexpr (ACT == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        const bool ok = ncol_ok && row < mleft;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd, (int)(ok ? voff : GOOR), 0, (PROBE & 32) ? 0 : (PROBE & 64) ? 16 : 2);
+        voff += vstep;
+        row += 2;
+      };
+      // plain / bias store: all 64 stores of a tile as straight-line code -- the compiler's count of what is in flight when
+      // the next stage first touches the prefetched operands must reach the counter's limit (`vmcnt(63)`: the sixteen loads
+      // and ONE store done); with the stores in a loop it assumed a single trip and waited for half of them.  (The Tanh
+      // store keeps the loop: 256 inlined tanhf would not fit the instruction cache.)
+      if constexpr (ACT == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_rows(r);
+      } else {
+#pragma unroll 2
+        for (int r = 0; r < 16; ++r) store_rows(r);
+      }
+    }
+  };
+
+  // ---- prologue: stage 0 of the first tile -> LDS, its stage 1 -> registers
+  {
+    const unsigned t0 = load_mask(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t0, 0); rb[i] = bload4(bsrd, boffs[i] | t0, 0); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stage_ab(lds, i);
+    const unsigned t1 = load_mask(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t1, GBK * 4); rb[i] = bload4(bsrd, boffs[i] | t1, GBK * 4); }
+  }
+  __syncthreads();
+  int par = 0;
+  bool more = true, live = false;
+  int64_t n_m0 = 0, n_n0 = 0, p_m0 = 0, p_n0 = 0;
+  // from stage KT - 2 of a tile on, the loads (two stages ahead) belong to the next tile of the list
+  auto loader_stage = [&](int kt) __attribute__((always_inline)) -> int {
+    int ktl = kt + 2;
+    if (ktl == KT) {
+      more = next_tile();
+      set_tile_loads(more);
+      n_m0 = (int64_t)mt * GM;
+      n_n0 = (int64_t)nt * GN;
+    }
+    return ktl >= KT ? ktl - KT : ktl;
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  for (;;) {
+    // The store of the tile finished in the previous round (p_m0, p_n0), through the stage consumed last.  The FIRST round
+    // runs it too, with every store out of range: the stage body below then has ONE predecessor, and the compiler's count of
+    // the memory operations in flight at its first use of the prefetched operands is "16 loads, then 64 stores" on every
+    // path -- with a separate entry from the prologue it waited for `vmcnt(15)` there, i.e. for 49 of the 64 stores just
+    // issued (one in-order counter for loads and stores on this architecture).
+    epilogue(p_m0, p_n0, lds + (par ^ 1) * GSTAGE, live);
+    if (live && !more) break;
+    __syncthreads();                       // every wave's scratch is read before the next stage is written over it
+    {
+      const int ktl = loader_stage(0);
+      char* nxt = lds + (par ^ 1) * GSTAGE;
+      // stores stage 1 (registers), loads stage 2
+      body(std::true_type{}, lds + par * GSTAGE, nxt, ktl);
+      if (ktail && KT == 2) fix_tail(nxt);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      par ^= 1;
+    }
+    for (int kt = 1; kt < KT; ++kt) {
+      const int ktl = loader_stage(kt);
+      char* nxt = lds + (par ^ 1) * GSTAGE;
+      body(std::false_type{}, lds + par * GSTAGE, nxt, ktl);
+      if (ktail && kt + 1 == KT - 1) fix_tail(nxt);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      par ^= 1;
+    }
+    p_m0 = c_m0;
+    p_n0 = c_n0;
+    c_m0 = n_m0;
+    c_n0 = n_n0;
+    live = true;
+  }
+}
+
+}  // namespace
+
+int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call) {
+  using namespace gemm_detail;
+  void* const stream = call.stream;
+  if (g->a_kmajor || g->b_kmajor || sm.remap || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
+  // bias and the Tanh only: a store that reads (accumulate, the folded Tanh backward's aux operand) keeps the tiled kernel
+  // (N = 256 q + 1 keeps the tiled kernel with its VALU column: the column's partial sums do not fit beside this kernel's
+  // loop-carried registers -- 700 spills when built)
+  if (g->act > 1 || g->accumulate || g->N > PBIAS || (g->N & 3) || (sm.ldc & 3) || !aligned16(g->C)) return TSSEP_E_UNSUPPORTED;
+  if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B)) return TSSEP_E_UNSUPPORTED;
+  if (g->M < 4 * GM || g->K < 2 * GBK) return TSSEP_E_UNSUPPORTED;      // (two K stages: the loader's lead)
+  // 32-bit buffer offsets: one tile's rows and the whole K extent must stay below 2 GB
+  if ((int64_t)GM * g->lda * 4 + g->K * 4 >= (int64_t)1 << 31 || (int64_t)GN * g->ldb * 4 + g->K * 4 >= (int64_t)1 << 31 ||
+      (int64_t)(GM + 2) * sm.ldc * 4 >= (int64_t)1 << 31)
+    return TSSEP_E_UNSUPPORTED;
+  if (call.dry) return TSSEP_OK;
+  const TileMap tm = make_tile_map((g->M + GM - 1) / GM, (g->N + GN - 1) / GN, 1);
+  const int64_t nids = tile_map_blocks(tm);
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  // persistent: a multiple of 8 workgroups (a workgroup's ids stay on one XCD) unless the whole list fits the CUs once
+  const int ncu8 = ncu / NXCD * NXCD;
+  const int64_t grid = nids <= ncu8 || ncu8 == 0 ? nids : ncu8;
+  TileWalk walk;
+  walk.step = grid == nids ? 0 : (int)(grid / NXCD);
+  walk.dq = walk.step / tm.NG;
+  walk.dr = walk.step % tm.NG;
+#define PLAUNCH1(P_, ACT_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
+                     g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk)
+#define PLAUNCH(P_) do { if (g->act == 1) PLAUNCH1(P_, 1); else PLAUNCH1(P_, 0); } while (0)
+#ifdef TSSEP_GEMM_EXP
+  {
+    const char* pe = getenv("TSSEP_BIGP_PROBE");
+    switch (pe ? atoi(pe) : 0) {
+      case 24: PLAUNCH(24); return tssep_launch_status();
+      case 32: PLAUNCH(32); return tssep_launch_status();
+      case 64: PLAUNCH(64); return tssep_launch_status();
+      default: break;
+    }
+  }
+#endif
+  PLAUNCH(0);
+#undef PLAUNCH
+#undef PLAUNCH1
+  return tssep_launch_status();
+}
