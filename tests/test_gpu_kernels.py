@@ -333,6 +333,53 @@ def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K)
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(3072, 513, 600), (66048, 513, 448), (2048, 769, 2400), (24320, 513, 64)])
+def test_gemm_persistent_big_tile_extra_column(M, N, K):
+    """N = 256 q + 1 in the persistent big-tile kernel (M a multiple of 256: unclamped loads with a scalar row-group
+    offset): q MFMA tiles + column N - 1 on the VALU from the fp32 values being staged, the row of B in LDS, a tile's
+    finished column sums parked in LDS until its store.  Every column bit for bit against the tiled big-tile kernel
+    (same fmaf chain per row), fp64 as the reference; bias, bias + Tanh, padded rows of C untouched; more tiles than CUs."""
+    torch.manual_seed(9)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        ru = h.round_up
+        A = torch.randn(M, K); W = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        ldc = ru(N, 4)
+        Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+        ref = A.double() @ W.double().t()
+        outs = {}
+        for kern in ("big_p", "big"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                C = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C, ldc, M, N, K, bias=bd)
+                C2 = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C2, ldc, M, N, K, bias=bd, act=1)
+                C3 = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, K, Wd, K, C3, ldc, M, N, K)
+            h.GEMM_LOG = None
+            assert {k for k, *_ in log} == {kern}, log
+            outs[kern] = (C, C2, C3)
+        b = outs["big_p"]
+        close(b[0][:, :N], (ref + bias.double()).float(), rtol=2e-4, atol=2e-4, name="big_p xcol + bias")
+        close(b[1][:, :N], torch.tanh(ref + bias.double()).float(), rtol=2e-4, atol=2e-4, name="big_p xcol + bias + tanh")
+        close(b[2][:, :N], ref.float(), rtol=2e-4, atol=2e-4, name="big_p xcol plain")
+        for x, y in zip(outs["big_p"], outs["big"]):
+            assert bool(torch.isnan(x[:, N:]).all())
+            assert torch.equal(x[:, :N], y[:, :N])
+        for _ in range(3):
+            C5 = torch.full((M, ldc), float("nan"), device="cuda")
+            with h.prefer_gemm_kernels("big_p"):
+                h.gemm(Ad, K, Wd, K, C5, ldc, M, N, K)
+            assert torch.equal(C5[:, :N], outs["big"][2][:, :N])
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", [(1100, 1280, 320), (2048 + 37, 2400, 513), (1024, 1200, 47), (3000, 2052, 31),
                                    (70000, 1280, 64), (1500, 2400, 2400)])
 def test_gemm_big_tile_kernel_is_bit_identical_to_the_tiled_kernels(M, N, K):

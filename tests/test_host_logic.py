@@ -97,7 +97,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # input projections: the persistent big tile (plain / bias / Tanh store) since round 4's second half, any K
     assert plan(R, 2400, 556) == "big_p" and plan(4 * R, 2400, 516) == "big_p" and plan(4 * R, 2400, 320) == "big_p"
     assert plan(R, 1280, 2400, remap=True) == "big"                                  # ... a remapped store keeps the tiled kernel
-    assert plan(R, 513, 600) == "big"                                                # pre-net projection: 2 tiles + a VALU column
+    assert plan(R, 513, 600) == "big_p" and plan(R + 8, 513, 600) == "big"           # pre-net projection: 2 tiles + a VALU column
     assert plan(4 * R, 320, 600, act=1) == "nt_w160" and plan(4 * R, 320, 600, act=1, remap=True) == "nt_w160"
     assert plan(4 * R, 600, 320) == "big_p" and plan(4 * R, 1000, 320) == "big_p"    # dgrad proj dh: 768 columns computed for 600
     assert plan(4 * R, 780, 320) == "stream"                                         # ... 1024 for 780 is too many

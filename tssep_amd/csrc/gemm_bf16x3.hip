@@ -1213,6 +1213,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // ... and a one-workgroup-per-CU kernel whose last resident round is mostly empty loses it whole: 380 tiles = 1.48
     // rounds of 256 run at 74 % (the 8-speaker pre-net, 97 152 x 256 x 512: 261 against 312 TFLOP/s on the persistent kernel)
     auto rounds_ok = [&](int64_t col_tiles) { const int64_t t = mt256 * col_tiles; return t * 5 >= (t + 255) / 256 * 256 * 4; };
+    // (the persistent big tile against the persistent 256 x 128 tile, whose list is twice as fine: 90 %)
+    auto rounds_ok9 = [&](int64_t col_tiles) { const int64_t t = mt256 * col_tiles; return t * 10 >= (t + 255) / 256 * 256 * 9; };
     // big-tile kernel (gemm_bf16x3_big.hip) where the 256-wide tile applies.  (K < 448: a tile's life is mostly its
     // C store there -- the streaming kernel, which hides it, measured 4.14 against 4.56 ms at K = 320, N = 2400; from
     // K = 513 up this kernel wins: 6.55 / 6.63, 3.10 / 3.42 at K = 1280, 2.75 / 3.29 at K = 2400, N = 1280; sw.big 2 =
@@ -1228,8 +1230,10 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // also pays for more column padding than the tiled kernel's 10 %: N = 600 (768 columns computed) 1.05 against 1.12 ms on
     // the streaming kernel
     const bool pads_to_256_loosely = g->N >= 256 && n256 * 100 <= g->N * 130;
-    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && pads_to_256_loosely && !sm.remap && g->act <= 1 && !g->accumulate && fills(n256 / 256, 192) &&
-                                         rounds_ok(n256 / 256))) {
+    // (N = 256 q + 1 with M a multiple of 256: q tiles + the VALU column, as in the tiled kernel)
+    const int64_t ct_p = xcol_shape ? (g->N - 1) / 256 : n256 / 256;
+    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && (pads_to_256_loosely || (xcol_shape && g->M % 256 == 0)) && !sm.remap && g->act <= 1 && !g->accumulate &&
+                                         fills(ct_p, 192) && rounds_ok9(ct_p))) {
       const int rc = tssep_gemm_bf16x3_bigp_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG_P; return rc; }
     }

@@ -35,6 +35,7 @@ constexpr int GARR = GM * GROWB;                            // 16 384 B per plan
 constexpr int GSTAGE = 4 * GARR;                            // A hi, A lo, B hi, B lo = 65 536 B
 constexpr unsigned GOOR = 0x80000000u;                      // buffer offset beyond the range: loads return 0, stores are dropped
 constexpr int PBIAS = 4096;                                 // floats of bias kept in LDS (N beyond that: the tiled kernel)
+constexpr int XBIAS = 1024, XROW = 4096;                    // XCOL: bias (N <= 1024), row N - 1 of B (K <= 4096)
 
 // PROBE (experiment builds only, TIMING probes): 24 = no epilogue at all (garbage results), 32 = plain instead of
 // non-temporal stores, 64 = sc1 stores (results stay right); profiles/r4_gemm_big_p_probes.jsonl
@@ -43,20 +44,35 @@ constexpr int PBIAS = 4096;                                 // floats of bias ke
 // same XCD at a time (dq = step / NG, dr = step % NG from the host).  Scalar registers only.
 struct TileWalk { int step, dq, dr; };
 
-template <int PROBE, int ACT>
+// XCOL (N = 256 q + 1: the 513 frequency bins of `dgrad birnn0 dx` and of the pre-net projection), as in the tiled kernel:
+// the MFMA tiles cover the first N - 1 columns and column N - 1 is computed on the VALU from the raw fp32 A values every
+// thread stages anyway (exact fp32, 32 FMAs per thread and stage against row N - 1 of B, kept in LDS); every workgroup
+// computes it -- branch-free -- and those of the last column tile store it.  The twelve registers this takes come from
+// the load offsets: XCOL requires M % 256 == 0, so no row of a tile needs clamping and the sixteen per-piece lane
+// offsets become one per operand plus a scalar row-group offset.
+template <int PROBE, int ACT, bool XCOL>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N, int64_t K,
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull, int64_t K,
     int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk) {
+  const int64_t N = XCOL ? Nfull - 1 : Nfull;          // columns of the MFMA tiles
   __shared__ __attribute__((aligned(16))) char lds[2 * GSTAGE];
   // the bias, read by the store from LDS: a global load would sit behind the prefetched operand tiles in the in-order
   // memory counter
-  __shared__ __attribute__((aligned(16))) float bias_s[PBIAS];
+  // (XCOL: bias (N <= 1024) | row N - 1 of B, zero beyond K (K <= 4096) | the finished column sums of a tile, 8 per thread)
+  __shared__ __attribute__((aligned(16))) float extra_s[XCOL ? XBIAS + XROW + 8 * GNT : PBIAS];
+  float* const bias_s = extra_s;
+  float* const xrow_s = extra_s + XBIAS;
+  float* const xs_s = extra_s + XBIAS + XROW;
+  constexpr int NBIAS = XCOL ? XBIAS : PBIAS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int KT = (int)((K + GBK - 1) / GBK);
   const bool ktail = (K % GBK) != 0;
-  for (int i = tid; i < PBIAS; i += GNT) bias_s[i] = (bias && i < N) ? bias[i] : 0.f;      // (visible after the prologue's barrier)
+  for (int i = tid; i < NBIAS; i += GNT) bias_s[i] = (bias && i < Nfull) ? bias[i] : 0.f;      // (visible after the prologue's barrier)
+  if constexpr (XCOL) {
+    for (int i = tid; i < XROW; i += GNT) xrow_s[i] = i < K ? B[N * ldb + i] : 0.f;
+  }
 
   // ---- tile list of this workgroup (see TileWalk); `first`: the position of id = blockIdx.x itself is tried as it is
   const int xcd = (int)(blockIdx.x % NXCD);
@@ -91,23 +107,39 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
   // ---- loads: lane <-> (row tid / 8 + 32 i, 16-byte chunk tid % 8 of the row's 128-byte K slice)
   const int lrow = tid >> 3, lch = tid & 7;
   srd_t asrd = make_srd(A), bsrd = make_srd(B);
-  unsigned aoffs[8], boffs[8];
+  unsigned aoffs[XCOL ? 1 : 8], boffs[XCOL ? 1 : 8];
+  const unsigned la4 = (unsigned)lda * 4u, lb4 = (unsigned)ldb * 4u;
+  const int arow32 = (int)(32u * la4), brow32 = (int)(32u * lb4);      // XCOL: scalar offset of row group i = i x this
   auto set_tile_loads = [&](bool valid) __attribute__((always_inline)) {
     const int64_t m0 = (int64_t)mt * GM, n0 = (int64_t)nt * GN;
     asrd = make_srd(A + m0 * lda);
     bsrd = make_srd(B + n0 * ldb);
-    // rows beyond M / N repeat the last row (their products land in rows / columns the store drops)
-    const int mlim = (int)(M - 1 - m0 < GM - 1 ? M - 1 - m0 : GM - 1), nlim = (int)(N - 1 - n0 < GN - 1 ? N - 1 - n0 : GN - 1);
-    const unsigned la4 = (unsigned)lda * 4u, lb4 = (unsigned)ldb * 4u;
+    if constexpr (XCOL) {
+      aoffs[0] = valid ? (unsigned)lrow * la4 + (unsigned)(lch * 16) : GOOR;
+      boffs[0] = valid ? (unsigned)lrow * lb4 + (unsigned)(lch * 16) : GOOR;
+    } else {
+      // rows beyond M / N repeat the last row (their products land in rows / columns the store drops)
+      const int mlim = (int)(M - 1 - m0 < GM - 1 ? M - 1 - m0 : GM - 1), nlim = (int)(N - 1 - n0 < GN - 1 ? N - 1 - n0 : GN - 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ra_ = lrow + 32 * i < mlim ? lrow + 32 * i : mlim, rb_ = lrow + 32 * i < nlim ? lrow + 32 * i : nlim;
-      aoffs[i] = valid ? (unsigned)ra_ * la4 + (unsigned)(lch * 16) : GOOR;
-      boffs[i] = valid ? (unsigned)rb_ * lb4 + (unsigned)(lch * 16) : GOOR;
+      for (int i = 0; i < 8; ++i) {
+        const int ra_ = lrow + 32 * i < mlim ? lrow + 32 * i : mlim, rb_ = lrow + 32 * i < nlim ? lrow + 32 * i : nlim;
+        aoffs[i] = valid ? (unsigned)ra_ * la4 + (unsigned)(lch * 16) : GOOR;
+        boffs[i] = valid ? (unsigned)rb_ * lb4 + (unsigned)(lch * 16) : GOOR;
+      }
     }
+  };
+  // piece i of the stage at byte offset `so` of the rows, lanes masked by `mask`
+  auto load_a = [&](int i, unsigned mask, int so) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (XCOL) return bload4(asrd, aoffs[0] | mask, so + i * arow32);
+    else return bload4(asrd, aoffs[i] | mask, so);
+  };
+  auto load_b = [&](int i, unsigned mask, int so) __attribute__((always_inline)) -> f32x4 {
+    if constexpr (XCOL) return bload4(bsrd, boffs[0] | mask, so + i * brow32);
+    else return bload4(bsrd, boffs[i] | mask, so);
   };
   set_tile_loads(true);
   int64_t c_m0 = (int64_t)mt * GM, c_n0 = (int64_t)nt * GN;      // the tile being computed
+  bool c_last = nt == tmap.NT - 1;                                 // ... lies in the last column of tiles (XCOL: it stores column N)
   // chunks at or beyond K in the last, partial K stage read offset GOOR = zero; a chunk that straddles K is fixed up
   // in LDS after it was staged (fix_tail)
   const int ktail_k0 = (KT - 1) * GBK + lch * 4;
@@ -115,6 +147,14 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
   const int tail_keep = (ktail && ktail_k0 < K && ktail_k0 + 4 > K) ? (int)(K - ktail_k0) : 4;
   auto load_mask = [&](int kt) __attribute__((always_inline)) -> unsigned { return (tail_out && kt == KT - 1) ? GOOR : 0u; };
   f32x4 ra[8], rb[8];
+  // XCOL: rx = this lane's chunk of row N of B for the stage held in ra; xacc = this lane's partial sums of column N for
+  // rows lrow + 32 i of the tile whose stages are being STAGED (a tile's stage 0 is staged during the previous tile's last
+  // stage); a tile's finished sums wait for its store in LDS (xs_s)
+  f32x4 rx = {0.f, 0.f, 0.f, 0.f};
+  float xacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xacc[i] = 0.f;
+#define XDOT(i) xacc[i] = fmaf(ra[i][3], rx[3], fmaf(ra[i][2], rx[2], fmaf(ra[i][1], rx[1], fmaf(ra[i][0], rx[0], xacc[i]))))
   // ---- staging: 4 consecutive k of one row = 8 bytes of bf16, chunk (k / 8) ^ ((row >> 2) & 3) of the row
   const int soff = lrow * GROWB + (((lch >> 1) ^ ((tid >> 5) & 3)) << 4) + ((lch & 1) << 3);
   auto stage_ab = [&](char* st, int i) __attribute__((always_inline)) {
@@ -160,6 +200,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     const int fo0 = fsw, fo1 = fsw ^ 32;
     const int so = kt_load * GBK * 4;
     const unsigned tmask = load_mask(kt_load);
+    if constexpr (XCOL) rx = *reinterpret_cast<const f32x4*>(xrow_s + ((kt_load == 0 ? KT : kt_load) - 1) * GBK + lch * 4);
 #define SB __builtin_amdgcn_sched_barrier(0)
 #define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
 #define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
@@ -167,16 +208,16 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
                                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); } else MM(x, y, i, j)
     // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
-#define SA1(i) split2n(ra[i][0], ra[i][1], sh0, sl0)
+#define SA1(i) if constexpr (XCOL) XDOT(i); split2n(ra[i][0], ra[i][1], sh0, sl0)
 #define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
                *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
-               ra[i] = bload4(asrd, aoffs[i] | tmask, so)
+               ra[i] = load_a(i, tmask, so)
 #define SB1(i) split2n(rb[i][0], rb[i][1], sh0, sl0)
 #define SB2(i) split2n(rb[i][2], rb[i][3], sh1, sl1)
 #define SB3(i) { *reinterpret_cast<u32x2*>(nxt + 2 * GARR + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
                *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
-               rb[i] = bload4(bsrd, boffs[i] | tmask, so)
+               rb[i] = load_b(i, tmask, so)
 #include "gemm_bf16x3_big_schedule.inc"
 #undef SB3
 #undef SB2
@@ -192,7 +233,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
 
   // ---- epilogue of the tile at (m0, n0): per wave four blocks of 32 rows x 128 columns through a 16-KB scratch in
   // the stage that was consumed last.  Scratch row = 512 B = 32 chunks of 16 B, chunk c of row r at c ^ (r & 15).
-  auto epilogue = [&](int64_t m0, int64_t n0, char* scr_base, bool live) __attribute__((always_inline)) {
+  auto epilogue = [&](int64_t m0, int64_t n0, char* scr_base, bool live, bool last_col) __attribute__((always_inline)) {
     if (PROBE == 24) {
       float sacc = 0.f;
 #pragma unroll
@@ -202,6 +243,21 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
       if (sacc == 123.456f) C[tid] = sacc;
       return;
     }
+    if constexpr (XCOL) {
+      // column N of the full matrix: the 8 lanes of a row hold its eight 16-byte k chunks (same summation tree for every
+      // row; exact fp32 products, not bit-comparable with the MFMA columns' split arithmetic -- like the tiled kernels' column)
+      const float bx = bias_s[N < NBIAS ? N : 0];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v = xs_s[i * GNT + tid];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += bx;
+        if constexpr (ACT == 1) v = tanhf(v);
+        if (live && last_col && lch == 0) C[(m0 + lrow + 32 * i) * ldc + N] = v;
+      }
+    }
     char* scr = scr_base + wave * 16384;
     // (from an opaque copy of the lane index: as loop invariants of the tile loop the sixteen swizzled write addresses and
     // the store offsets would be hoisted out of it -- registers the stage body does not have)
@@ -210,7 +266,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     const int h = lv >> 5, ml = lv & 31;
     const int64_t mrow0 = m0 + (int64_t)wm * 128, ncol0 = n0 + (int64_t)wn * 128;
     const int64_t n = ncol0 + 4 * ml;                         // this lane's four columns in the read-back
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (n < PBIAS - 3 ? n : 0));
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + (n < NBIAS - 3 ? n : 0));
     const srd_t csrd = make_srd(C + mrow0 * ldc + ncol0);
     const bool ncol_ok = live && n + 3 < N;
     const int mleft = (int)(M - mrow0 < 128 ? M - mrow0 : 128);      // valid rows of the wave tile
@@ -262,16 +318,22 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
   {
     const unsigned t0 = load_mask(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t0, 0); rb[i] = bload4(bsrd, boffs[i] | t0, 0); }
+    for (int i = 0; i < 8; ++i) { ra[i] = load_a(i, t0, 0); rb[i] = load_b(i, t0, 0); }
+    if constexpr (XCOL) {
+      __syncthreads();                       // xrow_s
+      rx = *reinterpret_cast<const f32x4*>(xrow_s + lch * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) XDOT(i);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) stage_ab(lds, i);
     const unsigned t1 = load_mask(1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ra[i] = bload4(asrd, aoffs[i] | t1, GBK * 4); rb[i] = bload4(bsrd, boffs[i] | t1, GBK * 4); }
+    for (int i = 0; i < 8; ++i) { ra[i] = load_a(i, t1, GBK * 4); rb[i] = load_b(i, t1, GBK * 4); }
   }
   __syncthreads();
   int par = 0;
-  bool more = true, live = false;
+  bool more = true, live = false, n_last = false, p_last = false;
   int64_t n_m0 = 0, n_n0 = 0, p_m0 = 0, p_n0 = 0;
   // from stage KT - 2 of a tile on, the loads (two stages ahead) belong to the next tile of the list
   auto loader_stage = [&](int kt) __attribute__((always_inline)) -> int {
@@ -281,6 +343,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
       set_tile_loads(more);
       n_m0 = (int64_t)mt * GM;
       n_n0 = (int64_t)nt * GN;
+      n_last = nt == tmap.NT - 1;
     }
     return ktl >= KT ? ktl - KT : ktl;
   };
@@ -296,7 +359,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     // the memory operations in flight at its first use of the prefetched operands is "16 loads, then 64 stores" on every
     // path -- with a separate entry from the prologue it waited for `vmcnt(15)` there, i.e. for 49 of the 64 stores just
     // issued (one in-order counter for loads and stores on this architecture).
-    epilogue(p_m0, p_n0, lds + (par ^ 1) * GSTAGE, live);
+    epilogue(p_m0, p_n0, lds + (par ^ 1) * GSTAGE, live, p_last);
     if (live && !more) break;
     __syncthreads();                       // every wave's scratch is read before the next stage is written over it
     {
@@ -312,6 +375,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     for (int kt = 1; kt < KT; ++kt) {
       const int ktl = loader_stage(kt);
       char* nxt = lds + (par ^ 1) * GSTAGE;
+      if (XCOL && kt == KT - 1) {            // this stage body stages the NEXT tile's stage 0: the column sums of this tile are complete
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xs_s[i * GNT + tid] = xacc[i]; xacc[i] = 0.f; }      // (read back by the same thread, in the store)
+      }
       body(std::false_type{}, lds + par * GSTAGE, nxt, ktl);
       if (ktail && kt + 1 == KT - 1) fix_tail(nxt);
       __syncthreads();
@@ -320,10 +387,13 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     }
     p_m0 = c_m0;
     p_n0 = c_n0;
+    p_last = c_last;
     c_m0 = n_m0;
     c_n0 = n_n0;
+    c_last = n_last;
     live = true;
   }
+#undef XDOT
 }
 
 }  // namespace
@@ -333,9 +403,10 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   void* const stream = call.stream;
   if (g->a_kmajor || g->b_kmajor || sm.remap || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   // bias and the Tanh only: a store that reads (accumulate, the folded Tanh backward's aux operand) keeps the tiled kernel
-  // (N = 256 q + 1 keeps the tiled kernel with its VALU column: the column's partial sums do not fit beside this kernel's
-  // loop-carried registers -- 700 spills when built)
-  if (g->act > 1 || g->accumulate || g->N > PBIAS || (g->N & 3) || (sm.ldc & 3) || !aligned16(g->C)) return TSSEP_E_UNSUPPORTED;
+  // N = 256 q + 1: q tiles + one VALU column, when no row of a tile needs clamping (see the kernel)
+  const bool xcol = g->N > 256 && g->N % 256 == 1;
+  if (xcol && ((g->K & 3) || g->K > XROW || g->N > XBIAS || g->M % GM)) return TSSEP_E_UNSUPPORTED;
+  if (g->act > 1 || g->accumulate || g->N > PBIAS || (!xcol && (g->N & 3)) || (sm.ldc & 3) || !aligned16(g->C)) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B)) return TSSEP_E_UNSUPPORTED;
   if (g->M < 4 * GM || g->K < 2 * GBK) return TSSEP_E_UNSUPPORTED;      // (two K stages: the loader's lead)
   // 32-bit buffer offsets: one tile's rows and the whole K extent must stay below 2 GB
@@ -343,7 +414,7 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
       (int64_t)(GM + 2) * sm.ldc * 4 >= (int64_t)1 << 31)
     return TSSEP_E_UNSUPPORTED;
   if (call.dry) return TSSEP_OK;
-  const TileMap tm = make_tile_map((g->M + GM - 1) / GM, (g->N + GN - 1) / GN, 1);
+  const TileMap tm = make_tile_map((g->M + GM - 1) / GM, xcol ? (g->N - 1) / GN : (g->N + GN - 1) / GN, 1);
   const int64_t nids = tile_map_blocks(tm);
   static const int ncu = [] {
     int dev = 0, n = 256;
@@ -357,9 +428,10 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   walk.step = grid == nids ? 0 : (int)(grid / NXCD);
   walk.dq = walk.step / tm.NG;
   walk.dr = walk.step % tm.NG;
-#define PLAUNCH1(P_, ACT_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
+#define PLAUNCH1(P_, ACT_, X_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk)
-#define PLAUNCH(P_) do { if (g->act == 1) PLAUNCH1(P_, 1); else PLAUNCH1(P_, 0); } while (0)
+#define PLAUNCH(P_) do { if (xcol) { if (g->act == 1) PLAUNCH1(P_, 1, true); else PLAUNCH1(P_, 0, true); }      \
+                         else { if (g->act == 1) PLAUNCH1(P_, 1, false); else PLAUNCH1(P_, 0, false); } } while (0)
 #ifdef TSSEP_GEMM_EXP
   {
     const char* pe = getenv("TSSEP_BIGP_PROBE");
