@@ -320,9 +320,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    SETUP_STEPS = 3      # before the W warm-up steps: allocator growth, derived weight layouts, first-launch code loading
+
     def timed_run(steps, warmup):
         out = None
-        for _ in range(warmup):
+        for _ in range(SETUP_STEPS + warmup):
             out = step()
         H.KERNEL_TIMERS.clear(); H.KERNEL_FLOPS.clear(); H.KERNEL_BYTES.clear(); H.KERNEL_OWN_BYTES.clear()
         H.KERNEL_TIMING = gstep is None      # events cannot be read back out of a graph replay: see below
@@ -555,6 +557,7 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world,
                        "units": UNITS, "optimizer": "global-norm clip + Adam (fused), in the timed step",
                        "projs": PROJS, "parallelism": f"dp{world}",
+                       "setup_steps": SETUP_STEPS,      # untimed, before the W warm-up steps (allocator, weight layouts)
                        "collective": collective,
                        "arithmetic": arithmetic(args.gemm), "recurrence": args.recurrence,
                        "hip_graph": ("forward + loss + backward replayed as one captured hipGraph; optimizer eager; "

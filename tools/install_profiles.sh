@@ -12,7 +12,7 @@ for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16
          bench_f32.json gemm_in_step_b768.jsonl step_clock.json ab_fusions.jsonl splitk_sweep.jsonl \
          ab_gemm_stream_shapes.jsonl ab_gemm_big_shapes.jsonl ab_wgrad_big_shapes.jsonl ab_gemm_kernels.jsonl ab_wgrad_tile.jsonl \
          ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_microbench.jsonl \
-         bench_default.json store_flavour_probe_16384.json store_flavour_probe_81920.json; do
+         bench_default.json store_flavour_probe_16384.json store_flavour_probe_81920.json ab_gemm_big_p.jsonl; do
   [ -s $F/$f ] && cp $F/$f ${P}_$f
 done
 python - <<PY
@@ -29,13 +29,13 @@ def table(src, dst, header):
             f.write(f"{n[:78]:78s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
     return rows
 cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --no-cpu-baseline --no-exact-f32"
-rows = table('$F/stats/s_kernel_stats.csv', '${P}_kernel_stats_default_b${B}_${G}.txt', cmd % "--steps 6 --warmup 2" + "   (default config: batch $B, $G; 8 steps in total)")
-table('$F/stats_f32/s_kernel_stats.csv', '${P}_kernel_stats_b${B}_f32.txt', cmd % "--gemm f32 --steps 6 --warmup 2" + "   (fp32 GEMMs; 8 steps in total)")
-table('$F/stats_cfg4/s_kernel_stats.csv', '${P}_kernel_stats_cfg4_b8.txt', cmd % "--workload cfg4 --graph off --steps 10 --warmup 3" + "   (8 utterances per GPU: the configs[3] shard; 13 steps in total)")
-table('$F/stats_cfg5/s_kernel_stats.csv', '${P}_kernel_stats_cfg5_b96.txt', cmd % "--workload cfg5 --steps 3 --warmup 1" + "   (8 speakers x 30 s, batch 96; 4 steps in total)")
+rows = table('$F/stats/s_kernel_stats.csv', '${P}_kernel_stats_default_b${B}_${G}.txt', cmd % "--steps 6 --warmup 2" + "   (default config: batch $B, $G; 3 setup + 2 warm-up + 6 timed = 11 steps in total)")
+table('$F/stats_f32/s_kernel_stats.csv', '${P}_kernel_stats_b${B}_f32.txt', cmd % "--gemm f32 --steps 6 --warmup 2" + "   (fp32 GEMMs; 11 steps in total)")
+table('$F/stats_cfg4/s_kernel_stats.csv', '${P}_kernel_stats_cfg4_b8.txt', cmd % "--workload cfg4 --graph off --steps 10 --warmup 3" + "   (8 utterances per GPU: the configs[3] shard; 16 steps in total)")
+table('$F/stats_cfg5/s_kernel_stats.csv', '${P}_kernel_stats_cfg5_b96.txt', cmd % "--workload cfg5 --steps 3 --warmup 1" + "   (8 speakers x 30 s, batch 96; 7 steps in total)")
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 g = sum(int(r['TotalDurationNs']) for r in rows if 'gemm' in r['Name'])
 rec = sum(int(r['TotalDurationNs']) for r in rows if 'blstm' in r['Name'])
-print("busy ms/step", round(tot / 8 / 1e6, 2), "gemm %", round(100 * g / tot, 1), "recurrence %", round(100 * rec / tot, 1))
+print("busy ms/step", round(tot / 11 / 1e6, 2), "gemm %", round(100 * g / tot, 1), "recurrence %", round(100 * rec / tot, 1))
 PY
 ls profiles | grep "^r${R}_" | head -40
