@@ -333,6 +333,56 @@ def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K)
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("B,T,K,F,P", [(5, 253, 4, 513, 320), (40, 253, 4, 513, 64), (3, 100, 4, 601, 96), (9, 64, 2, 150, 128), (2, 300, 4, 130, 320)])
+def test_gemm_persistent_big_tile_remapped_store(B, T, K, F, P):
+    """The remapped store in the persistent big-tile kernel (buffer stores with 32-bit float offsets on the whole tensor,
+    permutation entries of a wave tile's two utterances loaded before its first store, straddling lanes element by
+    element): the logit layer (column groups of F bins, permuted per utterance) and the speaker combination with the
+    Tanh, bit for bit against the tiled kernels' remapped stores and against the permuted fp64 reference; more tiles
+    than CUs (the second shape)."""
+    torch.manual_seed(29)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        A = torch.randn(B * T, P, device="cuda"); W = torch.randn(K * F, P, device="cuda") / P ** 0.5
+        bias = torch.randn(K * F, device="cuda")
+        perm = torch.stack([torch.randperm(K) for _ in range(B)]).int().cuda()
+        raw = (A.double() @ W.double().t() + bias.double()).view(B, T, K, F).permute(0, 2, 1, 3)       # [B,K,T,F] by position
+        ref = torch.empty(B, K, T, F, device="cuda", dtype=torch.float64)
+        for b in range(B):
+            for k in range(K):
+                ref[b, perm[b, k]] = raw[b, k]
+        A4 = torch.randn(B * K * T, P, device="cuda")
+        F4 = (F + 3) // 4 * 4 if B * K * T >= 1024 else F
+        W4 = torch.randn(256 + F4, P, device="cuda") / P ** 0.5       # >= 256 columns: the persistent kernel's tile applies
+        b4 = torch.randn(256 + F4, device="cuda")
+        N4 = 256 + F4
+        outs = {}
+        for kern in ("big_p", "tall2"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                rm = dict(T=T, K=1, sb=K * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=K)
+                C = torch.full((B, K, T, F), float("nan"), device="cuda")
+                h.gemm(A, P, W, P, C, 0, B * T, K * F, P, bias=bias, remap=rm)
+                # speaker combination: rows (b, k, t) x N4 -> [B, T, K * N4], one column group, Tanh
+                C4 = torch.full((B, T, K * N4), float("nan"), device="cuda")
+                h.gemm(A4, P, W4, P, C4, 0, B * K * T, N4, P, bias=b4, act=1,
+                       remap=dict(T=T, K=K, sb=T * K * N4, sk=N4, st=K * N4))
+            h.GEMM_LOG = None
+            if B * T >= 1024:
+                assert {k for k, *_ in log} == {kern}, log
+            outs[kern] = (C, C4)
+        for a, b in zip(outs["big_p"], outs["tall2"]):
+            assert torch.equal(a, b), f"{(a != b).sum().item()} differ"
+        close(outs["big_p"][0], ref.float(), rtol=2e-4, atol=2e-4, name="logit remap, persistent kernel")
+        ref4 = torch.tanh(A4.double() @ W4.double().t() + b4.double()).view(B, K, T, N4).permute(0, 2, 1, 3).reshape(B, T, K * N4)
+        close(outs["big_p"][1], ref4.float(), rtol=2e-4, atol=2e-4, name="combine + tanh, persistent kernel")
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("M,N,K", [(3072, 513, 600), (66048, 513, 448), (2048, 769, 2400), (24320, 513, 64)])
 def test_gemm_persistent_big_tile_extra_column(M, N, K):
     """N = 256 q + 1 in the persistent big-tile kernel (M a multiple of 256: unclamped loads with a scalar row-group

@@ -96,7 +96,8 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     R = 768 * 253
     # input projections: the persistent big tile (plain / bias / Tanh store) since round 4's second half, any K
     assert plan(R, 2400, 556) == "big_p" and plan(4 * R, 2400, 516) == "big_p" and plan(4 * R, 2400, 320) == "big_p"
-    assert plan(R, 1280, 2400, remap=True) == "big"                                  # ... a remapped store keeps the tiled kernel
+    assert plan(R, 1280, 2400, remap=True) == "big_p"                                # ... also with a remapped store (< 2 GB)
+    assert plan(R, 1280, 2400, remap=True, act=1) == "big_p" and plan(4 * R, 5120, 2400, remap=True) == "big"      # (4 GB: 64-bit addresses)
     assert plan(R, 513, 600) == "big_p" and plan(R + 8, 513, 600) == "big"           # pre-net projection: 2 tiles + a VALU column
     assert plan(4 * R, 320, 600, act=1) == "nt_w160" and plan(4 * R, 320, 600, act=1, remap=True) == "nt_w160"
     assert plan(4 * R, 600, 320) == "big_p" and plan(4 * R, 1000, 320) == "big_p"    # dgrad proj dh: 768 columns computed for 600
@@ -109,7 +110,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the
     # 160-wide tile, its weight gradient (M = 2052) and the 8-speaker one (4104) on the big weight-gradient tile, one /
     # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
-    assert plan(R, 2052, 320, remap=True) == "tall2" and plan(2052, 320, R, wgrad=True) == "tn_big"
+    assert plan(R, 2052, 320, remap=True) == "big_p" and plan(2052, 320, R, wgrad=True) == "tn_big"
     assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
     assert plan(4 * R, 256, 1024, act=1) == "big_p" and plan(4 * R, 256, 256, act=1) == "big_p"
     assert plan(R // 2, 4104, 256, remap=True) == "tall2"

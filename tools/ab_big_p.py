@@ -56,6 +56,32 @@ def main():
         del A, W, outs, calls
         torch.cuda.empty_cache()
     print(json.dumps({"total_ms": {k: round(v, 3) for k, v in tot.items()}}))
+    # the logit layer: 4 x 513 bins per frame, remapped to [B, K, T, F] with the per-utterance speaker permutation
+    Kspk, F, P, T = 4, 513, 320, 253
+    A = torch.randn(R1, P, device="cuda"); W = torch.randn(Kspk * F, P, device="cuda") / P ** 0.5
+    bias = torch.randn(Kspk * F, device="cuda")
+    perm = torch.stack([torch.randperm(Kspk) for _ in range(B)]).int().cuda()
+    rm = dict(T=T, K=1, sb=Kspk * T * F, sk=0, st=F, cm=F, co=T * F, perm=perm, perm_ld=Kspk)
+    outs, calls = {}, {}
+    for kern in ("big_p", "big", "tall4", "tall2", "nt_w160", "pipe"):
+        C = torch.empty(B, Kspk, T, F, device="cuda")
+
+        def call(kern=kern, C=C):
+            with H.prefer_gemm_kernels(kern):
+                H.gemm(A, P, W, P, C, 0, R1, Kspk * F, P, bias=bias, remap=rm)
+
+        log = H.GEMM_LOG = []
+        call()
+        H.GEMM_LOG = None
+        if log[0][0] == kern:
+            outs[kern], calls[kern] = C, call
+    ms = time_calls(calls, 5)
+    rec = dict(name="linear2 (logit layer, remapped)", M=R1, N=Kspk * F, K=P)
+    for k, v in ms.items():
+        rec[k + "_ms"] = round(v, 4)
+        rec[k + "_tflops"] = round(2 * R1 * Kspk * F * P / v / 1e9, 1)
+        rec[k + "_bit_identical"] = bool(torch.equal(outs[k], outs["tall2"]))
+    print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

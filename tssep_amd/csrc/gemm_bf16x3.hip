@@ -1225,14 +1225,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // (280 against 230 at 194 304 x 1280 x 1024; at K = 2400, the default size, this kernel leads 338 to 300)
     const bool aux_remap_short = g->act == 2 && sm.remap && g->K < 1536;
     // persistent big tile (gemm_bf16x3_bigp.hip, round 4): the same tile without the per-tile drain / dispatch / prologue and
-    // with a four times cheaper transposition -- plain / bias / Tanh stores, any K.  profiles/r4_ab_gemm_big_p.jsonl: 5.57
+    // with a four times cheaper transposition -- plain / bias / Tanh stores, also remapped (the logit layer), any K.  profiles/r4_ab_gemm_big_p.jsonl: 5.57
     // against 6.46 ms (big) at 777 216 x 2400 x 513, 3.53 against 4.15 (stream) at K = 320; the shorter fixed part of a tile
     // also pays for more column padding than the tiled kernel's 10 %: N = 600 (768 columns computed) 1.05 against 1.12 ms on
     // the streaming kernel
     const bool pads_to_256_loosely = g->N >= 256 && n256 * 100 <= g->N * 130;
     // (N = 256 q + 1 with M a multiple of 256: q tiles + the VALU column, as in the tiled kernel)
     const int64_t ct_p = xcol_shape ? (g->N - 1) / 256 : n256 / 256;
-    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && (pads_to_256_loosely || (xcol_shape && g->M % 256 == 0)) && !sm.remap && g->act <= 1 && !g->accumulate &&
+    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && (pads_to_256_loosely || (xcol_shape && g->M % 256 == 0 && !sm.remap)) && sm.remap <= 1 && g->act <= 1 && !g->accumulate &&
                                          fills(ct_p, 192) && rounds_ok9(ct_p))) {
       const int rc = tssep_gemm_bf16x3_bigp_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG_P; return rc; }

@@ -50,10 +50,14 @@ struct TileWalk { int step, dq, dr; };
 // computes it -- branch-free -- and those of the last column tile store it.  The twelve registers this takes come from
 // the load offsets: XCOL requires M % 256 == 0, so no row of a tile needs clamping and the sixteen per-piece lane
 // offsets become one per operand plus a scalar row-group offset.
-template <int PROBE, int ACT, bool XCOL>
+// REMAP: the remapped store of gemm_common.h (row m = (b K + k) T + t, column n = q cm + r -> b sb + k sk + t st +
+// perm_b(q) co + r; groups of any size: the logit layer's 513 bins per speaker): a lane's four columns leave as one
+// 16-byte store at a 4-byte-aligned address where they lie in one group, element by element where they straddle two; the
+// permutation entries of the (at most two) utterances of a wave tile are loaded before the tile's first store.
+template <int PROBE, int ACT, bool XCOL, bool REMAP>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull, int64_t K,
-    int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk) {
+    int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk, StoreMap sm) {
   const int64_t N = XCOL ? Nfull - 1 : Nfull;          // columns of the MFMA tiles
   __shared__ __attribute__((aligned(16))) char lds[2 * GSTAGE];
   // the bias, read by the store from LDS: a global load would sit behind the prefetched operand tiles in the in-order
@@ -273,6 +277,42 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     // byte offset of (row h, columns 4 ml ..) from the wave tile's first element; + 2 rows per store
     unsigned voff = ((unsigned)h * (unsigned)ldc + 4u * (unsigned)ml) * 4u;
     const unsigned vstep = (unsigned)ldc * 8u;
+    // REMAP (the whole remapped tensor lies below 2 GB -- the launcher checks --, so float offsets fit 32 bits and the
+    // store is a buffer store on C that out-of-range offsets switch off): this lane's column part for the two utterances
+    // the wave tile's rows can lie in (K T >= 128), its row part for row h of the tile, advanced by two rows per store with
+    // one carry per level.  The four permutation entries are loaded together, before the tile's first store.
+    int cof[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, roff = 0, rt = 0, rk = 0;
+    bool rsecond = false, one = false;
+    const srd_t rsrd = make_srd(C);
+    if constexpr (REMAP) {
+      const unsigned cm = (unsigned)sm.cm, cq0 = (unsigned)n / cm, cr0 = (unsigned)n - cq0 * cm;
+      one = n + 3 < N && cr0 + 3 < cm;
+      const int64_t q0 = mrow0 / sm.T;
+      const int t0 = (int)(mrow0 - q0 * sm.T);
+      const int64_t b0 = q0 / sm.K;
+      const int k0 = (int)(q0 - b0 * sm.K);
+      const int64_t mlast = mrow0 + 127 < M ? mrow0 + 127 : M - 1;
+      const int64_t b1 = mlast / sm.T / sm.K;
+      const unsigned qlast = (unsigned)((N - 1) / sm.cm);          // (lanes beyond N read a valid entry and store nothing)
+      const unsigned qa = cq0 < qlast ? cq0 : qlast, qb = cq0 + 1 < qlast ? cq0 + 1 : qlast;
+      int pg[2][2] = {{(int)qa, (int)qb}, {(int)qa, (int)qb}};      // [utterance][group of the first column, the next group]
+      if (sm.perm) {
+        pg[0][0] = sm.perm[b0 * sm.perm_ld + qa]; pg[0][1] = sm.perm[b0 * sm.perm_ld + qb];
+        pg[1][0] = sm.perm[b1 * sm.perm_ld + qa]; pg[1][1] = sm.perm[b1 * sm.perm_ld + qb];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool wrap = cr0 + q >= cm;
+        const int cr = (int)(cr0 + q) - (wrap ? (int)cm : 0);
+        cof[0][q] = pg[0][wrap ? 1 : 0] * (int)sm.co + cr;
+        cof[1][q] = pg[1][wrap ? 1 : 0] * (int)sm.co + cr;
+      }
+      rt = t0 + h;
+      rk = k0;
+      roff = (int)(b0 * sm.sb + (int64_t)k0 * sm.sk + (int64_t)rt * sm.st);
+      if (rt >= sm.T) { rt -= (int)sm.T; ++rk; roff += (int)(sm.sk - sm.T * sm.st); }
+      if (rk >= sm.K) { rk -= (int)sm.K; rsecond = true; roff += (int)(sm.sb - sm.K * sm.sk); }
+    }
     char* wp = scr + ml * 512;
     const int wsw = ml & 15;
 #pragma unroll
@@ -295,9 +335,25 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
         }
-        const bool ok = ncol_ok && row < mleft;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd, (int)(ok ? voff : GOOR), 0, (PROBE & 32) ? 0 : (PROBE & 64) ? 16 : 2);
-        voff += vstep;
+        if constexpr (!REMAP) {
+          const bool ok = ncol_ok && row < mleft;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd, (int)(ok ? voff : GOOR), 0, (PROBE & 32) ? 0 : (PROBE & 64) ? 16 : 2);
+          voff += vstep;
+        } else {
+          const bool ok = live && row < mleft;
+          const int base = roff + (rsecond ? cof[1][0] : cof[0][0]);
+          // (unconditional, like the plain store: the straight-line count of stores is what the next stage's wait relies on)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrd, (int)(ok && one ? (unsigned)base * 4u : GOOR), 0, 2);
+          if (!one && ok) {      // the lane's four columns straddle two groups or the matrix edge (3 lanes in 513): one by one
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (n + q < N) C[roff + (rsecond ? cof[1][q] : cof[0][q])] = v[q];
+          }
+          rt += 2;
+          roff += 2 * (int)sm.st;
+          if (rt >= sm.T) { rt -= (int)sm.T; ++rk; roff += (int)(sm.sk - sm.T * sm.st); }
+          if (rk >= sm.K) { rk -= (int)sm.K; rsecond = true; roff += (int)(sm.sb - sm.K * sm.sk); }
+        }
         row += 2;
       };
       // plain / bias store: all 64 stores of a tile as straight-line code -- the compiler's count of what is in flight when
@@ -401,17 +457,26 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
 int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call) {
   using namespace gemm_detail;
   void* const stream = call.stream;
-  if (g->a_kmajor || g->b_kmajor || sm.remap || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
+  if (g->a_kmajor || g->b_kmajor || g->splitk > 1 || g->kperiod > 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
+  // the remapped store: groups of >= 4 columns, >= 64 frames, a wave tile's 128 rows within two utterances
+  const bool remap = sm.remap != 0;
+  if (remap) {
+    if (sm.remap != 1 || sm.T < 64 || sm.cm < 4 || sm.K * sm.T < 128) return TSSEP_E_UNSUPPORTED;
+    // 32-bit float offsets into the remapped tensor (buffer stores): its last element below 2 GB
+    const int64_t last = ((g->M - 1) / (sm.T * sm.K)) * sm.sb + (sm.K - 1) * sm.sk + (sm.T - 1) * sm.st + ((g->N - 1) / sm.cm) * sm.co + sm.cm;
+    if (last >= ((int64_t)1 << 29) || sm.sb < 0 || sm.sk < 0 || sm.st < 0 || sm.co < 0) return TSSEP_E_UNSUPPORTED;
+  }
   // bias and the Tanh only: a store that reads (accumulate, the folded Tanh backward's aux operand) keeps the tiled kernel
   // N = 256 q + 1: q tiles + one VALU column, when no row of a tile needs clamping (see the kernel)
-  const bool xcol = g->N > 256 && g->N % 256 == 1;
+  const bool xcol = !remap && g->N > 256 && g->N % 256 == 1;
   if (xcol && ((g->K & 3) || g->K > XROW || g->N > XBIAS || g->M % GM)) return TSSEP_E_UNSUPPORTED;
-  if (g->act > 1 || g->accumulate || g->N > PBIAS || (!xcol && (g->N & 3)) || (sm.ldc & 3) || !aligned16(g->C)) return TSSEP_E_UNSUPPORTED;
+  if (g->act > 1 || g->accumulate || g->N > PBIAS) return TSSEP_E_UNSUPPORTED;
+  if (!remap && ((!xcol && (g->N & 3)) || (sm.ldc & 3) || !aligned16(g->C))) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B)) return TSSEP_E_UNSUPPORTED;
   if (g->M < 4 * GM || g->K < 2 * GBK) return TSSEP_E_UNSUPPORTED;      // (two K stages: the loader's lead)
   // 32-bit buffer offsets: one tile's rows and the whole K extent must stay below 2 GB
   if ((int64_t)GM * g->lda * 4 + g->K * 4 >= (int64_t)1 << 31 || (int64_t)GN * g->ldb * 4 + g->K * 4 >= (int64_t)1 << 31 ||
-      (int64_t)(GM + 2) * sm.ldc * 4 >= (int64_t)1 << 31)
+      (!remap && (int64_t)(GM + 2) * sm.ldc * 4 >= (int64_t)1 << 31))
     return TSSEP_E_UNSUPPORTED;
   if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + GM - 1) / GM, xcol ? (g->N - 1) / GN : (g->N + GN - 1) / GN, 1);
@@ -428,10 +493,11 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   walk.step = grid == nids ? 0 : (int)(grid / NXCD);
   walk.dq = walk.step / tm.NG;
   walk.dr = walk.step % tm.NG;
-#define PLAUNCH1(P_, ACT_, X_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
-                     g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk)
-#define PLAUNCH(P_) do { if (xcol) { if (g->act == 1) PLAUNCH1(P_, 1, true); else PLAUNCH1(P_, 0, true); }      \
-                         else { if (g->act == 1) PLAUNCH1(P_, 1, false); else PLAUNCH1(P_, 0, false); } } while (0)
+#define PLAUNCH1(P_, ACT_, X_, R_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_, R_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
+                     g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk, sm)
+#define PLAUNCH(P_) do { if (remap) { if (g->act == 1) PLAUNCH1(P_, 1, false, true); else PLAUNCH1(P_, 0, false, true); }      \
+                         else if (xcol) { if (g->act == 1) PLAUNCH1(P_, 1, true, false); else PLAUNCH1(P_, 0, true, false); }      \
+                         else { if (g->act == 1) PLAUNCH1(P_, 1, false, false); else PLAUNCH1(P_, 0, false, false); } } while (0)
 #ifdef TSSEP_GEMM_EXP
   {
     const char* pe = getenv("TSSEP_BIGP_PROBE");
