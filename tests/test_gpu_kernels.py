@@ -299,7 +299,9 @@ def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K)
         A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
         W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
         bias = torch.randn(N)
-        Ad, Wd, bd = A.cuda(), W.cuda(), bias.cuda()
+        ldy = ru(N, 4)
+        Y = torch.zeros(M, ldy); Y[:, :N] = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
         ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
         outs = {}
         for mode, kern in (("1", "big_p"), ("0", "tall2")):
@@ -312,10 +314,13 @@ def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K)
                 h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, bias=bd)
                 C3 = torch.full((M, N), float("nan"), device="cuda")
                 h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K)
+                C6 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C6, N, M, N, K, act=2, aux=(Yd, ldy))      # the folded Tanh backward
             h.GEMM_LOG = None
             assert {k for k, *_ in log} == {kern}, log          # the named kernel really ran
-            outs[mode] = (C, C2, C3)
+            outs[mode] = (C, C2, C3, C6)
         p1 = outs["1"]
+        close(p1[3], (ref - bias) * (1 - Y[:, :N] ** 2), rtol=2e-4, atol=2e-4, name="big_p (1 - y^2)")
         close(p1[0][:, :N], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="big_p nt+bias+tanh")
         assert bool(torch.isnan(p1[0][:, N:]).all())
         close(p1[1], ref, rtol=2e-4, atol=2e-4, name="big_p bias")
@@ -358,6 +363,9 @@ def test_gemm_persistent_big_tile_remapped_store(B, T, K, F, P):
         W4 = torch.randn(256 + F4, P, device="cuda") / P ** 0.5       # >= 256 columns: the persistent kernel's tile applies
         b4 = torch.randn(256 + F4, device="cuda")
         N4 = 256 + F4
+        Fa5 = (F + 3) // 4 * 4
+        W5 = torch.randn(K * Fa5, P, device="cuda") / P ** 0.5
+        Y5 = torch.tanh(torch.randn(B * T, K * Fa5, device="cuda"))
         outs = {}
         for kern in ("big_p", "tall2"):
             log = h.GEMM_LOG = []
@@ -369,15 +377,22 @@ def test_gemm_persistent_big_tile_remapped_store(B, T, K, F, P):
                 C4 = torch.full((B, T, K * N4), float("nan"), device="cuda")
                 h.gemm(A4, P, W4, P, C4, 0, B * K * T, N4, P, bias=b4, act=1,
                        remap=dict(T=T, K=K, sb=T * K * N4, sk=N4, st=K * N4))
+                # un-combine with the Tanh backward folded in (dgrad of the layer behind the speaker combination)
+                Fa = (F + 3) // 4 * 4
+                C3 = torch.full((B * K * T, Fa), float("nan"), device="cuda")
+                h.gemm(A, P, W5, P, C3, 0, B * T, K * Fa, P, act=2, aux=(Y5, K * Fa),
+                       remap=dict(T=T, K=1, sb=K * T * Fa, sk=0, st=Fa, cm=Fa, co=T * Fa))
             h.GEMM_LOG = None
             if B * T >= 1024:
                 assert {k for k, *_ in log} == {kern}, log
-            outs[kern] = (C, C4)
+            outs[kern] = (C, C4, C3)
         for a, b in zip(outs["big_p"], outs["tall2"]):
             assert torch.equal(a, b), f"{(a != b).sum().item()} differ"
         close(outs["big_p"][0], ref.float(), rtol=2e-4, atol=2e-4, name="logit remap, persistent kernel")
         ref4 = torch.tanh(A4.double() @ W4.double().t() + b4.double()).view(B, K, T, N4).permute(0, 2, 1, 3).reshape(B, T, K * N4)
         close(outs["big_p"][1], ref4.float(), rtol=2e-4, atol=2e-4, name="combine + tanh, persistent kernel")
+        ref3 = ((A.double() @ W5.double().t()) * (1 - Y5.double() ** 2)).view(B, T, K, Fa5).permute(0, 2, 1, 3).reshape(B * K * T, Fa5)
+        close(outs["big_p"][2], ref3.float(), rtol=2e-4, atol=2e-4, name="un-combine + tanh backward, persistent kernel")
     finally:
         h.GEMM_LOG = None
         h.GEMM_PRECISION = old

@@ -82,6 +82,32 @@ def main():
         rec[k + "_tflops"] = round(2 * R1 * Kspk * F * P / v / 1e9, 1)
         rec[k + "_bit_identical"] = bool(torch.equal(outs[k], outs["tall2"]))
     print(json.dumps(rec), flush=True)
+    # dgrad of birnn2's input: d(gates) x W_ih with the Tanh backward of the layer below folded into the store and the
+    # speaker combination undone ([B T, K 320] -> rows (b, k, t) x 320)
+    hd, G = 320, 2400
+    A = torch.randn(R1, G, device="cuda"); W = torch.randn(Kspk * hd, G, device="cuda") / G ** 0.5
+    Y = torch.tanh(torch.randn(R1, Kspk * hd, device="cuda"))
+    rm = dict(T=T, K=1, sb=Kspk * T * hd, sk=0, st=hd, cm=hd, co=T * hd)
+    outs, calls = {}, {}
+    for kern in ("big_p", "big", "tall4", "tall2"):
+        C = torch.empty(R1 * Kspk, hd, device="cuda")
+
+        def call(kern=kern, C=C):
+            with H.prefer_gemm_kernels(kern):
+                H.gemm(A, G, W, G, C, 0, R1, Kspk * hd, G, act=2, aux=(Y, Kspk * hd), remap=rm)
+
+        log = H.GEMM_LOG = []
+        call()
+        H.GEMM_LOG = None
+        if log[0][0] == kern:
+            outs[kern], calls[kern] = C, call
+    ms = time_calls(calls, 5)
+    rec = dict(name="dgrad birnn2 dx (folded Tanh backward, un-combined)", M=R1, N=Kspk * hd, K=G)
+    for k, v in ms.items():
+        rec[k + "_ms"] = round(v, 4)
+        rec[k + "_tflops"] = round(2 * R1 * Kspk * hd * G / v / 1e9, 1)
+        rec[k + "_bit_identical"] = bool(torch.equal(outs[k], outs["tall2"]))
+    print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

@@ -1232,7 +1232,7 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     const bool pads_to_256_loosely = g->N >= 256 && n256 * 100 <= g->N * 130;
     // (N = 256 q + 1 with M a multiple of 256: q tiles + the VALU column, as in the tiled kernel)
     const int64_t ct_p = xcol_shape ? (g->N - 1) / 256 : n256 / 256;
-    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && (pads_to_256_loosely || (xcol_shape && g->M % 256 == 0 && !sm.remap)) && sm.remap <= 1 && g->act <= 1 && !g->accumulate &&
+    if (gemm_try(call, TSSEP_GEMM_BIG_P, sw.big_p && (pads_to_256_loosely || (xcol_shape && g->M % 256 == 0 && !sm.remap)) && sm.remap <= 1 && !g->accumulate &&
                                          fills(ct_p, 192) && rounds_ok9(ct_p))) {
       const int rc = tssep_gemm_bf16x3_bigp_launch(g, sm, call);
       if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG_P; return rc; }

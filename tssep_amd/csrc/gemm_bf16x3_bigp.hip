@@ -315,6 +315,21 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     }
     char* wp = scr + ml * 512;
     const int wsw = ml & 15;
+    // ACT 2 (the folded Tanh backward, C = acc (1 - y^2)): y of the block after next is requested before a block's stores
+    // -- one in-order counter: a load issued behind stores is only seen complete after them -- into two register sets
+    f32x4 ya[ACT == 2 ? 2 : 1][ACT == 2 ? 16 : 1];
+    const srd_t ysrd = make_srd(ACT == 2 ? sm.aux + mrow0 * sm.ldaux + ncol0 : nullptr);
+    const unsigned yoff = ((unsigned)h * (unsigned)sm.ldaux + 4u * (unsigned)ml) * 4u, ystep = (unsigned)sm.ldaux * 8u;
+    auto load_aux = [&](int i, f32x4 (&dst)[ACT == 2 ? 16 : 1]) __attribute__((always_inline)) {
+      if constexpr (ACT == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool ok = live && n + 3 < N && i * 32 + 2 * r + h < mleft;
+          dst[r] = bload4(ysrd, ok ? yoff + (unsigned)(i * 16 + r) * ystep : GOOR, 0);
+        }
+      }
+    };
+    if constexpr (ACT == 2) { load_aux(0, ya[0]); load_aux(1, ya[1]); }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -334,6 +349,10 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
         if constexpr (ACT == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        }
+        if constexpr (ACT == 2) {
+          const f32x4 y = ya[i & 1][r];
+          v *= 1.f - y * y;
         }
         if constexpr (!REMAP) {
           const bool ok = ncol_ok && row < mleft;
@@ -360,12 +379,15 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
       // the next stage first touches the prefetched operands must reach the counter's limit (`vmcnt(63)`: the sixteen loads
       // and ONE store done); with the stores in a loop it assumed a single trip and waited for half of them.  (The Tanh
       // store keeps the loop: 256 inlined tanhf would not fit the instruction cache.)
-      if constexpr (ACT == 0) {
+      if constexpr (ACT != 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) store_rows(r);
       } else {
 #pragma unroll 2
         for (int r = 0; r < 16; ++r) store_rows(r);
+      }
+      if constexpr (ACT == 2) {
+        if (i + 2 < 4) load_aux(i + 2, ya[i & 1]);
       }
     }
   };
@@ -468,9 +490,11 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   }
   // bias and the Tanh only: a store that reads (accumulate, the folded Tanh backward's aux operand) keeps the tiled kernel
   // N = 256 q + 1: q tiles + one VALU column, when no row of a tile needs clamping (see the kernel)
-  const bool xcol = !remap && g->N > 256 && g->N % 256 == 1;
+  const bool xcol = !remap && g->act != 2 && g->N > 256 && g->N % 256 == 1;
   if (xcol && ((g->K & 3) || g->K > XROW || g->N > XBIAS || g->M % GM)) return TSSEP_E_UNSUPPORTED;
-  if (g->act > 1 || g->accumulate || g->N > PBIAS) return TSSEP_E_UNSUPPORTED;
+  if (g->accumulate || g->N > PBIAS) return TSSEP_E_UNSUPPORTED;
+  // the folded Tanh backward: 16-byte rows of y, a wave tile's 128 rows below 2 GB
+  if (g->act == 2 && (!sm.aux || (sm.ldaux & 3) || !aligned16(sm.aux) || (g->N & 3) || (int64_t)130 * sm.ldaux * 4 >= (int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
   if (!remap && ((!xcol && (g->N & 3)) || (sm.ldc & 3) || !aligned16(g->C))) return TSSEP_E_UNSUPPORTED;
   if ((g->lda & 3) || (g->ldb & 3) || !aligned16(g->A) || !aligned16(g->B)) return TSSEP_E_UNSUPPORTED;
   if (g->M < 4 * GM || g->K < 2 * GBK) return TSSEP_E_UNSUPPORTED;      // (two K stages: the loader's lead)
@@ -495,9 +519,9 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   walk.dr = walk.step % tm.NG;
 #define PLAUNCH1(P_, ACT_, X_, R_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_, R_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk, sm)
-#define PLAUNCH(P_) do { if (remap) { if (g->act == 1) PLAUNCH1(P_, 1, false, true); else PLAUNCH1(P_, 0, false, true); }      \
+#define PLAUNCH(P_) do { if (remap) { if (g->act == 2) PLAUNCH1(P_, 2, false, true); else if (g->act == 1) PLAUNCH1(P_, 1, false, true); else PLAUNCH1(P_, 0, false, true); }      \
                          else if (xcol) { if (g->act == 1) PLAUNCH1(P_, 1, true, false); else PLAUNCH1(P_, 0, true, false); }      \
-                         else { if (g->act == 1) PLAUNCH1(P_, 1, false, false); else PLAUNCH1(P_, 0, false, false); } } while (0)
+                         else { if (g->act == 2) PLAUNCH1(P_, 2, false, false); else if (g->act == 1) PLAUNCH1(P_, 1, false, false); else PLAUNCH1(P_, 0, false, false); } } while (0)
 #ifdef TSSEP_GEMM_EXP
   {
     const char* pe = getenv("TSSEP_BIGP_PROBE");
