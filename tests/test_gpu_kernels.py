@@ -338,6 +338,90 @@ def test_gemm_persistent_big_tile_is_bit_identical_to_the_tiled_kernels(M, N, K)
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 320, 600), (2048 + 37, 320, 2400), (1024, 300, 64), (4096 + 255, 600, 320),
+                                   (3000, 640, 553), (9000, 1280, 65), (60000, 320, 96), (52000, 600, 130)])
+def test_gemm_persistent_320_wide_tile_is_bit_identical_to_the_tiled_kernels(M, N, K):
+    """The 192 x 320 persistent kernel (csrc/gemm_bf16x3_bigp320.hip: wave tiles of 3 x 5 MFMA tiles, generated slot
+    schedule, a 32-row block stored in two passes -- columns 0-127, then 128-159) against fp64, and bit for bit against
+    the tiled kernel ("tall2"): plain, bias, bias + Tanh into padded rows, the folded Tanh backward; K tails, K = 64,
+    ragged last row / column tiles (N = 300, 600), more tiles than CUs, several column tiles (N = 640, 1280)."""
+    torch.manual_seed(7)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4)); A[:, :K] = torch.randn(M, K)
+        W = torch.zeros(N, ru(K, 4)); W[:, :K] = torch.randn(N, K) / K ** 0.5
+        bias = torch.randn(N)
+        Y = torch.tanh(torch.randn(M, N))
+        Ad, Wd, bd, Yd = A.cuda(), W.cuda(), bias.cuda(), Y.cuda()
+        ref = (A[:, :K].double() @ W[:, :K].double().t() + bias.double()).float()
+        outs = {}
+        for kern in ("big_p320", "tall2"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                ldc = N + 8                         # padded rows: the pad columns must stay untouched
+                C = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C, ldc, M, N, K, bias=bd, act=1)
+                C2 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C2, N, M, N, K, bias=bd)
+                C3 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C3, N, M, N, K)
+                C6 = torch.full((M, N), float("nan"), device="cuda")
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C6, N, M, N, K, act=2, aux=(Yd, N))
+            h.GEMM_LOG = None
+            assert {k for k, *_ in log} == {kern}, log          # the named kernel really ran
+            outs[kern] = (C, C2, C3, C6)
+        p1 = outs["big_p320"]
+        close(p1[0][:, :N], torch.tanh(ref), rtol=2e-4, atol=2e-4, name="big_p320 nt+bias+tanh")
+        assert bool(torch.isnan(p1[0][:, N:]).all())
+        close(p1[1], ref, rtol=2e-4, atol=2e-4, name="big_p320 bias")
+        close(p1[2], ref - bias, rtol=2e-4, atol=2e-4, name="big_p320 plain")
+        close(p1[3], (ref - bias) * (1 - Y ** 2), rtol=2e-4, atol=2e-4, name="big_p320 (1 - y^2)")
+        for a, b in zip(outs["big_p320"], outs["tall2"]):
+            assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+        for _ in range(3):
+            C5 = torch.full((M, N), float("nan"), device="cuda")
+            with h.prefer_gemm_kernels("big_p320"):
+                h.gemm(Ad, A.shape[1], Wd, W.shape[1], C5, N, M, N, K)
+            assert torch.equal(C5, outs["tall2"][2])
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
+@pytest.mark.parametrize("B,T,K,F,P", [(5, 253, 4, 320, 600), (64, 253, 4, 320, 64), (3, 100, 4, 600, 96), (9, 96, 2, 300, 128)])
+def test_gemm_persistent_320_wide_tile_speaker_combination(B, T, K, F, P):
+    """The remapped rows of the 192 x 320 kernel: rows (b, k, t) x F -> [B, T, K F] (the speaker combination behind birnn1,
+    net.py:608-611) with the Tanh, bit for bit against the tiled kernel and against fp64; more tiles than CUs."""
+    torch.manual_seed(31)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        A4 = torch.randn(B * K * T, P, device="cuda")
+        W = torch.randn(F, P, device="cuda") / P ** 0.5
+        bias = torch.randn(F, device="cuda")
+        outs = {}
+        for kern in ("big_p320", "tall2"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                C4 = torch.full((B, T, K * F), float("nan"), device="cuda")
+                h.gemm(A4, P, W, P, C4, 0, B * K * T, F, P, bias=bias, act=1,
+                       remap=dict(T=T, K=K, sb=T * K * F, sk=F, st=K * F))
+            h.GEMM_LOG = None
+            if B * K * T >= 1024:
+                assert {k for k, *_ in log} == {kern}, log
+            outs[kern] = C4
+        assert torch.equal(outs["big_p320"], outs["tall2"])
+        ref4 = torch.tanh(A4.double() @ W.double().t() + bias.double()).view(B, K, T, F).permute(0, 2, 1, 3).reshape(B, T, K * F)
+        close(outs["big_p320"], ref4.float(), rtol=2e-4, atol=2e-4, name="combine + tanh, 320-wide persistent kernel")
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("B,T,K,F,P", [(5, 253, 4, 513, 320), (40, 253, 4, 513, 64), (3, 100, 4, 601, 96), (9, 64, 2, 150, 128), (2, 300, 4, 130, 320)])
 def test_gemm_persistent_big_tile_remapped_store(B, T, K, F, P):
     """The remapped store in the persistent big-tile kernel (buffer stores with 32-bit float offsets on the whole tensor,

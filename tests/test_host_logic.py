@@ -99,8 +99,9 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     assert plan(R, 1280, 2400, remap=True) == "big_p"                                # ... also with a remapped store (< 2 GB)
     assert plan(R, 1280, 2400, remap=True, act=1) == "big_p" and plan(4 * R, 5120, 2400, remap=True) == "big"      # (4 GB: 64-bit addresses)
     assert plan(R, 513, 600) == "big_p" and plan(R + 8, 513, 600) == "big"           # pre-net projection: 2 tiles + a VALU column
-    assert plan(4 * R, 320, 600, act=1) == "nt_w160" and plan(4 * R, 320, 600, act=1, remap=True) == "nt_w160"
-    assert plan(4 * R, 600, 320) == "big_p" and plan(4 * R, 1000, 320) == "big_p"    # dgrad proj dh: 768 columns computed for 600
+    # N = 320 (Tanh projections, with and without the speaker combination) and N = 600: the 192 x 320 persistent tile
+    assert plan(4 * R, 320, 600, act=1) == "big_p320" and plan(4 * R, 320, 600, act=1, remap=True) == "big_p320"
+    assert plan(4 * R, 600, 320) == "big_p320" and plan(4 * R, 1000, 320) == "big_p"  # dgrad proj dh: 640 columns computed for 600
     assert plan(4 * R, 780, 320) == "stream"                                         # ... 1024 for 780 is too many
     assert plan(2400, 557, R, wgrad=True, ones=True) == "tn_big"
     assert plan(1200, 300, 4 * R, wgrad=True, shifted=True) == "tn_w160"

@@ -19,7 +19,8 @@ def main():
     shapes = [("pre_net in", R1, 2400, 553, 0), ("birnn0 in", R4, 2400, 513, 0), ("birnn1 in", R4, 2400, 320, 0),
               ("birnn2 in", R1, 2400, 1280, 0), ("dgrad proj dh", R4, 600, 320, 0), ("dgrad proj dh (pre)", R1, 600, 513, 0),
               ("proj 600->256 tanh", R4, 256, 600, 1), ("proj 1200->512 tanh", R1, 512, 600, 1),
-              ("dgrad birnn0 dx", R4, 513, 2400, 0), ("pre_net proj", R1, 513, 600, 0)]
+              ("dgrad birnn0 dx", R4, 513, 2400, 0), ("pre_net proj", R1, 513, 600, 0),
+              ("proj 600->320 tanh", R4, 320, 600, 1), ("proj 1200->320 tanh (pre)", R1, 320, 600, 1)]
     H.GEMM_PRECISION = "bf16x3"
     tot = {}
     for name, M, N, K, act in shapes:
@@ -28,7 +29,7 @@ def main():
         bias = torch.randn(N, device="cuda")
         outs, calls = {}, {}
         probes = [p for p in os.environ.get("AB_BIGP_PROBES", "").split(",") if p]      # (experiment build, TSSEP_HIP_LIB)
-        for kern in ["big_p"] + ["big_p@" + p for p in probes] + ["big", "stream", "tall4", "tall4_xcol", "tall2"]:
+        for kern in ["big_p", "big_p320"] + ["big_p@" + p for p in probes] + ["big", "stream", "nt_w160", "tall4", "tall4_xcol", "tall2"]:
             C = torch.empty(M, H.round_up(N, 4), device="cuda")
             kname, _, probe = kern.partition("@")
 
@@ -82,6 +83,31 @@ def main():
         rec[k + "_tflops"] = round(2 * R1 * Kspk * F * P / v / 1e9, 1)
         rec[k + "_bit_identical"] = bool(torch.equal(outs[k], outs["tall2"]))
     print(json.dumps(rec), flush=True)
+    # dgrad of birnn1's input: d(gates) x W_ih with the Tanh backward folded in, N = 320
+    A = torch.randn(R4, 2400, device="cuda"); W = torch.randn(320, 2400, device="cuda") / 2400 ** 0.5
+    Y = torch.tanh(torch.randn(R4, 320, device="cuda"))
+    outs, calls = {}, {}
+    for kern in ("big_p320", "nt_w160", "big", "tall2"):
+        C = torch.empty(R4, 320, device="cuda")
+
+        def call(kern=kern, C=C):
+            with H.prefer_gemm_kernels(kern):
+                H.gemm(A, 2400, W, 2400, C, 320, R4, 320, 2400, act=2, aux=(Y, 320))
+
+        log = H.GEMM_LOG = []
+        call()
+        H.GEMM_LOG = None
+        if log[0][0] == kern:
+            outs[kern], calls[kern] = C, call
+    ms = time_calls(calls, 5)
+    rec = dict(name="dgrad birnn1 dx (folded Tanh backward)", M=R4, N=320, K=2400)
+    for k, v in ms.items():
+        rec[k + "_ms"] = round(v, 4)
+        rec[k + "_tflops"] = round(2 * R4 * 320 * 2400 / v / 1e9, 1)
+        rec[k + "_bit_identical"] = bool(torch.equal(outs[k], outs["tall2"]))
+    print(json.dumps(rec), flush=True)
+    del A, W, Y, outs, calls
+    torch.cuda.empty_cache()
     # dgrad of birnn2's input: d(gates) x W_ih with the Tanh backward of the layer below folded into the store and the
     # speaker combination undone ([B T, K 320] -> rows (b, k, t) x 320)
     hd, G = 320, 2400

@@ -359,7 +359,7 @@ extern "C" int tssep_gemm_plan(const tssep_gemm_args* g, int32_t force, int32_t*
 
 extern "C" const char* tssep_gemm_kernel_name(int32_t kernel) {
   static const char* const names[] = {"auto", "f32", "pipe", "tall2", "tall4", "tall4_xcol", "big", "stream", "nt_w160",
-                                      "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160", "big_p"};
+                                      "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160", "big_p", "big_p320"};
   return kernel >= 0 && kernel <= TSSEP_GEMM_KERNEL_LAST ? names[kernel] : "?";
 }
 

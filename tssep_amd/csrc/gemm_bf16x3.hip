@@ -1224,6 +1224,17 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
     // un-combining remap reads its aux operand in the unhidden epilogue -- below K = 1536 the eight-wave tiles win
     // (280 against 230 at 194 304 x 1280 x 1024; at K = 2400, the default size, this kernel leads 338 to 300)
     const bool aux_remap_short = g->act == 2 && sm.remap && g->K < 1536;
+    // 192 x 320 persistent tile (gemm_bf16x3_bigp320.hip, round 4) where 320-wide column tiles compute at least 10 % fewer
+    // columns than 256-wide ones (N = 320: the Tanh projections and d(input) of birnn1; N = 600: 640 against 768 columns)
+    {
+      const int64_t n320 = (g->N + 319) / 320 * 320, mt192 = (g->M + 191) / 192;
+      const int64_t t320 = mt192 * (n320 / 320);
+      if (gemm_try(call, TSSEP_GEMM_BIG_P320, sw.big_p320 && n320 * 11 <= n256 * 10 && n320 * 10 <= g->N * 11 && !g->accumulate && sm.remap <= 1 &&
+                                               t320 >= 192 && t320 * 10 >= (t320 + 255) / 256 * 256 * 9)) {
+        const int rc = tssep_gemm_bf16x3_bigp320_launch(g, sm, call);
+        if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_BIG_P320; return rc; }
+      }
+    }
     // persistent big tile (gemm_bf16x3_bigp.hip, round 4): the same tile without the per-tile drain / dispatch / prologue and
     // with a four times cheaper transposition -- plain / bias / Tanh stores, also remapped (the logit layer), any K.  profiles/r4_ab_gemm_big_p.jsonl: 5.57
     // against 6.46 ms (big) at 777 216 x 2400 x 513, 3.53 against 4.15 (stream) at K = 320; the shorter fixed part of a tile

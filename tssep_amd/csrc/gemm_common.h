@@ -472,6 +472,8 @@ int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail:
 int tssep_gemm_bf16x3_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);
 // ... persistent over the tile list, plain / bias / Tanh stores (gemm_bf16x3_bigp.hip)
 int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);
+// ... 192 x 320 tile for N = 320 q (gemm_bf16x3_bigp320.hip)
+int tssep_gemm_bf16x3_bigp320_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, const gemm_detail::GemmCall& call);
 // weight gradients (both operands k-major, no time shift): 512 x 128 tile, 128 x 128 wave tiles, three LDS stages
 // (gemm_bf16x3_tn_big.hip)
 int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);

@@ -14,7 +14,7 @@
 namespace gemm_detail {
 
 struct GemmSwitches {
-  int tall, big, big_p, stream, nt_w160, wide, xcol;      // row x row family
+  int tall, big, big_p, big_p320, stream, nt_w160, wide, xcol;      // row x row family
   int tn, tn_big, tn_w160, tn_h160, tn_tall, tn_xc; // weight-gradient family (tn_tall: 4 = the tuned rule)
   int remap_wide, f32_rows;                         // store variants
   int hack;                                         // timing probes (experiment build only)
@@ -30,6 +30,7 @@ inline GemmSwitches gemm_switches() {
   s.tall = env_int_("TSSEP_GEMM_TALL", 1);
   s.big = env_int_("TSSEP_GEMM_BIG", 1);
   s.big_p = env_int_("TSSEP_GEMM_BIG_P", 1);
+  s.big_p320 = env_int_("TSSEP_GEMM_BIG_P320", 1);
   s.stream = env_int_("TSSEP_GEMM_STREAM", 1);
   s.nt_w160 = env_int_("TSSEP_GEMM_NT_W160", 1);
   s.wide = env_int_("TSSEP_GEMM_WIDE", 1);
@@ -46,7 +47,7 @@ inline GemmSwitches gemm_switches() {
   return s;
 }
 #else
-constexpr GemmSwitches gemm_switches() { return GemmSwitches{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 1, 1, 1, 0}; }
+constexpr GemmSwitches gemm_switches() { return GemmSwitches{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 1, 1, 1, 0}; }
 #endif
 
 // How a launcher is being driven: launch (stream), or answer "would you take this?" without launching.
