@@ -125,7 +125,7 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity_only=False):
+def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity_only=False, parity_batch=4, assert_bars=True):
     """The CPU oracle (a port of the reference's torch code path, pinned to it by tests) timed on
     this host: same model size and chunk length, a bounded sample of `batch` utterances.  Thread
     count: a sweep over {8, 16, 32, 64} (capped at the host's logical CPUs) -- torch's CPU LSTM stops
@@ -136,7 +136,7 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity
     is asserted in this run."""
     from oracle import model as omodel
     torch.manual_seed(0)
-    B = 4                                    # parity sample; the timing sample below is `batch` utterances
+    B = parity_batch                         # parity sample; the timing sample below is `batch` utterances
     obs, aux, tgt = synth_batch(B if parity_only else max(B, batch), K_SPK, N_SAMPLES, 1234)
     timing_x = [torch.as_tensor(a) for a in (obs, aux, tgt)]
     obs, aux, tgt = obs[:B], aux[:B], tgt[:B]
@@ -189,7 +189,7 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity
                       bar_outputs=1e-3, bar_gradients=1e-2)
         # the north star bounds the OUTPUTS (masks / posteriors) at 1e-3; gradients are reported,
         # with the looser smoke-test bound (they carry 253 steps of split-bf16 rounding)
-        assert merr < 1e-3 and lrel < 1e-3 and grel < 1e-2, parity
+        assert not assert_bars or (merr < 1e-3 and lrel < 1e-3 and grel < 1e-2), parity
         for v in p.values():
             v.grad = None
         opt.zero_grad()
@@ -384,7 +384,7 @@ def main():
             name, (n_launch, total_ms) = max(mfma.items(), key=lambda kv: kv[1][1])
             avg_ms = total_ms / n_launch
             ach = H.KERNEL_FLOPS[name] / n_launch / (avg_ms * 1e-3) / 1e12
-            split = name in ("gemm_bf16x3", "blstm_onchip_fwd", "blstm_onchip_bwd")
+            split = name in ("gemm_bf16x3", "gemm_bf16", "blstm_onchip_fwd", "blstm_onchip_bwd")
             peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             alg_bytes = H.KERNEL_BYTES.get(name, 0) // n_launch
             roofline = dict(bound="mfma", kernel=name, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
@@ -522,6 +522,27 @@ def main():
                 two_prod["parity_vs_cpu_oracle"] = cpu_baseline(model, opt, parity_only=True)
         finally:
             H.WGRAD_PRODUCTS = 3
+    plain_bf16 = None
+    if args.gemm == "bf16x3" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3" and gstep is None:
+        # side line for the literal "bf16" of BASELINE configs[2], NOT the headline: the row x row GEMMs on the
+        # persistent kernels with ONE bf16 product per k-step (tssep_gemm_args.precision = 3: operands rounded to bf16, fp32
+        # accumulation), the weight gradients with dY as plain bf16 (precision = 2); recurrences, features, mask head, losses
+        # as in the headline.  Its errors against the CPU oracle are measured here on 8 utterances with the same kernels
+        # forced (at that size the library would pick others) and REPORTED, not held to the headline's bars.
+        H.GEMM_PRECISION = "bf16"
+        try:
+            dt3, T3, med3 = timed_run(args.steps, args.warmup)
+            r3, _ = rooflines(dt3, "bf16")
+            plain_bf16 = dict(value=round(B * T3 * args.steps / dt3, 1), unit="frames/s", ms_per_step=round(dt3 / args.steps * 1e3, 3),
+                              ms_per_step_median=round(med3, 3), steps=args.steps, warmup=args.warmup, dtype="bf16 GEMMs + bf16x3 recurrence",
+                              arithmetic="row x row GEMMs: operands rounded to bf16, one MFMA product, fp32 accumulate; weight gradients: "
+                                         "dY plain bf16, X split-bf16; recurrences split-bf16 as in the headline",
+                              dominant_kernel=r3["kernel"], dominant_tflops=r3["achieved"], dominant_share_of_step=r3["share_of_step"])
+            if not args.no_cpu_baseline:
+                with H.prefer_gemm_kernels("big_p320", "big_p"):
+                    plain_bf16["parity_vs_cpu_oracle"] = cpu_baseline(model, opt, parity_only=True, parity_batch=8, assert_bars=False)
+        finally:
+            H.GEMM_PRECISION = args.gemm
     collective = None
     if world > 1:
         # what the first hardware run of the RCCL path should show at a glance: the collective's own time (HIP
@@ -571,7 +592,7 @@ def main():
                                 "gradients run as GEMMs, the h.W_hh products and their BPTT inside the recurrence kernels")},
             "roofline": roofline, "roofline_mask_head": mask_head,
             "f32_gemms_bf16x3_recurrence": exact, "reference_width": ref_width,
-            "two_product_wgrad": two_prod,
+            "two_product_wgrad": two_prod, "plain_bf16_gemms": plain_bf16,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload == "cfg5")
             else cpu_baseline(model, opt),
         }

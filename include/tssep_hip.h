@@ -179,7 +179,10 @@ typedef struct tssep_gemm_args {
    *     the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
    *     (per-product relative error <= ~2^-16, i.e. fp32-class for the 1e-3 parity bar);
    * 2 = weight gradients only (a_kmajor = b_kmajor = 1): as 1 with the A_lo * B_hi product dropped -- dY enters as
-   *     plain bf16, X keeps hi + lo (opt-in side line of bench.py, never the default). */
+   *     plain bf16, X keeps hi + lo (opt-in side line of bench.py, never the default);
+   * 3 = plain bf16 (opt-in side line, never the default): both operands rounded to bf16, ONE product per k-step, fp32
+   *     accumulation -- in the kernels that have the variant (the persistent row x row kernels TSSEP_GEMM_BIG_P /
+   *     _BIG_P320); every other kernel computes a precision-3 request as precision 1 (at least as accurate). */
   int32_t precision;
   /* k-major B only, precision 1 only: column N-1 of B is VIRTUAL and reads as 1.0 for every valid
    * k, so column N-1 of C holds the column sums of A -- the bias gradient comes out of the

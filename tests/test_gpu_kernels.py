@@ -422,6 +422,51 @@ def test_gemm_persistent_320_wide_tile_speaker_combination(B, T, K, F, P):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("kern,M,N,K", [("big_p", 3000, 1280, 320), ("big_p", 40000, 512, 130), ("big_p", 2048, 513, 600),
+                                        ("big_p320", 3000, 320, 600), ("big_p320", 52000, 600, 130)])
+def test_gemm_plain_bf16_side_line(kern, M, N, K):
+    """tssep_gemm_args.precision = 3 (hip_ops.GEMM_PRECISION = "bf16") on the persistent kernels: operands rounded to bf16
+    (round to nearest even), ONE MFMA product per k-step, fp32 accumulation -- against the same arithmetic spelled out
+    with torch (bf16-rounded operands multiplied in fp64), the Tanh store and the folded Tanh backward included; and the
+    bf16-sized distance to the unrounded product, so that the variant is known to be what runs."""
+    torch.manual_seed(41)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16"
+    try:
+        ru = h.round_up
+        A = torch.zeros(M, ru(K, 4), device="cuda"); A[:, :K] = torch.randn(M, K, device="cuda")
+        W = torch.zeros(N, ru(K, 4), device="cuda"); W[:, :K] = torch.randn(N, K, device="cuda") / K ** 0.5
+        bias = torch.randn(N, device="cuda")
+        ldy = ru(N, 4)
+        Y = torch.zeros(M, ldy, device="cuda"); Y[:, :N] = torch.tanh(torch.randn(M, N, device="cuda"))
+        rb = lambda t: t.bfloat16().double()      # noqa: E731  (bf16 RNE)
+        ref = rb(A[:, :K]) @ rb(W[:, :K]).t()
+        exact = A[:, :K].double() @ W[:, :K].double().t()
+        ldc = ru(N, 4)
+        log = h.GEMM_LOG = []
+        with h.prefer_gemm_kernels(kern):
+            C = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(A, A.shape[1], W, W.shape[1], C, ldc, M, N, K, bias=bias, act=1)
+            C2 = torch.full((M, ldc), float("nan"), device="cuda")
+            h.gemm(A, A.shape[1], W, W.shape[1], C2, ldc, M, N, K)
+            if N % 4 == 0:
+                C3 = torch.full((M, ldc), float("nan"), device="cuda")
+                h.gemm(A, A.shape[1], W, W.shape[1], C3, ldc, M, N, K, act=2, aux=(Y, ldy))
+        h.GEMM_LOG = None
+        assert {k for k, *_ in log} == {kern}, log
+        nm = N - 1 if N % 256 == 1 else N          # (N = 256 q + 1: the last column is the exact-fp32 VALU column)
+        close(C2[:, :nm], ref[:, :nm].float(), rtol=2e-5, atol=2e-5, name="plain bf16: one product of rounded operands")
+        close(C[:, :nm], torch.tanh(ref[:, :nm] + bias[:nm].double()).float(), rtol=2e-5, atol=2e-5, name="plain bf16 + bias + tanh")
+        if N % 4 == 0:
+            close(C3[:, :N], (ref * (1 - Y[:, :N].double() ** 2)).float(), rtol=2e-5, atol=2e-5, name="plain bf16 (1 - y^2)")
+        d = float((C2[:, :nm].double() - exact[:, :nm]).abs().max())
+        assert 2e-4 < d < 5e-2, d                  # a bf16-sized error: the single product really ran
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("B,T,K,F,P", [(5, 253, 4, 513, 320), (40, 253, 4, 513, 64), (3, 100, 4, 601, 96), (9, 64, 2, 150, 128), (2, 300, 4, 130, 320)])
 def test_gemm_persistent_big_tile_remapped_store(B, T, K, F, P):
     """The remapped store in the persistent big-tile kernel (buffer stores with 32-bit float offsets on the whole tensor,

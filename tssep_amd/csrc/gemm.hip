@@ -285,7 +285,7 @@ static int gemm_dispatch(const tssep_gemm_args* g, GemmCall& call) {
   const GemmSwitches sw = gemm_switches();
   StoreMap sm = make_store_map(g);
   if (sm.remap && !sw.remap_wide) sm.remap = 2;      // (experiment build: the 4-byte-per-lane remapped store)
-  if (g->precision == 1 || g->precision == 2) return tssep_gemm_bf16x3_launch(g, sm, splitk, call);
+  if (g->precision >= 1 && g->precision <= 3) return tssep_gemm_bf16x3_launch(g, sm, splitk, call);
   if (g->precision != 0 || g->b_ones_col) return TSSEP_E_UNSUPPORTED;
   if (call.force != TSSEP_GEMM_AUTO && call.force != TSSEP_GEMM_F32) return TSSEP_E_UNSUPPORTED;
   call.chosen = TSSEP_GEMM_F32;

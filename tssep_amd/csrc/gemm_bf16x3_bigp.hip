@@ -54,7 +54,9 @@ struct TileWalk { int step, dq, dr; };
 // perm_b(q) co + r; groups of any size: the logit layer's 513 bins per speaker): a lane's four columns leave as one
 // 16-byte store at a 4-byte-aligned address where they lie in one group, element by element where they straddle two; the
 // permutation entries of the (at most two) utterances of a wave tile are loaded before the tile's first store.
-template <int PROBE, int ACT, bool XCOL, bool REMAP>
+// ONE (tssep_gemm_args.precision = 3, the plain-bf16 side line): operands rounded to bf16, ONE product a_hi b_hi per k-step --
+// the lo planes are neither staged nor read, a stage has 32 MFMAs per wave.
+template <int PROBE, int ACT, bool XCOL, bool REMAP, bool ONE>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull, int64_t K,
     int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk, StoreMap sm) {
@@ -206,21 +208,39 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     const unsigned tmask = load_mask(kt_load);
     if constexpr (XCOL) rx = *reinterpret_cast<const f32x4*>(xrow_s + ((kt_load == 0 ? KT : kt_load) - 1) * GBK + lch * 4);
 #define SB __builtin_amdgcn_sched_barrier(0)
-#define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
-#define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
-#define MMZ(x, y, i, j) if constexpr (FIRST) { const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-                                               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); } else MM(x, y, i, j)
+#define FRAG_RD(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
+#define FRAG(dst, base, i, fo) FRAG_##dst(dst, base, i, fo)
+#define FRAG_ah(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_bh(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_ah1(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_bh1(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_al(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_bl(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_al1(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_bl1(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define MMA(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
+#define MMA0(x, y, i, j) { const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); }
+    // the six products of a stage by operand names; the first one executed starts the tile's accumulators in a FIRST stage
+#define MM(x, y, i, j) MM_##x##_##y(x, y, i, j)
+#define MMZ(x, y, i, j) if constexpr (!ONE) { if constexpr (FIRST) MMA0(x, y, i, j) else MMA(x, y, i, j); }
+#define MM_ah_bl(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah_bh(x, y, i, j) if constexpr (ONE && FIRST) MMA0(x, y, i, j) else MMA(x, y, i, j)
+#define MM_al1_bh1(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah1_bl1(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah1_bh1(x, y, i, j) MMA(x, y, i, j)
     // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
-#define SA1(i) if constexpr (XCOL) XDOT(i); split2n(ra[i][0], ra[i][1], sh0, sl0)
-#define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SPLIT(a_, b_, h_, l_) if constexpr (ONE) h_ = bf16_pair(a_, b_); else split2n(a_, b_, h_, l_)
+#define SA1(i) if constexpr (XCOL) XDOT(i); SPLIT(ra[i][0], ra[i][1], sh0, sl0)
+#define SA2(i) SPLIT(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
-               *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                ra[i] = load_a(i, tmask, so)
-#define SB1(i) split2n(rb[i][0], rb[i][1], sh0, sl0)
-#define SB2(i) split2n(rb[i][2], rb[i][3], sh1, sl1)
+#define SB1(i) SPLIT(rb[i][0], rb[i][1], sh0, sl0)
+#define SB2(i) SPLIT(rb[i][2], rb[i][3], sh1, sl1)
 #define SB3(i) { *reinterpret_cast<u32x2*>(nxt + 2 * GARR + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
-               *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                rb[i] = load_b(i, tmask, so)
 #include "gemm_bf16x3_big_schedule.inc"
 #undef SB3
@@ -229,9 +249,26 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
 #undef SA3
 #undef SA2
 #undef SA1
+#undef SPLIT
+#undef MM_ah1_bh1
+#undef MM_ah1_bl1
+#undef MM_al1_bh1
+#undef MM_ah_bh
+#undef MM_ah_bl
 #undef MMZ
 #undef MM
+#undef MMA0
+#undef MMA
+#undef FRAG_bl1
+#undef FRAG_al1
+#undef FRAG_bl
+#undef FRAG_al
+#undef FRAG_bh1
+#undef FRAG_ah1
+#undef FRAG_bh
+#undef FRAG_ah
 #undef FRAG
+#undef FRAG_RD
 #undef SB
   };
 
@@ -517,8 +554,10 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   walk.step = grid == nids ? 0 : (int)(grid / NXCD);
   walk.dq = walk.step / tm.NG;
   walk.dr = walk.step % tm.NG;
-#define PLAUNCH1(P_, ACT_, X_, R_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_, R_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
+  const bool one = g->precision == 3;      // the plain-bf16 side line
+#define PLAUNCH2(P_, ACT_, X_, R_, O_) hipLaunchKernelGGL((gemm_bf16x3_bigp_kernel<P_, ACT_, X_, R_, O_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk, sm)
+#define PLAUNCH1(P_, ACT_, X_, R_) do { if (one) PLAUNCH2(P_, ACT_, X_, R_, true); else PLAUNCH2(P_, ACT_, X_, R_, false); } while (0)
 #define PLAUNCH(P_) do { if (remap) { if (g->act == 2) PLAUNCH1(P_, 2, false, true); else if (g->act == 1) PLAUNCH1(P_, 1, false, true); else PLAUNCH1(P_, 0, false, true); }      \
                          else if (xcol) { if (g->act == 1) PLAUNCH1(P_, 1, true, false); else PLAUNCH1(P_, 0, true, false); }      \
                          else { if (g->act == 2) PLAUNCH1(P_, 2, false, false); else if (g->act == 1) PLAUNCH1(P_, 1, false, false); else PLAUNCH1(P_, 0, false, false); } } while (0)
@@ -536,5 +575,6 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   PLAUNCH(0);
 #undef PLAUNCH
 #undef PLAUNCH1
+#undef PLAUNCH2
   return tssep_launch_status();
 }

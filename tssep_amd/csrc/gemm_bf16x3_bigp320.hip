@@ -36,7 +36,9 @@ struct TileWalk { int step, dq, dr; };
 
 // ACT: 0 plain / bias, 1 Tanh, 2 the folded Tanh backward (C = acc (1 - y^2), y = sm.aux).  REMAP: row m = (b K + k) T + t
 // -> b sb + k sk + t st, columns unchanged (one group, no permutation), the whole tensor below 2 GB.
-template <int ACT, bool REMAP>
+// ONE (tssep_gemm_args.precision = 3, the plain-bf16 side line): operands rounded to bf16, ONE product a_hi b_hi per k-step --
+// the lo planes are neither staged nor read, a stage has 30 MFMAs per wave.
+template <int ACT, bool REMAP, bool ONE>
 __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp320_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N, int64_t K,
     int64_t lda, int64_t ldb, int64_t ldc, const float* __restrict__ bias, TileMap tmap, TileWalk walk, StoreMap sm) {
@@ -165,21 +167,39 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp320_kernel(
     const int so = kt_load * GBK * 4;
     const unsigned tmask = load_mask(kt_load);
 #define SB __builtin_amdgcn_sched_barrier(0)
-#define FRAG(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
-#define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
-#define MMZ(x, y, i, j) if constexpr (FIRST) { const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
-                                               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); } else MM(x, y, i, j)
+#define FRAG_RD(dst, base, i, fo) dst[i] = *reinterpret_cast<const bf16x8*>(cur + (base) + (i) * 32 * GROWB + (fo))
+#define FRAG(dst, base, i, fo) FRAG_##dst(dst, base, i, fo)
+#define FRAG_ah(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_bh(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_ah1(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_bh1(d, b, i, f) FRAG_RD(d, b, i, f)
+#define FRAG_al(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_bl(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_al1(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define FRAG_bl1(d, b, i, f) if constexpr (!ONE) FRAG_RD(d, b, i, f)
+#define MMA(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], acc[i][j], 0, 0, 0)
+#define MMA0(x, y, i, j) { const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+                           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[i], z16, 0, 0, 0); }
+    // the six products of a stage by operand names; the first one executed starts the tile's accumulators in a FIRST stage
+#define MM(x, y, i, j) MM_##x##_##y(x, y, i, j)
+#define MMZ(x, y, i, j) if constexpr (!ONE) { if constexpr (FIRST) MMA0(x, y, i, j) else MMA(x, y, i, j); }
+#define MM_ah_bl(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah_bh(x, y, i, j) if constexpr (ONE && FIRST) MMA0(x, y, i, j) else MMA(x, y, i, j)
+#define MM_al1_bh1(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah1_bl1(x, y, i, j) if constexpr (!ONE) MMA(x, y, i, j)
+#define MM_ah1_bh1(x, y, i, j) MMA(x, y, i, j)
     // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
-#define SA1(i) split2n(ra[i][0], ra[i][1], sh0, sl0)
-#define SA2(i) split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SPLIT(a_, b_, h_, l_) if constexpr (ONE) h_ = bf16_pair(a_, b_); else split2n(a_, b_, h_, l_)
+#define SA1(i) SPLIT(ra[i][0], ra[i][1], sh0, sl0)
+#define SA2(i) SPLIT(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
-               *reinterpret_cast<u32x2*>(nxt + AR_A + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + AR_A + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                ra[i] = bload4(asrd, aoffs[i] | tmask, so)
-#define SB1(i) split2n(rb[i][0], rb[i][1], sh0, sl0)
-#define SB2(i) split2n(rb[i][2], rb[i][3], sh1, sl1)
+#define SB1(i) SPLIT(rb[i][0], rb[i][1], sh0, sl0)
+#define SB2(i) SPLIT(rb[i][2], rb[i][3], sh1, sl1)
 #define SB3(i) { *reinterpret_cast<u32x2*>(nxt + 2 * AR_A + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
-               *reinterpret_cast<u32x2*>(nxt + 2 * AR_A + AR_B + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + 2 * AR_A + AR_B + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                rb[i] = bload4(bsrd, boffs[i] | tmask, so)
 #include "gemm_bf16x3_bigp320_schedule.inc"
 #undef SB3
@@ -188,9 +208,26 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp320_kernel(
 #undef SA3
 #undef SA2
 #undef SA1
+#undef SPLIT
+#undef MM_ah1_bh1
+#undef MM_ah1_bl1
+#undef MM_al1_bh1
+#undef MM_ah_bh
+#undef MM_ah_bl
 #undef MMZ
 #undef MM
+#undef MMA0
+#undef MMA
+#undef FRAG_bl1
+#undef FRAG_al1
+#undef FRAG_bl
+#undef FRAG_al
+#undef FRAG_bh1
+#undef FRAG_ah1
+#undef FRAG_bh
+#undef FRAG_ah
 #undef FRAG
+#undef FRAG_RD
 #undef SB
   };
 
@@ -407,10 +444,13 @@ int tssep_gemm_bf16x3_bigp320_launch(const tssep_gemm_args* g, const gemm_detail
   walk.step = grid == nids ? 0 : (int)(grid / NXCD);
   walk.dq = walk.step / tm.NG;
   walk.dr = walk.step % tm.NG;
-#define QLAUNCH(ACT_, R_) hipLaunchKernelGGL((gemm_bf16x3_bigp320_kernel<ACT_, R_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
+  const bool one = g->precision == 3;      // the plain-bf16 side line
+#define QLAUNCH2(ACT_, R_, O_) hipLaunchKernelGGL((gemm_bf16x3_bigp320_kernel<ACT_, R_, O_>), dim3((unsigned)grid), dim3(GNT), 0, (hipStream_t)stream, \
                      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, walk, sm)
+#define QLAUNCH(ACT_, R_) do { if (one) QLAUNCH2(ACT_, R_, true); else QLAUNCH2(ACT_, R_, false); } while (0)
   if (remap) { if (g->act == 2) QLAUNCH(2, true); else if (g->act == 1) QLAUNCH(1, true); else QLAUNCH(0, true); }
   else { if (g->act == 2) QLAUNCH(2, false); else if (g->act == 1) QLAUNCH(1, false); else QLAUNCH(0, false); }
+#undef QLAUNCH2
 #undef QLAUNCH
   return tssep_launch_status();
 }

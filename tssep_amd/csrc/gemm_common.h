@@ -461,6 +461,14 @@ __device__ __forceinline__ void split2n(float a, float b, unsigned& hi, unsigned
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// bf16_rne of two values, packed (the single-product side line: precision = 3)
+__device__ __forceinline__ unsigned bf16_pair(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
 }  // namespace gemm_detail
 
 // split-bf16 (bf16x3) family, defined in gemm_bf16x3*.hip.  Every launcher checks what its kernel REQUIRES and returns

@@ -266,7 +266,7 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0, statistics_axis="tf"):
 # bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The recurrence
 # kernel (exact fp32 or split-bf16) is chosen separately by recurrence_kernel().
 GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
-_PREC = {"f32": 0, "bf16x3": 1}
+_PREC = {"f32": 0, "bf16x3": 1, "bf16": 3}      # "bf16": the plain-bf16 side line (tssep_gemm_args.precision = 3)
 
 
 def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, bias=None, act=0,
@@ -408,8 +408,8 @@ def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False,
     ldp = round_up(Nc, 4) if with_colsum else N      # 16-byte rows keep the vector epilogue
     g = _gemm_args(dY, ld_dy, X, ld_x, X, ldp, M, Nc, R, a_kmajor=True, b_kmajor=True, b_kshift=b_kshift,
                    kperiod=kperiod, splitk=8, split_stride=M * ldp, b_ones_col=with_colsum)
-    if WGRAD_PRODUCTS == 2 and GEMM_PRECISION == "bf16x3":
-        g.precision = 2
+    if (WGRAD_PRODUCTS == 2 and GEMM_PRECISION == "bf16x3") or GEMM_PRECISION == "bf16":
+        g.precision = 2      # (the plain-bf16 side line: dY as plain bf16 in the weight gradients, X keeps hi + lo)
     S = splitk
     if not S:
         S = int(_lib.lib().tssep_gemm_wgrad_splits(ctypes.byref(g)))
@@ -425,7 +425,7 @@ def wgrad(dY, ld_dy, X, ld_x, M, N, R, b_kshift=0, kperiod=0, with_colsum=False,
 
 def fused_colsum():
     """Whether weight-gradient GEMMs can also produce the bias gradient (b_ones_col)."""
-    return GEMM_PRECISION == "bf16x3"
+    return GEMM_PRECISION in ("bf16x3", "bf16")
 
 
 def reduce_splits(part, S, count, dst, accumulate=False):
