@@ -84,12 +84,14 @@ class _RNNP(torch.autograd.Function):
         cf = cb = wf3 = wb3 = None
         if "cluster" in (kf, kb):
             cf, cb = H.derived("pack_cluster", [w_hh, w_hh_r], lambda: H.lstm_pack_cluster(w_hh, w_hh_r, Hh))
-        if "onchip" in (kf, kb):
+        # the 32-sequence W-stationary kernels' packed weights only where one of the two directions of time runs on them
+        g16 = H.onchip16_groups(N, Hh, dev) if kf == "onchip" and (2 * Hp) % 4 == 0 and Hp % 4 == 0 else 0
+        g16b = H.onchip16_bwd_groups(N, Hh, dev) if kb == "onchip" and Hp % 4 == 0 else 0
+        if (kf == "onchip" and not g16) or (kb == "onchip" and not g16b):
             wf3, wb3 = H.derived("pack_onchip", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip(w_hh, w_hh_r, Hh))
         if kf == "cluster":
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
         elif kf == "onchip":
-            g16 = H.onchip16_groups(N, Hh, dev) if (2 * Hp) % 4 == 0 and Hp % 4 == 0 else 0
             if g16:      # interleaved 16-sequence groups (round 3)
                 wf16 = H.derived("pack_onchip16", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip16(w_hh, w_hh_r, Hh))
                 H.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16, N, T, Hh, g16)
@@ -99,6 +101,7 @@ class _RNNP(torch.autograd.Function):
             H.blstm_fwd(gates, cell, hout, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
         pk["whh_cb"] = cb if kb == "cluster" else None
         pk["whh_ob"] = wb3 if kb == "onchip" else None
+        pk["bwd_onchip"] = kb == "onchip"
         # projection weight in the (possibly padded) [hdim, 2*Hp] column layout of hout
         wp = H.derived("proj_layout", [w_proj], lambda: _proj_layout(w_proj, Hh, Hp))
         if combine:
@@ -199,7 +202,7 @@ class _RNNP(torch.autograd.Function):
         H.gemm(dz, ld_dz, wpT, ld_t, dhout, 2 * Hp, R, 2 * Hp, hdim)
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
-        elif pk.get("whh_ob") is not None:
+        elif pk.get("bwd_onchip"):
             g16 = H.onchip16_bwd_groups(N, Hh, gates.device) if Hp % 4 == 0 else 0
             if g16:      # interleaved 16-sequence groups (round 3)
                 w_hh, w_hh_r = ctx.params[1], ctx.params[5]
