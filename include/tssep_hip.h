@@ -213,7 +213,8 @@ int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 #define TSSEP_GEMM_TN_H160 13    /* weight gradient, 320 x 128                                                 */
 #define TSSEP_GEMM_BIG_P 14      /* row x row, 256 x 256 persistent: plain / bias / Tanh store hidden behind tiles */
 #define TSSEP_GEMM_BIG_P320 15   /* row x row, 192 x 320 persistent (N = 320 q): plain / bias / Tanh / its backward  */
-#define TSSEP_GEMM_KERNEL_LAST 15
+#define TSSEP_GEMM_TN_P320 16    /* weight gradient, 192 x 320 (N = 320 q, + the ones column)                  */
+#define TSSEP_GEMM_KERNEL_LAST 16
 /* As tssep_gemm_f32, on the kernel named (TSSEP_GEMM_AUTO = tssep_gemm_f32); TSSEP_E_UNSUPPORTED when that
  * kernel does not cover the request. */
 int tssep_gemm_f32_on(const tssep_gemm_args* args, int32_t kernel, void* stream);

@@ -664,6 +664,46 @@ def test_gemm_big_tile_extra_column(M, N, K):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("R,M,N,S,ones", [(4096, 2400, 321, 8, True), (2048, 2052, 320, 1, False), (6400, 1000, 641, 4, True),
+                                          (1024 * 3, 2400, 300, 2, False), (16 * 70, 772, 1281, 1, True), (8192, 2400, 321, 16, True)])
+def test_gemm_wgrad_320_wide_tile_against_the_tn_kernels(R, M, N, S, ones):
+    """The 192 x 320 weight-gradient tile (csrc/gemm_bf16x3_tn_p320.hip: wave tiles of 3 x 5 MFMA tiles, A and B rows in one
+    LDS plane, wave-loads assigned so that every load instruction has one operand) against fp64 and bit for bit against
+    the 128 x 128 tn kernel for the same split count: ragged last row / column tiles, the ones column (column sums of dY,
+    accumulated on the VALU and reduced in a fixed order -- compared with fp64, and bit for bit between two runs), several
+    column tiles, splits shorter than the three-stage pipeline's lead."""
+    torch.manual_seed(13)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        nr = N - 1 if ones else N
+        dY = torch.randn(R, h.round_up(M, 4), device="cuda"); X = torch.full((R, h.round_up(N, 4)), 3.0, device="cuda")
+        X[:, :nr] = torch.randn(R, nr, device="cuda")
+        outs = {}
+        for kern in ("tn_p320", "tn"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, nr, R, with_colsum=ones, splitk=S)
+            h.GEMM_LOG = None
+            assert [k for k, *_ in log] == [kern], log
+            outs[kern] = part.clone()
+        ldp = h.round_up(N, 4) if ones else N
+        a, b = outs["tn_p320"].view(S, M, ldp), outs["tn"].view(S, M, ldp)
+        assert torch.equal(a[:, :, :nr], b[:, :, :nr])
+        got = a.double().sum(0)
+        ref = dY[:, :M].double().t() @ X[:, :nr].double()
+        close(got[:, :nr].float(), ref.float(), rtol=2e-4, atol=3e-3, name="320-wide wgrad")
+        if ones:
+            close(got[:, nr].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="320-wide wgrad column sums")
+            with h.prefer_gemm_kernels("tn_p320"):
+                again = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, nr, R, with_colsum=True, splitk=S)[0]
+            assert torch.equal(again.view(S, M, ldp)[:, :, :N], a[:, :, :N])      # the same bits every run
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("R,M,N,S", [(4096, 2400, 321, 8), (2048, 1024, 130, 1), (6400, 2400, 514, 4), (1024 * 3, 1100, 129, 2),
                                      (16 * 70, 2400, 1281, 1)])
 def test_gemm_wgrad_big_tile_against_the_tn_kernels(R, M, N, S):

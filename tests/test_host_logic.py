@@ -52,7 +52,7 @@ def test_splitk_choice():
     old = H.GEMM_PRECISION
     H.GEMM_PRECISION = "bf16x3"
     try:
-        assert H.pick_splitk(2400, 321, 777216, ones_col=True) == 16 and H.pick_splitk(2400, 514, 777216, ones_col=True) == 24
+        assert H.pick_splitk(2400, 321, 777216, ones_col=True) == 56 and H.pick_splitk(2400, 514, 777216, ones_col=True) == 24      # (N = 320 + 1: the 192 x 320 tile, 13 tiles x 7 slabs = 91 / 96)
         assert H.pick_splitk(2400, 1281, 194304, ones_col=True) == 24
         assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 8               # 25 tiles -> 1 slab (25 / 32)
         # dW_hh: not the big tile (M pads to 1536) but the 256 x 160 one: 10 tiles, two workgroups per CU -> 48 splits
@@ -111,7 +111,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the
     # 160-wide tile, its weight gradient (M = 2052) and the 8-speaker one (4104) on the big weight-gradient tile, one /
     # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
-    assert plan(R, 2052, 320, remap=True) == "big_p" and plan(2052, 320, R, wgrad=True) == "tn_big"
+    assert plan(R, 2052, 320, remap=True) == "big_p" and plan(2052, 320, R, wgrad=True) == "tn_p320"
     assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
     assert plan(4 * R, 256, 1024, act=1) == "big_p" and plan(4 * R, 256, 256, act=1) == "big_p"
     assert plan(R // 2, 4104, 256, remap=True) == "tall2"

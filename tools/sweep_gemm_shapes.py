@@ -206,7 +206,7 @@ def why_slow(d, tfl):
 def sweep(configs, B, reps, out=None, check_bits=True):
     lines = []
     nt_family = ("pipe", "tall2", "tall4", "tall4_xcol", "big", "big_p", "big_p320", "stream", "nt_w160")
-    tn_family = ("pipe", "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160")
+    tn_family = ("pipe", "tn", "tn_tall", "tn_big", "tn_p320", "tn_w160", "tn_h160")
     for units, projs, K in configs:
         m = build(units, projs, K)
         par = parity(m, units, projs, K)

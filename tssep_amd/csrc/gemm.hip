@@ -359,7 +359,7 @@ extern "C" int tssep_gemm_plan(const tssep_gemm_args* g, int32_t force, int32_t*
 
 extern "C" const char* tssep_gemm_kernel_name(int32_t kernel) {
   static const char* const names[] = {"auto", "f32", "pipe", "tall2", "tall4", "tall4_xcol", "big", "stream", "nt_w160",
-                                      "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160", "big_p", "big_p320"};
+                                      "tn", "tn_tall", "tn_big", "tn_w160", "tn_h160", "big_p", "big_p320", "tn_p320"};
   return kernel >= 0 && kernel <= TSSEP_GEMM_KERNEL_LAST ? names[kernel] : "?";
 }
 
@@ -398,6 +398,18 @@ extern "C" int tssep_gemm_wgrad_splits(const tssep_gemm_args* g) {
       const int64_t wg = tiles * (S / 8);
       const double w = (double)rup(wg, 32) / (double)wg;
       if (w < waste) { waste = w; best = S; }
+    }
+    return best;
+  }
+  if (kid == TSSEP_GEMM_TN_P320 && K >= 16 * 64) {
+    // 192 x 320 tiles, ONE workgroup per CU, the tiles of a K slab on one XCD (32 CUs): the multiple of 8 that fills whole
+    // rounds of 32 best (13 tiles: 56 splits = 91 workgroups per XCD in 3 rounds)
+    const int64_t tiles = cdiv(M, 192) * cdiv(N - (g->b_ones_col ? 1 : 0), 320);
+    int best = 8; double waste = 1e30;
+    for (int S = 8; S <= 64 && (int64_t)S * 8 <= ktiles; S += 8) {
+      const int64_t wg = tiles * (S / 8);
+      const double w = (double)rup(wg, 32) / (double)wg;
+      if (w < waste - 1e-9) { waste = w; best = S; }
     }
     return best;
   }

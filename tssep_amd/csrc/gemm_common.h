@@ -485,6 +485,8 @@ int tssep_gemm_bf16x3_bigp320_launch(const tssep_gemm_args* g, const gemm_detail
 // weight gradients (both operands k-major, no time shift): 512 x 128 tile, 128 x 128 wave tiles, three LDS stages
 // (gemm_bf16x3_tn_big.hip)
 int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
+// ... 192 x 320 tile for N = 320 q (+ the ones column), wave tiles of 96 x 160 (gemm_bf16x3_tn_p320.hip)
+int tssep_gemm_bf16x3_tn_p320_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 // (gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_h160.hip)
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);

@@ -15,7 +15,7 @@ namespace gemm_detail {
 
 struct GemmSwitches {
   int tall, big, big_p, big_p320, stream, nt_w160, wide, xcol;      // row x row family
-  int tn, tn_big, tn_w160, tn_h160, tn_tall, tn_xc; // weight-gradient family (tn_tall: 4 = the tuned rule)
+  int tn, tn_big, tn_p320, tn_w160, tn_h160, tn_tall, tn_xc; // weight-gradient family (tn_tall: 4 = the tuned rule)
   int remap_wide, f32_rows;                         // store variants
   int hack;                                         // timing probes (experiment build only)
 };
@@ -37,6 +37,7 @@ inline GemmSwitches gemm_switches() {
   s.xcol = env_int_("TSSEP_GEMM_XCOL", 1);
   s.tn = env_int_("TSSEP_GEMM_TN", 1);
   s.tn_big = env_int_("TSSEP_GEMM_TN_BIG", 1);
+  s.tn_p320 = env_int_("TSSEP_GEMM_TN_P320", 1);
   s.tn_w160 = env_int_("TSSEP_GEMM_TN_W160", 1);
   s.tn_h160 = env_int_("TSSEP_GEMM_TN_H160", 1);
   s.tn_tall = env_int_("TSSEP_GEMM_TN_TALL", 4);
@@ -47,7 +48,7 @@ inline GemmSwitches gemm_switches() {
   return s;
 }
 #else
-constexpr GemmSwitches gemm_switches() { return GemmSwitches{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 1, 1, 1, 0}; }
+constexpr GemmSwitches gemm_switches() { return GemmSwitches{1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 4, 1, 1, 1, 0}; }
 #endif
 
 // How a launcher is being driven: launch (stream), or answer "would you take this?" without launching.

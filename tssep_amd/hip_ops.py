@@ -305,7 +305,7 @@ def _gemm_args(A, lda, B, ldb, C, ldc, M, N, K, a_kmajor=False, b_kmajor=False, 
 # A/B tools may name kernels to be tried first: GEMM_PREFER = ("stream", "tall2") launches the first one of them that
 # covers the request (asked through tssep_gemm_plan) and the library's own choice when none does.
 GEMM_KERNELS = {"auto": 0, "f32": 1, "pipe": 2, "tall2": 3, "tall4": 4, "tall4_xcol": 5, "big": 6, "stream": 7,
-                "nt_w160": 8, "tn": 9, "tn_tall": 10, "tn_big": 11, "tn_w160": 12, "tn_h160": 13, "big_p": 14, "big_p320": 15}
+                "nt_w160": 8, "tn": 9, "tn_tall": 10, "tn_big": 11, "tn_w160": 12, "tn_h160": 13, "big_p": 14, "big_p320": 15, "tn_p320": 16}
 GEMM_KERNEL_NAMES = {v: k for k, v in GEMM_KERNELS.items()}
 GEMM_PREFER = ()
 GEMM_LOG = None          # a list: (kernel name, M, N, K) of every launch is appended (tests)
