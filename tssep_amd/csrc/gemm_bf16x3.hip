@@ -1321,14 +1321,14 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       // rows -> 15 splits; the 256 x 160 tile of dW_hh then has 150 workgroups at most: 54 against 89 TFLOP/s on 128 x 128)
       const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, ((g->K + 15) / 16) / 8));
       auto tn_fills = [&](int64_t tiles) { return tiles * max_splits >= 192; };
-      {   // 192 x 320 tile (gemm_bf16x3_tn_p320.hip, round 4) where it computes at least 15 % less than the 512 x 128 tile:
+      {   // 192 x 320 tile (gemm_bf16x3_tn_p320.hip, round 4) where it computes at least 10 % less than the 512 x 128 tile:
           // N = 320 (+ the ones column) -- dW_ih of birnn1: 2496 x 320 against 2560 x 384, the logit layer's weight gradient
           // (M = 2052): 2112 x 320 against 2560 x 384
         const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
         const int64_t a320 = ((g->M + 191) / 192 * 192) * ((nr + 319) / 320 * 320);
         const int64_t rem = g->N % 128, xcn = (g->N > 128 && rem >= 1 && rem <= 2 && rem - (g->b_ones_col ? 1 : 0) <= 1) ? g->N / 128 * 128 : (g->N + 127) / 128 * 128;
         const int64_t a512 = ((g->M + 511) / 512 * 512) * xcn;
-        if (gemm_try(call, TSSEP_GEMM_TN_P320, sw.tn_p320 && !shift && !two && g->M >= 768 && a320 * 100 <= a512 * 85 &&
+        if (gemm_try(call, TSSEP_GEMM_TN_P320, sw.tn_p320 && !shift && !two && g->M >= 768 && a320 * 100 <= a512 * 90 &&
                                                    tn_fills(((g->M + 191) / 192) * ((nr + 319) / 320)))) {
           const int rc = tssep_gemm_bf16x3_tn_p320_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_P320; return rc; }

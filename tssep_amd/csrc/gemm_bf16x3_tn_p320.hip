@@ -22,6 +22,8 @@
 //    runs q column tiles + the column sums of dY -- accumulated by the A pieces' threads of the LAST column tile's
 //    workgroups in the fixed order of the k rows, reduced through LDS in a fixed order (deterministic);
 //  * same k order and MFMA sequence per output element as the tn kernels: bit-identical for equal split counts.
+// (A time-shifted variant for dW_hh -- M = 1200 pads to 1344 here -- measured 1.96 against the 256 x 160 tile's 2.00 ms at
+// 3 072 sequences and 0.52 against 0.51 at 768: not kept.)
 #include <cstdlib>
 #include <type_traits>
 #include "gemm_common.h"
