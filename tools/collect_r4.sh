@@ -33,6 +33,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 bash tools/pmc_sq.sh > /dev/null 2>&1; cp gpurun_out/pmc_sq/summary.jsonl $O/sq_wave_states.jsonl
 python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null
 python tools/ab_big_p.py 768 > $O/ab_gemm_big_p.jsonl 2>/dev/null
+python tools/ab_tn_p320.py 768 > $O/ab_wgrad_tn_p320.jsonl 2>/dev/null
 python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
 # the store-flavour probe (16 KB and 80 KB per workgroup: 0.47 and 2.34 MB of rewritten lines per XCD)
 for BY in 16384 81920; do
