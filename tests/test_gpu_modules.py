@@ -915,6 +915,56 @@ def test_data_parallel_trainer_two_ranks_on_one_gpu(tmp_path):
     assert len(list((sd / "checkpoints").glob("ckpt_*.pth"))) >= 2         # ckpt_3 + the links, once
 
 
+def test_rccl_communicator_single_rank():
+    """What a one-GPU box can show of the production backend: `nccl` (= RCCL) initialises with the arguments
+    `distributed.init_from_env` passes (device_id, long timeout), the host-side gloo control group is created next to it,
+    and the collectives of the data-parallel step run on it -- the in-place SUM all-reduce of a flat fp32 gradient of the
+    real size on the compute stream (between two kernels of that stream), a parameter broadcast, the MIN / MAX replica
+    check, the int64 control exchange on the gloo group.  One rank: RCCL refuses two ranks per device; the N > 1 logic
+    is covered with gloo (test_distributed.py, the two-rank tests above)."""
+    import socket
+    import subprocess
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    code = textwrap.dedent("""
+        import datetime, os, sys, torch
+        import torch.distributed as dist
+        sys.path.insert(0, %r)
+        from tssep_amd import distributed as D
+        torch.cuda.set_device(0)
+        timeout = datetime.timedelta(seconds=600)
+        dist.init_process_group("nccl", rank=0, world_size=1, timeout=timeout, device_id=torch.device("cuda", 0))
+        D._make_control_group("nccl", timeout)
+        assert D._CONTROL is not None and dist.get_backend() == "nccl"
+        flat = torch.arange(10_850_000, device="cuda", dtype=torch.float32) * 1e-3      # 41 MiB, the K = 4 model's bucket
+        want = flat * 2 + 1
+        flat.mul_(2)                                   # a kernel in front of the collective on the same stream
+        w = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        w.wait()
+        flat.add_(1)                                   # ... and one behind it
+        assert torch.equal(flat, want)
+        p = torch.randn(1000, device="cuda"); q = p.clone()
+        dist.broadcast(p, src=0)
+        assert torch.equal(p, q)
+        stat = torch.stack([p.double().sum(), (p.double() ** 2).sum()])
+        lo, hi = stat.clone(), stat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi)
+        t, group = D._control_tensor([3, 0])
+        assert not t.is_cuda and group is D._CONTROL
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        assert t.tolist() == [3, 0]
+        dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        print("rccl ok")
+    """ % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_bench_default_flags_print_one_json_line():
     """`python bench.py` with its default flags (split-bf16 line + the exact-fp32 secondary line + the rooflines)
     at a small batch: ONE JSON line on stdout with the contract's keys.  (The exact-fp32 leg once crashed on a
