@@ -644,7 +644,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16x3_tall_kernel(
           a = m * sm.ldc + n;
         }
         v += bv;
-        if (act == 1) v = tanhf(v);
+        if (act == 1) v = gemm_tanh(v);
         if (accumulate) v += C[a];
         C[a] = v;
       }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_big_kernel(
           a = m * sm.ldc + n;
         }
         v += bv;
-        if (act == 1) v = tanhf(v);
+        if (act == 1) v = gemm_tanh(v);
         if (act == 2) { const float y = sm.aux[m * sm.ldaux + n]; v *= 1.f - y * y; }
         if (accumulate) v += C[a];
         C[a] = v;

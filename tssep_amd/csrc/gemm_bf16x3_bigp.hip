@@ -295,7 +295,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += bx;
-        if constexpr (ACT == 1) v = tanhf(v);
+        if constexpr (ACT == 1) v = gemm_tanh(v);
         if (live && last_col && lch == 0) C[(m0 + lrow + 32 * i) * ldc + N] = v;
       }
     }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
         v += bv;
         if constexpr (ACT == 1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+          for (int e = 0; e < 4; ++e) v[e] = gemm_tanh(v[e]);
         }
         if constexpr (ACT == 2) {
           const f32x4 y = ya[i & 1][r];
@@ -412,17 +412,11 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
         }
         row += 2;
       };
-      // plain / bias store: all 64 stores of a tile as straight-line code -- the compiler's count of what is in flight when
-      // the next stage first touches the prefetched operands must reach the counter's limit (`vmcnt(63)`: the sixteen loads
-      // and ONE store done); with the stores in a loop it assumed a single trip and waited for half of them.  (The Tanh
-      // store keeps the loop: 256 inlined tanhf would not fit the instruction cache.)
-      if constexpr (ACT != 1) {
+      // all 64 stores of a tile as straight-line code -- the compiler's count of what is in flight when the next stage first
+      // touches the prefetched operands must reach the counter's limit (`vmcnt(63)`: the sixteen loads and ONE store done);
+      // with the stores in a loop it assumed a single trip and waited for half of them
 #pragma unroll
-        for (int r = 0; r < 16; ++r) store_rows(r);
-      } else {
-#pragma unroll 2
-        for (int r = 0; r < 16; ++r) store_rows(r);
-      }
+      for (int r = 0; r < 16; ++r) store_rows(r);
       if constexpr (ACT == 2) {
         if (i + 2 < 4) load_aux(i + 2, ya[i & 1]);
       }

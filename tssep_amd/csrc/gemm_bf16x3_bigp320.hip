@@ -277,7 +277,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp320_kernel(
       v += bv;
       if constexpr (ACT == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+        for (int e = 0; e < 4; ++e) v[e] = gemm_tanh(v[e]);
       }
       if constexpr (ACT == 2) v *= 1.f - y * y;
       return v;
@@ -314,13 +314,8 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp320_kernel(
         v = finish(v, bv1, ya[ACT == 2 ? r : 0]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), csrd, (int)(ok1 && row < mleft ? row_off(row, n1) : GOOR), 0, 2);
       };
-      if constexpr (ACT != 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) store1(r);
-      } else {
-#pragma unroll 2
-        for (int r = 0; r < 16; ++r) store1(r);
-      }
+      for (int r = 0; r < 16; ++r) store1(r);
       // ---- pass 2: columns 128-159 (MFMA tile j = 4): lane (row lane % 32, half h) holds columns 8 q + 4 h .. + 3
 #pragma unroll
       for (int q = 0; q < 4; ++q)
