@@ -157,7 +157,8 @@ typedef struct tssep_gemm_args {
   int64_t b_kshift, kperiod;
   /* epilogue */
   const float* bias;              /* [N] added to every row; NULL = off */
-  int32_t act;                    /* 0 none, 1 tanh (Tanh between post-net layers, net.py:623-625),
+  int32_t act;                    /* 0 none, 1 tanh (Tanh between post-net layers, net.py:623-625; computed as
+                                   * 1 - 2 / (1 + e^2x) on the hardware exp / rcp: absolute error <= 3e-7),
                                    * 2 multiply by 1 - aux^2: the BACKWARD of that Tanh folded into the store of
                                    * the d(input) GEMM of the layer that consumed its output (aux = that input) */
   int32_t accumulate;             /* C += result */
