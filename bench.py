@@ -176,8 +176,8 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity
         opt.bucket.sync()
         torch.cuda.synchronize()
         _, o = one_step(keep=True)
-        merr = float((out.mask.detach().cpu() - o["mask"]).abs().max())
-        lrel = abs(float(loss) - float(o["loss"].sum())) / max(abs(float(o["loss"].sum())), 1e-12)
+        merr = float((out.mask.detach().cpu() - o["mask"].detach()).abs().max())
+        lrel = abs(float(loss.detach()) - float(o["loss"].sum().detach())) / max(abs(float(o["loss"].sum().detach())), 1e-12)
         gerrs = {k: float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max()
                           / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
                  for k, v in hip_model.mask_estimator.named_parameters()}
@@ -186,6 +186,7 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity
         parity = dict(sample=f"batch {B} x 4 s, same weights, same np.random seed", max_abs_mask_err=merr,
                       rel_loss_err=lrel, max_rel_grad_err=grel, worst_gradient=worst,
                       median_rel_grad_err=float(np.median(list(gerrs.values()))),
+                      worst_five={k: float(f"{gerrs[k]:.3g}") for k in sorted(gerrs, key=gerrs.get, reverse=True)[:5]},
                       bar_outputs=1e-3, bar_gradients=1e-2)
         # the north star bounds the OUTPUTS (masks / posteriors) at 1e-3; gradients are reported,
         # with the looser smoke-test bound (they carry 253 steps of split-bf16 rounding)
