@@ -53,12 +53,19 @@ template <bool TWO, int XC>
 __global__ __launch_bounds__(WNT, 1) void gemm_bf16x3_tn_big_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
     int64_t K, int64_t lda, int64_t ldb, int accumulate, int64_t ldc, int splitk, int64_t c_split_stride,
-    TileMap tmap, int b_ones_col) {
+    TileMap tmap, int b_ones_col, int slow_first) {
   __shared__ __attribute__((aligned(16))) char lds[3 * WSTAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int mt, nt, zsplit;
   if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  if (XC > 0 && slow_first) {
+    // the workgroups of the last column tile carry the VALU columns and run ~10 % longer: they take the FIRST ids, so
+    // that a launch of more than one round of workgroups ends on the short ones (split index fastest, as in the map)
+    const int tile = mt * tmap.NT + nt;
+    if (tile < tmap.MT) { mt = tile; nt = tmap.NT - 1; }
+    else { mt = (tile - tmap.MT) / (tmap.NT - 1); nt = (tile - tmap.MT) % (tmap.NT - 1); }
+  }
   const int64_t m0 = (int64_t)mt * WM, n0 = (int64_t)nt * WN;
   const int64_t ktiles = K / WBK;
   const int64_t per = (ktiles + splitk - 1) / splitk;
@@ -349,8 +356,9 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
   if (gemm_switches().tn_xc && g->N > WN && rem >= 1 && rem <= 2 && rem - ones <= 1)
     xc = 10 * (rem - ones) + ones;
   const TileMap tm = make_tile_map((g->M + WM - 1) / WM, xc ? g->N / WN : (g->N + WN - 1) / WN, splitk);
+  const int slow_first = splitk > 1 && tm.NT > 1 && gemm_switches().hack != 7;
 #define TNB_LAUNCH(TW, XC_) hipLaunchKernelGGL((gemm_bf16x3_tn_big_kernel<TW, XC_>), dim3((unsigned)tile_map_blocks(tm)), dim3(WNT), 0, \
-      (hipStream_t)stream, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, g->b_ones_col)
+      (hipStream_t)stream, g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, g->b_ones_col, slow_first)
 #define TNB_XC(TW) do { if (xc == 11) TNB_LAUNCH(TW, 11); else if (xc == 10) TNB_LAUNCH(TW, 10); else if (xc == 1) TNB_LAUNCH(TW, 1); \
                         else TNB_LAUNCH(TW, 0); } while (0)
   if (two) TNB_XC(true); else TNB_XC(false);
