@@ -823,6 +823,22 @@ def test_graphed_step_replays_the_eager_step(units):
     opt.zero_grad()
     l3e = float(m.review(dict(ex3), m(dict(ex3)))["loss"])
     assert l3 == pytest.approx(l3e, rel=1e-6) and abs(l3 - ref5[0]) > 1e-4
+    # the weight packs / transposes are built INSIDE the graph (as a branch at its start: hip_ops.prepare_derived) from
+    # the weights of the moment: after optimizer steps a replay still equals the eager step
+    assert H.PREPARED_HITS > 0
+    for _ in range(3):
+        np.random.seed(5)
+        g(dict(ex))
+        opt.step()
+    ref7 = eager(7)
+    assert abs(ref7[0] - ref5[0]) > 1e-6 * abs(ref5[0])           # the weights did move
+    np.random.seed(7)
+    out7, s7 = g(dict(ex))
+    torch.cuda.synchronize()
+    assert float(s7["loss"]) == pytest.approx(ref7[0], rel=1e-6)
+    close(out7.mask, ref7[1].detach().cpu().numpy(), rtol=1e-5, atol=1e-6, name="mask after optimizer steps")
+    assert float((opt.bucket.flat - ref7[2]).abs().max()) <= 1e-5 * float(ref7[2].abs().max())
+    H.check_cluster_errors("cuda")
 
 
 def test_fused_tail_equals_materialised_chain():

@@ -198,7 +198,9 @@ class _RNNP(torch.autograd.Function):
             d_w_proj, d_b_proj = proj_wgrads()
         # ---- critical path: dhout, BPTT (gates <- d pre-activations)
         dhout = torch.empty(R, 2 * Hp, device=dev, dtype=torch.float32)
-        wpT, ld_t = H.derived("proj_T", [params[8]], lambda: H.transposed(wp, hdim, 2 * Hp))
+        w_proj = params[8]      # (the builds read the parameters, not this step's tensors: hip_ops.prepare_derived)
+        wpT, ld_t = H.derived("proj_T", [w_proj], lambda: H.transposed(
+            H.derived("proj_layout", [w_proj], lambda: _proj_layout(w_proj, Hh, Hp)), hdim, 2 * Hp))
         H.gemm(dz, ld_dz, wpT, ld_t, dhout, 2 * Hp, R, 2 * Hp, hdim)
         if pk.get("whh_cb") is not None:
             H.blstm_cluster_bwd(gates, cell, dhout, 2 * Hp, Hp, pk["whh_cb"], N, T, Hh)
@@ -254,8 +256,12 @@ class _RNNP(torch.autograd.Function):
             lstm_grads = lstm_wgrads()
         dx = None
         if ctx.needs_input_grad[0]:
-            wihT, ld_t = H.derived("wih_T", [params[0], params[4]],
-                                   lambda: H.transposed(pk["wih_p"].view(G, pk["ld_i"]), G, I))
+            lstm_params = list(params[:8])
+
+            def wih_t():
+                pk_ = H.derived("lstm_pack", lstm_params, lambda: H.lstm_pack(lstm_params, Hh, I))
+                return H.transposed(pk_["wih_p"].view(G, pk_["ld_i"]), G, I)
+            wihT, ld_t = H.derived("wih_T", [params[0], params[4]], wih_t)
             if in_tanh and not in_link.observed():
                 # my input is a Tanh output: its backward rides on this GEMM's store and the result travels on
                 # the link; x receives a dummy (its true gradient is never formed -- hence not when it is watched)
@@ -424,7 +430,8 @@ class _Head(torch.autograd.Function):
             H.reduce_splits(part, S, Nout * P, dw)
             db = H.colsum(dv, ld_d, R, Nout)
         dxb, ld_dx = H.padded(R, P, dev, zero=True)
-        wvT, ld_t = H.derived("head_T", [ctx.params[0]], lambda: H.transposed(wv, Nout, P))
+        weight = ctx.params[0]
+        wvT, ld_t = H.derived("head_T", [weight], lambda: H.transposed(H.rows_view(weight.detach())[0], Nout, P))
         H.gemm(dv, ld_d, wvT, ld_t, dxb, ld_dx, R, P, Nout)
         dx = dxb[:, :P]
         if tuple(ctx.x_shape) != tuple(dx.shape):

@@ -4,6 +4,7 @@ PyTorch is used for device memory and the current HIP stream only; every computa
 is a call into libtssep_hip.so.  Nothing here falls back to ATen math.
 """
 import ctypes
+import itertools
 import math
 import os as _os
 
@@ -468,11 +469,33 @@ def weights_changed():
     WEIGHTS_VERSION += 1
 
 
+_BUILDER_SEQ = itertools.count()      # order of first use: a build may read what an earlier one made
+_PREPARED = None                      # while a step is being captured: (id(params[0]), tag) -> (event, value, stream, waiters)
+PREPARED_HITS = 0                     # layouts handed out from there (tests)
+PREPARE_DERIVED = True                # False: every layout is built where it is first used (A/B, tools)
+
+
 def derived(tag, params, build):
     """build() -> any structure of tensors derived from `params`; memoised until a parameter changes.
     The memo lives ON the first parameter object (it dies with the module: a recycled device address of
     another model can never hit it) and is stamped with every parameter's address and version, the global
-    update counter and the stream it was built on."""
+    update counter and the stream it was built on.  A `build` must reach everything it reads THROUGH the
+    parameters (or through `derived` again): `prepare_derived` calls it at the start of a later step."""
+    key = (id(params[0]), tag)
+    if _PREPARED is not None:
+        hit = _PREPARED.get(key)
+        if hit is not None:
+            global PREPARED_HITS
+            PREPARED_HITS += 1
+            ev, val, built_on, waited = hit
+            cur = torch.cuda.current_stream().cuda_stream
+            if cur != built_on and cur not in waited:      # (never a stream on its own event, never twice: one edge each)
+                torch.cuda.current_stream().wait_event(ev)
+                waited.add(cur)
+            return val
+    builders = params[0].__dict__.setdefault("_tssep_builders", {})      # on the parameter, like the memo below
+    if tag not in builders:
+        builders[tag] = (next(_BUILDER_SEQ), build)
     if torch.cuda.is_current_stream_capturing():
         return build()
     memo = params[0].__dict__.setdefault("_tssep_derived", {})
@@ -484,6 +507,47 @@ def derived(tag, params, build):
     val = build()
     memo[tag] = (stamp, val)
     return val
+
+
+class prepare_derived:
+    """Context of ONE step that is being captured into a hipGraph (train/graph.py): the derived weight layouts the
+    previous (warm-up) steps asked for -- gate / projection packs, the W-stationary packs, the dgrad transposes; functions
+    of the parameters only -- are built at the START of the step on the side stream, as a branch of the graph beside the
+    STFT / feature kernels, instead of one small kernel after the other in front of the recurrences they feed
+    (8 utterances per GPU: ~25 launches of 4-20 us, 0.2 ms of a 7.8-ms step).  `derived` hands out the prepared value
+    after making the consumer's stream wait for the event behind it.  Outside a capture the memo above does the job."""
+
+    def __init__(self, parameters, device):
+        self.builds = sorted((seq, id(p), tag, build) for p in parameters
+                             for tag, (seq, build) in p.__dict__.get("_tssep_builders", {}).items())
+        self.device = device
+
+    def __enter__(self):
+        global _PREPARED
+        assert _PREPARED is None
+        main = torch.cuda.current_stream(self.device)
+        side = side_stream(self.device)
+        if side is main or not PREPARE_DERIVED or not torch.cuda.is_current_stream_capturing():
+            return self
+        prepared = {}
+        side.wait_stream(main)
+        _PREPARED = prepared            # builds that go through `derived` again find what is already there
+        try:
+            with torch.cuda.stream(side):
+                for _, pid, tag, build in self.builds:
+                    val = build()
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    prepared[(pid, tag)] = (ev, val, side.cuda_stream, set())
+        except BaseException:
+            _PREPARED = None
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        global _PREPARED
+        _PREPARED = None
+        return False
 
 
 # ------------------------------------------------------------------------------ BLSTM

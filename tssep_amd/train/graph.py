@@ -18,6 +18,9 @@ What would otherwise be frozen into the graph is routed through device memory:
     (``MaskEstimator_v2.permutation_source``);
   * the W-stationary recurrences take their launch epoch from device memory (csrc/common.h);
   * inputs live in static device tensors (a batch that already IS the static tensor is not copied).
+
+The derived weight layouts (packs, transposes: ~25 small launches) are built at the start of the captured step on the
+weight-gradient stream, beside the STFT / feature kernels, not in front of each recurrence (``hip_ops.prepare_derived``).
 """
 import numpy as np
 import torch
@@ -48,9 +51,11 @@ class GraphedStep:
 
     def _eager(self, ex):
         self.optimizer.zero_grad()
-        out = self.model(ex)
-        summary = self.model.review(ex, out)
-        summary["loss"].backward()
+        # (while capturing: the weight packs / transposes of the whole step as a branch of the graph, hip_ops.py)
+        with H.prepare_derived(list(self.model.parameters()), next(self.model.parameters()).device):
+            out = self.model(ex)
+            summary = self.model.review(ex, out)
+            summary["loss"].backward()
         self.optimizer.bucket.sync()
         return out, summary
 
