@@ -93,7 +93,11 @@ def _worker(rank, world, port, q):
     lin(x[lo:hi]).abs().sum().backward()          # loss summed over the shard
     bucket.all_reduce()
     # (numpy, not torch: a tensor travels through the queue as a shared-memory handle that dies with this process)
-    q.put((rank, bucket.flat.detach().numpy().copy(), float(bucket.global_norm())))
+    # (the flat buffer lays every tensor on a 256-byte boundary with zero gaps: compare the tensors, check the gaps)
+    grads = torch.cat([p_.grad.flatten() for p_ in bucket.params])
+    assert abs(float(bucket.flat.abs().sum()) - float(grads.abs().sum())) <= 1e-5 * float(grads.abs().sum())
+    assert all((p_.grad.data_ptr() - bucket.flat.data_ptr()) % 256 == 0 for p_ in bucket.params)
+    q.put((rank, grads.detach().numpy().copy(), float(bucket.global_norm())))
     dist.destroy_process_group()
 
 
@@ -180,7 +184,7 @@ def _model_worker(rank, world, port, q):
     loss = _oracle_loss(p, obs, aux, tgt)
     loss.backward()
     bucket.all_reduce()
-    q.put((rank, bucket.flat.detach().numpy().copy(), float(loss)))
+    q.put((rank, torch.cat([p_.grad.flatten() for p_ in bucket.params]).detach().numpy().copy(), float(loss)))
     dist.destroy_process_group()
 
 

@@ -7,7 +7,7 @@ import torch
 
 from .. import _lib
 from ..configurable import Configurable
-from ..distributed import GradBucket
+from ..distributed import GradBucket, flat_offsets
 
 
 class Adam(Configurable):
@@ -27,13 +27,11 @@ class Adam(Configurable):
         state_dict are unchanged) and attach a flat gradient bucket."""
         params = [p for p in parameters if p.requires_grad]
         dev = params[0].device
-        n = sum(p.numel() for p in params)
-        self.flat_param = torch.empty(n, device=dev, dtype=torch.float32)
-        off = 0
-        for p in params:
+        offsets, n = flat_offsets(params)      # the gradient bucket's layout: 256-byte aligned tensors, zero gaps
+        self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, off in zip(params, offsets):
             self.flat_param[off:off + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + p.numel()].view_as(p)
-            off += p.numel()
         self.params = params
         from .. import hip_ops
         hip_ops.weights_changed()
