@@ -520,6 +520,50 @@ def test_fused_adam_matches_torch_adam_with_clipping():
             close(p, q, rtol=1e-4, atol=1e-6, name=f"param after step {it}")
 
 
+def test_optimizer_state_survives_a_checkpoint_round_trip():
+    """Adam.state_dict / load_state_dict carry the moments per parameter (the flat buffers pad every tensor to a 256-byte
+    boundary: distributed.flat_offsets): a second optimizer over a copy of the model continues bit for bit after loading,
+    also from the single unpadded flat tensor that checkpoints written before the aligned layout hold; the weights sit
+    on 256-byte boundaries and the gaps of every flat buffer stay zero."""
+    from tssep_amd.train.optimizer import Adam
+    torch.manual_seed(1)
+    a = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).cuda()
+    b = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).cuda()
+    c = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).cuda()
+    oa = Adam(gradient_clipping=0.5, lr=1e-2)
+    oa.set_parameters(a.parameters())
+    xs = [torch.randn(64, 33, device="cuda") for _ in range(4)]
+
+    def step(m, o, x):
+        o.zero_grad()
+        m(x).pow(2).sum().backward()
+        o.step()
+
+    for x in xs[:2]:
+        step(a, oa, x)
+    assert all(p.data_ptr() % 256 == 0 and p.grad.data_ptr() % 256 == 0 for p in a.parameters())
+    used = sum(p.numel() for p in a.parameters())
+    assert oa.flat_param.numel() > used
+    sd = oa.state_dict()
+    legacy = dict(step=sd["step"], exp_avg=torch.cat([t.reshape(-1) for t in sd["exp_avg"]]),
+                  exp_avg_sq=torch.cat([t.reshape(-1) for t in sd["exp_avg_sq"]]))
+    for m, state in ((b, sd), (c, legacy)):
+        m.load_state_dict(a.state_dict())
+        o = Adam(gradient_clipping=0.5, lr=1e-2)
+        o.set_parameters(m.parameters())
+        o.load_state_dict(state)
+        m._opt = o
+    for x in xs[2:]:
+        step(a, oa, x)
+        step(b, b._opt, x)
+        step(c, c._opt, x)
+    for p, q, r in zip(a.parameters(), b.parameters(), c.parameters()):
+        assert torch.equal(p, q) and torch.equal(p, r)
+    for flat in (oa.flat_param, oa.exp_avg, oa.exp_avg_sq, oa.bucket.flat):      # the gaps never move
+        assert float(flat.abs().sum()) == pytest.approx(
+            float(sum(t.abs().sum() for t in oa._per_parameter(flat))), rel=1e-6)
+
+
 def test_toy_experiments_tsvad_then_tssep(tmp_path):
     """BASELINE configs[0]/[1]: the toy TS-VAD run (8 speakers, 2 averaged permutations), then TS-SEP
     initialised from its checkpoint, each as the reference's two child processes -- ``init with ...`` then

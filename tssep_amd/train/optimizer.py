@@ -33,6 +33,7 @@ class Adam(Configurable):
             self.flat_param[off:off + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.flat_param[off:off + p.numel()].view_as(p)
         self.params = params
+        self._offsets = offsets
         from .. import hip_ops
         hip_ops.weights_changed()
         self.bucket = GradBucket(params)
@@ -70,10 +71,22 @@ class Adam(Configurable):
         hip_ops.weights_changed()            # derived weight layouts (packs, transposes) are stale now
         return self.grad_norm
 
+    def _per_parameter(self, flat):
+        return [flat[off:off + p.numel()] for p, off in zip(self.params, self._offsets)]
+
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu())
+        """Moments per parameter, in parameter order (independent of the padding of the flat buffers)."""
+        return dict(step=self.step_count, exp_avg=[t.cpu().clone() for t in self._per_parameter(self.exp_avg)],
+                    exp_avg_sq=[t.cpu().clone() for t in self._per_parameter(self.exp_avg_sq)])
 
     def load_state_dict(self, sd):
         self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            src = sd[key]
+            if torch.is_tensor(src):      # checkpoints written before the aligned layout: one unpadded flat tensor
+                sizes = [p.numel() for p in self.params]
+                assert src.numel() == sum(sizes), (src.numel(), sum(sizes))
+                src = list(torch.split(src.reshape(-1), sizes))
+            assert len(src) == len(self.params), (len(src), len(self.params))
+            for dst, t in zip(self._per_parameter(flat), src):
+                dst.copy_(t.reshape(-1))
