@@ -39,7 +39,7 @@ def run(verbose=True):
                             cfg=dict(odim=513, combination="mul", ts_vad=K, output_resolution="tf"),
                             fast=True)
     o["loss"].sum().backward()
-    merr = float((out.mask.detach().cpu() - o["mask"]).abs().max())
+    merr = float((out.mask.detach().cpu() - o["mask"].detach()).abs().max())
     lerr = abs(float(summary["loss"]) - float(o["loss"].sum()))
     gerr = max(float((v.grad.cpu() - p["mask_estimator." + k].grad).abs().max()
                      / (p["mask_estimator." + k].grad.abs().max() + 1e-12))
