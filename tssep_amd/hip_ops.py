@@ -90,11 +90,12 @@ def rows_view(t):
     return buf, ld
 
 
-def padded(rows, cols, device, zero=False):
-    """[rows, cols] view of a buffer with leading dimension round_up(cols, 4)."""
+def padded(rows, cols, device, zero=True):
+    """[rows, cols] view of a buffer with leading dimension round_up(cols, 4).  zero: the pad columns get a defined
+    value here (consumers read whole 16-byte groups); False where the producer writes them itself."""
     ld = round_up(cols, 4)
     buf = torch.empty(rows, ld, device=device, dtype=torch.float32)
-    if ld != cols:            # only the pad columns need a defined value (the producers write the rest)
+    if zero and ld != cols:   # only the pad columns (the producers write the rest)
         buf[:, cols:].zero_()
     return buf, ld
 
@@ -858,7 +859,10 @@ def cond_fwd(pre, ld_pre, aux, B, K, T, F, trials, combination):
     aux2, ld_aux = rows_view(aux)
     E = aux.shape[-1]
     W = F if combination == "mul" else F + E
-    xs, ld = padded(B * trials * K * T, W, pre.device, zero=True)
+    # (the 16-byte path of cond_mul_fwd_kernel writes the pad columns itself: products of the inputs' zero pads)
+    writes_pads = combination == "mul" and F <= 1024 and ld_pre % 4 == 0 and ld_pre >= round_up(F, 4) \
+        and pre.data_ptr() % 16 == 0 and aux2.data_ptr() % 16 == 0
+    xs, ld = padded(B * trials * K * T, W, pre.device, zero=not writes_pads)
     if combination == "mul":
         assert E == F, (E, F)
         check(L.tssep_cond_mul_fwd(_p(pre), ld_pre, _p(aux2), ld_aux, _p(xs), ld, B, K, T, F,
@@ -871,8 +875,11 @@ def cond_fwd(pre, ld_pre, aux, B, K, T, F, trials, combination):
 
 def cond_bwd(dxs, ld_dxs, auxinfo, B, K, T, F, trials, combination):
     L = _lib.lib()
-    dpre, ld = padded(B * T, F, dxs.device, zero=True)
     aux2, ld_aux = auxinfo
+    # (cond_mul_bwd_v4_kernel sums the pad columns too: zero in both inputs)
+    writes_pads = combination == "mul" and ld_dxs % 4 == 0 and ld_dxs >= round_up(F, 4) and dxs.data_ptr() % 16 == 0 \
+        and aux2.data_ptr() % 16 == 0
+    dpre, ld = padded(B * T, F, dxs.device, zero=not writes_pads)
     if combination == "mul":
         check(L.tssep_cond_mul_bwd(_p(dxs), ld_dxs, _p(aux2), ld_aux, _p(dpre), ld, B, K, T, F,
                                    trials, _stream()), "cond_mul_bwd")
