@@ -1373,7 +1373,13 @@ def test_conditioning_tanh_colsum():
     aux = torch.rand(B, K, F)
     idx = ((np.arange(K)[:, None] + np.arange(K)[None, :]) % K)[:trials].ravel()
     for comb, a in (("mul", aux), ("cat", torch.rand(B, K, E))):
+        # (poison the allocator's free blocks: where cond_fwd / cond_bwd leave the pad columns of their outputs to the
+        # 16-byte kernels, those must have written them -- the GEMMs behind read whole 16-byte groups)
+        poison = [torch.full((n,), float("nan"), device="cuda") for n in (B * trials * K * T * 12, B * T * 12, 4096)]
+        del poison
         xs, ld, info = h.cond_fwd(pre_p.cuda(), 12, a.cuda(), B, K, T, F, trials, comb)
+        Wc = F if comb == "mul" else F + E
+        assert xs.shape[1] == ld > Wc and bool(torch.isfinite(xs).all()) and float(xs[:, Wc:].abs().max()) == 0.0
         p4 = pre.view(B, 1, T, F)
         full = p4 * a[:, :, None] if comb == "mul" else torch.cat(
             [p4.expand(B, K, T, F), a[:, :, None].expand(B, K, T, a.shape[-1])], -1)
@@ -1381,7 +1387,11 @@ def test_conditioning_tanh_colsum():
         W = ref.shape[-1]
         close(xs[:, :W].view(B, trials * K, T, W), ref, name=f"cond {comb}")
         dxs = torch.randn(B * trials * K * T, ld)
+        dxs[:, (F if comb == "mul" else F + E):] = 0.0       # (pad columns of a gradient buffer are zero in the step)
+        poison = [torch.full((n,), float("nan"), device="cuda") for n in (B * T * 12, 4096)]
+        del poison
         dpre, ldp = h.cond_bwd(dxs.cuda(), ld, info, B, K, T, F, trials, comb)
+        assert bool(torch.isfinite(dpre).all()) and float(dpre[:, F:].abs().max()) == 0.0
         d4 = dxs[:, :F].view(B, trials * K, T, F)
         if comb == "mul":
             dref = (d4 * a[:, idx][:, :, None]).sum(1)
