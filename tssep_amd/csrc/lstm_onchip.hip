@@ -894,7 +894,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip_bwd_kernel(
 //    NGA so that it divides the number of groups (every bundle is full).
 // NGA = 4: four phases per step; NGA = 2: the four phases are two steps; NGA = 1: four steps (T-tail masked).
 #ifndef ONCHIP16_ABL
-#define ONCHIP16_ABL 0   // experiment builds (results wrong): 1 no MFMAs, 2 no cell arithmetic, 4 no io arm, 8 no exchange, 16 no tag polling
+#define ONCHIP16_ABL 0   // experiment builds (results wrong): 1 no MFMAs, 2 no cell arithmetic, 4 no io arm, 8 no exchange, 16 no tag polling,
+                         // 32 half of the forward's MFMAs (one of a wave's two row blocks: what a cluster of ten workgroups would leave)
 #endif
 constexpr int SQ = 16;
 constexpr int KP2 = 320, KS2 = 10;
@@ -1189,12 +1190,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
             nl = *reinterpret_cast<const bf16x8*>(hl + (ks + 1) * 64);
           }
           __builtin_amdgcn_sched_barrier(0);
+          constexpr int NRB = (ONCHIP16_ABL & 32) ? 1 : 2;
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wl[rb][ks]), bh, acc[rb]);
+          for (int rb = 0; rb < NRB; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wl[rb][ks]), bh, acc[rb]);
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bl, acc[rb]);
+          for (int rb = 0; rb < NRB; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bl, acc[rb]);
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bh, acc[rb]);
+          for (int rb = 0; rb < NRB; ++rb) acc[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bh, acc[rb]);
           __builtin_amdgcn_sched_barrier(0);
           bh = nh; bl = nl;
           if constexpr (!IO && FGAT >= 2) {
