@@ -921,8 +921,14 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
     const int i = lane & 15, kg = lane >> 4;
     const int unit = 64 * g + 8 * wave + 4 * rb + (i >> 2), gate = i & 3;
     const float* w = d ? w_hh_r : w_hh_f;
+    // the k axis of workgroup g starts at its OWN slice: local k <-> hidden unit (k + 64 g) mod 64 G (the operand image in
+    // LDS is rotated the same way) -- the k-steps of the own slice are 0 and 1 for every workgroup, a compile-time index
     float x[8];
-    for (int j = 0; j < 8; ++j) x[j] = unit < H ? w_at(w, H, gate * H + unit, 32 * ks + 8 * kg + j) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int kl = 32 * ks + 8 * kg + j;
+      const int kc = kl < 64 * G ? (kl + 64 * g) % (64 * G) : H;
+      x[j] = unit < H ? w_at(w, H, gate * H + unit, kc) : 0.f;
+    }
     unsigned h[4], l[4];
     for (int j = 0; j < 4; ++j) split2(x[2 * j], x[2 * j + 1], h[j], l[j]);
     wf[e] = hl ? u32x4{l[0], l[1], l[2], l[3]} : u32x4{h[0], h[1], h[2], h[3]};
@@ -946,12 +952,23 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_GATHER
 #define ONCHIP16_FWD_GATHER 4
 #endif
+// one group per cluster: the own slice's products of the NEXT step behind the publish (see `accn` in the kernel), and the
+// pause that is left between them and the first request of the peers' values.  The twelve MFMAs are the pause: 0.692 ->
+// 0.620 ms at 8 sequences, 0.682 -> 0.617 at 32 with none (3: 0.638 / 0.632, 6: 0.657 / 0.654, 10: 0.686 / 0.682;
+// profiles/r4_onchip16_fwd_own_early.jsonl)
+#ifndef ONCHIP16_FWD_OWN_EARLY
+#define ONCHIP16_FWD_OWN_EARLY 1
+#endif
+#ifndef ONCHIP16_FWD_G1_DELAY_OWN
+#define ONCHIP16_FWD_G1_DELAY_OWN 0
+#endif
 template <int NGA, bool NT>
 __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters,
     int layout) {
+  constexpr bool OWN_EARLY = NGA == 1 && ONCHIP16_FWD_OWN_EARLY && !(ONCHIP16_ABL & 12);
   const unsigned tagbase = tag16_base(err);
   __shared__ __attribute__((aligned(16))) char hs[NGA * 2 * SQ * HP2];       // [group][hi | lo][seq][k] bf16
   __shared__ __attribute__((aligned(16))) float pub[SQ * PUBPITCH];          // h_t [seq][unit] of the phase
@@ -998,6 +1015,12 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     float cst[NGA][2];
 #pragma unroll
     for (int p = 0; p < NGA; ++p) cst[p][0] = cst[p][1] = 0.f;
+    // ONE group per cluster (small batches): the products of the workgroup's OWN 64 units of h_t (k-steps 0 and 1) are
+    // formed right behind the barrier that completes h_t -- from the fp32 values in LDS, rounded as the peers will see
+    // them -- while the publish travels; the phase of step t + 1 starts from these sums and multiplies the eight k-steps
+    // of the peers' slices only
+    f32x4 accn[2];
+    accn[0] = accn[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t SN = layout ? 1 : T, ST = layout ? 32 : 1;
     // The per-lane offsets and masks of the io arm are REBUILT in every phase from an opaque copy of the thread index
     // (a dozen vector instructions): as loop invariants the compiler hoisted six masked offsets per group out of the
@@ -1090,8 +1113,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       const int slot = (int)((st - 1) & 1);
 #pragma unroll
       for (int gs = 0; gs < 5; ++gs)
-        vg[gs] = gs < G ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1)
-                        : u32x4{0u, 0u, 0u, 0u};
+        vg[gs] = (gs < G && !(OWN_EARLY && gs == g))
+                     ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1)
+                     : u32x4{0u, 0u, 0u, 0u};
     };
     auto gather_finish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
@@ -1102,13 +1126,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       for (;;) {
         bool ok = true;
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs) ok = ok && (gs >= G || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
+        for (int gs = 0; gs < 5; ++gs)
+          ok = ok && (gs >= G || (OWN_EARLY && gs == g) || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
         if (ok || (ONCHIP16_ABL & 16)) break;
         if (++spins > SPIN_LIMIT) { fail = true; break; }
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int gs = 0; gs < 5; ++gs)
-          if (gs < G && !((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want))
+          if (gs < G && !(OWN_EARLY && gs == g) && !((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want))
             vg[gs] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1);
       }
       if (fail) s_fail = 1;
@@ -1116,8 +1141,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2 * HP2;
 #pragma unroll
       for (int gs = 0; gs < 5; ++gs) {
-        if (gs < G) {
-          const int k = 64 * gs + 4 * uq;
+        if (gs < G && !(OWN_EARLY && gs == g)) {
+          const int k = 64 * (gs >= g ? gs - g : gs - g + G) + 4 * uq;      // (the k axis starts at the own slice)
           const u32x4 w = vg[gs];
           unsigned h0, l0, h1, l1;
           split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
@@ -1177,17 +1202,19 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       }
       f32x4 acc[2];
       acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int KS0 = OWN_EARLY ? 2 : 0;      // (OWN_EARLY: k-steps 0 and 1 are in accn already)
+      if constexpr (OWN_EARLY) { acc[0] = accn[0]; acc[1] = accn[1]; }
       if (st > 0 && !(ONCHIP16_ABL & 1)) {
-        const char* hh = hs + (P * 2 + 0) * SQ * HP2 + foff;
-        const char* hl = hs + (P * 2 + 1) * SQ * HP2 + foff;
+        const char* hh = hs + (P * 2 + 0) * SQ * HP2 + foff + KS0 * 64;
+        const char* hl = hs + (P * 2 + 1) * SQ * HP2 + foff + KS0 * 64;
         // fragments one k-step ahead, pinned: hoisting all twenty reads would cost 80 registers the kernel does not have
         bf16x8 bh = *reinterpret_cast<const bf16x8*>(hh), bl = *reinterpret_cast<const bf16x8*>(hl);
 #pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) {
+        for (int ks = KS0; ks < KS2; ++ks) {
           bf16x8 nh = bh, nl = bl;
           if (ks + 1 < KS2) {
-            nh = *reinterpret_cast<const bf16x8*>(hh + (ks + 1) * 64);
-            nl = *reinterpret_cast<const bf16x8*>(hl + (ks + 1) * 64);
+            nh = *reinterpret_cast<const bf16x8*>(hh + (ks + 1 - KS0) * 64);
+            nl = *reinterpret_cast<const bf16x8*>(hl + (ks + 1 - KS0) * 64);
           }
           __builtin_amdgcn_sched_barrier(0);
           constexpr int NRB = (ONCHIP16_ABL & 32) ? 1 : 2;
@@ -1225,9 +1252,34 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         cellb[jv * PUBPITCH + ul] = cn;
       }
       lds_barrier();
+      // OWN_EARLY: h_t of the own slice x its weight columns, for step t + 1 (every wave: it needs the whole slice as B)
+      auto own_products = [&]() __attribute__((always_inline)) {
+        accn[0] = accn[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (st + 1 < T && !(ONCHIP16_ABL & 1)) {
+          auto r24 = [](float x) { return __uint_as_float((__float_as_uint(x) + 0x80u) & 0xffffff00u); };      // = the granules
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const float* pr = pub + jv * PUBPITCH + 32 * ks + 8 * upv;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pr), b = *reinterpret_cast<const f32x4*>(pr + 4);
+            unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+            split2(r24(a[0]), r24(a[1]), h0, l0);
+            split2(r24(a[2]), r24(a[3]), h1, l1);
+            split2(r24(b[0]), r24(b[1]), h2, l2);
+            split2(r24(b[2]), r24(b[3]), h3, l3);
+            const bf16x8 bh = as_bf16x8(u32x4{h0, h1, h2, h3}), bl = as_bf16x8(u32x4{l0, l1, l2, l3});
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) accn[rb] = MFMA16_BF16(as_bf16x8(wl[rb][ks]), bh, accn[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) accn[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bl, accn[rb]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) accn[rb] = MFMA16_BF16(as_bf16x8(wh[rb][ks]), bh, accn[rb]);
+          }
+        }
+      };
       if constexpr (!IO) {
         if (!(ONCHIP16_ABL & 8)) {
           publish(P, st);
+          if constexpr (OWN_EARLY) own_products();
           if (NGA < 4) {
             // (two groups: the next phase's h is decoded in front of its barrier -- decoding it here, behind the publish,
             // measured slower even with the early request: 1.42 -> 1.50 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
@@ -1235,7 +1287,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
               // (one group: the peers publish these values at this very moment -- a request issued at once finds stale tags
               // and pays a second round trip; 14 x 64 cycles later it usually finds them: 0.722 -> 0.685 ms at 32 sequences,
               // 0.743 -> 0.70 at 160; 8: 0.70, 20: 0.72, 28: 0.78 -- profiles/r3_onchip16_g1_delay.jsonl)
-              if (NGA == 1 && ONCHIP16_FWD_G1_DELAY) __builtin_amdgcn_s_sleep(ONCHIP16_FWD_G1_DELAY);
+              if (NGA == 1 && !OWN_EARLY && ONCHIP16_FWD_G1_DELAY) __builtin_amdgcn_s_sleep(ONCHIP16_FWD_G1_DELAY);
+              if (OWN_EARLY && ONCHIP16_FWD_G1_DELAY_OWN) __builtin_amdgcn_s_sleep(ONCHIP16_FWD_G1_DELAY_OWN);
               gather_issue(P1, st1);
             }
           } else {
@@ -1249,6 +1302,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         // (storing the activations a phase later, beside the next phase's MFMAs -- what the backward does with its d(gates) --
         // measured SLOWER here: 1.37 -> 1.49 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
         io_flush(slot_tag, P, st);
+        if constexpr (OWN_EARLY) own_products();
         // (beyond the last step the copy is repeated for step T - 1 into a slot nobody reads any more: every phase
         // queues exactly four copies, or `vmcnt(10)` above would not cover the tiles of the last phases)
         if constexpr (!(NGA == 1 && ONCHIP16_FWD_EARLY_DMA)) io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
