@@ -1380,6 +1380,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
 #ifndef ONCHIP16_BWD_GATHER
 #define ONCHIP16_BWD_GATHER 2
 #endif
+// 1: the unit axis of every workgroup is rotated so that its OWN 64 output units are the block of the shared tiles: all
+// sixteen whole tiles of the waves then belong to peers and leave straight from the accumulators, the shared tiles (own
+// destination) stay in LDS -- no publish behind the third barrier any more.  ONE group per cluster in addition forms the own
+// block's products AFTER the peers' tiles have left (the step chain waits for the peers' data, not for its own)
+#ifndef ONCHIP16_BWD_OWN_SHARED
+#define ONCHIP16_BWD_OWN_SHARED 1
+#endif
 constexpr int DP2 = 256 * 2 + 16;            // 528 B per sequence row of the bf16 d(gates) image (conflict-free: 4 mod 64 dwords)
 constexpr int PP2 = 5 * UPW + 4;             // floats per row of partial dh
 constexpr int OWNP = UPW + 4;                // floats per row of the own slice
@@ -1400,7 +1407,9 @@ __global__ void pack_onchip16_bwd_kernel(const float* w_hh_f, const float* w_hh_
     const int tile = f < 16 ? 2 * wave + f / 8 : 16 + (wave >> 1);
     const int ks = f < 16 ? f % 8 : 4 * (wave & 1) + f - 16;
     const int i = lane & 15, kg = lane >> 4;
-    const int uo = 16 * tile + i;
+    // (ONCHIP16_BWD_OWN_SHARED: tile block b' of workgroup g holds the units of workgroup (b' + g + 1) mod G -- block 4,
+    // the shared tiles, its own)
+    const int uo = ONCHIP16_BWD_OWN_SHARED ? 64 * ((tile / 4 + g + 1) % G) + 16 * (tile % 4) + i : 16 * tile + i;
     const float* w = d ? w_hh_r : w_hh_f;
     float x[8];
     for (int j = 0; j < 8; ++j) {
@@ -1594,6 +1603,10 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       for (int b = ONCHIP16_BWD_DIRECT ? 4 : 0; b < 5; ++b) {           // unit block b = the 64 units of workgroup b
         f32x4 v = *reinterpret_cast<const f32x4*>(psum + s2 * PSW + 64 * b - (ONCHIP16_BWD_DIRECT ? 256 : 0) + 4 * uq);
         if (b == 4) v += *reinterpret_cast<const f32x4*>(psum2 + s2 * OWNP + 4 * uq);
+        if constexpr (ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED) {      // the shared tiles ARE the own block
+          *reinterpret_cast<f32x4*>(pown + (p * SQ + s2) * OWNP + 4 * uq) = v;
+          continue;
+        }
         const u32x2 ga = pack_granule(tag, v[0], v[1]), gb = pack_granule(tag, v[2], v[3]);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
                                                (int)(b != g ? (unsigned)((((slot * G + g) * SQ + s2) * Hp + 64 * b + 4 * uq) * 4) : OOR), 0, SC0);
@@ -1690,6 +1703,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         const int foff = (lvm & 15) * DP2 + (lvm >> 4) * 16;       // B fragment offset (row = sequence, 16-byte k chunk)
         // fragments one k-step ahead, pinned (all sixteen reads hoisted would cost 64 registers: W fragments spilled)
         bf16x8 bh = *reinterpret_cast<const bf16x8*>(dg_hi + foff), bl = *reinterpret_cast<const bf16x8*>(dg_lo + foff);
+        // (one group, own block = shared tiles: the shared tile's products follow the peers' tiles, below)
+        constexpr bool OWN_LAST = NGA == 1 && ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           bf16x8 nh = bh, nl = bl;
@@ -1701,13 +1716,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           acc0 = MFMA16_BF16(as_bf16x8(wl[ks]), bh, acc0);
           acc1 = MFMA16_BF16(as_bf16x8(wl[8 + ks]), bh, acc1);
           // (wave-uniform: this k-step also belongs to the wave's half of the shared tile)
-          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wl[16 + (ks & 3)]), bh, accs);
+          if (!OWN_LAST && (ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wl[16 + (ks & 3)]), bh, accs);
           acc0 = MFMA16_BF16(as_bf16x8(wh[ks]), bl, acc0);
           acc1 = MFMA16_BF16(as_bf16x8(wh[8 + ks]), bl, acc1);
-          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bl, accs);
+          if (!OWN_LAST && (ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bl, accs);
           acc0 = MFMA16_BF16(as_bf16x8(wh[ks]), bh, acc0);
           acc1 = MFMA16_BF16(as_bf16x8(wh[8 + ks]), bh, acc1);
-          if ((ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bh, accs);
+          if (!OWN_LAST && (ks >> 2) == (wave & 1)) accs = MFMA16_BF16(as_bf16x8(wh[16 + (ks & 3)]), bh, accs);
           __builtin_amdgcn_sched_barrier(0);
           bh = nh; bl = nl;
           if constexpr (!IO && GAT >= 3) {
@@ -1721,14 +1736,36 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
           const int bw = wave >> 1;
           const auto prs = payload_srd(P);
           const unsigned tag = mk_tag(tagbase, st + 1);
-          const unsigned off = (unsigned)(((((int)(st & 1) * G + g) * SQ + j) * Hp + 32 * wave + r4) * 4);
           const u32x2 a0 = pack_granule(tag, acc0[0], acc0[1]), a1 = pack_granule(tag, acc0[2], acc0[3]);
           const u32x2 c0 = pack_granule(tag, acc1[0], acc1[1]), c1 = pack_granule(tag, acc1[2], acc1[3]);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], a1[0], a1[1]}, prs, (int)(bw != g ? off : OOR), 0, SC0);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0[0], c0[1], c1[0], c1[1]}, prs, (int)(bw != g ? off + 64u : OOR), 0, SC0);
-          if (bw == g) {
-            *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + r4) = acc0;
-            *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + 16 + r4) = acc1;
+          if constexpr (ONCHIP16_BWD_OWN_SHARED) {
+            // tile block bw holds the units of workgroup (bw + g + 1) mod G: always a peer
+            int bd = bw + g + 1;
+            bd = bd >= G ? bd - G : bd;
+            const unsigned off = (unsigned)(((((int)(st & 1) * G + g) * SQ + j) * Hp + 64 * bd + 32 * (wave & 1) + r4) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], a1[0], a1[1]}, prs, (int)off, 0, SC0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0[0], c0[1], c1[0], c1[1]}, prs, (int)(off + 64u), 0, SC0);
+          } else {
+            const unsigned off = (unsigned)(((((int)(st & 1) * G + g) * SQ + j) * Hp + 32 * wave + r4) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0[0], a0[1], a1[0], a1[1]}, prs, (int)(bw != g ? off : OOR), 0, SC0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{c0[0], c0[1], c1[0], c1[1]}, prs, (int)(bw != g ? off + 64u : OOR), 0, SC0);
+            if (bw == g) {
+              *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + r4) = acc0;
+              *reinterpret_cast<f32x4*>(pown + (P * SQ + j) * OWNP + 32 * (wave & 1) + 16 + r4) = acc1;
+            }
+          }
+          if constexpr (OWN_LAST) {
+            // the own block's partial sums: this wave's four k-steps of shared tile 16 + (wave >> 1), behind the peers' stores
+            const int kb = __builtin_amdgcn_readfirstlane(4 * (wave & 1));
+            __builtin_amdgcn_sched_barrier(0);      // (the stores above are ISSUED first)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bf16x8 sh_ = *reinterpret_cast<const bf16x8*>(dg_hi + foff + (kb + q) * 64);
+              const bf16x8 sl_ = *reinterpret_cast<const bf16x8*>(dg_lo + foff + (kb + q) * 64);
+              accs = MFMA16_BF16(as_bf16x8(wl[16 + q]), sh_, accs);
+              accs = MFMA16_BF16(as_bf16x8(wh[16 + q]), sl_, accs);
+              accs = MFMA16_BF16(as_bf16x8(wh[16 + q]), sh_, accs);
+            }
           }
         } else {
           *reinterpret_cast<f32x4*>(psum + j * PP2 + 32 * wave + r4) = acc0;
