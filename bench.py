@@ -224,6 +224,107 @@ def cpu_baseline(hip_model=None, opt=None, seconds_budget=24.0, batch=16, parity
                 parity_vs_hip=parity)
 
 
+def headline_parity(model, opt, ex0, K, N_s, gemm, recurrence, oracle_utterances=16):
+    """The batch the headline is TIMED on, checked (round 3's headline ran on a GEMM that corrupted
+    ~100 elements per launch at multi-tile sizes while every batch-4 parity check was green -- at small batches the
+    library picks other kernels).  On the SAME resident inputs and the same speaker permutations:
+      (1) the headline arithmetic (split-bf16 persistent / big-tile GEMMs + W-stationary split-bf16 recurrences) against
+          the fp32 end-to-end leg -- exact-fp32 MFMA GEMMs (gemm.hip) + the streaming fp32 recurrence (lstm.hip): different
+          kernels for every GEMM and every recurrence of the step -- masks, time-domain estimates, per-utterance losses and
+          every parameter gradient of the full batch;
+      (2) both against the CPU oracle on the first `oracle_utterances` utterances of that batch (forward: masks, losses),
+          AmplitudeToDB's batch-global floor taken from the oracle's own mel spectra of the WHOLE batch.
+    Bars: outputs 1e-3 (north star), gradients 1e-2 of each tensor's largest entry (they carry T steps of BPTT)."""
+    from oracle import features as ofeat, model as omodel, stft as ostft
+    from tssep_amd import hip_ops as H
+    dev = ex0["observation"].device
+    B = ex0["observation"].shape[0]
+    t_start = time.time()
+
+    def leg(gemm_p, rec):
+        old = H.GEMM_PRECISION, H.RECURRENCE
+        H.GEMM_PRECISION, H.RECURRENCE = gemm_p, rec
+        H.GEMM_LOG = []                          # which GEMM kernels ran (names): reported, so that the record shows
+        try:                                      # the check went through the kernels of the timed step
+            opt.zero_grad()
+            np.random.seed(9753)                  # the same permutations in both legs and in the oracle
+            ex = dict(ex0)
+            out = model(ex)
+            summ = model.review(ex, out)
+            summ["loss"].backward()
+            opt.bucket.sync()
+            with torch.no_grad():
+                mask = out.mask.detach().squeeze(-3)          # [B,K,T,F] (the sigmoid kernel on the step's logits)
+            torch.cuda.synchronize()
+            H.check_cluster_errors(dev)
+            losses = torch.stack([v.reshape(()) for v in summ["scalars"][f"bench_{model.loss.name}"]]).double()
+            return dict(mask=mask, est=out.time_estimate.detach(), loss=losses, grad=opt.bucket.flat.clone(),
+                        kernels=sorted({str(e[0]) for e in H.GEMM_LOG}))
+        finally:
+            H.GEMM_PRECISION, H.RECURRENCE = old
+            H.GEMM_LOG = None
+            opt.zero_grad()
+
+    a = leg(gemm, recurrence)
+    ref_rec = "stream" if B * K >= 256 else "cluster"
+    b = leg("f32", ref_rec)
+    kernels_a, kernels_b = a["kernels"], b["kernels"]
+    merr = float((a["mask"] - b["mask"]).abs().max())
+    eerr = float((a["est"] - b["est"]).abs().max() / b["est"].abs().max())
+    lrel = float(((a["loss"] - b["loss"]).abs() / b["loss"].abs().clamp_min(1e-12)).max())
+    gerrs = {}
+    names = [n for n, p_ in model.named_parameters() if p_.requires_grad]
+    for name, p_, off in zip(names, opt.params, opt._offsets):
+        ga, gb = a["grad"][off:off + p_.numel()], b["grad"][off:off + p_.numel()]
+        gerrs[name] = float((ga - gb).abs().max() / (gb.abs().max() + 1e-30))
+    worst = max(gerrs, key=gerrs.get)
+    finite = bool(torch.isfinite(a["grad"]).all() and torch.isfinite(a["mask"]).all() and torch.isfinite(a["est"]).all())
+    res = dict(batch=B, sample="the timed batch itself: same resident inputs, same np.random permutations in both legs",
+               headline_arithmetic=dict(gemm=gemm, recurrence=recurrence, gemm_kernels=kernels_a),
+               against=dict(gemm="f32", recurrence=ref_rec, gemm_kernels=kernels_b,
+                            what="fp32 end to end: exact-fp32 MFMA GEMMs + exact-fp32 recurrence"),
+               max_abs_mask_err=merr, max_rel_time_estimate_err=eerr, max_rel_loss_err=lrel,
+               max_rel_grad_err=gerrs[worst], worst_gradient=worst,
+               median_rel_grad_err=float(np.median(list(gerrs.values()))),
+               worst_five={k: float(f"{gerrs[k]:.3g}") for k in sorted(gerrs, key=gerrs.get, reverse=True)[:5]},
+               all_finite=finite, bar_outputs=1e-3, bar_gradients=1e-2,
+               gradient_metric="max |g_a - g_b| over a parameter tensor / max |g_b| of that tensor, all tensors of the full-batch gradient")
+    # ---- (2) the CPU oracle on a slice of the same batch
+    n = min(oracle_utterances, B)
+    if n:
+        obs_all = ex0["observation"].cpu()
+        fb, dct = ofeat.mfcc_tables(1024)
+        db_max = -1e30
+        for i in range(0, B, 64):                        # mel-dB maximum of the WHOLE batch (AmplitudeToDB's floor is batch-global)
+            X = ostft.stft(obs_all[i:i + 64], size=1024, shift=256, window="hann")[..., 0, :, :]
+            db_max = max(db_max, ofeat.mel_db_max(X, fb))
+        p = {"mask_estimator." + k: v.detach().cpu().clone() for k, v in model.mask_estimator.state_dict().items()}
+        cfg = dict(odim=FBINS, combination="mul", ts_vad=K, output_resolution="tf")
+        old_threads = torch.get_num_threads()
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        try:
+            with torch.no_grad():
+                np.random.seed(9753)                     # utterance i draws the i-th permutation, as on the GPU
+                o = omodel.forward_loss(p, obs_all[:n], ex0["auxInput"][:n].cpu(),
+                                        ex0["speaker_reverberation_early_ch0"][:n].cpu(), cfg=cfg, fast=True, mel_db_max=db_max)
+        finally:
+            torch.set_num_threads(old_threads)
+        om, ol = o["mask"].squeeze(-3), o["loss"].double()
+        orc = {}
+        for key, g in (("headline", a), ("fp32_leg", b)):
+            orc[key] = dict(max_abs_mask_err=float((g["mask"][:n].cpu() - om).abs().max()),
+                            max_rel_loss_err=float(((g["loss"][:n].cpu() - ol).abs() / ol.abs().clamp_min(1e-12)).max()))
+        res["against_cpu_oracle"] = dict(utterances=n, slice="the first utterances of the timed batch, forward only",
+                                         mel_db_max_of_whole_batch=round(db_max, 4), **orc)
+    res["seconds"] = round(time.time() - t_start, 1)
+    ok = finite and merr < 1e-3 and eerr < 1e-3 and lrel < 1e-3 and gerrs[worst] < 1e-2
+    if n:
+        ok = ok and all(v["max_abs_mask_err"] < 1e-3 and v["max_rel_loss_err"] < 1e-3 for v in res["against_cpu_oracle"].values()
+                        if isinstance(v, dict))
+    res["within_bars"] = bool(ok)
+    return res
+
+
 def newest_profile(suffix):
     """profiles/r<N>_<suffix> of the latest round that has one (PMC passes are collected per round)."""
     import glob
@@ -254,6 +355,8 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step as a captured hipGraph (auto: small batches, where launches dominate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-headline-parity", action="store_true",
+                    help="skip the correctness check of the timed batch (headline arithmetic vs fp32 kernels vs CPU oracle slice)")
     ap.add_argument("--no-exact-f32", action="store_true",
                     help="skip the secondary measurements (fp32 GEMMs, the fp32 end-to-end reference-width line, two-product weight gradients)")
     args = ap.parse_args()
@@ -544,6 +647,11 @@ def main():
                     plain_bf16["parity_vs_cpu_oracle"] = cpu_baseline(model, opt, parity_only=True, parity_batch=8, assert_bars=False)
         finally:
             H.GEMM_PRECISION = args.gemm
+    at_batch = None
+    if world == 1 and not args.no_headline_parity and args.gemm != "f32":
+        # the batch the headline was timed on, checked against different kernels end to end and the CPU oracle
+        at_batch = headline_parity(model, opt, ex0, K, N_s, args.gemm, args.recurrence,
+                                   oracle_utterances=0 if args.no_cpu_baseline else (16 if args.workload != "cfg5" else 2))
     collective = None
     if world > 1:
         # what the first hardware run of the RCCL path should show at a glance: the collective's own time (HIP
@@ -592,12 +700,15 @@ def main():
                            note="algorithmic, 2 flop per MAC, forward + backward (SURVEY 8d); the dW_hh weight "
                                 "gradients run as GEMMs, the h.W_hh products and their BPTT inside the recurrence kernels")},
             "roofline": roofline, "roofline_mask_head": mask_head,
+            "parity_at_headline_batch": at_batch,
             "f32_gemms_bf16x3_recurrence": exact, "reference_width": ref_width,
             "two_product_wgrad": two_prod, "plain_bf16_gemms": plain_bf16,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or args.workload == "cfg5")
             else cpu_baseline(model, opt),
         }
         print(json.dumps(line), flush=True)
+        if at_batch is not None and not at_batch["within_bars"]:
+            raise SystemExit("bench.py: the timed batch is outside the parity bars: " + json.dumps(at_batch))
     if world > 1:
         dist.destroy_process_group()
 

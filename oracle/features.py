@@ -49,23 +49,35 @@ def mfcc_tables(size=1024, sample_rate=16000, n_mfcc=40, f_min=40.0,
     return fb, create_dct(n_mfcc, n_mels, dct_norm)
 
 
-def amplitude_to_db_power(x, top_db=80.0):
+def amplitude_to_db_power(x, top_db=80.0, db_max=None):
     """torchaudio AmplitudeToDB('power', top_db) incl. its batching quirk:
     3-D input is treated as the channels of ONE item (max over everything),
-    4-D as [batch, channel, freq, time] (max per batch item)."""
+    4-D as [batch, channel, freq, time] (max per batch item).
+    ``db_max`` (checker-only extension, not in the reference): the 3-D input is
+    a SLICE of a larger batch whose dB maximum is given -- the floor is then the
+    one the reference would have applied to the whole batch (`mel_db_max`)."""
     x_db = 10.0 * torch.log10(torch.clamp(x, min=1e-10))
     shape = x_db.size()
     packed_channels = shape[-3] if x_db.dim() > 2 else 1
     v = x_db.reshape(-1, packed_channels, shape[-2], shape[-1])
-    v = torch.max(v, (v.amax(dim=(-3, -2, -1)) - top_db).view(-1, 1, 1, 1))
+    top = v.amax(dim=(-3, -2, -1)) if db_max is None else torch.full((v.shape[0],), float(db_max))
+    v = torch.max(v, (top - top_db).view(-1, 1, 1, 1))
     return v.reshape(shape)
 
 
-def torch_mfcc(X, fb, dct, top_db=80.0):
+def mel_db_max(X, fb):
+    """Maximum of 10 log10(mel power) over a whole batch X[B, T, F]: what
+    `amplitude_to_db_power` takes its floor from for a 3-D input."""
+    power = abs(X).to(torch.float32) ** 2
+    mel = torch.matmul(power, fb)
+    return float((10.0 * torch.log10(torch.clamp(mel, min=1e-10))).amax())
+
+
+def torch_mfcc(X, fb, dct, top_db=80.0, db_max=None):
     """feature_extractor_torchaudio.py:93-106.  X[..., T, F] complex."""
     power = abs(X.transpose(-1, -2)).to(torch.float32) ** 2   # [..., F, T]
     mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
-    mel = amplitude_to_db_power(mel, top_db)                  # [..., n_mels, T]
+    mel = amplitude_to_db_power(mel, top_db, db_max)          # [..., n_mels, T]
     return torch.matmul(mel.transpose(-1, -2), dct)           # [..., T, n_mfcc]
 
 
@@ -81,7 +93,7 @@ def log1p_max_norm_abs(X, statistics_axis="tf"):
     return torch.log1p(s)
 
 
-def concat_features(X, fb, dct):
+def concat_features(X, fb, dct, db_max=None):
     """ConcaternatedSTFTFeatures(TorchMFCC, Log1pMaxNormAbsSTFT)
     (feature_extractor.py:352-360, init_cfg_common.yaml:13-50) -> [..., T, 553]."""
-    return torch.concat([torch_mfcc(X, fb, dct), log1p_max_norm_abs(X)], dim=-1)
+    return torch.concat([torch_mfcc(X, fb, dct, db_max=db_max), log1p_max_norm_abs(X)], dim=-1)

@@ -39,16 +39,18 @@ def init_mask_estimator_params(*, idim, odim, units, projs, layers=3,
 
 def forward_loss(p, observation, aux, target, *, cfg, loss="LogMAE",
                  fe_tables=None, window="hann", size=1024, shift=256,
-                 mfcc=True, perm=None, fast=False):
+                 mfcc=True, perm=None, fast=False, mel_db_max=None):
     """observation [B,1,N] f32, aux [B,K,E], target [B,K,N] (LogMAE) or
     Vad [B,K,T] (VADSigmoidBCE).  ``cfg`` = MaskEstimator kwargs for
     :func:`oracle.net.mask_estimator_forward`.  Returns dict with
-    Observation, Input, mask, logit, stft_estimate, time_estimate, loss[B]."""
+    Observation, Input, mask, logit, stft_estimate, time_estimate, loss[B].
+    ``mel_db_max`` (checker-only): the batch is a slice of a larger one whose mel-dB
+    maximum is given (features.mel_db_max) -- AmplitudeToDB's floor is batch-global."""
     X = ostft.stft(observation, size=size, shift=shift, window=window)  # [B,1,T,F]
     Xr = X[..., 0, :, :]
     if mfcc:
         fb, dct = fe_tables if fe_tables is not None else features.mfcc_tables(size)
-        inp = features.concat_features(Xr, fb, dct).to(torch.float32)
+        inp = features.concat_features(Xr, fb, dct, db_max=mel_db_max).to(torch.float32)
     else:
         inp = features.log1p_max_norm_abs(Xr).to(torch.float32)
     out = net.mask_estimator_forward(p, inp, aux, perm=perm, fast=fast, **cfg)

@@ -1694,6 +1694,55 @@ def test_blstm_onchip_long_sequences(N, T, Hh, groups):
     close(g_stream, g_ref, rtol=1e-3, atol=2e-5 + 1e-4 * float(g_ref.abs().max()), name="dgates")
 
 
+def test_blstm_onchip_at_the_headline_size():
+    """VERDICT r4 #1c: ONE launch of each W-stationary recurrence at the size the headline step runs them -- 3 072 sequences
+    (768 utterances x 4 speakers) of 253 frames, H = 300, the group counts the library picks there -- against the exact-fp32
+    streaming kernels (lstm.hip: no exchange, no MFMA): hidden states, cell states, saved gate activations forward; d(gates)
+    backward on the same saved activations.  A 32-sequence slice of the forward also against the CPU oracle
+    (tssep/train/rnnp.py:146-153: sequences are independent).  Every test below 768 sequences runs ONE resident round of
+    clusters; this one runs the multi-round, all-XCD schedule of the timed step."""
+    h = H()
+    N, T, Hh, I = 3072, 253, 300, 12
+    dev = torch.device("cuda", 0)
+    p, x = _lstm_case(N, T, I, Hh, 29)
+    assert h.recurrence_kernel(N, Hh, False, T, dev) == "onchip" and h.recurrence_kernel(N, Hh, True, T, dev) == "onchip"
+    gf, gb = h.onchip16_groups(N, Hh, dev), h.onchip16_bwd_groups(N, Hh, dev)
+    assert gf and gb, (gf, gb)
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    plist = [p[n] for n in names] + [p[n + "_reverse"] for n in names]
+    pk = h.lstm_pack([t.cuda() for t in plist], Hh, I)
+    ld_x = h.round_up(I, 4)
+    xd = torch.zeros(N * T, ld_x, device="cuda"); xd[:, :I] = x.reshape(N * T, I).cuda()
+    gates = torch.empty(N * T, 8 * Hh, device="cuda")
+    h.gemm(xd, ld_x, pk["wih_p"], pk["ld_i"], gates, 8 * Hh, N * T, 8 * Hh, I, bias=pk["bias_p"])
+    g_stream = gates.clone()
+    Hp = h.round_up(Hh, 4)
+    cell = torch.full((N, T, 2, Hh), float("nan"), device="cuda")
+    hout = torch.full((N, T, 2 * Hp), float("nan"), device="cuda")
+    whf, whr = p["weight_hh_l0"].cuda(), p["weight_hh_l0_reverse"].cuda()
+    h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, h.lstm_pack_onchip16(whf, whr, Hh), N, T, Hh, gf)
+    h.check_cluster_errors()
+    cell2 = torch.empty_like(cell); hout2 = torch.zeros_like(hout)
+    h.blstm_fwd(g_stream, cell2, hout2, 2 * Hp, Hp, pk["whh_f"], N, T, Hh)
+    assert bool(torch.isfinite(hout).all()) and bool(torch.isfinite(cell).all()) and bool(torch.isfinite(gates).all())
+    close(hout, hout2, rtol=1e-3, atol=1e-4, name="h vs streaming fp32")
+    close(cell, cell2, rtol=1e-3, atol=1e-4, name="cell vs streaming fp32")
+    close(gates, g_stream, rtol=1e-3, atol=1e-4, name="gate activations vs streaming fp32")
+    for sl in (slice(0, 16), slice(N - 16, N)):          # first and last group of the launch against the CPU oracle
+        with torch.no_grad():
+            ref = ornnp.blstm(x[sl], p, "")
+        got = torch.cat([hout[sl, :, :Hh], hout[sl, :, Hp:Hp + Hh]], -1)
+        close(got, ref, rtol=1e-3, atol=1e-4, name=f"h vs oracle, sequences {sl}")
+    dhd = torch.zeros(N, T, 2 * Hp, device="cuda")
+    dhd[..., :Hh] = torch.randn(N, T, Hh, device="cuda"); dhd[..., Hp:Hp + Hh] = torch.randn(N, T, Hh, device="cuda")
+    g_ref = g_stream.clone()
+    h.blstm_onchip16_bwd(g_stream, cell2, dhd, 2 * Hp, Hp, h.lstm_pack_onchip16_bwd(whf, whr, Hh), N, T, Hh, gb)
+    h.check_cluster_errors()
+    h.blstm_bwd(g_ref, cell2, dhd, 2 * Hp, Hp, pk["whh_b"], N, T, Hh)
+    assert bool(torch.isfinite(g_stream).all())
+    close(g_stream, g_ref, rtol=1e-3, atol=2e-5 + 1e-4 * float(g_ref.abs().max()), name="dgates")
+
+
 def test_recurrence_falls_back_loudly_beyond_the_offset_limit():
     """Beyond the 32-bit lane offsets of the W-stationary kernels (14 913 frames at H = 300) the streaming kernels run --
     announced by a warning, and with the right result (RNNP over 15 000 frames against the CPU oracle)."""
