@@ -494,6 +494,38 @@ def test_tanh_fold_survives_a_second_consumer_and_a_hook(combine):
     assert h._tssep_tanh_link.observed()
 
 
+@pytest.mark.parametrize("combine", [0, 2])
+def test_tanh_fold_with_two_folded_consumers(combine):
+    """an activation that feeds TWO consumers which both fold its Tanh backward into their d(input) GEMM: each
+    leaves its d(pre-activation) on the producer's link -- the second must ADD to the first, not replace it (the dummies
+    autograd sums for the activation are zeros either way, so nothing else would notice the loss).  Reference semantics:
+    plain autograd through nn.Tanh (net.py:623-625)."""
+    from tssep_amd import functional as Fn
+    torch.manual_seed(5)
+    K = combine or 1
+    B, T, I, Hh, hd = 2, 7, 12, 8, 8
+    N = B * K
+    l0, p0 = torch.nn.LSTM(I, Hh, bidirectional=True, batch_first=True).cuda(), torch.nn.Linear(2 * Hh, hd).cuda()
+    cons = [(torch.nn.LSTM(hd * K, Hh, bidirectional=True, batch_first=True).cuda(), torch.nn.Linear(2 * Hh, hd).cuda())
+            for _ in range(2)]
+    params = [*l0.parameters(), *p0.parameters()] + [q for l, p in cons for q in (*l.parameters(), *p.parameters())]
+    x0 = torch.randn(N * T, I, device="cuda")
+    g_out = [torch.randn(B * T, hd, device="cuda") for _ in cons]
+
+    def run(fold):
+        for p in params:
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        h = Fn.rnnp_layer(x, l0, p0, N, T, act=1, combine=combine, dz_given=fold)
+        loss = sum((Fn.rnnp_layer(h, l, p, B, T, in_tanh=(K if fold else 0)) * g).sum() for (l, p), g in zip(cons, g_out))
+        loss.backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    ref, got = run(False), run(True)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        close(a, b, rtol=1e-4, atol=1e-6 + 1e-5 * float(b.abs().max()), name=f"grad {i}")
+
+
 def test_fused_adam_matches_torch_adam_with_clipping():
     """tssep_adam_step == torch.nn.utils.clip_grad_norm_(10) + torch.optim.Adam (the reference's
     optimizer settings, tssep/train/experiment.py:147-150) over three steps."""

@@ -62,7 +62,10 @@ def scan(path):
                 break                   # an explicit wait state / a drain in between
             if not op.startswith("v_") or (op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and "_e64" not in op):
                 continue
-            dst = nxt.split(None, 1)[1].split(",")[0].strip()
+            parts = nxt.split(None, 1)
+            if len(parts) < 2:          # an operand-less VALU instruction (v_nop) or a truncated last line: writes nothing
+                continue
+            dst = parts[1].split(",")[0].strip()
             if vregs(dst) & data:
                 kn = max((n for n in names if n <= i), default=None)
                 hits.append((os.path.basename(path), names.get(kn, "?")[:70], i + 1, l, nxt, ahead))

@@ -369,18 +369,39 @@ extern "C" const char* tssep_gemm_kernel_name(int32_t kernel) {
 // that prices whole rounds of 512 resident workgroups predicts up to 20 % from other factors; measured, the large-K
 // shapes get SLOWER with more splits (the tiles of a K slab share it through one L2 only while they run together),
 // and these rules are within 0..5 % of the best S on every shape of the step.
+static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid);
 extern "C" int tssep_gemm_wgrad_splits(const tssep_gemm_args* g) {
   if (!g) return TSSEP_E_NULL;
   if (g->M <= 0 || g->N <= 0 || g->K <= 0) return TSSEP_E_SHAPE;
   tssep_gemm_args a = normalised(g);
   a.splitk = 8; a.c_split_stride = 0;
-  int32_t kid = TSSEP_GEMM_AUTO;
-  {
+  auto planned = [&](int splitk, int32_t* kid) {
+    a.splitk = splitk;
     GemmCall call{nullptr, true, TSSEP_GEMM_AUTO, TSSEP_GEMM_AUTO};
     const int rc = gemm_dispatch(&a, call);
+    *kid = call.chosen;
+    return rc;
+  };
+  int32_t kid = TSSEP_GEMM_AUTO;
+  {
+    const int rc = planned(8, &kid);
     if (rc != TSSEP_OK) return rc;
-    kid = call.chosen;
   }
+  // The split rule is written for the kernel the dispatcher picks at splitk = 8; a launcher may refuse the S that rule
+  // gives (a non-multiple of 8, the `S * 8 <= ktiles` limit of tn_p320) and the launch then falls through to ANOTHER
+  // kernel than the one the rule was written for.  So: plan again with the S just chosen and, when the kernel
+  // changed, apply THAT kernel's rule -- until the (kernel, S) pair is a fixed point (two rounds at most in practice).
+  int S = wgrad_split_rule(g, kid);
+  for (int round = 0; round < 3; ++round) {
+    int32_t kid2 = TSSEP_GEMM_AUTO;
+    if (planned(S, &kid2) != TSSEP_OK || kid2 == kid) break;
+    kid = kid2;
+    S = wgrad_split_rule(g, kid);
+  }
+  return S;
+}
+
+static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid) {
   auto cdiv = [](int64_t x, int64_t y) { return (x + y - 1) / y; };
   auto rup = [&](int64_t x, int64_t y) { return cdiv(x, y) * y; };
   const int64_t M = g->M, N = g->N, K = g->K, ktiles = cdiv(K, 16);

@@ -536,11 +536,7 @@ int tssep_gemm_bf16x3_bigp_launch(const tssep_gemm_args* g, const gemm_detail::S
   if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + GM - 1) / GM, xcol ? (g->N - 1) / GN : (g->N + GN - 1) / GN, 1);
   const int64_t nids = tile_map_blocks(tm);
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = current_device_cus();      // (per device, gemm_common.h)
   // persistent: a multiple of 8 workgroups (a workgroup's ids stay on one XCD) unless the whole list fits the CUs once
   const int ncu8 = ncu / NXCD * NXCD;
   const int64_t grid = nids <= ncu8 || ncu8 == 0 ? nids : ncu8;

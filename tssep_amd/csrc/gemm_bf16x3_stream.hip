@@ -364,11 +364,7 @@ int tssep_gemm_bf16x3_stream_launch(const tssep_gemm_args* g, const gemm_detail:
   if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map((g->M + SM - 1) / SM, (g->N + SN - 1) / SN, 1);
   const int64_t nids = tile_map_blocks(tm);
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int ncu = current_device_cus();      // (per device, gemm_common.h)
   const int64_t grid = nids < ncu ? nids : ncu;
 #define SLAUNCH(P_) hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<P_>, dim3((unsigned)grid), dim3(SNT), 0, (hipStream_t)stream, g->A, g->B, \
                      g->C, g->M, g->N, g->K, g->lda, g->ldb, sm.ldc, g->bias, tm, nids)

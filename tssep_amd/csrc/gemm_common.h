@@ -5,6 +5,21 @@
 
 namespace gemm_detail {
 
+// CU count of the CURRENT device for the persistent kernels' grids, remembered per device ordinal (a process with mixed
+// devices gets each device's own count -- ADVICE r4; the value of a device never changes, so the memo is not state a
+// caller could observe)
+static inline int current_device_cus() {
+  static int memo[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = __atomic_load_n(&memo[dev], __ATOMIC_RELAXED);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&memo[dev], n, __ATOMIC_RELAXED);
+  }
+  return n;
+}
+
 // Tanh of the fused store (act = 1), the same in every GEMM kernel: 1 - 2 / (1 + e^(2x)) on v_exp_f32 / v_rcp_f32 (the
 // recurrence kernels' fast_tanh): absolute error <= 3e-7, saturates correctly for large |x|, four instructions instead of
 // the ~40 of OCML's tanhf -- which cost a third of a K = 600 tile's life in the persistent kernels' store (240 calls per lane).

@@ -123,18 +123,32 @@ _CONTROL = None
 
 
 def _make_control_group(backend, timeout):
+    """COLLECTIVE (every rank of the default group).  `dist.new_group` may fail on SOME ranks only (interface selection),
+    and TSSEP_DIST_CONTROL may differ between them: ranks that exchanged control values on different groups would wait for
+    each other until the watchdog fires.  The outcome is therefore agreed over the default group (all-reduce MIN of a
+    success flag) and the control group is used by all ranks or by none."""
     global _CONTROL
     import os
     _CONTROL = None
-    if backend != "nccl" or os.environ.get("TSSEP_DIST_CONTROL", "1") == "0":
+    if backend != "nccl":
         return
-    try:
-        _CONTROL = dist.new_group(backend="gloo", timeout=timeout)
-    except Exception as e:                                   # noqa: BLE001 -- every rank fails alike or none does
+    group, err = None, None
+    want = os.environ.get("TSSEP_DIST_CONTROL", "1") != "0"
+    wanted = torch.tensor([1 if want else 0], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(wanted, op=dist.ReduceOp.MIN)            # new_group is itself collective: all ranks try, or none
+    if int(wanted.item()):
+        try:
+            group = dist.new_group(backend="gloo", timeout=timeout)
+        except Exception as e:                               # noqa: BLE001 -- agreed on below
+            err = e
+    ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=wanted.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()):
+        _CONTROL = group
+    elif want:
         import warnings
-        warnings.warn(f"tssep_amd.distributed: no host-side control group ({e}); control exchanges will "
-                      "synchronise with the GPU stream")
-        _CONTROL = None
+        warnings.warn(f"tssep_amd.distributed: no host-side control group on every rank ({err or 'a peer has none'}); "
+                      "control exchanges will synchronise with the GPU stream")
 
 
 def _control_tensor(values, device=None):

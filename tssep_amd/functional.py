@@ -273,7 +273,8 @@ class _RNNP(torch.autograd.Function):
                     hd = I // Kc
                     remap = dict(T=T, K=1, sb=Kc * T * hd, sk=0, st=hd, cm=hd, co=T * hd)
                 H.gemm(gates, G, wihT, ld_t, dxb, 0 if remap else I, R, I, G, act=2, aux=(xv, ld_x), remap=remap)
-                in_link.payload = dxb
+                # (accumulated, like head_link below: the activation may feed TWO folded consumers -- ADVICE r4)
+                in_link.payload = dxb if in_link.payload is None else in_link.payload + dxb.view_as(in_link.payload)
                 dx = _dummy_grad(xv, ctx.x_shape)
             else:
                 dxb, ld_dx = H.padded(R, I, dev, zero=True)
