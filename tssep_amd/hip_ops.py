@@ -474,6 +474,23 @@ _BUILDER_SEQ = itertools.count()      # order of first use: a build may read wha
 _PREPARED = None                      # while a step is being captured: (id(params[0]), tag) -> (event, value, stream, waiters)
 PREPARED_HITS = 0                     # layouts handed out from there (tests)
 PREPARE_DERIVED = True                # False: every layout is built where it is first used (A/B, tools)
+_DERIVED_SEEN = None                  # while `record_derived` is open: (id(params[0]), tag) of every layout asked for
+
+
+class record_derived:
+    """``with record_derived() as seen:`` -- the layouts a step asks `derived` for (train/graph.py records them over the
+    warm-up passes of ONE input signature and prepares exactly those in its graph: a builder another signature registered --
+    the 32-sequence packs of a small validation batch, say -- is not rebuilt in every replay for nobody)."""
+
+    def __enter__(self):
+        global _DERIVED_SEEN
+        self.old, _DERIVED_SEEN = _DERIVED_SEEN, set()
+        return _DERIVED_SEEN
+
+    def __exit__(self, *exc):
+        global _DERIVED_SEEN
+        _DERIVED_SEEN = self.old
+        return False
 
 
 def derived(tag, params, build):
@@ -483,6 +500,8 @@ def derived(tag, params, build):
     update counter and the stream it was built on.  A `build` must reach everything it reads THROUGH the
     parameters (or through `derived` again): `prepare_derived` calls it at the start of a later step."""
     key = (id(params[0]), tag)
+    if _DERIVED_SEEN is not None:
+        _DERIVED_SEEN.add(key)
     if _PREPARED is not None:
         hit = _PREPARED.get(key)
         if hit is not None:
@@ -518,9 +537,11 @@ class prepare_derived:
     (8 utterances per GPU: ~25 launches of 4-20 us, 0.2 ms of a 7.8-ms step).  `derived` hands out the prepared value
     after making the consumer's stream wait for the event behind it.  Outside a capture the memo above does the job."""
 
-    def __init__(self, parameters, device):
+    def __init__(self, parameters, device, only=None):
+        """only: a set of (id(parameter), tag) -- what `record_derived` saw -- restricts the branch to those layouts."""
         self.builds = sorted((seq, id(p), tag, build) for p in parameters
-                             for tag, (seq, build) in p.__dict__.get("_tssep_builders", {}).items())
+                             for tag, (seq, build) in p.__dict__.get("_tssep_builders", {}).items()
+                             if only is None or (id(p), tag) in only)
         self.device = device
 
     def __enter__(self):

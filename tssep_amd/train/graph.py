@@ -49,10 +49,10 @@ class GraphedStep:
         return tuple((k, tuple(ex[k].shape), ex[k].dtype) for k in self._tensor_keys(ex)) + \
             (("training", self.model.training),)
 
-    def _eager(self, ex):
+    def _eager(self, ex, derived_tags=None):
         self.optimizer.zero_grad()
         # (while capturing: the weight packs / transposes of the whole step as a branch of the graph, hip_ops.py)
-        with H.prepare_derived(list(self.model.parameters()), next(self.model.parameters()).device):
+        with H.prepare_derived(list(self.model.parameters()), next(self.model.parameters()).device, only=derived_tags):
             out = self.model(ex)
             summary = self.model.review(ex, out)
             summary["loss"].backward()
@@ -84,8 +84,8 @@ class GraphedStep:
                 return _p[0], _p[1]
             st["source"] = source
 
-        def run():
-            return self._eager({**st["rest"], **st["static"]})
+        def run(tags=None):
+            return self._eager({**st["rest"], **st["static"]}, tags)
 
         prev = me.permutation_source
         if shuffled:
@@ -93,15 +93,16 @@ class GraphedStep:
         try:
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
+            with torch.cuda.stream(s), H.record_derived() as seen:
                 for _ in range(self.warmup):       # same stream as the capture: side stream, caches, tables exist
                     run()
+            st["derived_tags"] = frozenset(seen) if self.warmup > 0 else None     # the layouts THIS signature reads
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             H.check_cluster_errors(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s):
-                st["out"], st["summary"] = run()
+                st["out"], st["summary"] = run(st["derived_tags"])
             st["graph"] = g
         finally:
             me.permutation_source = prev
