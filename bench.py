@@ -345,10 +345,13 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg3",
                     help="cfg3 = the headline configuration (BASELINE configs[2]); cfg4 = its 8-utterance "
                          "per-GPU shard of configs[3]; cfg5 = 8 speakers x 30 s (configs[4])")
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TSSEP_BENCH_BATCH", 0)),
+    ap.add_argument("--batch", type=int, default=0,
                     help="utterances per GPU (weak scaling: global batch = batch * gpus); 0 = the workload's default")
-    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default=os.environ.get("TSSEP_GEMM_PRECISION", "bf16x3"),
-                    help="arithmetic of the non-recurrent GEMMs")
+    ap.add_argument("--gemm", choices=["f32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the non-recurrent GEMMs (bf16x3 = the product's default, tssep_amd/train/runtime.py)")
+    ap.add_argument("--runtime", nargs="*", default=[], metavar="KEY=VALUE",
+                    help="runtime policy overrides as an experiment would state them under eg.runtime "
+                         "(tssep_amd/train/runtime.py), e.g. --runtime onchip16_bwd=false fold_tail=0")
     ap.add_argument("--recurrence", choices=["auto", "stream", "cluster", "onchip"], default="auto",
                     help="recurrence kernel: auto = hip_ops.recurrence_kernel's policy (split-bf16 W-stationary "
                          "for H >= 128); stream / cluster = exact fp32")
@@ -382,8 +385,9 @@ def main():
     K, N_s = wl["K"], wl["N"]
     B = args.batch or wl["batch"]
     from tssep_amd import hip_ops as H
-    H.GEMM_PRECISION = args.gemm
-    H.RECURRENCE = args.recurrence
+    from tssep_amd.train import runtime as RT
+    RT.apply(RT.parse_overrides(args.runtime))
+    RT.apply(gemm_precision=args.gemm, recurrence=args.recurrence)
     model = build_model(K).to(dev)
     from tssep_amd.train.optimizer import Adam
     opt = Adam(gradient_clipping=10.0, lr=1e-5)          # clipping as tssep/exp/init_cfg_common.yaml:85-94
@@ -690,6 +694,7 @@ def main():
                        "setup_steps": SETUP_STEPS,      # untimed, before the W warm-up steps (allocator, weight layouts)
                        "collective": collective,
                        "arithmetic": arithmetic(args.gemm), "recurrence": args.recurrence,
+                       "runtime_policy": {k: v for k, v in RT.current().items() if v != RT.defaults()[k]} or "defaults (tssep_amd/train/runtime.py)",
                        "hip_graph": ("forward + loss + backward replayed as one captured hipGraph; optimizer eager; "
                                      "roofline timings from an eager pass after the timed region") if graphed else None,
                        "tflop_per_step": dict(

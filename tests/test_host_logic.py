@@ -169,7 +169,34 @@ def test_abi_argument_validation_without_gpu():
 
 
 def test_side_stream_rows_policy():
-    assert H.SIDE_STREAM_MAX_ROWS == 512 * 253
+    assert H.SIDE_STREAM_MAX_SEQS == 512
+
+
+def test_runtime_policy_is_recorded_not_read_from_the_environment(monkeypatch):
+    """the host layer's policy (arithmetic, recurrence family, folds, side stream, graph replay) lives in
+    tssep_amd.train.runtime -- defaults = what bench.py measures (split-bf16 GEMMs), deviations come from `eg.runtime` in
+    the YAML and are frozen into config.yaml; hip_ops reads no TSSEP_* environment variable."""
+    import inspect
+    from tssep_amd.train import experiment, runtime
+    src = inspect.getsource(H)
+    assert "os.environ" not in src and "getenv" not in src and "import os" not in src
+    assert runtime.defaults()["gemm_precision"] == "bf16x3" == H.GEMM_PRECISION
+    assert runtime.current() == runtime.defaults()
+    monkeypatch.setenv("TSSEP_GEMM_PRECISION", "f32")            # ignored: not a channel any more
+    assert runtime.current()["gemm_precision"] == "bf16x3"
+    with runtime.applied(gemm_precision="f32", fold_tail=0, onchip16_bwd=0):
+        assert (H.GEMM_PRECISION, H.FOLD_TAIL, H.ONCHIP16_BWD) == ("f32", 0, False)
+    assert runtime.current() == runtime.defaults()
+    with pytest.raises(KeyError):
+        runtime.apply(gemm_precison="f32")                       # a typo must not train on the default silently
+    with pytest.raises(ValueError):
+        runtime.apply(gemm_precision="fp8")
+    assert runtime.parse_overrides(["gemm_precision=f32", "side_stream_max_seqs=0", "fold_tanh=false"]) == \
+        dict(gemm_precision="f32", side_stream_max_seqs=0, fold_tanh=False)
+    # the frozen configuration carries the COMPLETE policy, with the experiment's deviations
+    cfg = experiment.Experiment.get_config({"runtime": {"gemm_precision": "f32"}})
+    assert cfg["runtime"] == dict(runtime.defaults(), gemm_precision="f32")
+    assert experiment.Experiment.get_config({})["runtime"] == runtime.defaults()
 
 
 def test_lazy_dataset_stages_and_threaded_prefetch():

@@ -6,7 +6,6 @@ is a call into libtssep_hip.so.  Nothing here falls back to ATen math.
 import ctypes
 import itertools
 import math
-import os as _os
 
 import numpy as np
 import torch
@@ -264,10 +263,13 @@ def feat_fwd(X, fb, dct, n_mfcc, top_db=80.0, statistics_axis="tf"):
 
 
 # ------------------------------------------------------------------------------- GEMM
-# Arithmetic of the non-recurrent GEMMs: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 on the
-# bf16 MFMA with fp32 accumulation (fp32-class accuracy, see gemm_bf16x3.hip).  The recurrence
-# kernel (exact fp32 or split-bf16) is chosen separately by recurrence_kernel().
-GEMM_PRECISION = _os.environ.get("TSSEP_GEMM_PRECISION", "f32")
+# Arithmetic of the non-recurrent GEMMs: "bf16x3" = split-bf16 on the bf16 MFMA with fp32 accumulation (fp32-class
+# accuracy: masks 3e-6 from the CPU oracle, see gemm_bf16x3.hip) -- the DEFAULT since round 5: what bench.py measures is
+# what `python -m tssep_amd.exp.run_tssep` trains with; "f32" = exact fp32 MFMA (the reference's GEMM arithmetic).  The
+# recurrence kernel (exact fp32 or split-bf16) is chosen separately by recurrence_kernel().
+# This module reads NO environment variable: every policy attribute below has its default here and is set -- recorded
+# in config.yaml / log/runtime.json -- through tssep_amd.train.runtime (`eg.runtime.*`, `bench.py --runtime k=v`).
+GEMM_PRECISION = "bf16x3"
 _PREC = {"f32": 0, "bf16x3": 1, "bf16": 3}      # "bf16": the plain-bf16 side line (tssep_gemm_args.precision = 3)
 
 
@@ -311,6 +313,12 @@ GEMM_KERNELS = {"auto": 0, "f32": 1, "pipe": 2, "tall2": 3, "tall4": 4, "tall4_x
 GEMM_KERNEL_NAMES = {v: k for k, v in GEMM_KERNELS.items()}
 GEMM_PREFER = ()
 GEMM_LOG = None          # a list: (kernel name, M, N, K) of every launch is appended (tests)
+RECURRENCE_LOG = None    # a list: dict(kernel, direction, N, T, H, groups) of every recurrence launch (Trainer: the kernel plan)
+
+
+def _log_recurrence(kernel, direction, N, T, H, groups=0):
+    if RECURRENCE_LOG is not None:
+        RECURRENCE_LOG.append(dict(kernel=kernel, direction=direction, sequences=N, frames=T, units=H, groups=groups))
 
 
 class prefer_gemm_kernels:
@@ -598,12 +606,14 @@ def lstm_pack(params, H, I):
 
 
 def blstm_fwd(gates, cell, hout, ldo, dstride, whh_f, N, T, H):
+    _log_recurrence("stream_f32", "fwd", N, T, H, 0)
     with _timed("blstm_fwd", 2 * 2 * N * T * 4 * H * H):
         check(_lib.lib().tssep_blstm_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(whh_f), N,
                                          T, H, _stream()), "blstm_fwd")
 
 
 def blstm_bwd(gates, cell, dhout, ldo, dstride, whh_b, N, T, H):
+    _log_recurrence("stream_f32", "bwd", N, T, H, 0)
     with _timed("blstm_bwd", 2 * 2 * N * T * 4 * H * H):
         check(_lib.lib().tssep_blstm_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(whh_b), N,
                                          T, H, _stream()), "blstm_bwd")
@@ -707,6 +717,7 @@ def lstm_pack_cluster(w_hh_f, w_hh_r, H):
 
 
 def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H, ms=2):
+    _log_recurrence("cluster_f32", "fwd", N, T, H, 0)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 0, cus, ms)) // 8 + 1,
@@ -718,6 +729,7 @@ def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H, ms=2):
 
 
 def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H, ms=2):
+    _log_recurrence("cluster_f32", "bwd", N, T, H, 0)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 1, cus, ms)) // 8 + 1,
@@ -740,6 +752,7 @@ def lstm_pack_onchip(w_hh_f, w_hh_r, H):
 
 
 def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
+    _log_recurrence("onchip32_bf16x3", "fwd", N, T, H, 0)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 0)) // 8 + 2, device=gates.device,
@@ -750,18 +763,22 @@ def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
                                        _stream()), "blstm_onchip_fwd")
 
 
-# interleaved forward (16-sequence groups in rotation): TSSEP_ONCHIP16=0 switches it off (read per call)
+# interleaved forward (16-sequence groups in rotation); policy: runtime.onchip16 / onchip16_groups / onchip16_min_n
+ONCHIP16 = True
+ONCHIP16_GROUPS = 0      # 1 | 2 | 4: forced group count where it divides the number of 16-sequence groups (A/B)
+ONCHIP16_MIN_N = 1       # (a one-group step is 3.5 us against 5.2: the latency regime gains too)
+ONCHIP16_BWD = True
+ONCHIP16_BWD_GROUPS = 2  # at most: a backward phase is paced by its three barriers and the publish (see onchip16_bwd_groups)
+
+
 def onchip16_groups(N, H, device):
-    if _os.environ.get("TSSEP_ONCHIP16", "1") == "0":
+    if not ONCHIP16:
         return 0
-    forced = int(_os.environ.get("TSSEP_ONCHIP16_GROUPS", "0"))
+    forced = ONCHIP16_GROUPS
     g = int(_lib.lib().tssep_blstm_onchip16_groups(N, H, n_cus(device)))
     if g and forced in (1, 2, 4) and ((N + 15) // 16) % forced == 0:
         return forced
     return g if N >= ONCHIP16_MIN_N else 0
-
-
-ONCHIP16_MIN_N = int(_os.environ.get("TSSEP_ONCHIP16_MIN_N", "1"))     # (a one-group step is 3.5 us against 5.2: the latency regime gains too)
 
 
 def lstm_pack_onchip16(w_hh_f, w_hh_r, H):
@@ -773,6 +790,7 @@ def lstm_pack_onchip16(w_hh_f, w_hh_r, H):
 
 
 def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, layout=0):
+    _log_recurrence("onchip16_bf16x3", "fwd", N, T, H, groups)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
@@ -783,12 +801,12 @@ def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, l
 
 
 def onchip16_bwd_groups(N, H, device):
-    """group count of the interleaved backward (0: use the 32-sequence kernel); TSSEP_ONCHIP16_BWD=0 switches it off"""
-    if _os.environ.get("TSSEP_ONCHIP16_BWD", "1") == "0" or not (256 < H <= 320):
+    """group count of the interleaved backward (0: use the 32-sequence kernel; policy runtime.onchip16_bwd)"""
+    if not ONCHIP16_BWD or not (256 < H <= 320):
         return 0
     # (two groups at most: a backward phase is paced by its three barriers and the publish, 7.1 against 7.8 ms per launch
     # at 3 072 sequences with four -- profiles/r3_onchip16_backward.jsonl)
-    return min(onchip16_groups(N, H, device), int(_os.environ.get("TSSEP_ONCHIP16_BWD_GROUPS", "2")))
+    return min(onchip16_groups(N, H, device), ONCHIP16_BWD_GROUPS)
 
 
 def lstm_pack_onchip16_bwd(w_hh_f, w_hh_r, H):
@@ -800,6 +818,7 @@ def lstm_pack_onchip16_bwd(w_hh_f, w_hh_r, H):
 
 
 def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, layout=0):
+    _log_recurrence("onchip16_bf16x3", "bwd", N, T, H, groups)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_bwd_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
@@ -810,6 +829,7 @@ def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, 
 
 
 def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
+    _log_recurrence("onchip32_bf16x3", "bwd", N, T, H, 0)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 1)) // 8 + 2, device=gates.device,
@@ -830,16 +850,14 @@ def lstm_unpack(src, ld, nsplit, split_stride, H, ncols, dst_f, dst_r, accumulat
 # with a GradBucket attached they are accumulated straight into the flat gradient buffer on a
 # second HIP stream, overlapping the T-sequential recurrences of the layers still to come.
 _SIDE = {}
-OVERLAP_WGRAD = _os.environ.get("TSSEP_OVERLAP_WGRAD", "1") != "0"
-FOLD_TANH = _os.environ.get("TSSEP_FOLD_TANH", "1") != "0"   # Tanh backward inside the consumer's d(input) GEMM store
-FOLD_TAIL = int(_os.environ.get("TSSEP_FOLD_TAIL", "1"))    # (2: the loss only, 3: the un-map only -- experiments)   # LogMAE / MAE backward and the logit un-map inside the fused tail's backward
-
-
-SIDE_STREAM = _os.environ.get("TSSEP_SIDE_STREAM", "1") != "0"
+OVERLAP_WGRAD = True
+FOLD_TANH = True         # Tanh backward inside the consumer's d(input) GEMM store
+FOLD_TAIL = 1            # LogMAE / MAE backward and the logit un-map inside the fused tail's backward (0: off; 2: the loss only, 3: the un-map only -- experiments)
+SIDE_STREAM = True
+SIDE_STREAM_MAX_SEQS = 512   # layers with more sequences (x 253 frames) stay on the compute stream: beyond this the GEMMs of the two streams only slow each other
 ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
-
-
-SIDE_STREAM_MAX_ROWS = int(_os.environ.get("TSSEP_SIDE_STREAM_MAX_SEQS", 512)) * 253   # beyond this the GEMMs of the two streams only slow each other
+GRAPH_STEP = "auto"      # Trainer: hipGraph replay of forward + loss + backward ("auto": batches of <= GRAPH_MAX_UTTERANCES utterances)
+GRAPH_MAX_UTTERANCES = 32
 
 
 def side_stream(device, rows=0):
@@ -848,7 +866,7 @@ def side_stream(device, rows=0):
     run at 213 instead of 124 TFLOP/s --, -0.6 % for the 768-sequence layers of batch 768, so layers
     with more than 512 sequences stay on the compute stream."""
     cur = torch.cuda.current_stream(device)
-    if not SIDE_STREAM or rows > SIDE_STREAM_MAX_ROWS:
+    if not SIDE_STREAM or rows > SIDE_STREAM_MAX_SEQS * 253:
         return cur
     key = (str(device), cur.cuda_stream)
     if key not in _SIDE:

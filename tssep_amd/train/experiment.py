@@ -27,14 +27,20 @@ class Experiment(Configurable):
         config["trainer"] = trainer
         if config.get("init_ckpt") is None:
             config["init_ckpt"] = {"factory": InitCheckPoint}
+        # (new here, no counterpart in the reference: the host layer's runtime policy -- GEMM arithmetic, recurrence
+        # family, folds, graph replay; train/runtime.py -- frozen COMPLETE into config.yaml: a run is reproducible
+        # from its storage dir alone, whatever shell it was started from)
+        from . import runtime as _runtime
+        config["runtime"] = dict(_runtime.defaults(), **(config.get("runtime") or {}))
 
     def __init__(self, trainer=None, train_batchsize=None, validation_batchsize=None,
-                 init_ckpt=None, init_ckpt_strict=True):
+                 init_ckpt=None, init_ckpt_strict=True, runtime=None):
         self.trainer = trainer
         self.train_batchsize = train_batchsize
         self.validation_batchsize = validation_batchsize
         self.init_ckpt = init_ckpt if init_ckpt is not None else InitCheckPoint()
         self.init_ckpt_strict = init_ckpt_strict
+        self.runtime = dict(runtime or {})
 
     @property
     def device(self):
@@ -63,6 +69,8 @@ class Experiment(Configurable):
     def train(self):                                         # experiment.py:219-320
         t = self.trainer
         model = t.model
+        from . import runtime as _runtime
+        _runtime.apply(self.runtime)                         # the policy frozen in config.yaml (defaults: the benchmark's arithmetic)
         resume = (t.checkpoint_dir / "ckpt_latest.pth").exists()
         if not resume:
             self.init_ckpt(self)
@@ -70,6 +78,12 @@ class Experiment(Configurable):
         model.to(torch.device("cuda", dev))
         val = model.prepare_validate_dataset(device=dev, batch_size=self.validation_batchsize)
         train = model.prepare_train_dataset(device=dev, batch_size=self.train_batchsize)
+        from .. import distributed as _dist
+        if _dist.get_rank() == 0:                            # what this run computed with, beside its checkpoints
+            import json
+            log_dir = t.storage_dir / "log"
+            log_dir.mkdir(exist_ok=True, parents=True)
+            (log_dir / "runtime.json").write_text(json.dumps(_runtime.describe(torch.device("cuda", dev)), indent=1))
         t.test_run(train, val)
         t.register_validation_hook(val, max_checkpoints=None)
         return t.train(train, device=dev, resume=resume)

@@ -31,13 +31,20 @@ _INPUT_KEYS = ("observation", "auxInput", "Input", "Vad", "vad")
 
 
 class GraphedStep:
-    def __init__(self, model, optimizer, warmup=2, adopt_inputs=False):
+    def __init__(self, model, optimizer, warmup=2, adopt_inputs=False, zero_grad=True, max_graphs=0):
         """adopt_inputs: the tensors of the first batch of a signature BECOME the static inputs (no
-        clone, no per-step copy while the caller keeps passing the same tensors -- benchmarks)."""
+        clone, no per-step copy while the caller keeps passing the same tensors -- benchmarks).
+        zero_grad=False (Trainer): the graph does not clear the gradient bucket -- the caller accumulates the micro-steps
+        of a virtual minibatch (tssep/train/experiment.py:135-151) and clears it at the boundaries itself; the passes a
+        capture needs then leave the bucket exactly as they found it.
+        max_graphs > 0: input signatures beyond that many run eagerly (a corpus of many chunk lengths must not pile up
+        graphs, each with its own activation pool)."""
         self.model, self.optimizer, self.warmup = model, optimizer, int(warmup)
         self.adopt_inputs = bool(adopt_inputs)
+        self.zero_grad, self.max_graphs = bool(zero_grad), int(max_graphs)
         self._graphs = {}
         self.replays = 0
+        self.eager_steps = 0
 
     # ------------------------------------------------------------------------------ helpers
     def _tensor_keys(self, ex):
@@ -50,7 +57,8 @@ class GraphedStep:
             (("training", self.model.training),)
 
     def _eager(self, ex, derived_tags=None):
-        self.optimizer.zero_grad()
+        if self.zero_grad:
+            self.optimizer.zero_grad()
         # (while capturing: the weight packs / transposes of the whole step as a branch of the graph, hip_ops.py)
         with H.prepare_derived(list(self.model.parameters()), next(self.model.parameters()).device, only=derived_tags):
             out = self.model(ex)
@@ -58,6 +66,28 @@ class GraphedStep:
             summary["loss"].backward()
         self.optimizer.bucket.sync()
         return out, summary
+
+    def _host_side_targets(self, ex):
+        """What the loss would compute on the HOST inside `review` (loss.py:122-146: the frame activity `Vad` from the
+        sample activity `vad`, util/utils.stft_vad -- numpy, as in the reference) is computed here, in front of the graph,
+        and enters it as one more static input: a device-to-host copy cannot be captured."""
+        loss, fe = self.model.loss, getattr(self.model, "fe", None)
+        tgt = getattr(loss, "target", None)
+        if tgt == "Vad" and tgt not in ex and ex.get("vad") is not None and fe is not None:
+            from ..util.utils import stft_vad
+            dev = next(self.model.parameters()).device
+            v = stft_vad(ex["vad"], fe.window_length, fe.shift, fe.fading)
+            ex = dict(ex)
+            ex[tgt] = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v, dtype=torch.float32).to(dev)
+        return ex
+
+    def usable(self, ex):
+        """Whether this example can go through a graph at all: device-resident inputs, no snapshot this step (the snapshot
+        branch of `review` copies to the host)."""
+        return (isinstance(ex.get("observation", ex.get("Input")), torch.Tensor)
+                and ex.get("observation", ex.get("Input")).is_cuda
+                and isinstance(ex.get("auxInput"), torch.Tensor) and ex["auxInput"].is_cuda
+                and not getattr(self.model, "create_snapshot", False) and not H.KERNEL_TIMING)
 
     # ------------------------------------------------------------------------------ capture
     def _capture(self, ex):
@@ -76,8 +106,12 @@ class GraphedStep:
             st["perm_pinned"] = [torch.zeros(2, B, K, dtype=torch.int32).pin_memory() for _ in range(4)]
             st["perm_events"] = [None] * 4
             st["perm_shape"] = (B, K)
-            # warm-up and capture read the static buffer; a valid permutation must be in it
+            # warm-up and capture read the static buffer; a valid permutation must be in it.  Drawn with np.random's
+            # state put back: the step this capture serves draws ITS permutation in __call__, so a run through graphs
+            # consumes the global RNG exactly like the eager run -- one permutation per batch entry and step (net.py:824-826)
+            rng = np.random.get_state()
             st["perm_dev"].copy_(torch.as_tensor(me.draw_permutations(B, K)))
+            np.random.set_state(rng)
 
             def source(b, k, d, _p=st["perm_dev"]):
                 assert (b, k) == tuple(_p.shape[1:]), ((b, k), _p.shape)
@@ -90,6 +124,8 @@ class GraphedStep:
         prev = me.permutation_source
         if shuffled:
             me.permutation_source = st["source"]
+        # (zero_grad=False: the warm-up and capture passes accumulate into the caller's half-filled bucket -- put it back)
+        kept = None if self.zero_grad else [f.clone() for f in self.optimizer.bucket.flats]
         try:
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
@@ -106,6 +142,10 @@ class GraphedStep:
             st["graph"] = g
         finally:
             me.permutation_source = prev
+            if kept is not None:
+                torch.cuda.synchronize(dev)
+                for f, k in zip(self.optimizer.bucket.flats, kept):
+                    f.copy_(k)
         return st
 
     # ------------------------------------------------------------------------------- replay
@@ -113,9 +153,13 @@ class GraphedStep:
         """-> (ForwardOutput, ReviewSummary) of this step; their tensors are STATIC buffers that the next
         call overwrites (lazily computed fields -- mask, stft_estimate -- are evaluated from them on
         access).  Gradients are in the optimizer's flat bucket afterwards (call ``optimizer.step()``)."""
+        ex = self._host_side_targets(ex)
         sig = self._signature(ex)
         st = self._graphs.get(sig)
         if st is None:
+            if self.max_graphs and len(self._graphs) >= self.max_graphs:
+                self.eager_steps += 1
+                return self._eager(ex)
             st = self._graphs[sig] = self._capture(ex)
         for k in st["keys"]:
             if ex[k].data_ptr() != st["static"][k].data_ptr():

@@ -106,6 +106,27 @@ class Trainer(Configurable):
         if who >= 0:
             raise RuntimeError(f"rank {_dist.get_rank()}: leaving because rank {who} failed")
 
+    @staticmethod
+    def _utterances(ex):
+        obs = ex.get("observation", ex.get("Input"))
+        return int(obs.shape[0]) if isinstance(obs, torch.Tensor) and obs.dim() == 3 else 1
+
+    def _log_kernel_plan(self, gemm_log, recurrence_log, chief):
+        """Once per run: the kernels behind the first training step -- GEMM kernel per request (the library's own choice,
+        `tssep_gemm_plan`), recurrence family and group counts -- and the runtime policy they ran under."""
+        from . import runtime as _runtime
+        plan = _runtime.summarise_plan(gemm_log, recurrence_log)
+        self.kernel_plan = plan
+        if not chief:
+            return
+        import json
+        (self.storage_dir / "log").mkdir(parents=True, exist_ok=True)
+        (self.storage_dir / "log" / "kernel_plan.json").write_text(json.dumps(
+            dict(policy=_runtime.current(), **plan), indent=1))
+        rec = sorted({f"{r['kernel']}/{r['direction']}" for r in plan["recurrence"]})
+        print(f"tssep_amd: arithmetic {_runtime.current()['gemm_precision']}; GEMM kernels "
+              f"{dict(sorted(plan['gemm'].items()))}; recurrences {rec} (log/kernel_plan.json)", flush=True)
+
     def validate(self):
         self.model.eval()
         losses = []
@@ -168,6 +189,20 @@ class Trainer(Configurable):
                 _dist.broadcast_(t, src=0)
             np.random.seed((int(np.random.get_state()[1][0]) + 7919 * rank) & 0x7FFFFFFF)
         chief = rank == 0
+        # hipGraph replay of forward + loss + backward (train/graph.py) for launch-bound micro-steps: policy
+        # runtime.graph_step = "auto" (batches of at most runtime.graph_max_utterances utterances: 8 x 4 s run 6.9 instead
+        # of 8.6 ms), "on", "off".  One graph per input shape, at most eight (further shapes run eagerly).  The gradient
+        # bucket stays the trainer's: cleared at the boundaries of the virtual minibatch below, never by the graph; the
+        # speaker permutations are drawn from np.random per step exactly as in the eager step, so a seeded run computes
+        # the same losses and parameters either way (tests: bit-identical over 24 iterations).
+        from .. import hip_ops as _H
+        gstep = None
+        on_gpu = next(self.model.parameters()).is_cuda
+        if _H.GRAPH_STEP != "off" and on_gpu and hasattr(getattr(self.model, "mask_estimator", None), "permutation_source"):
+            from .graph import GraphedStep
+            gstep = GraphedStep(self.model, self.optimizer, zero_grad=False, max_graphs=8)
+        self.graph_step = gstep
+        plan_logged = not on_gpu
         stop_n, stop_unit = self.stop_trigger
         assert stop_unit == "iteration", self.stop_trigger
         self.optimizer.zero_grad()
@@ -207,8 +242,23 @@ class Trainer(Configurable):
                             break
                     elif ex is None:
                         break
-                    summary = self.model.review(ex, self.model(ex))
-                    summary["loss"].backward()
+                    if not plan_logged:
+                        # the first micro-step of a run, eagerly, with the launch logs on: which kernels the library picks
+                        # for THIS model and batch (tssep_gemm_plan) and which recurrence family runs -> log/kernel_plan.json
+                        _H.GEMM_LOG, _H.RECURRENCE_LOG = [], []
+                        try:
+                            summary = self.model.review(ex, self.model(ex))
+                            summary["loss"].backward()
+                        finally:
+                            glog, rlog, _H.GEMM_LOG, _H.RECURRENCE_LOG = _H.GEMM_LOG, _H.RECURRENCE_LOG, None, None
+                        plan_logged = True
+                        self._log_kernel_plan(glog, rlog, chief)
+                    elif gstep is not None and gstep.usable(ex) and (
+                            _H.GRAPH_STEP == "on" or self._utterances(ex) <= _H.GRAPH_MAX_UTTERANCES):
+                        _, summary = gstep(ex)           # forward + loss + backward as one replayed hipGraph
+                    else:
+                        summary = self.model.review(ex, self.model(ex))
+                        summary["loss"].backward()
                     self.iteration += 1
                     if boundary:
                         self.optimizer.step()            # all-reduce(SUM) over ranks, clip, Adam
@@ -228,8 +278,10 @@ class Trainer(Configurable):
         if chief:                                    # the summary scalars, for runs driven as child processes
             import json
             (self.storage_dir / "log").mkdir(parents=True, exist_ok=True)
+            extra = {} if gstep is None else dict(graph_replays=gstep.replays, graph_eager_steps=gstep.eager_steps,
+                                                  graphs=len(gstep._graphs))
             (self.storage_dir / "log" / "history.json").write_text(json.dumps(
-                dict(iteration=self.iteration, epoch=self.epoch, loss=self.history)))
+                dict(iteration=self.iteration, epoch=self.epoch, loss=self.history, **extra)))
         if world > 1:
             # identical replicas fed with summed gradients must still be identical: anything else is a
             # lost or doubled all-reduce
