@@ -446,6 +446,7 @@ def main():
             marks[i + 1].record()
         barrier()
         dt_ = time.perf_counter() - t0
+        timed_run.local_s = dt_              # this rank's own clock (the reported time is the MAX over ranks)
         H.KERNEL_TIMING = False
         if gstep is not None:                # per-kernel roofline timings: an eager pass after the timed region
             H.KERNEL_TIMING = True
@@ -529,12 +530,16 @@ def main():
             own = sum(H.KERNEL_OWN_BYTES.get(k, 0) for k, _ in hb)
             phys_raw, phys_x2 = traffic.get("maskhead_fwd+bwd"), traffic_x2.get("maskhead_fwd+bwd")
             per_launch_s = ms * 1e-3 / n_l
-            mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd", achieved=round(gbps, 1),
-                             peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4),
-                             frac_is="EFFECTIVE: the unfused mask head's bytes (SURVEY 8d) over the fused kernels' time -- "
-                                     "not a bandwidth the kernels move; see frac_own_bytes / frac_physical",
-                             frac_own_bytes=round(own / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if own else None,
+            own_gbps = own / (ms * 1e-3) / 1e9 if own else gbps
+            mask_head = dict(bound="hbm", kernel="maskhead_fwd+bwd" + (" (fused with the inverse STFT / its adjoint + loss backward)" if own else ""),
+                             achieved=round(own_gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(own_gbps / PEAK_HBM_GBPS, 4),
+                             frac_is="PHYSICAL by accounting: the bytes the kernels that run must move (own_bytes_per_launch) over "
+                                     "their measured time; the PMC-measured figure is frac_physical",
                              own_bytes_per_launch=own // n_l if own else None,
+                             frac_effective=round(gbps / PEAK_HBM_GBPS, 4),
+                             frac_effective_is="the UNFUSED mask head's algorithmic bytes (SURVEY 8d: (16 K F + 8 F) per frame and "
+                                               "direction) over the FUSED kernels' time -- not a bandwidth anything moves (r1-r4 "
+                                               "reported this as `frac`)",
                              frac_physical=(dict(raw=round(phys_raw / per_launch_s / 1e9 / PEAK_HBM_GBPS, 4),
                                                  fetch_x2=round(phys_x2 / per_launch_s / 1e9 / PEAK_HBM_GBPS, 4))
                                             if phys_raw and phys_x2 else None),
@@ -542,15 +547,13 @@ def main():
                              pmc_source=traffic_src if phys_raw is not None else None,
                              launches=n_l,
                              avg_ms=round(ms / n_l, 4), algorithmic_bytes_per_launch=by // n_l,
-                             note="`frac` prices the FUSED kernels' time (mask head + inverse STFT forward; iSTFT adjoint + "
-                                  "mask-head backward + LogMAE backward + logit un-map) against the bytes of the UNFUSED mask "
-                                  "head of net.py:983 + enhancer.py:98-100, (16 K F + 8 F) per frame and direction; "
-                                  "`frac_own_bytes` against what the fused kernels themselves must move (logit + observation "
-                                  "in, K x 256 samples out / estimate + target in, d(logit) out); `frac_physical` against the "
-                                  "PMC bytes of the committed counter pass (as reported / fetch side x2).  The fused kernels "
-                                  "run three FFT passes per frame and are VALU-bound (profiles/r3_sq_wave_states.jsonl), so "
-                                  "the own-bytes fraction is their honest distance from the HBM roofline; `chain` prices the "
-                                  "same time against the whole unfused chain's bytes")
+                             note="the fused kernels (mask head + inverse STFT forward; iSTFT adjoint + mask-head backward + LogMAE "
+                                  "backward + logit un-map) read logit + observation and write K x 256 samples per frame / read "
+                                  "estimate + target and write d(logit): `frac` prices exactly those bytes.  They run three FFT "
+                                  "passes per frame and are VALU-bound (profiles/r3_sq_wave_states.jsonl); the stand-alone head "
+                                  "(`standalone_head`: tssep_maskhead_fwd / _bwd, the kernels behind out.mask / out.stft_estimate) "
+                                  "is the HBM-bound kernel the north star's 60 % speaks of; `chain` prices the fused time against "
+                                  "the whole unfused chain's bytes (an effective figure, > 1 possible)")
             chain = by + n_l * B * T * 8 * K * FBINS + n_l * 4 * B * K * N_s      # + estimate (8 K F) + samples
             folded = ""
             if H.FOLD_TAIL and "maskhead_bwd" in ktimes:      # what else the backward kernel now does per launch
@@ -566,6 +569,29 @@ def main():
                                       algorithmic_bytes_per_launch=chain // n_l, achieved=round(cg, 1),
                                       frac=round(cg / PEAK_HBM_GBPS, 4))
         return roofline, mask_head
+
+    def standalone_head(reps=5):
+        """The mask head by itself (sigmoid + Masking, net.py:983 + enhancer.py:98-100, and its backward) on the timed batch's
+        shapes: tssep_maskhead_fwd / tssep_maskhead_bwd -- what `out.mask` / `out.stft_estimate` run; HBM-bound, (16 K F + 8 F)
+        bytes per frame each way -- timed with HIP events on the launch stream."""
+        T = H.stft_frames(N_s)
+        g = torch.Generator(device=dev).manual_seed(3)
+        logit = torch.randn(B, K, T, FBINS, device=dev, generator=g)
+        obs_c = torch.view_as_complex(torch.randn(B, T, FBINS, 2, device=dev, generator=g))
+        nbytes = B * T * (16 * K * FBINS + 8 * FBINS)
+        mask, est = H.maskhead_fwd(logit, obs_c)
+        dlogit = H.maskhead_bwd(est, None, mask, obs_c)
+        res = {}
+        for name, call in (("fwd", lambda: H.maskhead_fwd(logit, obs_c)), ("bwd", lambda: H.maskhead_bwd(est, None, mask, obs_c))):
+            best = float("inf")
+            for _ in range(reps):
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(); call(); e_.record()
+                torch.cuda.synchronize()
+                best = min(best, s_.elapsed_time(e_))
+            res[name] = dict(ms=round(best, 4), achieved=round(nbytes / best / 1e6, 1), frac=round(nbytes / best / 1e6 / PEAK_HBM_GBPS, 4))
+        del logit, obs_c, mask, est, dlogit
+        return dict(bound="hbm", unit="GB/s", peak=PEAK_HBM_GBPS, bytes_per_launch=nbytes, best_of=reps, **res)
 
     def arithmetic(gemm_name):
         rec = ("split-bf16 (hi+lo) MFMA W-stationary recurrence" if args.recurrence in ("auto", "onchip")
@@ -609,8 +635,11 @@ def main():
                 H.RECURRENCE = old_rec
         H.GEMM_PRECISION = args.gemm
     dt, T, med = timed_run(args.steps, args.warmup)
+    dt_local = timed_run.local_s
     H.check_cluster_errors(dev)
     roofline, mask_head = rooflines(dt, args.gemm)
+    if mask_head is not None and world == 1:
+        mask_head["standalone_head"] = standalone_head()
     two_prod = None
     if args.gemm == "bf16x3" and world == 1 and not args.no_exact_f32 and args.workload == "cfg3" and gstep is None:
         # secondary line, opt-in arithmetic (tssep_gemm_args.precision = 2): the weight-gradient GEMMs drop the dY_lo x X_hi
@@ -666,7 +695,26 @@ def main():
         ar_ms = torch.tensor([float(np.mean(ar)) if ar else 0.0, float(np.max(ar)) if ar else 0.0], dtype=torch.float64,
                              device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        # per-rank step time (a slow GPU / link shows up as one outlier), the ring's bus bandwidth, and which library and
+        # transport settings are behind "nccl": the first 8-GPU record should explain itself
+        mine = torch.zeros(world, dtype=torch.float64, device=ar_ms.device)
+        mine[rank] = dt_local / args.steps * 1e3
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        nbytes = int(opt.bucket.flat.numel()) * 4
+        try:
+            lib_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:                                       # noqa: BLE001 -- informational only
+            lib_version = None
         collective = dict(op="all_reduce(SUM) of the flat fp32 gradient, once per step, in place",
+                          ms_per_step_by_rank=[round(float(v), 3) for v in mine.cpu()],
+                          allreduce_busbw_gbps=(round(2 * (world - 1) / world * nbytes / (float(ar_ms[0]) * 1e-3) / 1e9, 2)
+                                                if float(ar_ms[0]) > 0 else None),
+                          busbw_is="2 (N - 1) / N x bytes / mean all-reduce time: what a ring moves per GPU; xGMI: 7 links x ~153 GB/s, "
+                                   "a ring is bound by ONE link per direction",
+                          collective_library=("RCCL " + lib_version) if lib_version else dist.get_backend(),
+                          environment={k: v for k, v in os.environ.items()
+                                       if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE_GRAIN", "TSSEP_DIST_"))},
+                          device_names=sorted({torch.cuda.get_device_name(dev)}),
                           backend=dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (staged through the host: test configuration)"),
                           process_group_world_size=dist.get_world_size(), bytes=int(opt.bucket.flat.numel()) * 4,
                           allreduce_ms=round(float(ar_ms[0]), 4), allreduce_ms_max=round(float(ar_ms[1]), 4),

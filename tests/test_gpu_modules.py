@@ -1162,7 +1162,16 @@ def test_bench_default_flags_print_one_json_line():
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["roofline_mask_head"]["bound"] == "hbm" and "chain" in d["roofline_mask_head"]
     mh = d["roofline_mask_head"]
-    assert "frac_of_copy_ceiling" not in mh and 0 < mh["frac_own_bytes"] < 1 and mh["own_bytes_per_launch"] < mh["algorithmic_bytes_per_launch"]
+    # `frac` is the fused kernels' OWN bytes over their time (physical); the unfused head's bytes over the
+    # fused time is `frac_effective`; the stand-alone head (the HBM-bound kernel of the north star) is measured beside it
+    assert 0 < mh["frac"] < 1 and mh["own_bytes_per_launch"] < mh["algorithmic_bytes_per_launch"] and mh["frac"] < mh["frac_effective"]
+    assert mh["frac"] == pytest.approx(mh["own_bytes_per_launch"] / (mh["avg_ms"] * 1e-3) / 1e9 / 8000.0, rel=2e-2)
+    sh = mh["standalone_head"]
+    assert 0 < sh["fwd"]["frac"] < 1 and 0 < sh["bwd"]["frac"] < 1 and sh["bytes_per_launch"] == mh["algorithmic_bytes_per_launch"]
+    # the timed batch itself is checked in the same run (the oracle slice is skipped with --no-cpu-baseline)
+    pb = d["parity_at_headline_batch"]
+    assert pb["batch"] == 8 and pb["within_bars"] is True and pb["max_abs_mask_err"] < 1e-3 and pb["max_rel_grad_err"] < 1e-2
+    assert pb["against"]["gemm_kernels"] == ["f32"] and "f32" not in pb["headline_arithmetic"]["gemm_kernels"]
     assert d["roofline"]["traffic_algorithmic"] > 0          # (at batch 8 the dominant MFMA kernel is a recurrence: 40 / 44 B per cell)
     e = d["f32_gemms_bf16x3_recurrence"]
     assert e is not None and e["roofline"]["peak"] == pytest.approx(157.3) and e["dtype"] == "f32 GEMMs + bf16x3 recurrence"
@@ -1172,12 +1181,16 @@ def test_bench_default_flags_print_one_json_line():
     assert d["two_product_wgrad"] is not None and d["two_product_wgrad"]["value"] > 0
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("workload,batch,graph", [("cfg3", 4, "off"), ("cfg4", 8, "on")])
+def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
     """The N > 1 path of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
     --gpus 2`): rank-0 broadcast of the parameters, per-rank shards, barrier + max-over-ranks timing, the flat
     gradient all-reduce inside the optimizer step, ONE JSON line from rank 0 with n_gpus = 2 and the doubled global
     batch.  Two ranks share this box's single GPU, so the backend is gloo (RCCL refuses two ranks per device) and the
-    recurrences are the streaming ones (two processes must not run W-stationary launches concurrently)."""
+    recurrences are the streaming ones (two processes must not run W-stationary launches concurrently).
+    cfg4 + graph on: the per-GPU shard of configs[3] as the replayed hipGraph with the all-reduce +
+    optimizer outside it -- the replicas must still agree after the timed steps, i.e. the all-reduce sees the complete
+    gradient of replay i and replay i + 1 starts from the updated weights."""
     import json
     import socket
     import subprocess
@@ -1186,18 +1199,22 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, TSSEP_DIST_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--recurrence", "stream",
-                        "--no-cpu-baseline", "--no-exact-f32", "--graph", "off"],
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--batch", str(batch),
+                        "--recurrence", "stream", "--no-cpu-baseline", "--no-exact-f32", "--graph", graph],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2 * batch
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert (d["config"]["hip_graph"] is not None) == (graph == "on")
     c = d["config"]["collective"]
     assert c["process_group_world_size"] == 2 and c["replicas_agree"] is True and c["launches"] == 2
     assert c["allreduce_ms"] > 0 and c["bytes"] > 4e7
+    # what the first 8-GPU run should explain by itself: per-rank step times, bus bandwidth, the library behind "nccl"
+    assert len(c["ms_per_step_by_rank"]) == 2 and all(v > 0 for v in c["ms_per_step_by_rank"])
+    assert c["allreduce_busbw_gbps"] > 0 and "collective_library" in c and "environment" in c
 
 
 def test_headline_batch_gemm_requests_on_every_covering_kernel():
