@@ -1,4 +1,4 @@
-"""Micro-benchmark (GPU box): the exact-fp32 MFMA GEMM on the shapes of the TS-SEP step."""
+"""Micro-benchmark (GPU box): the GEMMs of the TS-SEP step, stand-alone.   python tools/bench_gemm.py [batch] [f32|bf16x3]"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,8 +36,7 @@ def run(name, M, N, K, kind):
                           tflops=round(2 * M * N * K / ms / 1e9, 1))), flush=True)
 
 
-import os as _o
-h.GEMM_PRECISION = _o.environ.get("TSSEP_GEMM_PRECISION", "f32")
+h.GEMM_PRECISION = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
 print("precision", h.GEMM_PRECISION)
 run("pre_net in", R1, 2400, 553, "nt")
 run("birnn0 in", R4, 2400, 513, "nt")

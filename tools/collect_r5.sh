@@ -1,18 +1,18 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): every measurement DESIGN.md cites for round 4, into gpurun_out/final/.
-# usage: bash tools/collect_r4.sh        then, in the build container: bash tools/install_profiles.sh 4
-# (round 4: the production library has no run-time switches; kernel-against-kernel comparisons come from
+# Runs on the GPU box (gpurun): every measurement DESIGN.md cites for round 5, into gpurun_out/final/.
+# usage: bash tools/collect_r5.sh        then, in the build container: bash tools/install_profiles.sh 5
+# (round 5: the production library has no run-time switches; kernel-against-kernel comparisons come from
 #  tools/sweep_gemm_shapes.py, which names kernels through tssep_gemm_f32_on)
 set -u
 O=gpurun_out/final; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="--no-cpu-baseline --no-exact-f32"
+B="--no-cpu-baseline --no-exact-f32 --no-headline-parity"
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python tools/bench_recurrence.py 8 32 64 128 256 512 768 1024 1536 2048 3072 > $O/recurrence_microbench.jsonl 2>/dev/null
 python tools/stress_recurrence.py 400 2>/dev/null | tail -1 > $O/recurrence_stress.json
 python tools/bench_onchip16.py 32 160 768 1536 3072 > $O/onchip16_microbench.jsonl 2>/dev/null
-TSSEP_GEMM_PRECISION=bf16x3 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
-TSSEP_GEMM_PRECISION=f32 python tools/bench_gemm.py 768 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
+python tools/bench_gemm.py 768 bf16x3 2>/dev/null | grep name > $O/gemm_microbench_bf16x3.jsonl
+python tools/bench_gemm.py 768 f32 2>/dev/null | grep name > $O/gemm_microbench_f32.jsonl
 python tools/bench_tail.py > $O/tail_microbench.jsonl 2>/dev/null
 python tools/grad_parity.py 4 > $O/parity_full_size.jsonl 2>/dev/null
 for b in 8 32 64 128 256 384 512 768 1152 1536; do

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copies what tools/collect_profiles.sh wrote under gpurun_out/final/ into profiles/ (tracked), names r<round>_*.
+# Copies what tools/collect_r5.sh wrote under gpurun_out/final/ into profiles/ (tracked), names r<round>_*.
 # usage: bash tools/install_profiles.sh [round] [batch] [gemm]      then re-run `python bench.py` on the GPU box
 # for the default line with the PMC fields filled (profiles/r<round>_bench_default.json).
 set -e
-R=${1:-4}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
+R=${1:-5}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
 python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G cfg3 > ${P}_traffic_pmc.json
 python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G cfg3 > ${P}_mfma_pmc.json
 for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16x3.jsonl gemm_microbench_bf16x3_wide0.jsonl \
@@ -28,7 +28,7 @@ def table(src, dst, header):
             n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '')
             f.write(f"{n[:78]:78s} {r['Calls']:>6s} {r['TotalDurationNs']:>12s} {float(r['AverageNs']):11.0f} {r['Percentage']:>6s} {r['MinNs']:>9s} {r['MaxNs']:>9s}\n")
     return rows
-cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --no-cpu-baseline --no-exact-f32"
+cmd = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py %s --no-cpu-baseline --no-exact-f32 --no-headline-parity"
 rows = table('$F/stats/s_kernel_stats.csv', '${P}_kernel_stats_default_b${B}_${G}.txt', cmd % "--steps 6 --warmup 2" + "   (default config: batch $B, $G; 3 setup + 2 warm-up + 6 timed = 11 steps in total)")
 table('$F/stats_f32/s_kernel_stats.csv', '${P}_kernel_stats_b${B}_f32.txt', cmd % "--gemm f32 --steps 6 --warmup 2" + "   (fp32 GEMMs; 11 steps in total)")
 table('$F/stats_cfg4/s_kernel_stats.csv', '${P}_kernel_stats_cfg4_b8.txt', cmd % "--workload cfg4 --graph off --steps 10 --warmup 3" + "   (8 utterances per GPU: the configs[3] shard; 16 steps in total)")
