@@ -11,6 +11,7 @@ torch.manual_seed(0)
 whh = [torch.randn(4 * Hh, Hh, device="cuda") * 0.05 for _ in range(2)]
 wf, wb = h.lstm_pack_onchip(whh[0], whh[1], Hh)
 wf16 = h.lstm_pack_onchip16(whh[0], whh[1], Hh)
+wf16q = h.lstm_pack_onchip16(whh[0], whh[1], Hh, 4)      # four-wave workgroups, ten per cluster, two per CU (round 5)
 
 
 def timeit(fn, reps=5):
@@ -47,9 +48,18 @@ for N in [int(a) for a in sys.argv[1:]] or [768, 3072]:
 
         row[f"g{g}_ms"] = round(timeit(new) - t_cp, 3)
         row[f"g{g}_maxdiff"] = float((hout - ref).abs().max())
+    for g in (1, 2):
+        if ((N + 15) // 16) % g:
+            continue
+
+        def newq():
+            gates.copy_(g0); h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16q, N, T, Hh, g, waves=4)
+
+        row[f"w4g{g}_ms"] = round(timeit(newq) - t_cp, 3)
+        row[f"w4g{g}_maxdiff"] = float((hout - ref).abs().max())
     h.check_cluster_errors()
     for k in list(row):
-        if k.endswith("_ms"):
+        if k.endswith("_ms") and not k.startswith("w4"):
             row[k.replace("_ms", "_us_per_step")] = round(row[k] * 1e3 / T / max(1, -(-N * 2 // (48 * (32 if k == "old_ms" else 16 * int(k[1]))))), 2)
     print(json.dumps(row), flush=True)
 

@@ -904,29 +904,30 @@ constexpr int TILE4 = SQ * UPW;              // f32x4 per gate tile (16 KB)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G, u32x4* wf) {
-  // wf[dir][g][wave 8][rb 2][ks 10][hl 2][lane 64]: A fragment (16 rows x 32 k) of row block rb, k-step ks:
+__global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, int H, int G, int NW, u32x4* wf) {
+  // wf[dir][g][wave NW][rb 2][ks 10][hl 2][lane 64]: A fragment (16 rows x 32 k) of row block rb, k-step ks:
   // lane (i = lane % 16, kg = lane / 16) holds W_hh[gate * H + unit][32 ks + 8 kg + 0..7], i = 4 u' + gate,
-  // unit = 64 g + 8 wave + 4 rb + u'
-  const int64_t n = (int64_t)2 * G * 8 * 2 * KS2 * 2 * 64;
+  // unit = 8 NW g + 8 wave + 4 rb + u'   (NW = 8: five workgroups of 64 units; NW = 4: ten of 32)
+  const int UW = 8 * NW;
+  const int64_t n = (int64_t)2 * G * NW * 2 * KS2 * 2 * 64;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = e;
     const int lane = (int)(r & 63); r >>= 6;
     const int hl = (int)(r & 1); r >>= 1;
     const int ks = (int)(r % KS2); r /= KS2;
     const int rb = (int)(r & 1); r >>= 1;
-    const int wave = (int)(r & 7); r >>= 3;
+    const int wave = (int)(r % NW); r /= NW;
     const int g = (int)(r % G);
     const int d = (int)(r / G);
     const int i = lane & 15, kg = lane >> 4;
-    const int unit = 64 * g + 8 * wave + 4 * rb + (i >> 2), gate = i & 3;
+    const int unit = UW * g + 8 * wave + 4 * rb + (i >> 2), gate = i & 3;
     const float* w = d ? w_hh_r : w_hh_f;
-    // the k axis of workgroup g starts at its OWN slice: local k <-> hidden unit (k + 64 g) mod 64 G (the operand image in
-    // LDS is rotated the same way) -- the k-steps of the own slice are 0 and 1 for every workgroup, a compile-time index
+    // the k axis of workgroup g starts at its OWN slice: local k <-> hidden unit (k + UW g) mod UW G (the operand image in
+    // LDS is rotated the same way) -- the k-steps of the own slice are the first ones for every workgroup, a compile-time index
     float x[8];
     for (int j = 0; j < 8; ++j) {
       const int kl = 32 * ks + 8 * kg + j;
-      const int kc = kl < 64 * G ? (kl + 64 * g) % (64 * G) : H;
+      const int kc = kl < UW * G ? (kl + UW * g) % (UW * G) : H;
       x[j] = unit < H ? w_at(w, H, gate * H + unit, kc) : 0.f;
     }
     unsigned h[4], l[4];
@@ -962,18 +963,36 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_G1_DELAY_OWN
 #define ONCHIP16_FWD_G1_DELAY_OWN 0
 #endif
-template <int NGA, bool NT>
-__global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
+// NW = waves per workgroup (round 5).  8: five workgroups of 64 units per cluster, one per CU -- the two waves of a SIMD
+// belong to ONE workgroup and stand in the same section of the same phase at all times (both in the MFMAs: they share the
+// pipe; both in the cell update; both parked at the barriers).  4: TEN workgroups of 32 units per cluster, TWO per CU from
+// different clusters (different sequence groups): the two waves of a SIMD then belong to two INDEPENDENT phase chains, and
+// the hardware interleaves one chain's matrix section with the other's exchange / cell / io sections without any
+// choreography (MI355X_MICROARCH.md "two waves per SIMD": matrix beside memory is the pairing that nets).  A wave holds the
+// same 160 weight registers and runs the same 60 MFMAs per phase either way; the exchange arm is waves 0 .. NW/2 - 1
+// (nine peers instead of four per gather, half as many threads), the io arm waves NW/2 .. NW - 1 (four copies + six stores
+// per wave and phase as before).
+template <int NGA, bool NT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
     float* __restrict__ gates, float* __restrict__ cell, float* __restrict__ hout, int64_t ldo,
     int64_t dstride, const u32x4* __restrict__ wf, unsigned* __restrict__ xhead,
     float* __restrict__ xpayload, int* __restrict__ err, int64_t N, int64_t T, int H, int G, int nclusters,
     int layout) {
   constexpr bool OWN_EARLY = NGA == 1 && ONCHIP16_FWD_OWN_EARLY && !(ONCHIP16_ABL & 12);
+  constexpr int UW = 8 * NW;                   // hidden units per workgroup (64 | 32)
+  constexpr int NTH = 64 * NW;                 // threads
+  constexpr int NEX = NW / 2, NIO = NW / 2;    // exchange waves 0 .. NEX - 1, io waves NEX .. NW - 1
+  constexpr int QW = UW / 4;                   // unit quads of the own slice (16 | 8)
+  constexpr int QB = UW / 16;                  // 16-unit blocks of the own slice (4 | 2)
+  constexpr int GMAX = 40 / NW;                // workgroups per cluster at most (K = 320): 5 | 10
+  constexpr int PUBP = UW + 4;                 // floats per LDS row of [seq][unit] scalars (h, c)
+  constexpr int TILEW = SQ * UW;               // f32x4 per gate tile (16 | 8 KB)
+  constexpr int KOWN = UW / 32;                // k-steps of the own slice (2 | 1)
   const unsigned tagbase = tag16_base(err);
   __shared__ __attribute__((aligned(16))) char hs[NGA * 2 * SQ * HP2];       // [group][hi | lo][seq][k] bf16
-  __shared__ __attribute__((aligned(16))) float pub[SQ * PUBPITCH];          // h_t [seq][unit] of the phase
-  __shared__ __attribute__((aligned(16))) float cellb[SQ * PUBPITCH];        // c_t
-  __shared__ f32x4 ring0[TILE4], ring1[TILE4], ring2[TILE4], ring3[TILE4];    // gate tiles of phases 0..3
+  __shared__ __attribute__((aligned(16))) float pub[SQ * PUBP];              // h_t [seq][unit] of the phase
+  __shared__ __attribute__((aligned(16))) float cellb[SQ * PUBP];            // c_t
+  __shared__ f32x4 ring0[TILEW], ring1[TILEW], ring2[TILEW], ring3[TILEW];    // gate tiles of phases 0..3
   __shared__ int s_fail, s_mem[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid == 0) s_fail = 0;
@@ -985,12 +1004,12 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
   const int g = __builtin_amdgcn_readfirstlane(mem.g);
   const int j = lane & 15, up = lane >> 4;                   // MFMA: sequence, unit within the row block
   const int foff = j * HP2 + up * 16;                        // B fragment offset of this lane
-  const bool io_wave = wave >= 4;
-  const int s2 = (tid & 255) >> 4, uq = tid & 15;            // exchange / io thread <-> (sequence s2, unit quad uq)
-  const int iow = wave & 3;                                  // (scalar: LDS addresses of the copies stay in SGPRs)
+  const bool io_wave = wave >= NEX;
+  const int s2 = (tid & (64 * NEX - 1)) / QW, uq = tid % QW; // exchange / io thread <-> (sequence s2, unit quad uq)
+  const int iow = wave % NIO;                                // (scalar: LDS addresses of the copies stay in SGPRs)
   constexpr unsigned OOR = 0x80000000u;
   // operand-image columns the gather never writes (k >= 64 G, when H <= 256) must be zero, not stale LDS: 0 x NaN
-  for (int i = tid; i < NGA * 2 * SQ * HP2 / 4; i += 512) reinterpret_cast<unsigned*>(hs)[i] = 0u;
+  for (int i = tid; i < NGA * 2 * SQ * HP2 / 4; i += NTH) reinterpret_cast<unsigned*>(hs)[i] = 0u;
 
   for (int round = 0;; ++round) {
     const int64_t bundle = next_item<true>(xhead, mem, round, (int)(2 * nb_dir), nclusters, s_mem);
@@ -1003,7 +1022,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     // stationary weights -> registers
     u32x4 wh[2][KS2], wl[2][KS2];
     {
-      const u32x4* wp = wf + ((((int64_t)(dir * G + g) * 8 + wave) * 2) * KS2 * 2) * 64 + lane;
+      const u32x4* wp = wf + ((((int64_t)(dir * G + g) * NW + wave) * 2) * KS2 * 2) * 64 + lane;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1027,20 +1046,31 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     // step loop -- 24 registers it did not have -- and reloaded them from scratch in front of every store
     // (`s_waitcnt vmcnt(0)`: the whole asynchronous io arm serialised).
     auto seq0_of = [&](int p) { return (sg0 + p) * SQ; };
-    struct IoLane { unsigned goff0, coff, hoff; bool uok[4]; };
+    // The gate tile in LDS is [16-unit block q][sequence 16][unit-in-block 16, XOR-swizzled with the sequence] f32x4; an io
+    // wave moves it in 1-KB pieces = 4 sequences x 16 units: piece i of its four is block i % QB of sequence chunk
+    // iow + NIO (i / QB) (NW = 8: its own chunk of all four blocks; NW = 4: two chunks of the two blocks).  The c / h rows
+    // are moved by thread <-> (sequence, unit quad) as in the exchange arm.
+    struct IoLane { unsigned goff[4], coff, hoff; bool uok[4]; };
+    auto io_piece = [&](int i, int& q, int& c) __attribute__((always_inline)) { q = i % QB; c = iow + NIO * (i / QB); };
     auto io_lane = [&](int p) __attribute__((always_inline)) {
       int tv = tid;
       asm volatile("" : "+v"(tv));
-      const int s2v = (tv & 255) >> 4, uqv = tv & 15, uswv = uqv ^ s2v;
+      const int s2v = (tv & (64 * NIO - 1)) / QW, uqv = tv % QW;       // c / h rows
       const unsigned lrv = (unsigned)(s2v * SN);
       IoLane L;
       const bool rok = seq0_of(p) + s2v < N;
-      const bool f4 = 64 * g + 4 * uqv + 4 <= H;
-      L.goff0 = (lrv * 2u * (unsigned)H + (unsigned)uswv) * 16u;
+      const bool f4 = UW * g + 4 * uqv + 4 <= H;
       L.coff = (rok && f4) ? (lrv * 2u * (unsigned)H + 4u * (unsigned)uqv) * 4u : OOR;
       L.hoff = (rok && f4) ? (lrv * (unsigned)ldo + 4u * (unsigned)uqv) * 4u : OOR;
+      const int sl = (tv & 63) >> 4, ub = tv & 15;                      // gate-tile pieces: sequence within the chunk, unit slot
 #pragma unroll
-      for (int q = 0; q < 4; ++q) L.uok[q] = rok && 64 * g + 16 * q + uswv < H;
+      for (int i = 0; i < 4; ++i) {
+        int q, c;
+        io_piece(i, q, c);
+        const int sv = 4 * c + sl, usw = ub ^ sv;
+        L.goff[i] = ((unsigned)(sv * SN) * 2u * (unsigned)H + (unsigned)usw) * 16u + (unsigned)q * 256u;
+        L.uok[i] = seq0_of(p) + sv < N && UW * g + 16 * q + usw < H;
+      }
       return L;
     };
 
@@ -1052,7 +1082,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
     };
     auto gates_base = [&](int p, int64_t st) {
       const int64_t t_ = dir ? T - 1 - st : st;
-      return reinterpret_cast<char*>(gates) + (((ROW(seq0_of(p), 0) + t_ * ST) * 2 + dir) * (int64_t)H + 64 * g) * 16;
+      return reinterpret_cast<char*>(gates) + (((ROW(seq0_of(p), 0) + t_ * ST) * 2 + dir) * (int64_t)H + UW * g) * 16;
     };
     auto ring_of = [&](auto slot_tag) -> f32x4* {
       constexpr int S = decltype(slot_tag)::value;
@@ -1068,19 +1098,21 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       // requested for two phases ahead.  The io waves wait explicitly (`vmcnt(4)` before the barrier that opens a
       // phase).  Scalar base + 32-bit lane offset: no 64-bit per-lane addresses to keep (or spill).  (No immediate
       // offset: the instruction adds it to the LDS address as well as to the global one.)
-#define DMA16(Q_, OFF_)                                                                                                    \
+#define DMA16(I_)                                                                                                          \
       {                                                                                                                \
         /* lanes outside N / H read the block's first bytes (a valid address) into cells nobody uses: the copy is     \
            issued unconditionally, so that every phase queues exactly four copies and six stores (vmcnt arithmetic) */ \
-        const unsigned vo = L.uok[Q_] ? L.goff0 + (OFF_) : 0u;                                                         \
+        const unsigned vo = L.uok[I_] ? L.goff[I_] : 0u;                                                               \
+        int q_, c_;                                                                                                    \
+        io_piece(I_, q_, c_);                                                                                          \
         const int la = __builtin_amdgcn_readfirstlane(                                                                 \
-            (int)(uintptr_t)(__attribute__((address_space(3))) void*)&rg[((Q_) * 4 + iow) * 64]);                      \
+            (int)(uintptr_t)(__attribute__((address_space(3))) void*)&rg[(q_ * 4 + c_) * 64]);                         \
         if (NT) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"                         \
                              :: "v"(vo), "s"(gb), "s"(la) : "memory");                                                 \
         else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                               \
                           :: "v"(vo), "s"(gb), "s"(la) : "memory");                                                    \
       }
-      DMA16(0, 0) DMA16(1, 256) DMA16(2, 512) DMA16(3, 768)
+      DMA16(0) DMA16(1) DMA16(2) DMA16(3)
 #undef DMA16
     };
     // flush of (group p, step st): c, h, then the activations of ring slot S (six stores)
@@ -1088,33 +1120,35 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       f32x4* rg = ring_of(slot_tag);
       const int64_t t_ = dir ? T - 1 - st : st;
       const int64_t row = ROW(seq0_of(p), 0) + t_ * ST;
-      const auto rc = srd_at(reinterpret_cast<char*>(cell) + ((row * 2 + dir) * (int64_t)H + 64 * g) * 4);
-      const auto rh = srd_at(reinterpret_cast<char*>(hout) + (row * ldo + dir * dstride + 64 * g) * 4);
+      const auto rc = srd_at(reinterpret_cast<char*>(cell) + ((row * 2 + dir) * (int64_t)H + UW * g) * 4);
+      const auto rh = srd_at(reinterpret_cast<char*>(hout) + (row * ldo + dir * dstride + UW * g) * 4);
       const auto rs = srd_at(gates_base(p, st));
       const IoLane L = io_lane(p);
-      const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s2 * PUBPITCH + 4 * uq);
-      const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s2 * PUBPITCH + 4 * uq);
+      const f32x4 cq = *reinterpret_cast<const f32x4*>(cellb + s2 * PUBP + 4 * uq);
+      const f32x4 hq = *reinterpret_cast<const f32x4*>(pub + s2 * PUBP + 4 * uq);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cq), rc, (int)L.coff, 0, NT ? 2 : 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hq), rh, (int)L.hoff, 0, NT ? 2 : 0);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = rg[(q * 4 + iow) * 64 + lane];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(L.uok[q] ? L.goff0 + q * 256 : OOR), 0, NT ? 2 : 0);
+      for (int i = 0; i < 4; ++i) {
+        int q, c;
+        io_piece(i, q, c);
+        const f32x4 v = rg[(q * 4 + c) * 64 + lane];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(L.uok[i] ? L.goff[i] : OOR), 0, NT ? 2 : 0);
       }
     };
     // exchange: payload of (group p): [slot 2][G][SQ][UPW] values as 8-byte granules of two
     auto payload_srd = [&](int p) {
       const int64_t item = ((sg0 + p) << 1) | dir;
-      return __builtin_amdgcn_make_buffer_rsrc(xpayload + item * 2 * G * SQ * UPW, 0, 2 * G * SQ * UPW * 4, 0x00020000);
+      return __builtin_amdgcn_make_buffer_rsrc(xpayload + item * 2 * G * SQ * UW, 0, 2 * G * SQ * UW * 4, 0x00020000);
     };
-    u32x4 vg[5];
+    u32x4 vg[GMAX];
     auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // h_{st-1} of group p
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
 #pragma unroll
-      for (int gs = 0; gs < 5; ++gs)
+      for (int gs = 0; gs < GMAX; ++gs)
         vg[gs] = (gs < G && !(OWN_EARLY && gs == g))
-                     ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1)
+                     ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UW + 4 * uq) * 4, 0, SC1)
                      : u32x4{0u, 0u, 0u, 0u};
     };
     auto gather_finish = [&](int p, int64_t st) __attribute__((always_inline)) {
@@ -1126,23 +1160,23 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       for (;;) {
         bool ok = true;
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs)
+        for (int gs = 0; gs < GMAX; ++gs)
           ok = ok && (gs >= G || (OWN_EARLY && gs == g) || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
         if (ok || (ONCHIP16_ABL & 16)) break;
         if (++spins > SPIN_LIMIT) { fail = true; break; }
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-        for (int gs = 0; gs < 5; ++gs)
+        for (int gs = 0; gs < GMAX; ++gs)
           if (gs < G && !(OWN_EARLY && gs == g) && !((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want))
-            vg[gs] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC1);
+            vg[gs] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UW + 4 * uq) * 4, 0, SC1);
       }
       if (fail) s_fail = 1;
       char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2 * HP2;
       char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2 * HP2;
 #pragma unroll
-      for (int gs = 0; gs < 5; ++gs) {
+      for (int gs = 0; gs < GMAX; ++gs) {
         if (gs < G && !(OWN_EARLY && gs == g)) {
-          const int k = 64 * (gs >= g ? gs - g : gs - g + G) + 4 * uq;      // (the k axis starts at the own slice)
+          const int k = UW * (gs >= g ? gs - g : gs - g + G) + 4 * uq;      // (the k axis starts at the own slice)
           const u32x4 w = vg[gs];
           unsigned h0, l0, h1, l1;
           split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
@@ -1156,10 +1190,10 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       const auto prs = payload_srd(p);
       const unsigned tag = mk_tag(tagbase, st + 1);
       const int slot = (int)(st & 1);
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2 * PUBPITCH + 4 * uq);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2 * PUBP + 4 * uq);
       const u32x2 ga = pack_granule(tag, pv[0], pv[1]), gb = pack_granule(tag, pv[2], pv[3]);
       __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
-                                             (((slot * G + g) * SQ + s2) * UPW + 4 * uq) * 4, 0, SC0);
+                                             (((slot * G + g) * SQ + s2) * UW + 4 * uq) * 4, 0, SC0);
     };
 
     // ---- one phase: ring slot S (static), group P (static), step st.  IO: the role of this wave -- the step loop
@@ -1202,7 +1236,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
       }
       f32x4 acc[2];
       acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int KS0 = OWN_EARLY ? 2 : 0;      // (OWN_EARLY: k-steps 0 and 1 are in accn already)
+      constexpr int KS0 = OWN_EARLY ? KOWN : 0;   // (OWN_EARLY: the k-steps of the own slice are in accn already)
       if constexpr (OWN_EARLY) { acc[0] = accn[0]; acc[1] = accn[1]; }
       if (st > 0 && !(ONCHIP16_ABL & 1)) {
         const char* hh = hs + (P * 2 + 0) * SQ * HP2 + foff + KS0 * 64;
@@ -1248,8 +1282,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         const float cn = fg * cst[P][rb] + ig * gg;
         cst[P][rb] = cn;
         *xp = f32x4{ig, fg, gg, og};
-        pub[jv * PUBPITCH + ul] = (64 * g + ul < H) ? og * (fake ? cn : fast_tanh(cn)) : 0.f;
-        cellb[jv * PUBPITCH + ul] = cn;
+        pub[jv * PUBP + ul] = (UW * g + ul < H) ? og * (fake ? cn : fast_tanh(cn)) : 0.f;
+        cellb[jv * PUBP + ul] = cn;
       }
       lds_barrier();
       // OWN_EARLY: h_t of the own slice x its weight columns, for step t + 1 (every wave: it needs the whole slice as B)
@@ -1258,8 +1292,8 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_fwd_kernel(
         if (st + 1 < T && !(ONCHIP16_ABL & 1)) {
           auto r24 = [](float x) { return __uint_as_float((__float_as_uint(x) + 0x80u) & 0xffffff00u); };      // = the granules
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const float* pr = pub + jv * PUBPITCH + 32 * ks + 8 * upv;
+          for (int ks = 0; ks < KOWN; ++ks) {
+            const float* pr = pub + jv * PUBP + 32 * ks + 8 * upv;
             const f32x4 a = *reinterpret_cast<const f32x4*>(pr), b = *reinterpret_cast<const f32x4*>(pr + 4);
             unsigned h0, l0, h1, l1, h2, l2, h3, l3;
             split2(r24(a[0]), r24(a[1]), h0, l0);
@@ -1955,64 +1989,83 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
 }
 
 // ---- interleaved forward (blstm_onchip16_fwd_kernel): own weight pack, own exchange layout (16-sequence items)
-extern "C" int64_t tssep_lstm_onchip16_pack_floats(int H) {
-  const int G = (H + UPW - 1) / UPW;
-  return (int64_t)2 * G * 8 * 2 * KS2 * 2 * 64 * 4;
+// `waves` = waves per workgroup: 8 (five workgroups of 64 units per cluster, one per CU) or 4 (ten of 32 units, two per CU)
+static inline bool waves_ok(int waves) { return waves == 8 || waves == 4; }
+static inline int g_of(int H, int waves) { return (H + 8 * waves - 1) / (8 * waves); }
+extern "C" int64_t tssep_lstm_onchip16w_pack_floats(int H, int waves) {
+  if (!waves_ok(waves)) return 0;
+  return (int64_t)2 * g_of(H, waves) * waves * 2 * KS2 * 2 * 64 * 4;
 }
-extern "C" int tssep_lstm_pack_onchip16(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream) {
+extern "C" int64_t tssep_lstm_onchip16_pack_floats(int H) { return tssep_lstm_onchip16w_pack_floats(H, 8); }
+extern "C" int tssep_lstm_pack_onchip16w(const float* w_hh_f, const float* w_hh_r, int H, int waves, float* wf, void* stream) {
   if (!w_hh_f || !w_hh_r || !wf) return TSSEP_E_NULL;
-  if (H <= 0 || H > KP2) return TSSEP_E_UNSUPPORTED;
+  if (H <= 0 || H > KP2 || !waves_ok(waves)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(wf)) return TSSEP_E_ALIGN;
-  const int G = (H + UPW - 1) / UPW;
-  const int64_t total = tssep_lstm_onchip16_pack_floats(H) / 4;
+  const int G = g_of(H, waves);
+  const int64_t total = tssep_lstm_onchip16w_pack_floats(H, waves) / 4;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(pack_onchip16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_hh_f, w_hh_r, H, G,
-                     (u32x4*)wf);
+                     waves, (u32x4*)wf);
   return tssep_launch_status();
 }
-extern "C" int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H) {
-  const int G = (H + UPW - 1) / UPW;
-  return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * G * SQ * UPW * 4;
+extern "C" int tssep_lstm_pack_onchip16(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream) {
+  return tssep_lstm_pack_onchip16w(w_hh_f, w_hh_r, H, 8, wf, stream);
 }
+extern "C" int64_t tssep_lstm_onchip16w_xbuf_bytes(int64_t N, int H, int waves) {
+  if (!waves_ok(waves)) return 0;
+  return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * g_of(H, waves) * SQ * (8 * waves) * 4;
+}
+extern "C" int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H) { return tssep_lstm_onchip16w_xbuf_bytes(N, H, 8); }
 // groups per cluster the launcher would use for N sequences (0: shape not supported -> use tssep_blstm_onchip_fwd):
 // 2 where that divides the number of 16-sequence groups and still gives every cluster a bundle, else 1 (four groups
-// -- `groups` = 4 -- stay available: slower than two since the two-group kernel requests its operands early)
-extern "C" int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs) {
-  const int G = (H + UPW - 1) / UPW;
-  if (N <= 0 || H <= 0 || H > KP2 || (H & 3) || G > 5 || max_wgs < 8 * G) return 0;
+// -- `groups` = 4 -- stay available: slower than two since the two-group kernel requests its operands early).
+// Four-wave workgroups: ONE group per workgroup -- the second chain of a CU is its second workgroup.
+extern "C" int tssep_blstm_onchip16w_groups(int64_t N, int H, int max_wgs, int waves) {
+  if (!waves_ok(waves)) return 0;
+  const int G = g_of(H, waves), slots = max_wgs * (8 / waves);
+  if (N <= 0 || H <= 0 || H > KP2 || (H & 3) || G > 40 / waves || slots < 8 * G) return 0;
+  if (waves == 4) return 1;
   const int64_t ng16 = (N + SQ - 1) / SQ;
-  const int64_t ncl = 8 * ((max_wgs / 8) / G);
+  const int64_t ncl = 8 * ((slots / 8) / G);
   for (int nga = 2; nga >= 1; nga >>= 1)
     if (ng16 % nga == 0 && (2 * ng16 / nga >= ncl || nga == 1)) return nga;
   return 1;
 }
-extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
-                                        const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
-                                        int max_wgs, int layout, int groups, void* stream) {
+extern "C" int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs) { return tssep_blstm_onchip16w_groups(N, H, max_wgs, 8); }
+extern "C" int tssep_blstm_onchip16w_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+                                         const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
+                                         int max_wgs, int layout, int groups, int waves, void* stream) {
   if (!gates || !cell || !hout || !wf || !xbuf || !err) return TSSEP_E_NULL;
   if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
-  const int G = (H + UPW - 1) / UPW;
-  const int nga = groups > 0 ? groups : tssep_blstm_onchip16_groups(N, H, max_wgs);
+  if (!waves_ok(waves)) return TSSEP_E_UNSUPPORTED;
+  const int G = g_of(H, waves), slots = max_wgs * (8 / waves);      // (four-wave workgroups: two per CU)
+  const int nga = groups > 0 ? groups : tssep_blstm_onchip16w_groups(N, H, max_wgs, waves);
   const int64_t ng16 = (N + SQ - 1) / SQ;
-  if (nga != 1 && nga != 2 && nga != 4) return TSSEP_E_UNSUPPORTED;
-  if (H > KP2 || (H & 3) || (ldo & 3) || (dstride & 3) || ng16 % nga || max_wgs < 8 * G) return TSSEP_E_UNSUPPORTED;
+  if (nga != 1 && nga != 2 && !(nga == 4 && waves == 8)) return TSSEP_E_UNSUPPORTED;
+  if (H > KP2 || (H & 3) || (ldo & 3) || (dstride & 3) || ng16 % nga || G > 40 / waves || slots < 8 * G) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(gates) || !aligned16(xbuf) || !aligned16(cell) || !aligned16(hout)) return TSSEP_E_ALIGN;
   if (2 * ng16 >= 0xffff || T > tssep_lstm_onchip_max_steps(H, SQ)) return TSSEP_E_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16_xbuf_bytes(N, H), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
+  if (tssep_xbuf_reset(xbuf, (size_t)tssep_lstm_onchip16w_xbuf_bytes(N, H, waves), err, s) != TSSEP_OK) return TSSEP_E_LAUNCH;
   int nc;
-  const unsigned grid = onchip_grid(2 * ng16 / nga, G, max_wgs, true, &nc);
+  const unsigned grid = onchip_grid(2 * ng16 / nga, G, slots, true, &nc);
   char* base = (char*)xbuf;
   const int klayout = layout & 1;
   const bool nt = N >= 160 && !(layout & 32);          // non-temporal activation stream (as in the 32-sequence kernel)
-#define L16(NGA_) if (nt) L16B(NGA_, true); else L16B(NGA_, false)
-#define L16B(NGA_, NT_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, NT_>), dim3(grid), dim3(512), 0, s, gates, cell, hout, ldo, dstride, \
-                    (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, klayout)
-  if (nga == 4) { L16(4); } else if (nga == 2) { L16(2); } else { L16(1); }
+#define L16(NGA_, NW_) if (nt) L16B(NGA_, true, NW_); else L16B(NGA_, false, NW_)
+#define L16B(NGA_, NT_, NW_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, NT_, NW_>), dim3(grid), dim3(64 * NW_), 0, s, gates, cell, hout, \
+                    ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, klayout)
+  if (waves == 4) { if (nga == 2) { L16(2, 4); } else { L16(1, 4); } }
+  else if (nga == 4) { L16(4, 8); } else if (nga == 2) { L16(2, 8); } else { L16(1, 8); }
 #undef L16
 #undef L16B
   return tssep_launch_status();
+}
+extern "C" int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+                                        const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
+                                        int max_wgs, int layout, int groups, void* stream) {
+  return tssep_blstm_onchip16w_fwd(gates, cell, hout, ldo, dstride, wf, xbuf, err, N, T, H, max_wgs, layout, groups, 8, stream);
 }
 
 // ---- interleaved backward (blstm_onchip16_bwd_kernel)
