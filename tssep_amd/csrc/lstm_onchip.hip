@@ -963,6 +963,12 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_G1_DELAY_OWN
 #define ONCHIP16_FWD_G1_DELAY_OWN 0
 #endif
+// Experiment builds only (-DONCHIP16_TRACE=1): wave 0 (exchange) and the first io wave of workgroup 0 of the first cluster
+// leave `s_memtime` stamps of steps 128 .. 131 of their first work item in the spare words of the exchange header
+// (words 96 ..: [wave role 2][step 4][stamp 8] 64-bit ticks + re-poll counts at [64 .. 71] of that block)
+#ifndef ONCHIP16_TRACE
+#define ONCHIP16_TRACE 0
+#endif
 // NW = waves per workgroup (round 5).  8: five workgroups of 64 units per cluster, one per CU -- the two waves of a SIMD
 // belong to ONE workgroup and stand in the same section of the same phase at all times (both in the MFMAs: they share the
 // pipe; both in the cell update; both parked at the barriers).  4: TEN workgroups of 32 units per cluster, TWO per CU from
@@ -1008,6 +1014,17 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
   const int s2 = (tid & (64 * NEX - 1)) / QW, uq = tid % QW; // exchange / io thread <-> (sequence s2, unit quad uq)
   const int iow = wave % NIO;                                // (scalar: LDS addresses of the copies stay in SGPRs)
   constexpr unsigned OOR = 0x80000000u;
+  int trace_round = -1;
+  int trace_spins = 0;
+  auto stamp = [&](int role, int64_t st, int idx) __attribute__((always_inline)) {
+    if constexpr (ONCHIP16_TRACE) {
+      if (trace_round == 0 && st >= 128 && st < 132 && lane == 0 && (wave == 0 || wave == NEX) && g == 0) {
+        unsigned long long* tb = reinterpret_cast<unsigned long long*>(xhead + 96);
+        tb[(role * 4 + (int)(st - 128)) * 8 + idx] = __builtin_readcyclecounter();
+        if (idx == 1 && role == 0) tb[64 + (int)(st - 128)] = (unsigned long long)trace_spins;
+      }
+    }
+  };
   // operand-image columns the gather never writes (k >= 64 G, when H <= 256) must be zero, not stale LDS: 0 x NaN
   for (int i = tid; i < NGA * 2 * SQ * HP2 / 4; i += NTH) reinterpret_cast<unsigned*>(hs)[i] = 0u;
 
@@ -1019,6 +1036,7 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
     }
     const int dir = (int)(bundle & 1);
     const int64_t sg0 = (bundle >> 1) * NGA;                 // first sequence group of the bundle
+    trace_round = bundle == 0 ? 0 : -1;      // (trace builds: the cluster that serves work item 0)
     // stationary weights -> registers
     u32x4 wh[2][KS2], wl[2][KS2];
     {
@@ -1164,6 +1182,7 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
           ok = ok && (gs >= G || (OWN_EARLY && gs == g) || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
         if (ok || (ONCHIP16_ABL & 16)) break;
         if (++spins > SPIN_LIMIT) { fail = true; break; }
+        if constexpr (ONCHIP16_TRACE) trace_spins = spins;
         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int gs = 0; gs < GMAX; ++gs)
@@ -1171,12 +1190,22 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
             vg[gs] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UW + 4 * uq) * 4, 0, SC1);
       }
       if (fail) s_fail = 1;
-      char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2 * HP2;
-      char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2 * HP2;
+      if constexpr (ONCHIP16_TRACE) {      // the peers' values have arrived (decode follows)
+        if (trace_round == 0 && st >= 128 && st < 132 && lane == 0 && wave == 0 && g == 0)
+          reinterpret_cast<unsigned long long*>(xhead + 96)[68 + (int)(st - 128)] = __builtin_readcyclecounter();
+      }
+      // (the lane part of the operand-image addresses is REBUILT here from an opaque copy of the thread index: as loop
+      // invariants the compiler kept one address register per peer -- ten with four-wave workgroups -- spilled them, and
+      // reloaded each from scratch in front of its LDS write: eight serialized memory round trips, 2 us per phase)
+      int tvd = tid;
+      asm volatile("" : "+v"(tvd));
+      const int s2d = (tvd & (64 * NEX - 1)) / QW, uqd = tvd % QW;
+      char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2d * HP2 + 8 * uqd;
+      char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2d * HP2 + 8 * uqd;
 #pragma unroll
       for (int gs = 0; gs < GMAX; ++gs) {
         if (gs < G && !(OWN_EARLY && gs == g)) {
-          const int k = UW * (gs >= g ? gs - g : gs - g + G) + 4 * uq;      // (the k axis starts at the own slice)
+          const int k = __builtin_amdgcn_readfirstlane(UW * (gs >= g ? gs - g : gs - g + G));      // (the k axis starts at the own slice)
           const u32x4 w = vg[gs];
           unsigned h0, l0, h1, l1;
           split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
@@ -1190,10 +1219,15 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
       const auto prs = payload_srd(p);
       const unsigned tag = mk_tag(tagbase, st + 1);
       const int slot = (int)(st & 1);
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2 * PUBP + 4 * uq);
+      int tvp = tid;                      // (lane offsets rebuilt from an opaque copy: see gather_finish)
+      asm volatile("" : "+v"(tvp));
+      const int s2p = (tvp & (64 * NEX - 1)) / QW, uqp = tvp % QW;
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pub + s2p * PUBP + 4 * uqp);
       const u32x2 ga = pack_granule(tag, pv[0], pv[1]), gb = pack_granule(tag, pv[2], pv[3]);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs,
-                                             (((slot * G + g) * SQ + s2) * UW + 4 * uq) * 4, 0, SC0);
+      const int wgoff = __builtin_amdgcn_readfirstlane((slot * G + g) * SQ * UW * 4);
+      // (the workgroup's offset rides in the LANE offset, soffset stays the immediate 0: a > 64-bit buffer store with a register
+      // soffset is not guarded against a VALU write of its data -- tools/scan_store_hazard.py)
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{ga[0], ga[1], gb[0], gb[1]}, prs, (s2p * UW + 4 * uqp) * 4 + wgoff, 0, SC0);
     };
 
     // ---- one phase: ring slot S (static), group P (static), step st.  IO: the role of this wave -- the step loop
@@ -1206,6 +1240,8 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
       if (st >= T) return;                                     // (T tail of NGA < 4; uniform)
       constexpr int FGAT = NGA == 2 ? ONCHIP16_FWD_GATHER : 0;
       f32x4* rg = ring_of(slot_tag);
+      if constexpr (ONCHIP16_TRACE) trace_spins = 0;
+      stamp(IO ? 1 : 0, st, 0);
       if constexpr (!IO) {
         // (NGA = 4: this phase's h was decoded into the operand image behind the previous phase's publish -- below --
         // so nothing stands between the exchange waves and the barrier)
@@ -1217,7 +1253,9 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         // (one group: the copies are requested at the START of a phase -- below -- so six more stores queue behind them)
         if (NGA == 1 && ONCHIP16_FWD_EARLY_DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
+      stamp(IO ? 1 : 0, st, 1);
       lds_barrier();
+      stamp(IO ? 1 : 0, st, 2);
       if (s_fail) return;
       // (group, step) of the next phase and of the phase after it
       constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
@@ -1265,6 +1303,7 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
           }
         }
       }
+      stamp(IO ? 1 : 0, st, 3);
       // cell update: lane (sequence j, unit 8 wave + 4 rb + up), the four gates in acc[rb]
       // (addresses rebuilt from an opaque copy of the lane index: hoisted out of the loop they were eight more
       // registers -- one per ring slot and row block -- that ended up in scratch)
@@ -1285,7 +1324,9 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         pub[jv * PUBP + ul] = (UW * g + ul < H) ? og * (fake ? cn : fast_tanh(cn)) : 0.f;
         cellb[jv * PUBP + ul] = cn;
       }
+      stamp(IO ? 1 : 0, st, 4);
       lds_barrier();
+      stamp(IO ? 1 : 0, st, 5);
       // OWN_EARLY: h_t of the own slice x its weight columns, for step t + 1 (every wave: it needs the whole slice as B)
       auto own_products = [&]() __attribute__((always_inline)) {
         accn[0] = accn[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1314,6 +1355,7 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         if (!(ONCHIP16_ABL & 8)) {
           publish(P, st);
           if constexpr (OWN_EARLY) own_products();
+          stamp(0, st, 6);
           if (NGA < 4) {
             // (two groups: the next phase's h is decoded in front of its barrier -- decoding it here, behind the publish,
             // measured slower even with the early request: 1.42 -> 1.50 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
@@ -1337,10 +1379,12 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         // measured SLOWER here: 1.37 -> 1.49 ms at 768 sequences, 5.5 -> 5.9 at 3 072)
         io_flush(slot_tag, P, st);
         if constexpr (OWN_EARLY) own_products();
+        stamp(1, st, 6);
         // (beyond the last step the copy is repeated for step T - 1 into a slot nobody reads any more: every phase
         // queues exactly four copies, or `vmcnt(10)` above would not cover the tiles of the last phases)
         if constexpr (!(NGA == 1 && ONCHIP16_FWD_EARLY_DMA)) io_dma(std::integral_constant<int, I2>{}, P2, st2 < T ? st2 : T - 1);
       }
+      stamp(IO ? 1 : 0, st, 7);
     };
     auto run = [&](auto io_tag) __attribute__((always_inline)) {
       constexpr bool IO = decltype(io_tag)::value;

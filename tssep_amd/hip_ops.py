@@ -771,6 +771,7 @@ ONCHIP16_BWD = True
 ONCHIP16_BWD_GROUPS = 2  # at most: a backward phase is paced by its three barriers and the publish (see onchip16_bwd_groups)
 
 
+KEEP_XBUF = None         # a list: the exchange buffers of the interleaved forward launches are appended (trace builds, tools)
 ONCHIP16_FWD_WAVES = 8   # waves per workgroup of the interleaved forward: 8 (five workgroups per cluster, one per CU) | 4 (ten, two per CU)
 
 
@@ -798,6 +799,8 @@ def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, l
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16w_xbuf_bytes(N, H, waves)) // 8 + 2, device=gates.device, dtype=torch.int64)
+    if KEEP_XBUF is not None:
+        KEEP_XBUF.append(xbuf)
     with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 40):      # gates in / activations out 16 + 16, c 4, h 4 B per cell
         check(L.tssep_blstm_onchip16w_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf),
                                           _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, waves, _stream()),
