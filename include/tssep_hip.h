@@ -64,7 +64,12 @@ int tssep_probe_rewrite(float* buf, int nblocks, int bytes_per_wg, int reps, int
  *   window [size]               analysis window
  *   tw     [size/2 + size/4..]  twiddle table built by tssep_fft_twiddles
  *   X      [rows, T, size/2+1]  complex64 out, T = tssep_stft_frames(N,...)
- * size must be 1024 (the only FFT plan built so far) -> else TSSEP_E_UNSUPPORTED. */
+ * FFT plans (tssep_stft_plan): 1 = size 1024 / shift 256, the plan of the reference's configs
+ * (tssep/exp/init_cfg_common.yaml:33-43; specialised kernels, the only plan of the fused tssep_mask_istft_* entry points);
+ * 2 = the general plan behind tssep_stft_fwd / tssep_istft_fwd / tssep_istft_bwd: size even, size / 2 = 2^a 3^b 5^c <= 2048,
+ * 1 <= shift <= min(size, 512) -- 512 / 128, TorchMFCC's own default 400 / 200
+ * (tssep/train/feature_extractor_torchaudio.py:24-25), ...; 0 = not built -> TSSEP_E_UNSUPPORTED. */
+int tssep_stft_plan(int size, int shift);
 int64_t tssep_stft_frames(int64_t N, int size, int shift, int window_length,
                           int pad, int fading);
 int tssep_fft_twiddles(int size, float* host_out /* HOST buffer, 2*(size/2 + size/2+1) floats */);
@@ -131,7 +136,9 @@ int tssep_mask_istft_bwd_loss(const float* est, const float* tgt, const float* s
  * (feature_extractor.py:239-242): 0 = 'tf' one per utterance (every shipped config), 1 = 't' one per
  * (utterance, frequency) over the frames, 2 = 'f' one per frame over the frequencies.
  * The dB floor (top_db) is taken over the WHOLE batch, as torchaudio's
- * AmplitudeToDB does for the 3-D input the reference passes. */
+ * AmplitudeToDB does for the 3-D input the reference passes.  top_db < 0 selects TorchMFCC's `log_mels`
+ * (feature_extractor_torchaudio.py:98-100): log(mel + 1e-6) instead of dB, no floor.  The filterbank may be any
+ * matrix whose columns are non-zero on ONE contiguous band (HTK or Slaney scale, with or without area normalisation). */
 int64_t tssep_feat_workspace_bytes(int64_t B, int64_t T, int n_mels, int F, int stat_axis);
 int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F,
                    const float* fb, const float* dct, int n_mels, int n_mfcc,

@@ -12,18 +12,41 @@ import numpy as np
 import torch
 
 
-def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
-    """torchaudio.functional.melscale_fbanks(norm=None, mel_scale='htk')."""
+def _hz_to_mel(freq, mel_scale="htk"):
+    """torchaudio.functional._hz_to_mel (2.0.2)."""
+    if mel_scale == "htk":
+        return 2595.0 * math.log10(1.0 + freq / 700.0)
+    f_sp = 200.0 / 3
+    mels = freq / f_sp
+    if freq >= 1000.0:
+        mels = 1000.0 / f_sp + math.log(freq / 1000.0) / (math.log(6.4) / 27.0)
+    return mels
+
+
+def _mel_to_hz(mels, mel_scale="htk"):
+    if mel_scale == "htk":
+        return 700.0 * (10 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_mel = 1000.0 / f_sp
+    log_t = mels >= min_log_mel
+    freqs[log_t] = 1000.0 * torch.exp((math.log(6.4) / 27.0) * (mels[log_t] - min_log_mel))
+    return freqs
+
+
+def melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    """torchaudio.functional.melscale_fbanks(norm=None | 'slaney', mel_scale='htk' | 'slaney')."""
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
-    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
-    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
-    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
-    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    m_pts = torch.linspace(_hz_to_mel(f_min, mel_scale), _hz_to_mel(f_max, mel_scale), n_mels + 2)
+    f_pts = _mel_to_hz(m_pts, mel_scale)
     f_diff = f_pts[1:] - f_pts[:-1]
     slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
     down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return torch.clamp(torch.min(down, up), min=0.0)  # [n_freqs, n_mels]
+    fb = torch.clamp(torch.min(down, up), min=0.0)  # [n_freqs, n_mels]
+    if norm == "slaney":
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb
 
 
 def create_dct(n_mfcc, n_mels, norm="ortho"):
@@ -40,12 +63,12 @@ def create_dct(n_mfcc, n_mels, norm="ortho"):
 
 
 def mfcc_tables(size=1024, sample_rate=16000, n_mfcc=40, f_min=40.0,
-                f_max=-400.0, n_mels=40, dct_norm="ortho"):
+                f_max=-400.0, n_mels=40, dct_norm="ortho", mel_norm=None, mel_scale="htk"):
     """fb[F, n_mels], dct[n_mels, n_mfcc] as built at
     feature_extractor_torchaudio.py:57-85 (negative f_max wraps to sr+f_max)."""
     if f_max and f_max < 0:
         f_max = sample_rate + f_max
-    fb = melscale_fbanks(size // 2 + 1, f_min, f_max, n_mels, sample_rate)
+    fb = melscale_fbanks(size // 2 + 1, f_min, f_max, n_mels, sample_rate, mel_norm, mel_scale)
     return fb, create_dct(n_mfcc, n_mels, dct_norm)
 
 
@@ -73,11 +96,14 @@ def mel_db_max(X, fb):
     return float((10.0 * torch.log10(torch.clamp(mel, min=1e-10))).amax())
 
 
-def torch_mfcc(X, fb, dct, top_db=80.0, db_max=None):
+def torch_mfcc(X, fb, dct, top_db=80.0, db_max=None, log_mels=False):
     """feature_extractor_torchaudio.py:93-106.  X[..., T, F] complex."""
     power = abs(X.transpose(-1, -2)).to(torch.float32) ** 2   # [..., F, T]
     mel = torch.matmul(power.transpose(-1, -2), fb).transpose(-1, -2)
-    mel = amplitude_to_db_power(mel, top_db, db_max)          # [..., n_mels, T]
+    if log_mels:                                              # :98-100
+        mel = torch.log(mel + 1e-6)
+    else:
+        mel = amplitude_to_db_power(mel, top_db, db_max)      # [..., n_mels, T]
     return torch.matmul(mel.transpose(-1, -2), dct)           # [..., T, n_mfcc]
 
 

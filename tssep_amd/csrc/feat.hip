@@ -83,7 +83,7 @@ constexpr int LMELS = 128;        // filters whose table fits in LDS (40 in ever
 __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restrict__ X, int64_t B,
                                                          int64_t T, int F,
                                                          const float* __restrict__ fb, int n_mels,
-                                                         int n_mfcc, void* ws, int stat) {
+                                                         int n_mfcc, void* ws, int stat, int log_mels) {
   __shared__ float pw[4][MAXF];
   __shared__ float cw[CWMAX];
   __shared__ int clo[LMELS], chi[LMELS], coff[LMELS + 1];
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void feat_pass1_kernel(const float2* __restric
           mine = (s0 + s1) + (s2 + s3);
         }
         if (lane < mm) {
-          const float db = 10.0f * log10f(fmaxf(mine, 1e-10f));
+          // AmplitudeToDB('power') -- or, `log_mels` (feature_extractor_torchaudio.py:98-100): log(mel + 1e-6), no floor
+          const float db = log_mels ? logf(mine + 1e-6f) : 10.0f * log10f(fmaxf(mine, 1e-10f));
           w.db[frame * n_mels + m0 + lane] = db;
           dbmax = fmaxf(dbmax, db);
         }
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(256) void feat_pass2_kernel(const float2* __restric
   const bool valid = frame < B * T;
   float* o = out + (valid ? frame : 0) * ld_out;
   if (n_mfcc > 0) {
-    const float floor_db = wave_max(unord(w.gmax[lane])) - top_db;      // merge the 64 slots
+    // (top_db < 0 = log_mels: no floor)
+    const float floor_db = top_db < 0.f ? -INFINITY : wave_max(unord(w.gmax[lane])) - top_db;      // merge the 64 slots
     for (int m0 = 0; m0 < n_mels; m0 += 64) {   // n_mels <= 64 in every config; loop kept general
       if (valid && m0 + lane < n_mels)
         dbl[wave][lane] = fmaxf(w.db[frame * n_mels + m0 + lane], floor_db);
@@ -283,7 +285,7 @@ extern "C" int tssep_feat_fwd(const float* X, int64_t B, int64_t T, int F, const
   const unsigned blocks = (unsigned)((B * T + 3) / 4);
   const unsigned blocks1 = (unsigned)((B * T + 4 * FPW - 1) / (4 * FPW));
   hipLaunchKernelGGL(feat_pass1_kernel, dim3(blocks1), dim3(256), 0, s, (const float2*)X, B, T, F,
-                     fb, n_mels, n_mfcc, ws, stat_axis);
+                     fb, n_mels, n_mfcc, ws, stat_axis, top_db < 0.f ? 1 : 0);
   hipLaunchKernelGGL(feat_pass2_kernel, dim3(blocks), dim3(256), 0, s, (const float2*)X, B, T, F,
                      dct, n_mels, n_mfcc, top_db, out, ld_out, ws, stat_axis);
   return tssep_launch_status();

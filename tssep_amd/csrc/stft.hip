@@ -479,9 +479,17 @@ extern "C" int64_t tssep_stft_frames(int64_t N, int size, int shift, int window_
   return (n - window_length) / shift + 1;
 }
 
+// the general plan (stft_generic.hip): every other size / shift the reference's `fe` slot may name
+int tssep_generic_plan_supported(int size, int shift);
+int tssep_generic_twiddles(int size, float* host_out);
+int tssep_generic_rfft(const float* x, int64_t rows, int64_t N, int size, int shift, int pad_left, const float* window,
+                       const float* tw, float* X, int64_t T, float s_in, float s_edge, void* stream);
+int tssep_generic_istft(const float* X, int64_t rows, int64_t T, int size, int shift, int pad_left, const float* wsyn,
+                        const float* tw, float* y, int64_t N, void* stream);
+
 extern "C" int tssep_fft_twiddles(int size, float* host_out) {
   if (!host_out) return TSSEP_E_NULL;
-  if (size != 1024) return TSSEP_E_UNSUPPORTED;
+  if (size != 1024) return tssep_generic_twiddles(size, host_out);      // (the same table layout for every plan)
   const int nh = size / 2;
   for (int k = 0; k < nh; ++k) {
     const double a = -2.0 * M_PI * (double)k / (double)nh;
@@ -500,14 +508,20 @@ static int check_plan(int size, int shift) {
   if (size != 1024 || shift != 256) return TSSEP_E_UNSUPPORTED;
   return TSSEP_OK;
 }
+static bool generic_plan(int size, int shift) { return check_plan(size, shift) != TSSEP_OK && tssep_generic_plan_supported(size, shift); }
+extern "C" int tssep_stft_plan(int size, int shift) {
+  return check_plan(size, shift) == TSSEP_OK ? 1 : (tssep_generic_plan_supported(size, shift) ? 2 : 0);
+}
 
 extern "C" int tssep_stft_fwd(const float* x, int64_t rows, int64_t N, int size, int shift,
                               int fading, const float* window, const float* tw, float* X,
                               int64_t T, void* stream) {
   if (!x || !window || !tw || !X) return TSSEP_E_NULL;
   if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
-  if (int e = check_plan(size, shift)) return e;
   if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)window) & 7u)) return TSSEP_E_ALIGN;
+  if (generic_plan(size, shift))
+    return tssep_generic_rfft(x, rows, N, size, shift, fading ? size - shift : 0, window, tw, X, T, 1.0f, 1.0f, stream);
+  if (int e = check_plan(size, shift)) return e;
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
@@ -524,8 +538,11 @@ extern "C" int tssep_istft_bwd(const float* dy, int64_t rows, int64_t N, int siz
                                int64_t T, void* stream) {
   if (!dy || !wsyn || !tw || !dX) return TSSEP_E_NULL;
   if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
-  if (int e = check_plan(size, shift)) return e;
   if ((((uintptr_t)dX) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;
+  if (generic_plan(size, shift))
+    return tssep_generic_rfft(dy, rows, N, size, shift, fading ? size - shift : 0, wsyn, tw, dX, T, 2.0f / (float)size,
+                              1.0f / (float)size, stream);
+  if (int e = check_plan(size, shift)) return e;
   const int iters = 4;
   const int64_t total = rows * T;
   const int64_t blocks = (total + 4 * iters - 1) / (4 * iters);
@@ -591,6 +608,12 @@ extern "C" int tssep_istft_fwd(const float* X, int64_t rows, int64_t T, int size
                                const float* tgt, float* abs_partial, void* stream) {
   if (!X || !wsyn || !tw || !y) return TSSEP_E_NULL;
   if (rows <= 0 || N <= 0 || T <= 0) return TSSEP_E_SHAPE;
+  if (generic_plan(size, shift)) {
+    // (the general plan has no fused |estimate - target| sums: a time-domain loss reads the estimate itself)
+    if (tgt || abs_partial) return TSSEP_E_UNSUPPORTED;
+    if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u)) return TSSEP_E_ALIGN;
+    return tssep_generic_istft(X, rows, T, size, shift, fading ? size - shift : 0, wsyn, tw, y, N, stream);
+  }
   if (int e = check_plan(size, shift)) return e;
   if (!fading) return TSSEP_E_UNSUPPORTED;
   if ((((uintptr_t)X) & 7u) || (((uintptr_t)tw) & 7u) || (((uintptr_t)wsyn) & 7u)) return TSSEP_E_ALIGN;

@@ -66,13 +66,19 @@ class STFT(Configurable):
         return p, p
 
     def _plain(self):
-        """The configuration the fused kernels are built for: full fading with a full-size window."""
-        return self.window_length == self.size and self.fading in (True, "full")
+        """The configuration the fused kernels are built for: the 1024 / 256 plan, full fading, a full-size window."""
+        return self.window_length == self.size and self.fading in (True, "full") and self._check_plan() == 1
 
     def _check_plan(self):
-        if (self.size, self.shift) != (1024, 256):
-            raise RuntimeError(f"unsupported FFT plan size={self.size}, shift={self.shift}: libtssep_hip.so builds the "
-                               "1024 / 256 plan of the reference's configs (TSSEP_E_UNSUPPORTED)")
+        """1: the plan specialised to the shipped configs (1024 / 256: fused mask head + inverse STFT); 2: the general plan
+        (stft_generic.hip: even sizes with size / 2 = 2^a 3^b 5^c <= 2048, shift <= min(size, 512) -- 512 / 128, TorchMFCC's
+        own default 400 / 200, ...); anything else raises, naming the plan."""
+        from .. import _lib
+        plan = int(_lib.lib().tssep_stft_plan(int(self.size), int(self.shift)))
+        if not plan:
+            raise RuntimeError(f"unsupported FFT plan size={self.size}, shift={self.shift}: libtssep_hip.so builds even sizes "
+                               "with size / 2 = 2^a 3^b 5^c <= 2048 and shift <= min(size, 512) (TSSEP_E_UNSUPPORTED)")
+        return plan
 
     def frames(self, num_samples):
         lead, tail = self._fade()
@@ -180,8 +186,16 @@ class TorchMFCC(STFT, torch.nn.Module):
         self.n_mfcc = n_mfcc
         STFT.__init__(self, size=size, shift=shift, window_length=window_length, pad=pad,
                       fading=fading, output_size=output_size, window=window)
-        if log_mels or mel_norm is not None or mel_scale != "htk" or dct_norm != "ortho":
-            raise NotImplementedError("only the shipped TorchMFCC options are built")
+        # every option of feature_extractor_torchaudio.py:22-39 (round 5; the shipped configs use the defaults): the mel scale
+        # ('htk' | 'slaney'), its area normalisation (None | 'slaney'), the DCT normalisation ('ortho' | None) are TABLES
+        # handed to tssep_feat_fwd, `log_mels` is an argument of the kernel -- restated from torchaudio 2.0.2 (absent here:
+        # parity unpinned like the defaults, oracle/features.py)
+        if mel_scale not in ("htk", "slaney"):
+            raise ValueError('mel_scale should be one of "htk" or "slaney"')        # (torchaudio's message)
+        if mel_norm is not None and mel_norm != "slaney":
+            raise ValueError('norm must be one of None or "slaney"')
+        if dct_norm is not None and dct_norm != "ortho":
+            raise ValueError("norm must be either 'ortho' or None")
         self.sample_rate, self.f_min = sample_rate, f_min
         if f_max and f_max < 0:
             f_max = sample_rate + f_max                       # :57-58
@@ -192,8 +206,8 @@ class TorchMFCC(STFT, torch.nn.Module):
         # ``dct_mat`` -> checkpoint keys ``<fe>.dct_mat`` and ``<fe>.mel_scale.fb``, so a checkpoint the
         # reference wrote loads with strict=True (init_cfg_tssep.yaml:22)
         self.amplitude_to_DB = _AmplitudeToDB("power", self.top_db)
-        self.mel_scale = _MelScale(n_mels, sample_rate, f_min, f_max, size // 2 + 1)
-        self.register_buffer("dct_mat", _create_dct(n_mfcc, n_mels))
+        self.mel_scale = _MelScale(n_mels, sample_rate, f_min, f_max, size // 2 + 1, mel_norm, mel_scale)
+        self.register_buffer("dct_mat", _create_dct(n_mfcc, n_mels, dct_norm))
 
     @property
     def fb(self):
@@ -207,18 +221,24 @@ class TorchMFCC(STFT, torch.nn.Module):
         if X.dim() == 2:        # un-batched example: the dB floor is per utterance (torchaudio 2-D case)
             return self.stft_to_feature(X[None])[0]
         assert X.dim() == 3, X.shape
-        out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self.top_db)
+        out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self._db_arg)
         return out[..., :self.n_mfcc]
+
+    @property
+    def _db_arg(self):
+        """top_db for tssep_feat_fwd; negative = `log_mels` (log(mel + 1e-6), no floor: include/tssep_hip.h)."""
+        return -1.0 if self.log_mels else float(self.top_db)
 
 
 class _MelScale(torch.nn.Module):
     """Holder of the mel filterbank under torchaudio's key (``MelScale.fb``, a persistent buffer
     [n_freqs, n_mels]); the filtering itself runs inside tssep_feat_fwd."""
 
-    def __init__(self, n_mels, sample_rate, f_min, f_max, n_stft):
+    def __init__(self, n_mels, sample_rate, f_min, f_max, n_stft, norm=None, mel_scale="htk"):
         super().__init__()
         self.n_mels, self.sample_rate, self.f_min, self.f_max = n_mels, sample_rate, f_min, f_max
-        self.register_buffer("fb", _melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate))
+        self.norm, self.mel_scale = norm, mel_scale
+        self.register_buffer("fb", _melscale_fbanks(n_stft, f_min, f_max, n_mels, sample_rate, norm, mel_scale))
 
 
 class _AmplitudeToDB(torch.nn.Module):
@@ -229,25 +249,56 @@ class _AmplitudeToDB(torch.nn.Module):
         self.stype, self.top_db = stype, top_db
 
 
-def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate):
+def _hz_to_mel(freq, mel_scale="htk"):
+    """torchaudio.functional._hz_to_mel (2.0.2): HTK 2595 log10(1 + f / 700); Slaney: linear below 1 kHz
+    (200 / 3 Hz per mel), logarithmic above (step log(6.4) / 27)."""
+    if mel_scale == "htk":
+        return 2595.0 * math.log10(1.0 + freq / 700.0)
+    f_sp = 200.0 / 3
+    mels = freq / f_sp
+    min_log_hz = 1000.0
+    if freq >= min_log_hz:
+        mels = min_log_hz / f_sp + math.log(freq / min_log_hz) / (math.log(6.4) / 27.0)
+    return mels
+
+
+def _mel_to_hz(mels, mel_scale="htk"):
+    if mel_scale == "htk":
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_mel = 1000.0 / f_sp
+    log_t = mels >= min_log_mel
+    freqs[log_t] = 1000.0 * torch.exp((math.log(6.4) / 27.0) * (mels[log_t] - min_log_mel))
+    return freqs
+
+
+def _melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, mel_scale="htk"):
+    """torchaudio.functional.melscale_fbanks (2.0.2) -> [n_freqs, n_mels]; norm='slaney': every triangle divided by the
+    width of its mel band (area normalisation)."""
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
-    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
-    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
-    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
-    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    m_pts = torch.linspace(_hz_to_mel(f_min, mel_scale), _hz_to_mel(f_max, mel_scale), n_mels + 2)
+    f_pts = _mel_to_hz(m_pts, mel_scale)
     f_diff = f_pts[1:] - f_pts[:-1]
     slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
     down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
     up = slopes[:, 2:] / f_diff[1:]
-    return torch.clamp(torch.min(down, up), min=0.0).contiguous()
+    fb = torch.clamp(torch.min(down, up), min=0.0)
+    if norm == "slaney":
+        fb = fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])).unsqueeze(0)
+    return fb.contiguous()
 
 
-def _create_dct(n_mfcc, n_mels):
+def _create_dct(n_mfcc, n_mels, norm="ortho"):
+    """torchaudio.functional.create_dct -> [n_mels, n_mfcc] (norm None: the DCT-II scaled by 2)."""
     n = torch.arange(float(n_mels))
     k = torch.arange(float(n_mfcc)).unsqueeze(1)
     dct = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)
-    dct[0] *= 1.0 / math.sqrt(2.0)
-    dct *= math.sqrt(2.0 / float(n_mels))
+    if norm is None:
+        dct *= 2.0
+    else:
+        dct[0] *= 1.0 / math.sqrt(2.0)
+        dct *= math.sqrt(2.0 / float(n_mels))
     return dct.t().contiguous()
 
 
@@ -283,7 +334,7 @@ class ConcaternatedSTFTFeatures(STFT, torch.nn.Module):
         if isinstance(self.fe1, TorchMFCC) and isinstance(self.fe2, Log1pMaxNormAbsSTFT) \
                 and X.dim() == 3:
             # one fused pass pair writes [mfcc | log1p] side by side (feature_extractor.py:352-360)
-            out, _ = H.feat_fwd(X, self.fe1.fb, self.fe1.dct_mat, self.fe1.n_mfcc, self.fe1.top_db,
+            out, _ = H.feat_fwd(X, self.fe1.fb, self.fe1.dct_mat, self.fe1.n_mfcc, self.fe1._db_arg,
                                 statistics_axis=self.fe2.statistics_axis)
             return out
         return torch.concat([self.fe1.stft_to_feature(X), self.fe2.stft_to_feature(X)], dim=-1)
