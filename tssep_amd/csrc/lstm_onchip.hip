@@ -963,6 +963,15 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_G1_DELAY_OWN
 #define ONCHIP16_FWD_G1_DELAY_OWN 0
 #endif
+// two groups per cluster: 1 = decode the next phase's h in front of this phase's second barrier when it has arrived (see
+// `early_decoded` in the kernel); 0 = always at the start of the next phase (rounds 3-4).  Measured (round 5, alternating on
+// one box, ms per launch, 0 -> 1): 768 sequences 1.395 -> 1.47, 1 536: 2.62 -> 2.72, 3 072: 5.26 -> 5.41 -- SLOWER: the trace
+// shows why: with many sequences the first barrier of a phase is gated by the io waves (the phase's gate tile lands ~1 700
+// cycles into it, behind the store acknowledgements queued in front of it), so a decode at the phase start was hidden
+// already, while in front of the second barrier it delays the publish (profiles/r5_onchip16_early_decode_rejected.jsonl)
+#ifndef ONCHIP16_FWD_EARLY_DECODE
+#define ONCHIP16_FWD_EARLY_DECODE 0
+#endif
 // Experiment builds only (-DONCHIP16_TRACE=1): wave 0 (exchange) and the first io wave of workgroup 0 of the first cluster
 // leave `s_memtime` stamps of steps 128 .. 131 of their first work item in the spare words of the exchange header
 // (words 96 ..: [wave role 2][step 4][stamp 8] 64-bit ticks + re-poll counts at [64 .. 71] of that block)
@@ -1160,6 +1169,12 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
       return __builtin_amdgcn_make_buffer_rsrc(xpayload + item * 2 * G * SQ * UW, 0, 2 * G * SQ * UW * 4, 0x00020000);
     };
     u32x4 vg[GMAX];
+    // Two groups per cluster: the NEXT phase's h (requested beside this phase's MFMAs) is decoded into its operand image at
+    // the END of this phase's cell update when it has arrived by then -- where the exchange waves otherwise wait at the
+    // second barrier for the io waves, which lose the MFMA arbitration and finish ~800 cycles later (trace, round 5) --
+    // instead of at the start of the next phase with every other wave parked at its first barrier.  Per wave: a wave
+    // whose granules are not all there decodes at the next phase's start as before.
+    int early_decoded = 0;
     auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // h_{st-1} of group p
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
@@ -1168,6 +1183,37 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         vg[gs] = (gs < G && !(OWN_EARLY && gs == g))
                      ? __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + gs) * SQ + s2) * UW + 4 * uq) * 4, 0, SC1)
                      : u32x4{0u, 0u, 0u, 0u};
+    };
+    // every granule this lane requested carries the tag of step st (no re-request: the early decode below only looks)
+    auto gather_arrived = [&](int64_t st) __attribute__((always_inline)) {
+      const unsigned want = mk_tag(tagbase, st);
+      bool ok = true;
+#pragma unroll
+      for (int gs = 0; gs < GMAX; ++gs)
+        ok = ok && (gs >= G || (OWN_EARLY && gs == g) || ((vg[gs][0] & 0xffffu) == want && (vg[gs][2] & 0xffffu) == want));
+      return ok;
+    };
+    auto gather_decode = [&](int p) __attribute__((always_inline)) {
+      // (the lane part of the operand-image addresses is REBUILT here from an opaque copy of the thread index: as loop
+      // invariants the compiler kept one address register per peer -- ten with four-wave workgroups -- spilled them, and
+      // reloaded each from scratch in front of its LDS write: eight serialized memory round trips, 2 us per phase)
+      int tvd = tid;
+      asm volatile("" : "+v"(tvd));
+      const int s2d = (tvd & (64 * NEX - 1)) / QW, uqd = tvd % QW;
+      char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2d * HP2 + 8 * uqd;
+      char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2d * HP2 + 8 * uqd;
+#pragma unroll
+      for (int gs = 0; gs < GMAX; ++gs) {
+        if (gs < G && !(OWN_EARLY && gs == g)) {
+          const int k = __builtin_amdgcn_readfirstlane(UW * (gs >= g ? gs - g : gs - g + G));      // (the k axis starts at the own slice)
+          const u32x4 w = vg[gs];
+          unsigned h0, l0, h1, l1;
+          split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
+          split2(granule_a(w[2], w[3]), granule_b(w[3]), h1, l1);
+          *reinterpret_cast<u32x2*>(hh + 2 * k) = u32x2{h0, h1};
+          *reinterpret_cast<u32x2*>(hl + 2 * k) = u32x2{l0, l1};
+        }
+      }
     };
     auto gather_finish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
@@ -1194,26 +1240,7 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         if (trace_round == 0 && st >= 128 && st < 132 && lane == 0 && wave == 0 && g == 0)
           reinterpret_cast<unsigned long long*>(xhead + 96)[68 + (int)(st - 128)] = __builtin_readcyclecounter();
       }
-      // (the lane part of the operand-image addresses is REBUILT here from an opaque copy of the thread index: as loop
-      // invariants the compiler kept one address register per peer -- ten with four-wave workgroups -- spilled them, and
-      // reloaded each from scratch in front of its LDS write: eight serialized memory round trips, 2 us per phase)
-      int tvd = tid;
-      asm volatile("" : "+v"(tvd));
-      const int s2d = (tvd & (64 * NEX - 1)) / QW, uqd = tvd % QW;
-      char* hh = hs + (p * 2 + 0) * SQ * HP2 + s2d * HP2 + 8 * uqd;
-      char* hl = hs + (p * 2 + 1) * SQ * HP2 + s2d * HP2 + 8 * uqd;
-#pragma unroll
-      for (int gs = 0; gs < GMAX; ++gs) {
-        if (gs < G && !(OWN_EARLY && gs == g)) {
-          const int k = __builtin_amdgcn_readfirstlane(UW * (gs >= g ? gs - g : gs - g + G));      // (the k axis starts at the own slice)
-          const u32x4 w = vg[gs];
-          unsigned h0, l0, h1, l1;
-          split2(granule_a(w[0], w[1]), granule_b(w[1]), h0, l0);
-          split2(granule_a(w[2], w[3]), granule_b(w[3]), h1, l1);
-          *reinterpret_cast<u32x2*>(hh + 2 * k) = u32x2{h0, h1};
-          *reinterpret_cast<u32x2*>(hl + 2 * k) = u32x2{l0, l1};
-        }
-      }
+      gather_decode(p);
     };
     auto publish = [&](int p, int64_t st) __attribute__((always_inline)) {
       const auto prs = payload_srd(p);
@@ -1245,7 +1272,8 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
       if constexpr (!IO) {
         // (NGA = 4: this phase's h was decoded into the operand image behind the previous phase's publish -- below --
         // so nothing stands between the exchange waves and the barrier)
-        if (NGA < 4 && st > 0 && !(ONCHIP16_ABL & 8)) gather_finish(P, st);
+        if (NGA < 4 && st > 0 && !(ONCHIP16_ABL & 8) && !early_decoded) gather_finish(P, st);
+        early_decoded = 0;
       } else {
         // the tile of this phase has landed: it was requested two phases ago, and exactly six stores + four copies
         // (the previous phase's) were queued behind it -- those may still be in flight (a store acknowledgement
@@ -1325,6 +1353,15 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
         cellb[jv * PUBP + ul] = cn;
       }
       stamp(IO ? 1 : 0, st, 4);
+      if constexpr (!IO && NGA == 2 && ONCHIP16_FWD_EARLY_DECODE) {
+        if (st1 > 0 && st1 < T && !(ONCHIP16_ABL & 8)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the requests of k-step FGAT - 2: long back)
+          if (__builtin_amdgcn_ballot_w64(!gather_arrived(st1)) == 0) {
+            gather_decode(P1);
+            early_decoded = 1;
+          }
+        }
+      }
       lds_barrier();
       stamp(IO ? 1 : 0, st, 5);
       // OWN_EARLY: h_t of the own slice x its weight columns, for step t + 1 (every wave: it needs the whole slice as B)
