@@ -32,5 +32,10 @@ for N in [int(a) for a in sys.argv[1:]] or [32, 3072]:
             if ((N + 15) // 16) % g:
                 continue
             row[f"w{waves}g{g}_ms"] = round(timeit(lambda: h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, packs[waves], N, T, Hh, g, waves=waves)), 3)
+    # the same launches with the rows in TIME-MAJOR order inside groups of 32 sequences (kernel argument `layout` = 1: the 16
+    # sequences a workgroup touches at one step are 16 consecutive rows instead of rows T apart) -- the access pattern only
+    if N % 32 == 0:
+        for g in (1, 2):
+            row[f"w8g{g}_timemajor_ms"] = round(timeit(lambda: h.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, packs[8], N, T, Hh, g, layout=1)), 3)
     h.cluster_error_code()
     print(json.dumps(row), flush=True)
