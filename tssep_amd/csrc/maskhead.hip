@@ -75,42 +75,69 @@ __global__ __launch_bounds__(256) void maskhead_fwd_kernel(
   }
 }
 
+// Backward: FOUR 128-element halves per wave and iteration with every load of the iteration issued before the first use
+// (8 streaming loads + 8 L2-served observation bins per lane in flight), non-temporal on all four streams: 4.71 -> 4.95 TB/s
+// at batch 768 (0.59 -> 0.62 of 8 TB/s; a torch copy of the same bytes 4.6-5.1), alternating builds on one box, round 5
+// (two halves + nt 4.85, four halves without nt 4.82, 16 workgroups per CU 4.65: profiles/r5_maskhead_bwd_variants.jsonl)
+#ifndef MH_HALVES
+#define MH_HALVES 4
+#endif
+#ifndef MH_NT_ALL
+#define MH_NT_ALL 1
+#endif
 __global__ __launch_bounds__(256) void maskhead_bwd_kernel(
     const float2* __restrict__ dest, const float* __restrict__ dmask,
     const float* __restrict__ mask, const float2* __restrict__ obs, float* __restrict__ dlogit,
     int64_t total, int64_t KTF, int64_t TF) {
+  constexpr int HV = MH_HALVES, WE = 128 * HV;
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
-  const int64_t stride = nwaves * 256;
+  const int64_t stride = nwaves * WE;
   const int64_t stride_tf = stride % TF;
-  int64_t base = wave * 256;
+  int64_t base = wave * WE;
   if (base >= total) return;
-  Pos p0, p1;
-  p0.init(base + 2 * lane < total ? base + 2 * lane : 0, KTF, TF);
-  p1.init(base + 128 + 2 * lane < total ? base + 128 + 2 * lane : 0, KTF, TF);
-  for (; base < total; base += stride, p0.advance(stride, stride_tf, KTF, TF),
-                       p1.advance(stride, stride_tf, KTF, TF)) {
+  Pos p[HV];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < HV; ++h) p[h].init(base + 128 * h + 2 * lane < total ? base + 128 * h + 2 * lane : 0, KTF, TF);
+  for (; base < total; base += stride) {
+    // all loads of the iteration first (2 HV streaming loads + 2 HV L2-served observation bins per lane in flight), then
+    // the arithmetic and the stores
+    f32x4 d[HV];
+    f32x2 m[HV], g[HV];
+    float2 x0[HV], x1[HV];
+    bool full[HV];
+#pragma unroll
+    for (int h = 0; h < HV; ++h) {
       const int64_t e = base + 128 * h + 2 * lane;
-      Pos q = h ? p1 : p0;
-      if (e + 2 <= total) {
-        const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dest + e));
-        const f32x2 m = *reinterpret_cast<const f32x2*>(mask + e);
-        f32x2 g = {0.f, 0.f};
-        if (dmask) g = *reinterpret_cast<const f32x2*>(dmask + e);
-        const float2 x0 = obs[q.ob + q.tf];
+      full[h] = e + 2 <= total;
+      Pos q = p[h];
+      g[h] = f32x2{0.f, 0.f};
+      if (full[h]) {
+        d[h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dest + e));
+        m[h] = MH_NT_ALL ? __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(mask + e))
+                         : *reinterpret_cast<const f32x2*>(mask + e);
+        if (dmask) g[h] = *reinterpret_cast<const f32x2*>(dmask + e);
+        x0[h] = obs[q.ob + q.tf];
         q.advance(1, 1, KTF, TF);
-        const float2 x1 = obs[q.ob + q.tf];
-        const float o0 = (x0.x * d[0] + x0.y * d[1] + g[0]) * m[0] * (1.0f - m[0]);
-        const float o1 = (x1.x * d[2] + x1.y * d[3] + g[1]) * m[1] * (1.0f - m[1]);
-        *reinterpret_cast<f32x2*>(dlogit + e) = f32x2{o0, o1};
-      } else if (e < total) {
-        const float2 x0 = obs[q.ob + q.tf], d = dest[e];
-        const float m = mask[e];
-        dlogit[e] = (x0.x * d.x + x0.y * d.y + (dmask ? dmask[e] : 0.f)) * m * (1.0f - m);
+        x1[h] = obs[q.ob + q.tf];
       }
+    }
+#pragma unroll
+    for (int h = 0; h < HV; ++h) {
+      const int64_t e = base + 128 * h + 2 * lane;
+      if (full[h]) {
+        const float o0 = (x0[h].x * d[h][0] + x0[h].y * d[h][1] + g[h][0]) * m[h][0] * (1.0f - m[h][0]);
+        const float o1 = (x1[h].x * d[h][2] + x1[h].y * d[h][3] + g[h][1]) * m[h][1] * (1.0f - m[h][1]);
+        if (MH_NT_ALL) __builtin_nontemporal_store(f32x2{o0, o1}, reinterpret_cast<f32x2*>(dlogit + e));
+        else *reinterpret_cast<f32x2*>(dlogit + e) = f32x2{o0, o1};
+      } else if (e < total) {
+        const Pos q = p[h];
+        const float2 xa = obs[q.ob + q.tf], da = dest[e];
+        const float ma = mask[e];
+        dlogit[e] = (xa.x * da.x + xa.y * da.y + (dmask ? dmask[e] : 0.f)) * ma * (1.0f - ma);
+      }
+      p[h].advance(stride, stride_tf, KTF, TF);
     }
   }
 }
@@ -139,7 +166,10 @@ __global__ __launch_bounds__(256) void mask_mul_kernel(
 
 inline unsigned stream_grid(int64_t total_vec4) {
   int64_t blocks = (total_vec4 + 255) / 256;
-  const int64_t cap = 256 * 8;  // 8 workgroups per CU, grid-stride beyond
+#ifndef MH_WGS_PER_CU
+#define MH_WGS_PER_CU 8
+#endif
+  const int64_t cap = 256 * MH_WGS_PER_CU;  // workgroups per CU, grid-stride beyond
   return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
 }
 
