@@ -35,12 +35,8 @@ python tools/gemm_in_step.py 768 > $O/gemm_in_step_b768.jsonl 2>/dev/null
 python tools/ab_big_p.py 768 > $O/ab_gemm_big_p.jsonl 2>/dev/null
 python tools/ab_tn_p320.py 768 > $O/ab_wgrad_tn_p320.jsonl 2>/dev/null
 python tools/step_clock.py 768 > $O/step_clock.json 2>/dev/null
-# the store-flavour probe (16 KB and 80 KB per workgroup: 0.47 and 2.34 MB of rewritten lines per XCD)
-for BY in 16384 81920; do
-  export PROBE_BYTES=$BY PROBE_REPS=100
-  (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/probe$BY -o w -- python3 $GRAFT_REPO_ROOT/tools/probe_rewrite.py > $GRAFT_REPO_ROOT/$O/probe$BY.log 2>&1)
-  f=$(find $O/probe$BY -name "*counter_collection.csv" | head -1); python tools/probe_rewrite.py --summarise $f > $O/store_flavour_probe_$BY.json
-done
+python tools/bench_maskhead.py 64 256 768 > $O/maskhead_microbench.jsonl 2>/dev/null
+python tools/abl_onchip16.py 32 768 3072 2>/dev/null | grep lib > $O/onchip16_fwd_variants.jsonl
 # raw counter tables are large: keep what install_profiles.sh reads
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 du -sh $O; ls $O | head -80

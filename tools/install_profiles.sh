@@ -12,7 +12,7 @@ for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16
          bench_f32.json gemm_in_step_b768.jsonl step_clock.json ab_fusions.jsonl splitk_sweep.jsonl \
          ab_gemm_stream_shapes.jsonl ab_gemm_big_shapes.jsonl ab_wgrad_big_shapes.jsonl ab_gemm_kernels.jsonl ab_wgrad_tile.jsonl \
          ab_wgrad_xc_shapes.jsonl ab_wgrad_w160_shapes.jsonl wgrad_w160_split_sweep.jsonl wgrad_xc_split_sweep.jsonl sq_wave_states.jsonl onchip16_microbench.jsonl \
-         bench_default.json store_flavour_probe_16384.json store_flavour_probe_81920.json ab_gemm_big_p.jsonl ab_wgrad_tn_p320.jsonl ab_prepare_derived.jsonl; do
+         bench_default.json store_flavour_probe_16384.json store_flavour_probe_81920.json ab_gemm_big_p.jsonl ab_wgrad_tn_p320.jsonl ab_prepare_derived.jsonl maskhead_microbench.jsonl onchip16_fwd_variants.jsonl; do
   [ -s $F/$f ] && cp $F/$f ${P}_$f
 done
 python - <<PY

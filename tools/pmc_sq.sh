@@ -4,7 +4,7 @@
 O=gpurun_out/pmc_sq; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES \
-  --output-format csv -d $O/raw -o q -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 "$@" > $O/run.log 2>&1
+  --output-format csv -d $O/raw -o q -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-headline-parity "$@" > $O/run.log 2>&1
 python - <<PY
 import csv, glob, collections, json
 f = glob.glob("$O/raw/**/*counter_collection.csv", recursive=True)[0]
