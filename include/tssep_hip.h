@@ -500,6 +500,12 @@ int64_t tssep_adam_workspace_bytes(void);
 int tssep_adam_step(float* param, float* exp_avg, float* exp_avg_sq, const float* grad, int64_t n,
                     int64_t step, float max_norm, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float* norm_out, void* ws, void* stream);
+/* The same step behind a device-side guard: err = the error flag of the W-stationary recurrences (err[0] != 0: a launch
+ * of this step gave up on a peer, the gradient is garbage) -> the update is skipped on the device, parameters and
+ * moments stay those of the last good step; the host raises at its next check of the flag.  err == NULL: no guard. */
+int tssep_adam_step_guarded(float* param, float* exp_avg, float* exp_avg_sq, const float* grad, int64_t n,
+                            int64_t step, float max_norm, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float* norm_out, void* ws, const int* err, void* stream);
 
 /* split-K / slab reduction: dst[i] (+)= sum_{s<nsplit} src[s*stride + i] */
 int tssep_reduce_splits(const float* src, int nsplit, int64_t stride, int64_t count, float* dst,

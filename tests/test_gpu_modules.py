@@ -556,6 +556,35 @@ def test_fused_adam_matches_torch_adam_with_clipping():
             close(p, q, rtol=1e-4, atol=1e-6, name=f"param after step {it}")
 
 
+def test_optimizer_skips_the_update_when_a_recurrence_timed_out():
+    """the only guard against a W-stationary launch that gave up on a peer (err[0]) was a host read at
+    summary / checkpoint time -- steps in between trained on garbage.  The fused clip + Adam launch now reads the flag on
+    the DEVICE and skips the update (tssep_adam_step_guarded): parameters and moments stay those of the last good step."""
+    from tssep_amd import hip_ops
+    from tssep_amd.train.optimizer import Adam
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(33, 17).cuda()
+    opt = Adam(gradient_clipping=10.0, lr=1e-2)
+    opt.set_parameters(lin.parameters())
+    x = torch.randn(8, 33, device="cuda")
+    opt.zero_grad()
+    lin(x).pow(2).sum().backward()
+    before = opt.flat_param.clone()
+    flag = hip_ops._err_flag(opt.flat_param.device)
+    flag[0] = 3                                   # what a timed-out forward recurrence leaves
+    try:
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat_param, before) and float(opt.exp_avg.abs().max()) == 0.0
+        with pytest.raises(RuntimeError, match="timed out"):
+            hip_ops.check_cluster_errors(opt.flat_param.device)      # (reads and clears the flag)
+    finally:
+        flag[0] = 0
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(opt.flat_param, before) and float(opt.exp_avg.abs().max()) > 0.0
+
+
 def test_optimizer_state_survives_a_checkpoint_round_trip():
     """Adam.state_dict / load_state_dict carry the moments per parameter (the flat buffers pad every tensor to a 256-byte
     boundary: distributed.flat_offsets): a second optimizer over a copy of the model continues bit for bit after loading,

@@ -35,8 +35,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(
     float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
     const float* __restrict__ g, int64_t n, const float* __restrict__ part, int nparts,
     float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-    float bc1, float bc2, float* __restrict__ norm_out) {
+    float bc1, float bc2, float* __restrict__ norm_out, const int* __restrict__ guard) {
   __shared__ float s_clip;
+  // guard[0] != 0: a W-stationary recurrence launch of this step gave up on a peer (err[0] of include/tssep_hip.h) --
+  // its outputs and therefore this gradient are garbage: the update is NOT applied (uniform over the grid; the host
+  // raises at its next check of the flag, with the parameters and moments of the last good step intact)
+  if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   if (threadIdx.x < 64) {        // fixed-order reduction of the partial sums (deterministic)
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
@@ -77,6 +81,14 @@ extern "C" int tssep_adam_step(float* param, float* exp_avg, float* exp_avg_sq, 
                                int64_t n, int64_t step, float max_norm, float lr, float beta1,
                                float beta2, float eps, float weight_decay, float* norm_out,
                                void* ws, void* stream) {
+  return tssep_adam_step_guarded(param, exp_avg, exp_avg_sq, grad, n, step, max_norm, lr, beta1, beta2, eps, weight_decay,
+                                 norm_out, ws, nullptr, stream);
+}
+
+extern "C" int tssep_adam_step_guarded(float* param, float* exp_avg, float* exp_avg_sq, const float* grad,
+                                       int64_t n, int64_t step, float max_norm, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, float* norm_out,
+                                       void* ws, const int* err, void* stream) {
   if (!param || !exp_avg || !exp_avg_sq || !grad || !ws) return TSSEP_E_NULL;
   if (n <= 0 || step <= 0) return TSSEP_E_SHAPE;
   if (!aligned16(grad)) return TSSEP_E_ALIGN;
@@ -88,6 +100,6 @@ extern "C" int tssep_adam_step(float* param, float* exp_avg, float* exp_avg_sq, 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, param, exp_avg,
                      exp_avg_sq, grad, n, (const float*)ws, SQ_BLOCKS, max_norm, lr, beta1, beta2,
-                     eps, weight_decay, bc1, bc2, norm_out);
+                     eps, weight_decay, bc1, bc2, norm_out, err);
   return tssep_launch_status();
 }

@@ -60,14 +60,17 @@ class Adam(Configurable):
             self.bucket.all_reduce()        # joins the side stream; SUM over ranks when distributed
         self.step_count += 1
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        rc = _lib.lib().tssep_adam_step(
+        from .. import hip_ops
+        # (guarded: when a W-stationary recurrence launch of this step timed out on a peer -- err[0] of the C ABI -- the
+        # kernel skips the update on the device: garbage is never trained on, the host raises at its next flag check)
+        guard = hip_ops._err_flag(self.flat_param.device) if self.flat_param.is_cuda else None
+        rc = _lib.lib().tssep_adam_step_guarded(
             p(self.flat_param), p(self.exp_avg), p(self.exp_avg_sq), p(self.bucket.flat),
             self.flat_param.numel(), self.step_count, float(self.gradient_clipping), float(self.lr),
             float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-            p(self.grad_norm), p(self._ws),
+            p(self.grad_norm), p(self._ws), p(guard) if guard is not None else None,
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _lib.check(rc, "adam_step")
-        from .. import hip_ops
         hip_ops.weights_changed()            # derived weight layouts (packs, transposes) are stale now
         return self.grad_norm
 
