@@ -168,6 +168,27 @@ def test_abi_argument_validation_without_gpu():
     assert L.tssep_stft_frames(480000, 1024, 256, 1024, 1, 1) == 1878
 
 
+def test_fft_plans_without_gpu():
+    """tssep_stft_plan / tssep_fft_twiddles are host-only: 1 = the 1024 / 256 plan of the shipped configs, 2 = the general
+    plan (even sizes, size / 2 = 2^a 3^b 5^c <= 2048, shift <= min(size, 512)), 0 = not built; the twiddle tables of both
+    plans share one layout ([size / 2] exp(-2 pi i k / (size / 2)), then [size / 2 + 1] exp(-2 pi i k / size))."""
+    L = _lib.lib()
+    assert L.tssep_stft_plan(1024, 256) == 1
+    for size, shift in ((512, 128), (400, 200), (256, 64), (2048, 512), (960, 240), (1000, 250), (60, 20), (1024, 128)):
+        assert L.tssep_stft_plan(size, shift) == 2, (size, shift)
+    for size, shift in ((1022, 256), (514, 128), (1023, 256), (4098, 512), (2048, 1024), (512, 600), (14, 7), (512, 0)):
+        assert L.tssep_stft_plan(size, shift) == 0, (size, shift)
+    for size in (1024, 400, 60):
+        nh = size // 2
+        buf = np.zeros(2 * (nh + nh + 1), dtype=np.float32)
+        assert L.tssep_fft_twiddles(size, buf.ctypes.data_as(ctypes.c_void_p)) == 0
+        tw = buf.view(np.complex64)
+        np.testing.assert_allclose(tw[:nh], np.exp(-2j * np.pi * np.arange(nh) / nh), atol=1e-6)
+        np.testing.assert_allclose(tw[nh:], np.exp(-2j * np.pi * np.arange(nh + 1) / size), atol=1e-6)
+    buf = np.zeros(4, dtype=np.float32)
+    assert L.tssep_fft_twiddles(1022, buf.ctypes.data_as(ctypes.c_void_p)) < 0
+
+
 def test_side_stream_rows_policy():
     assert H.SIDE_STREAM_MAX_SEQS == 512
 
