@@ -1239,7 +1239,8 @@ def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
     assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert (d["config"]["hip_graph"] is not None) == (graph == "on")
     c = d["config"]["collective"]
-    assert c["process_group_world_size"] == 2 and c["replicas_agree"] is True and c["launches"] == 2
+    # (graph on: the two timed replays + the two eager steps behind them that time the kernels for the roofline)
+    assert c["process_group_world_size"] == 2 and c["replicas_agree"] is True and c["launches"] == (4 if graph == "on" else 2)
     assert c["allreduce_ms"] > 0 and c["bytes"] > 4e7
     # what the first 8-GPU run should explain by itself: per-rank step times, bus bandwidth, the library behind "nccl"
     assert len(c["ms_per_step_by_rank"]) == 2 and all(v > 0 for v in c["ms_per_step_by_rank"])
