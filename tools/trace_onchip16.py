@@ -34,3 +34,24 @@ for rep in range(3):
                           exchange_wave=[[int(v - t0) for v in row] for row in st[0]],
                           io_wave=[[int(v - t0) for v in row] for row in st[1]], repolls=[int(v) for v in tb[64:68]], arrived=[int(v - t0) for v in tb[68:72]])))
 h.cluster_error_code()
+
+# ---- backward (group 0 of the bundle that serves work item 0, steps 128 and 129): stamps 0 phase start | 1 partial sums
+# gathered + summed (exchange) / tiles landed (io) | 2 first barrier | 3 cell backward done | 4 second barrier | 5 deferred flush /
+# request issued, MFMAs start | 6 MFMAs done | 7 partial sums published from the accumulators | 8 third barrier | 9 phase end
+if len(sys.argv) > 4 and sys.argv[4] == "bwd" and waves == 8:
+    wb16 = h.lstm_pack_onchip16_bwd(whh[0], whh[1], Hh)
+    gates = torch.rand(N * T, 8 * Hh, device="cuda") * 0.8 + 0.1
+    cell = torch.randn(N, T, 2, Hh, device="cuda") * 0.5
+    dh = torch.randn(N, T, 2 * Hp, device="cuda") * 0.1
+    for rep in range(3):
+        h.KEEP_XBUF = []
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        h.blstm_onchip16_bwd(gates, cell, dh, 2 * Hp, Hp, wb16, N, T, Hh, groups)
+        e.record(); torch.cuda.synchronize()
+        tb = h.KEEP_XBUF[0][48:48 + 40].cpu().numpy().astype("int64").reshape(2, 2, 10)
+        t0 = tb[0, 0, 0]
+        print(json.dumps(dict(direction="backward", N=N, groups=groups, ms=round(s.elapsed_time(e), 3),
+                              exchange_wave=[[int(v - t0) for v in row] for row in tb[0]],
+                              io_wave=[[int(v - t0) for v in row] for row in tb[1]])))
+    h.cluster_error_code()

@@ -963,6 +963,29 @@ __global__ void pack_onchip16_kernel(const float* w_hh_f, const float* w_hh_r, i
 #ifndef ONCHIP16_FWD_G1_DELAY_OWN
 #define ONCHIP16_FWD_G1_DELAY_OWN 0
 #endif
+// Two groups and more: the gather loads of the NEXT phase are requested beside this phase's MFMAs, and the exchange wave
+// issues its publish store(s) AFTER them.  The vector-memory counter retires in order, so at the next phase's start the
+// loads are long complete and only the publish stores are outstanding -- `vmcnt(<stores issued since>)` is the correct
+// wait.  The compiler cannot know that across the loop (its scoreboard restarts at the loop header with the loads as the
+// NEWEST operations) and emits vmcnt(3) .. vmcnt(0): the exchange waves wait for the ACKNOWLEDGEMENT of the publish stores
+// in front of every phase (trace, round 5: 1 100 cycles in the forward, 2 500 in the backward at 3 072 sequences).
+// 1 = the loads are issued through inline assembly (invisible to the compiler's wait insertion; their registers are
+// zero-filled first, so a copy the compiler might make before the data lands carries tag 0 and falls to the re-poll
+// path) and waited for with an explicit count.  Measured (round 5, alternating builds on one box, 3 072 sequences): the
+// exchange waves then reach the first barrier 1 100-1 200 cycles earlier -- and wait there for the io waves, whose tail
+// (six LDS copies, ~290 cycles each to issue under load) is as long: backward 6.19 -> 6.23 ms, forward 5.37 -> 5.55 (the
+// zero fills and wait states inside the MFMA section).  Kept as an option, default 0
+// (profiles/r5_onchip16_tails.jsonl).
+#ifndef ONCHIP16_ASM_GATHER
+#define ONCHIP16_ASM_GATHER 0
+#endif
+__device__ __forceinline__ void asm_gather_load(u32x4& v, const void* base, unsigned byte_off) {
+  v = u32x4{0u, 0u, 0u, 0u};
+  // (s_nop 4: the base may have been written by a VALU instruction -- v_readlane of a spilled SGPR -- immediately before;
+  // a vector-memory instruction that reads an SGPR needs five wait states behind such a write, and the compiler's
+  // hazard recognizer does not look into inline assembly: without it the load ran with a stale high half of the base)
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "+v"(v) : "v"(byte_off), "s"(base) : "memory");
+}
 // two groups per cluster: 1 = decode the next phase's h in front of this phase's second barrier when it has arrived (see
 // `early_decoded` in the kernel); 0 = always at the start of the next phase (rounds 3-4).  Measured (round 5, alternating on
 // one box, ms per launch, 0 -> 1): 768 sequences 1.395 -> 1.47, 1 536: 2.62 -> 2.72, 3 072: 5.26 -> 5.41 -- SLOWER: the trace
@@ -1175,9 +1198,23 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
     // instead of at the start of the next phase with every other wave parked at its first barrier.  Per wave: a wave
     // whose granules are not all there decodes at the next phase's start as before.
     int early_decoded = 0;
+    constexpr bool ASMG = ONCHIP16_ASM_GATHER && NGA == 2 && !(ONCHIP16_ABL & 24);      // (the request beside the MFMAs)
     auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // h_{st-1} of group p
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
+      if constexpr (ASMG) {
+        const int64_t item = ((sg0 + p) << 1) | dir;
+        const float* pb = xpayload + item * 2 * G * SQ * UW;
+        int tvg = tid;
+        asm volatile("" : "+v"(tvg));
+        const unsigned lo = (unsigned)(((tvg & (64 * NEX - 1)) / QW * UW + 4 * (tvg % QW)) * 4);
+#pragma unroll
+        for (int gs = 0; gs < GMAX; ++gs) {
+          if (gs < G) asm_gather_load(vg[gs], pb, lo + (unsigned)((slot * G + gs) * SQ * UW * 4));
+          else vg[gs] = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+      }
 #pragma unroll
       for (int gs = 0; gs < GMAX; ++gs)
         vg[gs] = (gs < G && !(OWN_EARLY && gs == g))
@@ -1221,6 +1258,16 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
       const unsigned want = mk_tag(tagbase, st);
       int spins = 0;
       bool fail = false;
+      if constexpr (ASMG) {
+        // issued since the requests: exactly ONE publish store (every phase publishes); scratch traffic, if any, only adds
+        // operations behind the loads -- the count stays a lower bound
+        static_assert(GMAX == 5 || GMAX == 10, "operand list below");
+        if constexpr (GMAX == 5)
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]), "+v"(vg[4]) :: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(1)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]), "+v"(vg[4]), "+v"(vg[5]),
+                       "+v"(vg[6]), "+v"(vg[7]), "+v"(vg[8]), "+v"(vg[9]) :: "memory");
+      }
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -1489,6 +1536,10 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
 #endif
 // ONE group per cluster: the tiles of phase + 2 are requested in the MFMA section (see the forward): 0.88 -> 0.76 ms at 160
 // sequences, 1.80 -> 1.59 at 768, equal at 32; with two groups it costs 6 % (profiles/r3_onchip16_early_dma.jsonl)
+#ifndef ONCHIP16_BWD_EARLY_DMA_G2
+#define ONCHIP16_BWD_EARLY_DMA_G2 0      // (the same for two groups and more: 6.15 -> 7.91 ms at 3 072 sequences, round 5 -- the copies'
+                                         //  issue stalls block the io waves' MFMAs; profiles/r5_onchip16_tails.jsonl)
+#endif
 #ifndef ONCHIP16_BWD_EARLY_DMA_G1
 #define ONCHIP16_BWD_EARLY_DMA_G1 1
 #endif
@@ -1571,6 +1622,14 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
   const bool io_wave = wave >= 4;
   const int iow = wave & 3;
   constexpr unsigned OOR = 0x80000000u;
+  // (trace builds: stamps of steps 128, 129 of work item 0, workgroup 0: [role 2][step 2][index 10] at words 96 ..)
+  int trace_on = 0;
+  auto stamp = [&](int role, int64_t st, int idx) __attribute__((always_inline)) {
+    if constexpr (ONCHIP16_TRACE) {
+      if (trace_on && st >= 128 && st < 130 && lane == 0 && (wave == 0 || wave == 4) && g == 0)
+        reinterpret_cast<unsigned long long*>(xhead + 96)[(role * 2 + (int)(st - 128)) * 10 + idx] = __builtin_readcyclecounter();
+    }
+  };
 
   for (int round = 0;; ++round) {
     const int64_t bundle = next_item<true>(xhead, mem, round, (int)(2 * nb_dir), nclusters, s_mem);
@@ -1580,6 +1639,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     }
     const int dir = (int)(bundle & 1);
     const int64_t sg0 = (bundle >> 1) * NGA;
+    trace_on = bundle == 0;
     u32x4 wh[20], wl[20];
     {
       const u32x4* wp = wb + (((int64_t)(dir * G + g) * 8 + wave) * 20 * 2) * 64 + lane;
@@ -1643,6 +1703,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       const char* gb = reinterpret_cast<const char*>(gates) + ((rowb(p, t_) * 2 + dir) * (int64_t)H + 64 * g) * 16;
       const char* cb = reinterpret_cast<const char*>(cell) + ((rowb(p, tp_) * 2 + dir) * (int64_t)H + 64 * g) * 4;
       const char* hb = reinterpret_cast<const char*>(dhout) + (rowb(p, t_) * ldo + dir * dstride + 64 * g) * 4;
+      if (ONCHIP16_ABL & (4 | 128)) return;      // (experiment builds: no tile copies)
 #pragma unroll
       for (int q = 0; q < 4; ++q) dma16(gb, L.uok[q] ? L.goff0 + q * 256 : 0u, &ringg[S][(q * 4 + iow) * 64]);
       dma16(cb, L.f4 ? L.coff : 0u, &ringc[S][iow * 256]);
@@ -1653,6 +1714,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     auto io_flush = [&](int S, int p, int64_t st, bool live) __attribute__((always_inline)) {
       const IoLane L = io_lane(p);
       const auto rs = srd_at(reinterpret_cast<char*>(gates) + ((rowb(p, t_of(st)) * 2 + dir) * (int64_t)H + 64 * g) * 16);
+      if (ONCHIP16_ABL & (4 | 64)) return;       // (experiment builds: no d(gates) stores)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         int lvf = lane;
@@ -1669,10 +1731,20 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     for (int i = 0; i < 4; ++i) srcw[i] = i + (i >= g ? 1 : 0);
     // (per-lane indices rebuilt from an opaque copy of the thread index in every use: see the forward kernel)
 #define EX_LANE() int tvx = tid; asm volatile("" : "+v"(tvx)); const int s2 = (tvx & 255) >> 4, uq = tvx & 15
+    // (the request behind the second barrier, two stores -- the direct publish -- behind it: see ONCHIP16_ASM_GATHER)
+    constexpr bool ASMG = ONCHIP16_ASM_GATHER && NGA >= 2 && ONCHIP16_BWD_GATHER == 2 && ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED;
     auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // partial dh for step st of group p
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
       EX_LANE();
+      if constexpr (ASMG) {
+        const int64_t item = ((sg0 + p) << 1) | dir;
+        const float* pb = xpayload + item * 2 * G * SQ * Hp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          asm_gather_load(vg[i], pb, (unsigned)((((slot * G + srcw[i]) * SQ + s2) * Hp + 64 * g + 4 * uq) * 4));
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         vg[i] = __builtin_amdgcn_raw_buffer_load_b128(prs, (((slot * G + srcw[i]) * SQ + s2) * Hp + 64 * g + 4 * uq) * 4, 0, SC1);
@@ -1684,6 +1756,12 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       EX_LANE();
       int spins = 0;
       bool fail = false;
+      if constexpr (ASMG) {
+        // issued since the requests: the two direct-publish stores of the requesting phase -- unless that phase was a group's
+        // LAST step (no partial sums to publish): st + 1 < T is a lower bound for both groups' predecessors
+        if (st + 1 < T) asm volatile("s_waitcnt vmcnt(2)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
+      }
       for (;;) {
         bool ok = true;
 #pragma unroll
@@ -1735,15 +1813,19 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       constexpr int S = decltype(slot_tag)::value, P = decltype(grp_tag)::value;
       if (st >= T) return;
       const bool has_prev = st + 1 < T;
+      constexpr int TR = IO ? 1 : 0;
+      stamp(TR, P == 0 ? st : -1, 0);
       if constexpr (!IO) {
         if (st > 0) gather_finish(S, P, st);
       } else {
         // this phase's tiles have landed (behind them: four stores + six copies, + the two direct publish stores)
-        if (ONCHIP16_BWD_DIRECT && NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        if (ONCHIP16_BWD_DIRECT && ((NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) || (NGA >= 2 && ONCHIP16_BWD_EARLY_DMA_G2))) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         else if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
+      stamp(TR, P == 0 ? st : -1, 1);
       lds_barrier();
+      stamp(TR, P == 0 ? st : -1, 2);
       if (s_fail) return;
       constexpr int GAT = NGA == 1 ? 0 : ONCHIP16_BWD_GATHER;
       constexpr int I1 = (S + 1) & 3, I2 = (S + 2) & 3;
@@ -1795,11 +1877,13 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         *reinterpret_cast<u32x4*>(dg_hi + o) = u32x4{h0, h1, h2, h3};
         *reinterpret_cast<u32x4*>(dg_lo + o) = u32x4{l0, l1, l2, l3};
       }
+      stamp(TR, P == 0 ? st : -1, 3);
       lds_barrier();
+      stamp(TR, P == 0 ? st : -1, 4);
       if constexpr (!IO && (GAT >= 2)) {
         if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
       }
-      if constexpr (IO && NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) io_dma(I2, P2, st2 < T ? st2 : T - 1);      // (one group: as in the forward)
+      if constexpr (IO && ((NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) || (NGA >= 2 && ONCHIP16_BWD_EARLY_DMA_G2))) io_dma(I2, P2, st2 < T ? st2 : T - 1);      // (one group: as in the forward)
       if constexpr (IO && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH) {
         // the d(gates) of the PREVIOUS phase leave here, beside the MFMAs, not between two phases where the publish waits
         // for issue slots (its ring slot is refilled a phase later)
@@ -1810,6 +1894,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         // (requesting the tiles of phase + 2 here as well measured -5 % with ONE group at 768 / 3 072 sequences, +6 % at the 32
         // sequences one group is used for, and +6 % with two groups: profiles/r3_onchip16_deferred_flush.jsonl -- not kept)
       }
+      stamp(TR, P == 0 ? st : -1, 5);
       if (has_prev) {
         // partial dh_(t-1): two own tiles over 8 k-steps + 4 k-steps of a shared tile (three accumulator chains)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, accs = acc0;
@@ -1844,6 +1929,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
             if (ks == GAT - 1 && st1 > 0 && st1 < T) gather_issue(P1, st1);
           }
         }
+        stamp(TR, P == 0 ? st : -1, 6);
         const int j = lvm & 15, r4 = 4 * (lvm >> 4);
         if constexpr (ONCHIP16_BWD_DIRECT) {
           // the wave's own two tiles (units 32 wave .. + 31 of block wave / 2) leave from the accumulators: a lane holds four
@@ -1894,7 +1980,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, prs, (int)OOR, 0, SC0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, prs, (int)OOR, 0, SC0);
       }
+      stamp(TR, P == 0 ? st : -1, 7);
       lds_barrier();
+      stamp(TR, P == 0 ? st : -1, 8);
       if constexpr (!IO) {
         if (has_prev) publish(P, st);
         if constexpr (GAT == 0) {
@@ -1903,8 +1991,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         }
       } else {
         if constexpr (!(NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH)) io_flush(S, P, st, true);
-        if constexpr (!(NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1)) io_dma(I2, P2, st2 < T ? st2 : T - 1);
+        if constexpr (!((NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) || (NGA >= 2 && ONCHIP16_BWD_EARLY_DMA_G2))) io_dma(I2, P2, st2 < T ? st2 : T - 1);
       }
+      stamp(TR, P == 0 ? st : -1, 9);
     };
     auto run = [&](auto io_tag) __attribute__((always_inline)) {
       constexpr bool IO = decltype(io_tag)::value;

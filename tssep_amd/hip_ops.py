@@ -829,6 +829,8 @@ def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, 
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_bwd_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
+    if KEEP_XBUF is not None:
+        KEEP_XBUF.append(xbuf)
     with _timed("blstm_onchip_bwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 44):      # activations 16, c 4 + 4, dh 4 in, d(gates) 16 out
         check(L.tssep_blstm_onchip16_bwd(_p(gates), _p(cell), _p(dhout), ldo, dstride, _p(wb16), _p(xbuf),
                                          _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream()),
