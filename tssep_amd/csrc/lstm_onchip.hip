@@ -1531,6 +1531,18 @@ __global__ __launch_bounds__(64 * NW, 2) void blstm_onchip16_fwd_kernel(
 // 1: the io waves store a phase's d(gates) during the NEXT phase's MFMA section instead of right behind its last barrier
 // (two groups and more; with ONE group the publish chain is the critical path and the stores in front of the io waves'
 // MFMAs delay it: 0.74 -> 0.77 ms at 32 sequences)
+// 1 (two groups and more, with the deferred flush): the d(gates) of the previous phase are stored by the EXCHANGE waves,
+// not by the io waves.  The trace of round 5 shows the io waves on the critical path of every section of a backward phase
+// (tiles -> cell backward -> four stores -> MFMAs, which they start a thousand cycles late -> publish -> six LDS copies:
+// ~7 100 of a 7 600-cycle phase) while the exchange waves idle ~2 500 cycles at the barriers.  With the stores behind the
+// exchange waves' gather requests the in-order counter needs the exact wait in front of the tag check (vmcnt(6): four
+// stores + the two direct-publish stores issued since), i.e. the inline-assembly gather of ONCHIP16_ASM_GATHER.
+// Measured (round 5, alternating builds on one box): 3 072 sequences 6.04 -> 5.95 ms (-1.4 %), 768 / 1 536 within noise:
+// WHO issues the stores hardly matters -- the launch moves its 28.9 GB at the box's copy rate either way.  Default 0 (the
+// inline-assembly gather is not worth 0.15 ms per step); profiles/r5_onchip16_tails.jsonl.
+#ifndef ONCHIP16_BWD_FLUSH_BY_EXCHANGE
+#define ONCHIP16_BWD_FLUSH_BY_EXCHANGE 0
+#endif
 #ifndef ONCHIP16_BWD_DEFER_FLUSH
 #define ONCHIP16_BWD_DEFER_FLUSH 1
 #endif
@@ -1732,7 +1744,9 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
     // (per-lane indices rebuilt from an opaque copy of the thread index in every use: see the forward kernel)
 #define EX_LANE() int tvx = tid; asm volatile("" : "+v"(tvx)); const int s2 = (tvx & 255) >> 4, uq = tvx & 15
     // (the request behind the second barrier, two stores -- the direct publish -- behind it: see ONCHIP16_ASM_GATHER)
-    constexpr bool ASMG = ONCHIP16_ASM_GATHER && NGA >= 2 && ONCHIP16_BWD_GATHER == 2 && ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED;
+    constexpr bool FBX = ONCHIP16_BWD_FLUSH_BY_EXCHANGE && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH && ONCHIP16_BWD_GATHER == 2 &&
+                         ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED;
+    constexpr bool ASMG = (ONCHIP16_ASM_GATHER || FBX) && NGA >= 2 && ONCHIP16_BWD_GATHER == 2 && ONCHIP16_BWD_DIRECT && ONCHIP16_BWD_OWN_SHARED;
     auto gather_issue = [&](int p, int64_t st) __attribute__((always_inline)) {      // partial dh for step st of group p
       const auto prs = payload_srd(p);
       const int slot = (int)((st - 1) & 1);
@@ -1759,7 +1773,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       if constexpr (ASMG) {
         // issued since the requests: the two direct-publish stores of the requesting phase -- unless that phase was a group's
         // LAST step (no partial sums to publish): st + 1 < T is a lower bound for both groups' predecessors
-        if (st + 1 < T) asm volatile("s_waitcnt vmcnt(2)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
+        // (FBX: + the four d(gates) stores of the requesting phase, issued unconditionally right behind the requests)
+        if (FBX) {
+          if (st + 1 < T) asm volatile("s_waitcnt vmcnt(6)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
+          else asm volatile("s_waitcnt vmcnt(4)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
+        } else if (st + 1 < T) asm volatile("s_waitcnt vmcnt(2)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(vg[0]), "+v"(vg[1]), "+v"(vg[2]), "+v"(vg[3]) :: "memory");
       }
       for (;;) {
@@ -1820,6 +1838,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       } else {
         // this phase's tiles have landed (behind them: four stores + six copies, + the two direct publish stores)
         if (ONCHIP16_BWD_DIRECT && ((NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) || (NGA >= 2 && ONCHIP16_BWD_EARLY_DMA_G2))) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (ONCHIP16_BWD_DIRECT && FBX) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // (no stores of their own: 2 + 6)
         else if (ONCHIP16_BWD_DIRECT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
       }
@@ -1884,7 +1903,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         if (st1 > 0 && st1 < T && (GAT == 2 || !has_prev)) gather_issue(P1, st1);
       }
       if constexpr (IO && ((NGA == 1 && ONCHIP16_BWD_EARLY_DMA_G1) || (NGA >= 2 && ONCHIP16_BWD_EARLY_DMA_G2))) io_dma(I2, P2, st2 < T ? st2 : T - 1);      // (one group: as in the forward)
-      if constexpr (IO && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH) {
+      if constexpr ((FBX ? !IO : IO) && NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH) {
         // the d(gates) of the PREVIOUS phase leave here, beside the MFMAs, not between two phases where the publish waits
         // for issue slots (its ring slot is refilled a phase later)
         constexpr int SP = (S + 3) & 3, PP = SP % NGA;
@@ -2011,11 +2030,11 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
         phase(io_tag, std::integral_constant<int, 3>{}, std::integral_constant<int, 3 % NGA>{}, base + 3 / NGA, base);
         if (s_fail) break;
       }
-      if constexpr (IO) {
+      if constexpr (FBX ? !IO : IO) {
         // (deferred flush: the last phase's d(gates) still sit in their ring slot)
         if (NGA >= 2 && ONCHIP16_BWD_DEFER_FLUSH && !s_fail) io_flush((int)((T * NGA - 1) & 3), NGA - 1, T - 1, true);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     if (io_wave) run(std::true_type{}); else run(std::false_type{});
     if (s_fail) {
