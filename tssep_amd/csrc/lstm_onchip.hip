@@ -1717,7 +1717,7 @@ __global__ __launch_bounds__(512, 2) void blstm_onchip16_bwd_kernel(
       const char* hb = reinterpret_cast<const char*>(dhout) + (rowb(p, t_) * ldo + dir * dstride + 64 * g) * 4;
       if (ONCHIP16_ABL & (4 | 128)) return;      // (experiment builds: no tile copies)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) dma16(gb, L.uok[q] ? L.goff0 + q * 256 : 0u, &ringg[S][(q * 4 + iow) * 64]);
+      for (int q = 0; q < ((ONCHIP16_ABL & 256) ? 2 : 4); ++q) dma16(gb, L.uok[q] ? L.goff0 + q * 256 : 0u, &ringg[S][(q * 4 + iow) * 64]);      // (256: half of the gate tile -- what 8-byte activations would move)
       dma16(cb, L.f4 ? L.coff : 0u, &ringc[S][iow * 256]);
       dma16(hb, L.f4 ? L.hoff : 0u, &ringd[S][iow * 256]);
     };
