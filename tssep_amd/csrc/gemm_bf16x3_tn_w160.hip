@@ -35,7 +35,12 @@ __device__ __forceinline__ bf16x8 trv(const char* p) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool SHIFT, bool TWO>
+// OOB (round 5): every mask of the steady state is a property of a whole four-column piece (M and N multiples of 4, no
+// ones column) or of a whole k row (the time shift's sequence boundary), so it is applied by the LOAD -- bit 31 of the
+// buffer offset puts the piece out of range and the hardware returns zeros -- instead of 56 v_cndmask + 18 compares per
+// 16-k stage on the VALU (249 -> 160 VALU instructions per two stages).  The time-shifted GEMMs always run this way.
+constexpr unsigned VOOR = 0x80000000u;
+template <bool SHIFT, bool TWO, bool OOB>
 __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
     int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
@@ -77,21 +82,21 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   const bool ones = !SHIFT && b_ones_col;         // (the fused ones column only exists for unshifted GEMMs)
   const int64_t Nreal = N - (ones ? 1 : 0);
   const int64_t Mp = (M + 3) & ~(int64_t)3, Np = (Nreal + 3) & ~(int64_t)3;
-  const int64_t ca = m0 + cqA <= Mp - 4 ? m0 + cqA : Mp - 4;
+  const int64_t ca = (OOB || m0 + cqA <= Mp - 4) ? m0 + cqA : Mp - 4;
   // buffer loads relative to the first row of this split (the launcher bounds a split's bytes by 2^31): scalar base
   // and stage offset, 32-bit lane offsets
   const int64_t k_begin = kt_begin * BK;
   const srd_t asrd = make_srd(A + k_begin * lda);
   const srd_t bsrd = make_srd(B + (k_begin + (SHIFT ? kshift : 0)) * ldb);
-  const unsigned avo = (unsigned)((krA * lda + ca) * 4);
+  const unsigned avo = (unsigned)((krA * lda + ca) * 4) | ((OOB && m0 + cqA >= M) ? VOOR : 0u);
   unsigned bvo[3], bm[3], bone[3];           // bit e of bm / bone: column e of the piece is a real column / the ones column
   unsigned am = 0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) am |= (m0 + cqA + e < M ? 1u : 0u) << e;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int64_t cb = n0 + cqB[i] <= Np - 4 ? n0 + cqB[i] : Np - 4;
-    bvo[i] = (unsigned)((krB[i] * ldb + cb) * 4);
+    const int64_t cb = (OOB || n0 + cqB[i] <= Np - 4) ? n0 + cqB[i] : Np - 4;
+    bvo[i] = (unsigned)((krB[i] * ldb + cb) * 4) | ((OOB && n0 + cqB[i] >= Nreal) ? VOOR : 0u);
     bm[i] = 0; bone[i] = 0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -108,32 +113,41 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   bool kokA[4] = {true, true, true, true}, kokB[3] = {true, true, true};    // row < K, of the tile held in registers
 
   f32x4 ra[4], rb[3];
+  // OOB: `ph` is the phase of the tile being LOADED (note_tile runs in front of the load), rows outside their sequence
+  // are put out of range
+  auto phase_oob = [&](int i) __attribute__((always_inline)) -> unsigned {      // (one unsigned compare: 0 <= q < kperiod)
+    if constexpr (OOB && SHIFT) return (unsigned)(ph[i] + kshift) < (unsigned)kperiod ? 0u : VOOR;
+    return 0u;
+  };
   auto gload_full = [&](int64_t kt) __attribute__((always_inline)) {
     const int soa = (int)((kt - kt_begin) * BK * lda * 4), sob = (int)((kt - kt_begin) * BK * ldb * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = bload4(asrd, avo + (unsigned)(i * 4 * lda * 4), soa);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) rb[i] = bload4(bsrd, bvo[i], sob);
+    for (int i = 0; i < 3; ++i) rb[i] = bload4(bsrd, bvo[i] | phase_oob(i), sob);
   };
   auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {       // rows clamped into the matrix
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t k = kt * BK + krA + 4 * i;
-      ra[i] = bload4(asrd, (unsigned)((((k < K ? k : K - 1) - k_begin) * lda + ca) * 4), 0);
+      ra[i] = bload4(asrd, (unsigned)((((k < K ? k : K - 1) - k_begin) * lda + ca) * 4) | (avo & VOOR), 0);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int64_t k = kt * BK + krB[i];
       int64_t kb = (k < K ? k : K - 1) + (SHIFT ? kshift : 0);
       kb = kb < 0 ? 0 : (kb > K - 1 ? K - 1 : kb);
-      rb[i] = bload4(bsrd, bvo[i] + (unsigned)((kb - (SHIFT ? kshift : 0) - k_begin - krB[i]) * ldb * 4), 0);
+      rb[i] = bload4(bsrd, (bvo[i] + (unsigned)((kb - (SHIFT ? kshift : 0) - k_begin - krB[i]) * ldb * 4)) | phase_oob(i), 0);
     }
   };
   int64_t held = kt_begin - 1;
   auto note_tile = [&](int64_t kt, bool full) __attribute__((always_inline)) {
     if (SHIFT && held >= kt_begin) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) { ph[i] += phstep; ph[i] = ph[i] >= kperiod ? ph[i] - kperiod : ph[i]; }
+      for (int i = 0; i < 3; ++i) {               // ph + phstep mod kperiod: the smaller of x and x - kperiod as unsigned
+        const unsigned x = (unsigned)(ph[i] + phstep), y = x - (unsigned)kperiod;
+        ph[i] = (int)(x < y ? x : y);
+      }
     }
     held = kt;
 #pragma unroll
@@ -172,7 +186,7 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           b[e] = (okb && ((bm[i] >> e) & 1)) ? b[e] : ((((bone[i] >> e) & 1) && kok) ? 1.f : 0.f);
-      } else if constexpr (SHIFT) {
+      } else if constexpr (SHIFT && !OOB) {
         const int q = ph[i] + kshift;
         const bool okb = q >= 0 && q < kperiod;
 #pragma unroll
@@ -214,24 +228,24 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   do {                                                                                          \
     compute(cur);                                                                               \
     stage(nxt, std::integral_constant<bool, EDGE_>{}, std::true_type{});                        \
-    gload_full((kt_) + 2);                                                                      \
     note_tile((kt_) + 2, true);                                                                 \
+    gload_full((kt_) + 2);                                                                      \
     __syncthreads();                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
 
   if (kt_begin < kt_end) {
+    note_tile(kt_begin, kt_begin < kt_full);        // (in front of the load: the loaders of the OOB variant mask by the phase)
     gload_any(kt_begin);
-    note_tile(kt_begin, kt_begin < kt_full);
     stage(lds0, std::true_type{}, std::false_type{});
-    if (kt_begin + 1 < kt_end) { gload_any(kt_begin + 1); note_tile(kt_begin + 1, kt_begin + 1 < kt_full); }
+    if (kt_begin + 1 < kt_end) { note_tile(kt_begin + 1, kt_begin + 1 < kt_full); gload_any(kt_begin + 1); }
     __syncthreads();
     int64_t kt = kt_begin;
     int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;
     // the pipelined loads read row k + kshift unconditionally (|kshift| <= 16 here): stay clear of the matrix's
     // last tiles (they never see the first ones: they start at tile kt_begin + 2)
     if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
-    const bool edge = SHIFT || m0 + VM > M || n0 + VN > Nreal;
+    const bool edge = !OOB && (SHIFT || m0 + VM > M || n0 + VN > Nreal);
     if (edge) {
       for (; kt < lim; kt += 2) {
         VPIPE(lds0, lds1, kt, true);
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
       char* nxt = par ? lds0 : lds1;
       compute(cur);
       if (kt + 1 < kt_end) stage(nxt, std::true_type{}, std::false_type{});
-      if (kt + 2 < kt_end) { gload_any(kt + 2); note_tile(kt + 2, kt + 2 < kt_full); }
+      if (kt + 2 < kt_end) { note_tile(kt + 2, kt + 2 < kt_full); gload_any(kt + 2); }
       __syncthreads();
     }
   }
@@ -284,6 +298,9 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
   const int64_t m256 = (g->M + VM - 1) / VM * VM;
   if (g->M < 1024 || (m256 - g->M) * 100 > 8 * g->M || (shift && ks > 16) || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
+  // masks by out-of-range loads: whole four-column pieces only (the time-shifted kernel exists in this form alone)
+  const bool oob = (g->M & 3) == 0 && (g->N & 3) == 0 && !g->b_ones_col;
+  if (shift && !oob) return TSSEP_E_UNSUPPORTED;
   // 32-bit buffer offsets inside a split
   const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
@@ -291,10 +308,11 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   if (call.dry) return TSSEP_OK;
   const TileMap tm = make_tile_map(m256 / VM, (g->N + VN - 1) / VN, splitk);
   const dim3 grid((unsigned)tile_map_blocks(tm));
-#define V_LAUNCH(SH, TW, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_w160_kernel<SH, TW>), grid, dim3(VNT), 0, (hipStream_t)stream, \
+#define V_LAUNCH(SH, TW, OB, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_w160_kernel<SH, TW, OB>), grid, dim3(VNT), 0, (hipStream_t)stream, \
       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, KS, KP, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, ONES)
-  if (shift) { if (two) V_LAUNCH(true, true, (int)g->b_kshift, (int)g->kperiod, 0); else V_LAUNCH(true, false, (int)g->b_kshift, (int)g->kperiod, 0); }
-  else { if (two) V_LAUNCH(false, true, 0, 1, g->b_ones_col); else V_LAUNCH(false, false, 0, 1, g->b_ones_col); }
+  if (shift) { if (two) V_LAUNCH(true, true, true, (int)g->b_kshift, (int)g->kperiod, 0); else V_LAUNCH(true, false, true, (int)g->b_kshift, (int)g->kperiod, 0); }
+  else if (oob) { if (two) V_LAUNCH(false, true, true, 0, 1, 0); else V_LAUNCH(false, false, true, 0, 1, 0); }
+  else { if (two) V_LAUNCH(false, true, false, 0, 1, g->b_ones_col); else V_LAUNCH(false, false, false, 0, 1, g->b_ones_col); }
 #undef V_LAUNCH
   return tssep_launch_status();
 }
