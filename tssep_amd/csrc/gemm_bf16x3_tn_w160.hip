@@ -40,6 +40,15 @@ __device__ __forceinline__ bf16x8 trv(const char* p) {
 // buffer offset puts the piece out of range and the hardware returns zeros -- instead of 56 v_cndmask + 18 compares per
 // 16-k stage on the VALU (249 -> 160 VALU instructions per two stages).  The time-shifted GEMMs always run this way.
 constexpr unsigned VOOR = 0x80000000u;
+#ifndef TNW160_PROBE
+#define TNW160_PROBE 0
+#endif
+#ifndef TNW160_SLOTTED
+#define TNW160_SLOTTED 1
+#endif
+#ifndef TNW160_WIDE
+#define TNW160_WIDE 1
+#endif
 template <bool SHIFT, bool TWO, bool OOB>
 __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
@@ -120,7 +129,11 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
     return 0u;
   };
   auto gload_full = [&](int64_t kt) __attribute__((always_inline)) {
+#if TNW160_PROBE == 1 || TNW160_PROBE == 4       // timing probe (wrong results): every stage re-reads the first rows of the split -- cache hits
+    const int soa = (int)((kt & 1) * BK * lda * 4), sob = (int)((kt & 1) * BK * ldb * 4);
+#else
     const int soa = (int)((kt - kt_begin) * BK * lda * 4), sob = (int)((kt - kt_begin) * BK * ldb * 4);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = bload4(asrd, avo + (unsigned)(i * 4 * lda * 4), soa);
 #pragma unroll
@@ -159,6 +172,21 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   int soffB[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) soffB[i] = 2 * VARR_A + krB[i] * VPB + cqB[i] * 2;
+  // the 640 B pieces of a stage are three per thread for waves 0-1 and two for waves 2-3: the third piece of waves 2-3 is
+  // a dummy (out-of-range load where the variant masks that way, 1 KB of the stage's spare bytes as its target), so
+  // that the stage body is ONE basic block the scheduler can interleave
+  static_assert(2 * VARR_A + 3 * VARR_B + 1024 <= VSTAGE, "dummy piece (hi at the end of the planes, lo VARR_B behind it) must fit");
+  if (!pv[2]) { soffB[2] = 2 * VARR_A + 2 * VARR_B + (tid - 128) * 8; if (OOB) bvo[2] |= VOOR; }
+#if TNW160_PROBE == 3 || TNW160_PROBE == 4       // timing probes (wrong results): no split arithmetic
+#define PSPLIT(x, y, h, l) do { h = __builtin_bit_cast(unsigned, x); l = __builtin_bit_cast(unsigned, y); } while (0)
+#else
+#define PSPLIT(x, y, h, l) split2n(x, y, h, l)
+#endif
+#if TNW160_PROBE == 5                             // timing probe (wrong results): the split, but no LDS writes
+#define PWRITE(ptr, v) asm volatile("" :: "v"(v))
+#else
+#define PWRITE(ptr, v) *reinterpret_cast<u32x2*>(ptr) = v
+#endif
   auto stage = [&](char* st, auto edge_tag, auto full_tag) __attribute__((always_inline)) {
     constexpr bool EDGE = decltype(edge_tag)::value;
     constexpr bool FULL = decltype(full_tag)::value;       // every k row of the tile in registers is a row of the matrix
@@ -170,14 +198,13 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
         for (int e = 0; e < 4; ++e) a[e] = ((FULL || kokA[i]) && ((am >> e) & 1)) ? a[e] : 0.f;
       }
       unsigned h0, l0, h1, l1;
-      split2n(a[0], a[1], h0, l0);
-      split2n(a[2], a[3], h1, l1);
-      *reinterpret_cast<u32x2*>(st + soffA + i * 4 * VPA) = u32x2{h0, h1};
-      if (!TWO) *reinterpret_cast<u32x2*>(st + VARR_A + soffA + i * 4 * VPA) = u32x2{l0, l1};
+      PSPLIT(a[0], a[1], h0, l0);
+      PSPLIT(a[2], a[3], h1, l1);
+      PWRITE(st + soffA + i * 4 * VPA, (u32x2{h0, h1}));
+      if (!TWO) PWRITE(st + VARR_A + soffA + i * 4 * VPA, (u32x2{l0, l1}));
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      if (i == 2 && !pv[2]) break;
       f32x4 b = rb[i];
       if constexpr (EDGE) {
         const bool kok = FULL || kokB[i];
@@ -193,10 +220,10 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
         for (int e = 0; e < 4; ++e) b[e] = okb ? b[e] : 0.f;
       }
       unsigned h0, l0, h1, l1;
-      split2n(b[0], b[1], h0, l0);
-      split2n(b[2], b[3], h1, l1);
-      *reinterpret_cast<u32x2*>(st + soffB[i]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(st + VARR_B + soffB[i]) = u32x2{l0, l1};
+      PSPLIT(b[0], b[1], h0, l0);
+      PSPLIT(b[2], b[3], h1, l1);
+      PWRITE(st + soffB[i], (u32x2{h0, h1}));
+      PWRITE(st + VARR_B + soffB[i], (u32x2{l0, l1}));
     }
   };
   // fragment address of this lane: 16-lane group g2 covers 16 m, lane ii = 4 (k row) + m quad
@@ -204,6 +231,9 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   const int fcol = (16 * g2 + 4 * (ii & 3)) * 2, frow = 8 * hk + (ii >> 2);
   const int aoff = frow * VPA + fcol + wave * 64 * 2, boff = 2 * VARR_A + frow * VPB + fcol;
   auto compute = [&](const char* st) __attribute__((always_inline)) {
+#if TNW160_PROBE == 2       // timing probe (wrong results): no fragment reads, no MFMAs -- the loads and the staging alone
+    return;
+#endif
     bf16x8 ah[2], al[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -223,6 +253,62 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
     }
+  };
+  // ---- the steady-state stage of the OOB variants, written slot by slot (one MFMA + at most one other piece of work between
+  // two scheduling barriers): B fragments one j ahead (b_hi double-buffered, b_lo re-read into its own registers once its
+  // last product is issued), every staged piece as {two splits} / {two LDS writes + the reload of its registers for the
+  // tile after the next}, so that the LDS writes and the loads are spread over the MFMA stream instead of following it
+  // in one burst (probes of round 5: the burst of 13 ds_write_b64 per wave cost 20 % of the launch, the load latency
+  // behind it 18 %).  Same products in the same order per accumulator as compute().
+  auto slotted = [&](const char* cur, char* nxt, int64_t ktl) __attribute__((always_inline)) {
+    note_tile(ktl, true);
+    const int soa = (int)((ktl - kt_begin) * BK * lda * 4), sob = (int)((ktl - kt_begin) * BK * ldb * 4);
+    bf16x8 ah[2], al[2], bhA, bhB, bl;
+    unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
+#define SLOT __builtin_amdgcn_sched_barrier(0)
+#define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0)
+#define MM1(x, y, i, j) if constexpr (!TWO) MM(x, y, i, j)
+#define SA12(i) split2n(ra[i][0], ra[i][1], sh0, sl0); split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SA3(i) *reinterpret_cast<u32x2*>(nxt + soffA + (i) * 4 * VPA) = u32x2{sh0, sh1};                          \
+               if constexpr (!TWO) *reinterpret_cast<u32x2*>(nxt + VARR_A + soffA + (i) * 4 * VPA) = u32x2{sl0, sl1}; \
+               ra[i] = bload4(asrd, avo + (unsigned)((i) * 4 * lda * 4), soa)
+#define SB12(i) split2n(rb[i][0], rb[i][1], sh0, sl0); split2n(rb[i][2], rb[i][3], sh1, sl1)
+#define SB3(i) *reinterpret_cast<u32x2*>(nxt + soffB[i]) = u32x2{sh0, sh1};                                       \
+               *reinterpret_cast<u32x2*>(nxt + VARR_B + soffB[i]) = u32x2{sl0, sl1};                              \
+               rb[i] = bload4(bsrd, bvo[i] | phase_oob(i), sob)
+#define FBH(dst, j) dst = trv<VPB>(cur + boff + (j) * 64)
+#define FBL(j) bl = trv<VPB>(cur + VARR_B + boff + (j) * 64)
+#define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                \
+    MM1(al[0], bh_, 0, j); X0; SLOT;                          \
+    MM1(al[1], bh_, 1, j); X1; SLOT;                          \
+    MM(ah[0], bl, 0, j); X2; SLOT;                            \
+    MM(ah[1], bl, 1, j); X3; SLOT;                            \
+    MM(ah[0], bh_, 0, j); X4; SLOT;                           \
+    MM(ah[1], bh_, 1, j); X5; SLOT
+    if constexpr (!TWO) al[0] = trv<VPA>(cur + VARR_A + aoff);
+    FBH(bhA, 0);
+    if constexpr (!TWO) al[1] = trv<VPA>(cur + VARR_A + aoff + 64);
+    ah[0] = trv<VPA>(cur + aoff);
+    FBL(0);
+    ah[1] = trv<VPA>(cur + aoff + 64);
+    SLOT;
+    JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), SA12(1), FBL(1), SA3(1));
+    JBLOCK(1, bhB, FBH(bhA, 2), SA12(2), SA3(2), SA12(3), FBL(2), SA3(3));
+    JBLOCK(2, bhA, FBH(bhB, 3), SB12(0), SB3(0), SB12(1), FBL(3), SB3(1));
+    JBLOCK(3, bhB, FBH(bhA, 4), SB12(2), SB3(2), (void)0, FBL(4), (void)0);
+    JBLOCK(4, bhA, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
+#undef JBLOCK
+#undef FBL
+#undef FBH
+#undef SB3
+#undef SB12
+#undef SA3
+#undef SA12
+#undef MM1
+#undef MM
+#undef SLOT
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   };
 #define VPIPE(cur, nxt, kt_, EDGE_)                                                             \
   do {                                                                                          \
@@ -246,7 +332,12 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
     // last tiles (they never see the first ones: they start at tile kt_begin + 2)
     if (SHIFT && lim > (K - 1) / BK - 4) lim = (K - 1) / BK - 4;
     const bool edge = !OOB && (SHIFT || m0 + VM > M || n0 + VN > Nreal);
-    if (edge) {
+    if constexpr (OOB && TNW160_SLOTTED) {
+      for (; kt < lim; kt += 2) {
+        slotted(lds0, lds1, kt + 2);
+        slotted(lds1, lds0, kt + 3);
+      }
+    } else if (edge) {
       for (; kt < lim; kt += 2) {
         VPIPE(lds0, lds1, kt, true);
         VPIPE(lds1, lds0, kt + 1, true);
@@ -287,6 +378,243 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256 (m) x 320 (n) variant, 512 threads: the two 160-column tiles of one row block in ONE workgroup -- eight waves as
+// 4 (m) x 2 (n), each the same 64 x 160 wave tile, one workgroup per CU (two waves per SIMD as before).  A stage stages
+// 256 + 320 columns instead of 2 x (256 + 160): 31 % fewer bytes loaded, split and written to LDS per MFMA.  Why that
+// matters (round 5 probes on the 256 x 160 kernel at 3 072 sequences, 1.86 ms per launch): no split arithmetic -2.7 %,
+// loads that hit the cache -18 %, no LDS writes -21 % -- the kernel pays for the bytes it moves through the vector
+// registers, not for the VALU.  Masks by out-of-range loads only (M, N multiples of 4, no ones column), every stage of the
+// steady state written slot by slot like `slotted` above; prologue and tail use a general loader (rows beyond K, time
+// shift at the ends of the matrix: all out of range).  Same k order and products per output element: bit-identical to
+// the other tn kernels for equal split counts.
+constexpr int XN = 320, XNT = 512;
+constexpr int XPB = XN * 2 + 64;                // 704 B per k row of a B plane (176 dwords = 48 mod 64: conflict-free transpose reads)
+constexpr int XARR_B = VBK * XPB;               // 11 264
+constexpr int XSTAGE = 2 * VARR_A + 2 * XARR_B; // 40 960 B: A hi, A lo, B hi, B lo
+static_assert(4 * 64 * EPITCH * 4 <= 2 * XSTAGE, "four epilogue scratches at a time");
+
+template <bool SHIFT, bool TWO>
+__global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
+    int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
+    int64_t c_split_stride, TileMap tmap) {
+  constexpr int BK = VBK;
+  __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
+  char* const lds0 = lds;
+  char* const lds1 = lds + XSTAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;        // (waves w and w + 4 share a SIMD: same rows, the two column halves)
+  int mt, nt, zsplit;
+  if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
+  const int64_t m0 = (int64_t)mt * VM, n0 = (int64_t)nt * XN;
+  const int64_t ktiles = (K + BK - 1) / BK;
+  const int64_t per = (ktiles + splitk - 1) / splitk;
+  const int64_t kt_begin = (int64_t)zsplit * per;
+  const int64_t kt_end = kt_begin + per < ktiles ? kt_begin + per : ktiles;
+  const int64_t kt_full = K / BK;
+  const int64_t k_begin = kt_begin * BK;
+
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // pieces (four columns of one k row): A thread <-> (k row tid / 64 + 8 i, columns 4 (tid % 64) ..), i < 2;
+  // B piece p = tid + 512 i (i < 3, p < 1280) <-> (k row p / 80, columns 4 (p % 80) ..): waves 0-3 have three, waves 4-7 two
+  // and a dummy (out of range, written to the spare kilobyte behind... no spare here: to its own second piece's place twice)
+  const int krA = tid >> 6, cqA = (tid & 63) << 2;
+  int krB[3], cqB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int p = tid + 512 * i < 1280 ? tid + 512 * i : tid + 512;      // the dummy repeats piece 1 (same values, same place)
+    krB[i] = p / 80;
+    cqB[i] = (p % 80) << 2;
+  }
+  const srd_t asrd = make_srd(A + k_begin * lda);
+  const srd_t bsrd = make_srd(B + (k_begin + (SHIFT ? kshift : 0)) * ldb);
+  const unsigned avo = (unsigned)((krA * lda + m0 + cqA) * 4) | (m0 + cqA >= M ? VOOR : 0u);
+  unsigned bvo[3];
+  int ph[3] = {0, 0, 0};                    // phase (k mod kperiod) of this thread's B rows of the tile loaded last
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    bvo[i] = (unsigned)((krB[i] * ldb + n0 + cqB[i]) * 4) | (n0 + cqB[i] >= N ? VOOR : 0u);
+    if (SHIFT) ph[i] = (int)((k_begin + krB[i]) % kperiod);
+  }
+  const int phstep = SHIFT ? BK % kperiod : 0;
+  auto advance_phase = [&]() __attribute__((always_inline)) {
+    if constexpr (SHIFT) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const unsigned x = (unsigned)(ph[i] + phstep), y = x - (unsigned)kperiod;
+        ph[i] = (int)(x < y ? x : y);
+      }
+    }
+  };
+  auto phase_oob = [&](int i) __attribute__((always_inline)) -> unsigned {
+    if constexpr (SHIFT) return (unsigned)(ph[i] + kshift) < (unsigned)kperiod ? 0u : VOOR;
+    return 0u;
+  };
+  f32x4 ra[2], rb[3];
+  // general loader (prologue, tail): tile kt, rows beyond K out of range; `ph` is the phase of tile kt
+  auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {
+    const int64_t rel = (kt - kt_begin) * BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      ra[i] = bload4(asrd, (avo + (unsigned)((rel + 8 * i) * lda * 4)) | (kt * BK + krA + 8 * i < K ? 0u : VOOR), 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      rb[i] = bload4(bsrd, (bvo[i] + (unsigned)(rel * ldb * 4)) | (kt * BK + krB[i] < K ? 0u : VOOR) | phase_oob(i), 0);
+  };
+  const int soffA = krA * VPA + (tid & 63) * 8;
+  int soffB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) soffB[i] = 2 * VARR_A + krB[i] * XPB + cqB[i] * 2;
+  auto stage_plain = [&](char* st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned h0, l0, h1, l1;
+      split2n(ra[i][0], ra[i][1], h0, l0);
+      split2n(ra[i][2], ra[i][3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffA + i * 8 * VPA) = u32x2{h0, h1};
+      if (!TWO) *reinterpret_cast<u32x2*>(st + VARR_A + soffA + i * 8 * VPA) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      unsigned h0, l0, h1, l1;
+      split2n(rb[i][0], rb[i][1], h0, l0);
+      split2n(rb[i][2], rb[i][3], h1, l1);
+      *reinterpret_cast<u32x2*>(st + soffB[i]) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(st + XARR_B + soffB[i]) = u32x2{l0, l1};
+    }
+  };
+  const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
+  const int fcol = (16 * g2 + 4 * (ii & 3)) * 2, frow = 8 * hk + (ii >> 2);
+  const int aoff = frow * VPA + fcol + wm * 64 * 2, boff = 2 * VARR_A + frow * XPB + fcol + wn * 160 * 2;
+  auto compute = [&](const char* st) __attribute__((always_inline)) {      // tail stages
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = trv<VPA>(st + aoff + i * 64);
+      if (!TWO) al[i] = trv<VPA>(st + VARR_A + aoff + i * 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bf16x8 bh = trv<XPB>(st + boff + j * 64);
+      const bf16x8 bl = trv<XPB>(st + XARR_B + boff + j * 64);
+      if (!TWO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+    }
+  };
+  // steady state: tile in `cur` computed, the registers' tile staged into `nxt`, tile ktl (full, inside the split) loaded
+  auto slotted = [&](const char* cur, char* nxt, int64_t ktl) __attribute__((always_inline)) {
+    advance_phase();
+    const int soa = (int)((ktl - kt_begin) * BK * lda * 4), sob = (int)((ktl - kt_begin) * BK * ldb * 4);
+    bf16x8 ah[2], al[2], bhA, bhB, bl;
+    unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
+#define SLOT __builtin_amdgcn_sched_barrier(0)
+#define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0)
+#define MM1(x, y, i, j) if constexpr (!TWO) MM(x, y, i, j)
+#define SA12(i) split2n(ra[i][0], ra[i][1], sh0, sl0); split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SA3(i) *reinterpret_cast<u32x2*>(nxt + soffA + (i) * 8 * VPA) = u32x2{sh0, sh1};                          \
+               if constexpr (!TWO) *reinterpret_cast<u32x2*>(nxt + VARR_A + soffA + (i) * 8 * VPA) = u32x2{sl0, sl1}; \
+               ra[i] = bload4(asrd, avo + (unsigned)((i) * 8 * lda * 4), soa)
+#define SB12(i) split2n(rb[i][0], rb[i][1], sh0, sl0); split2n(rb[i][2], rb[i][3], sh1, sl1)
+#define SB3(i) *reinterpret_cast<u32x2*>(nxt + soffB[i]) = u32x2{sh0, sh1};                                       \
+               *reinterpret_cast<u32x2*>(nxt + XARR_B + soffB[i]) = u32x2{sl0, sl1};                              \
+               rb[i] = bload4(bsrd, bvo[i] | phase_oob(i), sob)
+#define FBH(dst, j) dst = trv<XPB>(cur + boff + (j) * 64)
+#define FBL(j) bl = trv<XPB>(cur + XARR_B + boff + (j) * 64)
+#define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                \
+    MM1(al[0], bh_, 0, j); X0; SLOT;                          \
+    MM1(al[1], bh_, 1, j); X1; SLOT;                          \
+    MM(ah[0], bl, 0, j); X2; SLOT;                            \
+    MM(ah[1], bl, 1, j); X3; SLOT;                            \
+    MM(ah[0], bh_, 0, j); X4; SLOT;                           \
+    MM(ah[1], bh_, 1, j); X5; SLOT
+    if constexpr (!TWO) al[0] = trv<VPA>(cur + VARR_A + aoff);
+    FBH(bhA, 0);
+    if constexpr (!TWO) al[1] = trv<VPA>(cur + VARR_A + aoff + 64);
+    ah[0] = trv<VPA>(cur + aoff);
+    FBL(0);
+    ah[1] = trv<VPA>(cur + aoff + 64);
+    SLOT;
+    JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), (void)0, FBL(1), SA12(1));
+    JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), (void)0, SB12(0), FBL(2), SB3(0));
+    JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), (void)0, FBL(3), SB12(2));
+    JBLOCK(3, bhB, FBH(bhA, 4), SB3(2), (void)0, (void)0, FBL(4), (void)0);
+    JBLOCK(4, bhA, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
+#undef JBLOCK
+#undef FBL
+#undef FBH
+#undef SB3
+#undef SB12
+#undef SA3
+#undef SA12
+#undef MM1
+#undef MM
+#undef SLOT
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (kt_begin < kt_end) {
+    gload_any(kt_begin);
+    stage_plain(lds0);
+    if (kt_begin + 1 < kt_end) { advance_phase(); gload_any(kt_begin + 1); }
+    __syncthreads();
+    int64_t kt = kt_begin;
+    const int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;      // tiles kt + 2, kt + 3 full and inside the split
+    for (; kt < lim; kt += 2) {
+      slotted(lds0, lds1, kt + 2);
+      slotted(lds1, lds0, kt + 3);
+    }
+    for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
+      const char* cur = par ? lds1 : lds0;
+      char* nxt = par ? lds0 : lds1;
+      compute(cur);
+      if (kt + 1 < kt_end) stage_plain(nxt);
+      if (kt + 2 < kt_end) { advance_phase(); gload_any(kt + 2); }
+      __syncthreads();
+    }
+  }
+  float* Cz = C + (int64_t)zsplit * c_split_stride;
+  const int64_t nend = n0 + (wn + 1) * 160;
+  const int64_t nlim = nend < N ? nend : N;
+  for (int round = 0; round < 2; ++round) {          // four scratches of 17 KB at a time
+    if (round) __syncthreads();
+    if (wn == round) {
+      float* stg = reinterpret_cast<float*>(lds) + wm * 64 * EPITCH;
+#pragma unroll
+      for (int jh = 0; jh < 3; ++jh) {
+        f32x16 a2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a2[i][0] = acc[i][2 * jh];
+          if (jh < 2) a2[i][1] = acc[i][2 * jh + 1];
+          else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a2[i][1][e] = 0.f;
+          }
+        }
+        gemm_epilogue_rows(a2, stg, Cz, M, nlim, m0 + (int64_t)wm * 64, n0 + wn * 160 + jh * 64, lane, nullptr, 0, accumulate, ldc,
+                           splitk == 1);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // Returns TSSEP_E_UNSUPPORTED where the geometry does not apply: the caller (gemm_bf16x3.hip) has already checked the
@@ -306,7 +634,20 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
   if ((per + 4) * VBK * ldmax * 4 >= ((int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
   if (call.dry) return TSSEP_OK;
-  const TileMap tm = make_tile_map(m256 / VM, (g->N + VN - 1) / VN, splitk);
+  // an even number of 160-column tiles: pairs of them in one 512-thread workgroup (256 x 320)
+  const int64_t nt160 = (g->N + VN - 1) / VN;
+  if (TNW160_WIDE && oob && (nt160 & 1) == 0) {
+    const TileMap tmw = make_tile_map(m256 / VM, nt160 / 2, splitk);
+    const dim3 gridw((unsigned)tile_map_blocks(tmw));
+#define W_LAUNCH(SH, TW) hipLaunchKernelGGL((gemm_bf16x3_tn_w320_kernel<SH, TW>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
+      g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift, shift ? (int)g->kperiod : 1, g->accumulate, sm.ldc, \
+      splitk, g->c_split_stride, tmw)
+    if (shift) { if (two) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
+    else { if (two) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
+#undef W_LAUNCH
+    return tssep_launch_status();
+  }
+  const TileMap tm = make_tile_map(m256 / VM, nt160, splitk);
   const dim3 grid((unsigned)tile_map_blocks(tm));
 #define V_LAUNCH(SH, TW, OB, KS, KP, ONES) hipLaunchKernelGGL((gemm_bf16x3_tn_w160_kernel<SH, TW, OB>), grid, dim3(VNT), 0, (hipStream_t)stream, \
       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, KS, KP, g->accumulate, sm.ldc, splitk, g->c_split_stride, tm, ONES)
