@@ -1,0 +1,47 @@
+"""Would the 256 x 320 weight-gradient tile pay for the dW_ih GEMMs with N = 320 q (+ the ones column)?  The same
+shapes WITHOUT the ones column on tn_w160 (256 x 320 workgroups) at several split counts, beside the library's choice
+WITH the ones column (GPU box):   python tools/exp_wgrad_w320.py"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tssep_amd import hip_ops as h
+
+T = 253
+
+
+def timeit(fn, reps=6):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+for name, M, N, R in (("dW_ih birnn1", 2400, 320, 3072 * T), ("dW_ih birnn2", 2400, 1280, 768 * T)):
+    dy = torch.randn(R, M, device="cuda") * 0.1
+    x = torch.randn(R, h.round_up(N + 1, 4), device="cuda") * 0.5
+    h.GEMM_PREFER = ()
+    h.GEMM_LOG = []
+    part, S = h.wgrad(dy, M, x, x.shape[1], M, N, R, with_colsum=True)
+    ran = h.GEMM_LOG[-1][0]; h.GEMM_LOG = None
+    ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, with_colsum=True))
+    print(json.dumps({"gemm": name, "with_ones_column": True, "kernel": ran, "splits": S, "ms": round(ms, 4)}), flush=True)
+    for force in ("tn_w160", "tn_p320", "tn_big"):
+        for S in (8, 16, 24, 32, 48):
+            h.GEMM_PREFER = (force,)
+            h.GEMM_LOG = []
+            try:
+                h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S)
+            except Exception as e:
+                h.GEMM_LOG = None
+                continue
+            ran = h.GEMM_LOG[-1][0]; h.GEMM_LOG = None
+            if ran != force:
+                continue
+            ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S))
+            print(json.dumps({"gemm": name, "with_ones_column": False, "kernel": ran, "splits": S, "ms": round(ms, 4),
+                              "tflops": round(2 * M * N * R / ms / 1e9, 1)}), flush=True)
+h.GEMM_PREFER = ()

@@ -1321,6 +1321,18 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
       // rows -> 15 splits; the 256 x 160 tile of dW_hh then has 150 workgroups at most: 54 against 89 TFLOP/s on 128 x 128)
       const int64_t max_splits = std::min<int64_t>(64, std::max<int64_t>(1, ((g->K + 15) / 16) / 8));
       auto tn_fills = [&](int64_t tiles) { return tiles * max_splits >= 192; };
+      {   // 256 x 320 workgroups of gemm_bf16x3_tn_w160.hip (round 5) for the dW_ih GEMMs whose input width is a multiple of
+          // 320 (+ the ones column): birnn1 (N = 321) 3.14 against 3.79 ms on the 192 x 320 tile, birnn2 (N = 1281) 3.00 against
+          // 3.61 ms on the 512 x 128 tile (tools/exp_wgrad_w320.py) -- 31 % / 28 % fewer staged bytes per MFMA; M pads to 256
+          // by at most 8 % (the logit layer's M = 2052 stays on the 192-row tile)
+        const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
+        const int64_t m256w = (g->M + 255) / 256 * 256;
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && nr % 320 == 0 && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
+                                                   tn_w160_wide(g) && tn_fills((m256w / 256) * (nr / 320)))) {
+          const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
+          if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
+        }
+      }
       {   // 192 x 320 tile (gemm_bf16x3_tn_p320.hip, round 4) where it computes at least 10 % less than the 512 x 128 tile:
           // N = 320 (+ the ones column) -- dW_ih of birnn1: 2496 x 320 against 2560 x 384, the logit layer's weight gradient
           // (M = 2052): 2112 x 320 against 2560 x 384

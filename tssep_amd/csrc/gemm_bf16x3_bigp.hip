@@ -29,6 +29,9 @@ namespace {
 
 using namespace gemm_detail;
 
+#ifndef BIGP_PROBE_NOB
+#define BIGP_PROBE_NOB 0
+#endif
 constexpr int GM = 256, GN = 256, GBK = 32, GNT = 256;
 constexpr int GROWB = 64;                                   // bytes per LDS row: 32 bf16
 constexpr int GARR = GM * GROWB;                            // 16 384 B per plane
@@ -237,11 +240,22 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
 #define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
                if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                ra[i] = load_a(i, tmask, so)
+#if BIGP_PROBE_NOB == 2 // timing probe (wrong results): operand B as eight 1-KB LDS-DMA copies per wave and stage from somewhere valid
+#define SB1(i) (void)0
+#define SB2(i) (void)0
+#define SB3(i) { const int la_ = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(nxt + 2 * GARR + ((tid >> 6) * 8 + (i)) * 1024)); \
+                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((unsigned)(tid * 16 + (i) * 4096)), "s"(B), "s"(la_) : "memory"); }
+#elif BIGP_PROBE_NOB    // timing probe (wrong results): operand B is neither loaded, split nor written -- what a pre-split, LDS-DMA'd weight operand could save at most
+#define SB1(i) (void)0
+#define SB2(i) (void)0
+#define SB3(i) (void)0
+#else
 #define SB1(i) SPLIT(rb[i][0], rb[i][1], sh0, sl0)
 #define SB2(i) SPLIT(rb[i][2], rb[i][3], sh1, sl1)
 #define SB3(i) { *reinterpret_cast<u32x2*>(nxt + 2 * GARR + soff + i * 32 * GROWB) = u32x2{sh0, sh1}; \
                if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + 3 * GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                rb[i] = load_b(i, tmask, so)
+#endif
 #include "gemm_bf16x3_big_schedule.inc"
 #undef SB3
 #undef SB2

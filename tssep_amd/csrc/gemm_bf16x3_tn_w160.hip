@@ -395,11 +395,17 @@ constexpr int XARR_B = VBK * XPB;               // 11 264
 constexpr int XSTAGE = 2 * VARR_A + 2 * XARR_B; // 40 960 B: A hi, A lo, B hi, B lo
 static_assert(4 * 64 * EPITCH * 4 <= 2 * XSTAGE, "four epilogue scratches at a time");
 
-template <bool SHIFT, bool TWO>
+// ONES (unshifted only): N = 320 q + 1 with b_ones_col -- the MFMA tiles cover the first N - 1 columns, column N - 1 (the
+// column sums of A = the bias gradient) is accumulated on the VALU from the raw fp32 A pieces every thread stages anyway
+// (exact fp32 sums in the order of the k rows, the eight row groups of a workgroup reduced through LDS in a fixed order:
+// deterministic; the workgroups of the last column tile write it), as in gemm_bf16x3_tn_p320.hip.
+template <bool SHIFT, bool TWO, bool ONES>
 __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t N,
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull,
     int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
     int64_t c_split_stride, TileMap tmap) {
+  static_assert(!(SHIFT && ONES), "the ones column exists for unshifted GEMMs only");
+  const int64_t N = ONES ? Nfull - 1 : Nfull;       // columns of the MFMA tiles (all real)
   constexpr int BK = VBK;
   __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
   char* const lds0 = lds;
@@ -461,6 +467,8 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
     return 0u;
   };
   f32x4 ra[2], rb[3];
+  float xacc[4] = {0.f, 0.f, 0.f, 0.f};       // ONES: sums of this thread's four A columns over its k rows
+#define XSUM(i) if constexpr (ONES) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[c_] += ra[i][c_]; }
   // general loader (prologue, tail): tile kt, rows beyond K out of range; `ph` is the phase of tile kt
   auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {
     const int64_t rel = (kt - kt_begin) * BK;
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       unsigned h0, l0, h1, l1;
+      XSUM(i);
       split2n(ra[i][0], ra[i][1], h0, l0);
       split2n(ra[i][2], ra[i][3], h1, l1);
       *reinterpret_cast<u32x2*>(st + soffA + i * 8 * VPA) = u32x2{h0, h1};
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
 #define SLOT __builtin_amdgcn_sched_barrier(0)
 #define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0)
 #define MM1(x, y, i, j) if constexpr (!TWO) MM(x, y, i, j)
-#define SA12(i) split2n(ra[i][0], ra[i][1], sh0, sl0); split2n(ra[i][2], ra[i][3], sh1, sl1)
+#define SA12(i) XSUM(i); split2n(ra[i][0], ra[i][1], sh0, sl0); split2n(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) *reinterpret_cast<u32x2*>(nxt + soffA + (i) * 8 * VPA) = u32x2{sh0, sh1};                          \
                if constexpr (!TWO) *reinterpret_cast<u32x2*>(nxt + VARR_A + soffA + (i) * 8 * VPA) = u32x2{sl0, sl1}; \
                ra[i] = bload4(asrd, avo + (unsigned)((i) * 8 * lda * 4), soa)
@@ -589,7 +598,23 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
       __syncthreads();
     }
   }
+#undef XSUM
   float* Cz = C + (int64_t)zsplit * c_split_stride;
+  if constexpr (ONES) {
+    if (nt == tmap.NT - 1) {                  // workgroup-uniform
+      float* xs = reinterpret_cast<float*>(lds);
+      *reinterpret_cast<f32x4*>(xs + wave * 256 + (tid & 63) * 4) = f32x4{xacc[0], xacc[1], xacc[2], xacc[3]};
+      __syncthreads();
+      if (tid < 256 && m0 + tid < M) {
+        float v = xs[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v += xs[w * 256 + tid];
+        float* dst = Cz + (m0 + tid) * ldc + N;
+        *dst = accumulate ? *dst + v : v;
+      }
+      __syncthreads();
+    }
+  }
   const int64_t nend = n0 + (wn + 1) * 160;
   const int64_t nlim = nend < N ? nend : N;
   for (int round = 0; round < 2; ++round) {          // four scratches of 17 KB at a time
@@ -629,6 +654,7 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   // masks by out-of-range loads: whole four-column pieces only (the time-shifted kernel exists in this form alone)
   const bool oob = (g->M & 3) == 0 && (g->N & 3) == 0 && !g->b_ones_col;
   if (shift && !oob) return TSSEP_E_UNSUPPORTED;
+  const bool wide = gemm_detail::tn_w160_wide(g);
   // 32-bit buffer offsets inside a split
   const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
@@ -636,14 +662,16 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   if (call.dry) return TSSEP_OK;
   // an even number of 160-column tiles: pairs of them in one 512-thread workgroup (256 x 320)
   const int64_t nt160 = (g->N + VN - 1) / VN;
-  if (TNW160_WIDE && oob && (nt160 & 1) == 0) {
-    const TileMap tmw = make_tile_map(m256 / VM, nt160 / 2, splitk);
+  if (TNW160_WIDE && wide) {
+    const bool ones = g->b_ones_col != 0;
+    const TileMap tmw = make_tile_map(m256 / VM, ((g->N - (ones ? 1 : 0)) + XN - 1) / XN, splitk);
     const dim3 gridw((unsigned)tile_map_blocks(tmw));
-#define W_LAUNCH(SH, TW) hipLaunchKernelGGL((gemm_bf16x3_tn_w320_kernel<SH, TW>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
+#define W_LAUNCH(SH, TW, ON) hipLaunchKernelGGL((gemm_bf16x3_tn_w320_kernel<SH, TW, ON>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift, shift ? (int)g->kperiod : 1, g->accumulate, sm.ldc, \
       splitk, g->c_split_stride, tmw)
-    if (shift) { if (two) W_LAUNCH(true, true); else W_LAUNCH(true, false); }
-    else { if (two) W_LAUNCH(false, true); else W_LAUNCH(false, false); }
+    if (shift) { if (two) W_LAUNCH(true, true, false); else W_LAUNCH(true, false, false); }
+    else if (ones) { if (two) W_LAUNCH(false, true, true); else W_LAUNCH(false, false, true); }
+    else { if (two) W_LAUNCH(false, true, false); else W_LAUNCH(false, false, false); }
 #undef W_LAUNCH
     return tssep_launch_status();
   }

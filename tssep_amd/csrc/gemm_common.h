@@ -511,6 +511,16 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
 // ... 192 x 320 tile for N = 320 q (+ the ones column), wave tiles of 96 x 160 (gemm_bf16x3_tn_p320.hip)
 int tssep_gemm_bf16x3_tn_p320_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 // (gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_h160.hip)
+namespace gemm_detail {
+// tn_w160 runs its 256 x 320 workgroups (512 threads, ONE per CU; masks by out-of-range loads) where the MFMA columns come
+// in pairs of 160-column tiles: M, N multiples of 4 and no ones column, or N = 320 q + 1 with the ones column (unshifted).
+// The launcher and the split rule (gemm.hip) both ask here.
+inline bool tn_w160_wide(const tssep_gemm_args* g) {
+  if (g->M & 3) return false;
+  if (g->b_ones_col) return g->kperiod <= 0 && g->N > 1 && (g->N - 1) % 320 == 0;
+  return (g->N & 3) == 0 && (((g->N + 159) / 160) & 1) == 0;
+}
+}  // namespace gemm_detail
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 int tssep_gemm_bf16x3_tn_h160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 // (gemm_bf16x3_nt_w160.hip)
