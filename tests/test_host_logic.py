@@ -52,10 +52,14 @@ def test_splitk_choice():
     old = H.GEMM_PRECISION
     H.GEMM_PRECISION = "bf16x3"
     try:
-        assert H.pick_splitk(2400, 321, 777216, ones_col=True) == 56 and H.pick_splitk(2400, 514, 777216, ones_col=True) == 24      # (N = 320 + 1: the 192 x 320 tile, 13 tiles x 7 slabs = 91 / 96)
+        # round 5: the dW_ih GEMMs whose input width is 320 q or 256 q (+ 1) (+ the ones column) run the eight-wave
+        # workgroups of tn_w160 (256 x 320 / 256 x 256 tiles, one per CU, a K slab per XCD): the smallest multiple of 8
+        # within 7 % of the best fill of whole rounds of 32 -- 10, 20 and 40 tiles -> 3 slabs (30 / 32, 60 / 64, 120 / 128)
+        assert H.pick_splitk(2400, 321, 777216, ones_col=True) == 24 and H.pick_splitk(2400, 514, 777216, ones_col=True) == 24
         assert H.pick_splitk(2400, 1281, 194304, ones_col=True) == 24
-        assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 8               # 25 tiles -> 1 slab (25 / 32)
-        # dW_hh: not the big tile (M pads to 1536) but the 256 x 160 one: 10 tiles, two workgroups per CU -> 48 splits
+        # the 512 x 128 tile keeps what is left: N = 554 = 4 x 128 + 42 -> 5 column tiles, 25 tiles -> 1 slab (25 / 32)
+        assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 8
+        # dW_hh: both 160-column tiles in one 256 x 320 workgroup: 5 tiles -> 6 slabs per XCD (30 / 32)
         assert H.pick_splitk(1200, 300, 777216, shifted=True) == 48 and H.pick_splitk(1200, 300, 194304, shifted=True) == 48
         # the projection weight gradients (M = 320): the 320 x 128 tile, 5 column tiles, two workgroups per CU
         assert H.pick_splitk(320, 601, 777216, ones_col=True) == 96 and H.pick_splitk(320, 601, 25600, ones_col=True) == 96

@@ -20,7 +20,7 @@ def timeit(fn, reps=6):
     return ts[len(ts) // 2]
 
 
-for name, M, N, R in (("dW_ih birnn1", 2400, 320, 3072 * T), ("dW_ih birnn2", 2400, 1280, 768 * T)):
+for name, M, N, R in (("dW_ih birnn0", 2400, 513, 3072 * T), ("dW_ih birnn1", 2400, 320, 3072 * T), ("dW_ih birnn2", 2400, 1280, 768 * T)):
     dy = torch.randn(R, M, device="cuda") * 0.1
     x = torch.randn(R, h.round_up(N + 1, 4), device="cuda") * 0.5
     h.GEMM_PREFER = ()
@@ -30,18 +30,31 @@ for name, M, N, R in (("dW_ih birnn1", 2400, 320, 3072 * T), ("dW_ih birnn2", 24
     ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, with_colsum=True))
     print(json.dumps({"gemm": name, "with_ones_column": True, "kernel": ran, "splits": S, "ms": round(ms, 4)}), flush=True)
     for force in ("tn_w160", "tn_p320", "tn_big"):
-        for S in (8, 16, 24, 32, 48):
+        if "--sweep" not in sys.argv:
             h.GEMM_PREFER = (force,)
             h.GEMM_LOG = []
             try:
-                h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S)
+                part, S = h.wgrad(dy, M, x, x.shape[1], M, N, R, with_colsum=True)
+            except Exception:
+                h.GEMM_LOG = None
+                continue
+            ran = h.GEMM_LOG[-1][0]; h.GEMM_LOG = None
+            if ran == force:
+                ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, with_colsum=True))
+                print(json.dumps({"gemm": name, "with_ones_column": True, "forced": force, "splits": S, "ms": round(ms, 4)}), flush=True)
+            continue
+        for S in (8, 16, 24, 32, 48, 64):
+            h.GEMM_PREFER = (force,)
+            h.GEMM_LOG = []
+            try:
+                h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S, with_colsum=True)
             except Exception as e:
                 h.GEMM_LOG = None
                 continue
             ran = h.GEMM_LOG[-1][0]; h.GEMM_LOG = None
             if ran != force:
                 continue
-            ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S))
-            print(json.dumps({"gemm": name, "with_ones_column": False, "kernel": ran, "splits": S, "ms": round(ms, 4),
+            ms = timeit(lambda: h.wgrad(dy, M, x, x.shape[1], M, N, R, splitk=S, with_colsum=True))
+            print(json.dumps({"gemm": name, "with_ones_column": True, "kernel": ran, "splits": S, "ms": round(ms, 4),
                               "tflops": round(2 * M * N * R / ms / 1e9, 1)}), flush=True)
 h.GEMM_PREFER = ()

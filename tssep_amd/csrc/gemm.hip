@@ -435,19 +435,21 @@ static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid) {
     return best;
   }
   if (kid == TSSEP_GEMM_TN_W160 && ktiles >= 64 * 8) {
-    if (tn_w160_wide(g)) {
+    if (const int wide = tn_w160_wide(g)) {
       // 256 x 320 tiles, ONE workgroup per CU, the tiles of a K slab on one XCD (32 CUs): the multiple of 8 that fills whole
       // rounds of 32 best, the smallest one among equals, >= 64 K tiles per split (tools/exp_wgrad_w320.py: dW_ih of birnn1,
       // 10 tiles: 3.14 ms at S = 24, 3.25 at 48, 3.75 at 16; birnn2, 40 tiles: 3.00 at 32, 3.09 at 24, 3.43 at 48; dW_hh,
-      // 5 tiles: 48)
-      const int64_t tiles = (rup(M, 256) / 256) * cdiv(N - (g->b_ones_col ? 1 : 0), 320);
-      int best = 8; double waste = 1e30;
-      for (int S = 8; S <= 64 && (int64_t)S * 64 <= ktiles; S += 8) {
-        const int64_t wg = tiles * (S / 8);
-        const double w = (double)rup(wg, 32) / (double)wg;
-        if (w < waste - 1e-9) { waste = w; best = S; }
-      }
-      return best;
+      // 5 tiles: 48; tools/exp_wgrad_w320.py --sweep)
+      const int64_t nr = N - (g->b_ones_col ? 1 : 0);
+      const int64_t tiles = (rup(M, 256) / 256) * (wide == 5 ? cdiv(nr, 320) : nr / 256);      // (256-wide: the 513th column rides on the VALU)
+      // (the smallest S within 7 % of the best fill: dW_ih of birnn0, 20 tiles, 5.54 ms at S = 24 (60 per XCD), 5.69-5.79 at 64
+      // (160 = five full rounds) -- and a third of the partial sums to reduce)
+      auto fill = [&](int S) { const int64_t wg = tiles * (S / 8); return (double)rup(wg, 32) / (double)wg; };
+      double waste = 1e30;
+      for (int S = 8; S <= 64 && (int64_t)S * 64 <= ktiles; S += 8) waste = fill(S) < waste ? fill(S) : waste;
+      for (int S = 8; S <= 64 && (int64_t)S * 64 <= ktiles; S += 8)
+        if (fill(S) <= waste * 1.07) return S;
+      return 8;
     }
     // 256 x 160 tile, two workgroups per CU, one round of at most 512 (tools/sweep_wgrad_splits.py: dW_hh 2.00 ms at
     // S = 48, 2.30 at 40, 3.13 at 56)

@@ -1327,8 +1327,13 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
           // by at most 8 % (the logit layer's M = 2052 stays on the 192-row tile)
         const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
         const int64_t m256w = (g->M + 255) / 256 * 256;
-        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && nr % 320 == 0 && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
-                                                   tn_w160_wide(g) && tn_fills((m256w / 256) * (nr / 320)))) {
+        const int wide = tn_w160_wide(g);
+        // (256 x 256 workgroups, round 5: dW_ih of birnn0, N = 513 + 1 -- two column tiles + two VALU columns, 20 % fewer staged
+        // bytes per MFMA than the 512 x 128 tile)
+        const bool takes = (wide == 5 && nr % 320 == 0) || wide == 4;
+        const int64_t tilesw = (m256w / 256) * (wide == 4 ? nr / 256 : nr / 320);
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && takes && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
+                                                   tn_fills(tilesw))) {
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
         }

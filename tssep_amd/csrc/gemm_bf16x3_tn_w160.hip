@@ -380,42 +380,50 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256 (m) x 320 (n) variant, 512 threads: the two 160-column tiles of one row block in ONE workgroup -- eight waves as
-// 4 (m) x 2 (n), each the same 64 x 160 wave tile, one workgroup per CU (two waves per SIMD as before).  A stage stages
-// 256 + 320 columns instead of 2 x (256 + 160): 31 % fewer bytes loaded, split and written to LDS per MFMA.  Why that
-// matters (round 5 probes on the 256 x 160 kernel at 3 072 sequences, 1.86 ms per launch): no split arithmetic -2.7 %,
-// loads that hit the cache -18 %, no LDS writes -21 % -- the kernel pays for the bytes it moves through the vector
-// registers, not for the VALU.  Masks by out-of-range loads only (M, N multiples of 4, no ones column), every stage of the
-// steady state written slot by slot like `slotted` above; prologue and tail use a general loader (rows beyond K, time
-// shift at the ends of the matrix: all out of range).  Same k order and products per output element: bit-identical to
-// the other tn kernels for equal split counts.
-constexpr int XN = 320, XNT = 512;
-constexpr int XPB = XN * 2 + 64;                // 704 B per k row of a B plane (176 dwords = 48 mod 64: conflict-free transpose reads)
-constexpr int XARR_B = VBK * XPB;               // 11 264
-constexpr int XSTAGE = 2 * VARR_A + 2 * XARR_B; // 40 960 B: A hi, A lo, B hi, B lo
-static_assert(4 * 64 * EPITCH * 4 <= 2 * XSTAGE, "four epilogue scratches at a time");
+// Eight-wave variants, 512 threads, ONE workgroup per CU (two waves per SIMD as before): waves as 4 (m) x 2 (n), wave tile
+// 64 x 32 JW -- JW = 5: workgroup tile 256 x 320, the two 160-column tiles of one row block in one workgroup (dW_hh; the
+// dW_ih GEMMs with N = 320 q); JW = 4: 256 x 256 (dW_ih of birnn0: N = 512 + one more real column + the ones column).
+// A stage stages 256 + 320 columns instead of 2 x (256 + 160): 31 % fewer bytes loaded, split and written to LDS per
+// MFMA (JW = 4: 20 % fewer than the 512 x 128 tile).  Why that matters (round 5 probes on the 256 x 160 kernel at 3 072
+// sequences, 1.86 ms per launch): no split arithmetic -2.7 %, loads that hit the cache -18 %, no LDS writes -21 % -- the
+// kernel pays for the bytes it moves through the vector registers, not for the VALU.  Masks by out-of-range loads only
+// (M and the MFMA columns multiples of 4), every stage of the steady state written slot by slot like `slotted` above;
+// prologue and tail use a general loader (rows beyond K, time shift at the ends of the matrix: all out of range).  Same k
+// order and products per output element: bit-identical to the other tn kernels for equal split counts.
+// XC = 10 XR + XO (unshifted only, as in gemm_bf16x3_tn_big.hip): N = 64 JW q + XR + XO -- the MFMA tiles cover the first
+// columns; then XR <= 1 real columns of B and XO <= 1 virtual ones column (the bias gradient) are accumulated on the VALU
+// from the raw fp32 A pieces every thread stages anyway (exact fp32 chains in the order of the k rows, the eight row groups
+// of a workgroup reduced through LDS in a fixed order: deterministic; the workgroups of the last column tile write them).
+template <int JW> struct W8 {
+  static constexpr int WN = 64 * JW;                     // workgroup columns: 320 / 256
+  static constexpr int PB = WN * 2 + 64;                 // bytes per k row of a B plane: 704 / 576 (= 48 / 16 dwords mod 64: conflict-free transpose reads)
+  static constexpr int ARRB = VBK * PB;
+  static constexpr int STAGE = 2 * VARR_A + 2 * ARRB;    // A hi, A lo, B hi, B lo: 40 960 / 36 864 B
+  static constexpr int PPR = WN / 4;                     // 16-byte pieces per k row of B: 80 / 64
+  static constexpr int NPB = (VBK * PPR + 511) / 512;    // B pieces per thread: 3 (waves 4-7: two and a repeat) / 2
+};
+constexpr int XNT = 512;
 
-// ONES (unshifted only): N = 320 q + 1 with b_ones_col -- the MFMA tiles cover the first N - 1 columns, column N - 1 (the
-// column sums of A = the bias gradient) is accumulated on the VALU from the raw fp32 A pieces every thread stages anyway
-// (exact fp32 sums in the order of the k rows, the eight row groups of a workgroup reduced through LDS in a fixed order:
-// deterministic; the workgroups of the last column tile write it), as in gemm_bf16x3_tn_p320.hip.
-template <bool SHIFT, bool TWO, bool ONES>
-__global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
+template <bool SHIFT, bool TWO, int XC, int JW>
+__global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull,
     int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
     int64_t c_split_stride, TileMap tmap) {
-  static_assert(!(SHIFT && ONES), "the ones column exists for unshifted GEMMs only");
-  const int64_t N = ONES ? Nfull - 1 : Nfull;       // columns of the MFMA tiles (all real)
-  constexpr int BK = VBK;
-  __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
+  using G = W8<JW>;
+  constexpr int XR = XC / 10, XO = XC % 10, XN_ = XR + XO;
+  static_assert(!(SHIFT && XC), "extra columns exist for unshifted GEMMs only");
+  static_assert(4 * 64 * EPITCH * 4 <= 2 * G::STAGE, "four epilogue scratches at a time");
+  const int64_t N = Nfull - XN_;                    // columns of the MFMA tiles (all real)
+  constexpr int BK = VBK, NPB = G::NPB, PB = G::PB, ARRB = G::ARRB;
+  __shared__ __attribute__((aligned(16))) char lds[2 * G::STAGE];
   char* const lds0 = lds;
-  char* const lds1 = lds + XSTAGE;
+  char* const lds1 = lds + G::STAGE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;        // (waves w and w + 4 share a SIMD: same rows, the two column halves)
   int mt, nt, zsplit;
   if (!tile_map_decode(tmap, blockIdx.x, mt, nt, zsplit)) return;
-  const int64_t m0 = (int64_t)mt * VM, n0 = (int64_t)nt * XN;
+  const int64_t m0 = (int64_t)mt * VM, n0 = (int64_t)nt * G::WN;
   const int64_t ktiles = (K + BK - 1) / BK;
   const int64_t per = (ktiles + splitk - 1) / splitk;
   const int64_t kt_begin = (int64_t)zsplit * per;
@@ -423,40 +431,43 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
   const int64_t kt_full = K / BK;
   const int64_t k_begin = kt_begin * BK;
 
-  f32x16 acc[2][5];
+  f32x16 acc[2][JW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < JW; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // pieces (four columns of one k row): A thread <-> (k row tid / 64 + 8 i, columns 4 (tid % 64) ..), i < 2;
-  // B piece p = tid + 512 i (i < 3, p < 1280) <-> (k row p / 80, columns 4 (p % 80) ..): waves 0-3 have three, waves 4-7 two
-  // and a dummy (out of range, written to the spare kilobyte behind... no spare here: to its own second piece's place twice)
+  // B piece p = tid + 512 i <-> (k row p / PPR, columns 4 (p % PPR) ..); JW = 5: 1280 pieces, waves 0-3 have three, waves
+  // 4-7 two and a repeat of their second one (same values to the same place: the stage body stays branch-free)
   const int krA = tid >> 6, cqA = (tid & 63) << 2;
-  int krB[3], cqB[3];
+  int krB[NPB], cqB[NPB];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int p = tid + 512 * i < 1280 ? tid + 512 * i : tid + 512;      // the dummy repeats piece 1 (same values, same place)
-    krB[i] = p / 80;
-    cqB[i] = (p % 80) << 2;
+  for (int i = 0; i < NPB; ++i) {
+    const int p = tid + 512 * i < VBK * G::PPR ? tid + 512 * i : tid + 512;
+    krB[i] = p / G::PPR;
+    cqB[i] = (p % G::PPR) << 2;
   }
   const srd_t asrd = make_srd(A + k_begin * lda);
   const srd_t bsrd = make_srd(B + (k_begin + (SHIFT ? kshift : 0)) * ldb);
+  const int64_t nfull = (int64_t)tmap.NT * G::WN;           // first extra column (XC)
+  const srd_t xsrd = make_srd(B + k_begin * ldb + (XR ? nfull : 0));
   const unsigned avo = (unsigned)((krA * lda + m0 + cqA) * 4) | (m0 + cqA >= M ? VOOR : 0u);
-  unsigned bvo[3];
-  int ph[3] = {0, 0, 0};                    // phase (k mod kperiod) of this thread's B rows of the tile loaded last
+  const unsigned xvo = (unsigned)(krA * ldb * 4);
+  unsigned bvo[NPB];
+  int ph[NPB];                              // phase (k mod kperiod) of this thread's B rows of the tile loaded last
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < NPB; ++i) {
     bvo[i] = (unsigned)((krB[i] * ldb + n0 + cqB[i]) * 4) | (n0 + cqB[i] >= N ? VOOR : 0u);
-    if (SHIFT) ph[i] = (int)((k_begin + krB[i]) % kperiod);
+    ph[i] = SHIFT ? (int)((k_begin + krB[i]) % kperiod) : 0;
   }
   const int phstep = SHIFT ? BK % kperiod : 0;
   auto advance_phase = [&]() __attribute__((always_inline)) {
     if constexpr (SHIFT) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < NPB; ++i) {
         const unsigned x = (unsigned)(ph[i] + phstep), y = x - (unsigned)kperiod;
         ph[i] = (int)(x < y ? x : y);
       }
@@ -466,23 +477,32 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
     if constexpr (SHIFT) return (unsigned)(ph[i] + kshift) < (unsigned)kperiod ? 0u : VOOR;
     return 0u;
   };
-  f32x4 ra[2], rb[3];
-  float xacc[4] = {0.f, 0.f, 0.f, 0.f};       // ONES: sums of this thread's four A columns over its k rows
-#define XSUM(i) if constexpr (ONES) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[c_] += ra[i][c_]; }
+  f32x4 ra[2], rb[NPB];
+  float rx[2] = {0.f, 0.f};                   // XR: B[k row of A piece i][nfull]
+  float xacc[XN_ > 0 ? XN_ : 1][4];            // sums over this thread's k rows, for its four A columns: [real column][ones column]
+#pragma unroll
+  for (int e = 0; e < (XN_ > 0 ? XN_ : 1); ++e)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xacc[e][c] = 0.f;
+#define XSUM(i) { if constexpr (XR > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[0][c_] = fmaf(ra[i][c_], rx[i], xacc[0][c_]); } \
+                  if constexpr (XO > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[XR][c_] += ra[i][c_]; } }
   // general loader (prologue, tail): tile kt, rows beyond K out of range; `ph` is the phase of tile kt
   auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {
     const int64_t rel = (kt - kt_begin) * BK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      ra[i] = bload4(asrd, (avo + (unsigned)((rel + 8 * i) * lda * 4)) | (kt * BK + krA + 8 * i < K ? 0u : VOOR), 0);
+    for (int i = 0; i < 2; ++i) {
+      const unsigned tail = kt * BK + krA + 8 * i < K ? 0u : VOOR;
+      ra[i] = bload4(asrd, (avo + (unsigned)((rel + 8 * i) * lda * 4)) | tail, 0);
+      if constexpr (XR > 0) rx[i] = bload1(xsrd, (xvo + (unsigned)((rel + 8 * i) * ldb * 4)) | tail, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NPB; ++i)
       rb[i] = bload4(bsrd, (bvo[i] + (unsigned)(rel * ldb * 4)) | (kt * BK + krB[i] < K ? 0u : VOOR) | phase_oob(i), 0);
   };
   const int soffA = krA * VPA + (tid & 63) * 8;
-  int soffB[3];
+  int soffB[NPB];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) soffB[i] = 2 * VARR_A + krB[i] * XPB + cqB[i] * 2;
+  for (int i = 0; i < NPB; ++i) soffB[i] = 2 * VARR_A + krB[i] * PB + cqB[i] * 2;
   auto stage_plain = [&](char* st) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -494,17 +514,17 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
       if (!TWO) *reinterpret_cast<u32x2*>(st + VARR_A + soffA + i * 8 * VPA) = u32x2{l0, l1};
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NPB; ++i) {
       unsigned h0, l0, h1, l1;
       split2n(rb[i][0], rb[i][1], h0, l0);
       split2n(rb[i][2], rb[i][3], h1, l1);
       *reinterpret_cast<u32x2*>(st + soffB[i]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(st + XARR_B + soffB[i]) = u32x2{l0, l1};
+      *reinterpret_cast<u32x2*>(st + ARRB + soffB[i]) = u32x2{l0, l1};
     }
   };
   const int ii = lane & 15, g2 = (lane >> 4) & 1, hk = lane >> 5;
   const int fcol = (16 * g2 + 4 * (ii & 3)) * 2, frow = 8 * hk + (ii >> 2);
-  const int aoff = frow * VPA + fcol + wm * 64 * 2, boff = 2 * VARR_A + frow * XPB + fcol + wn * 160 * 2;
+  const int aoff = frow * VPA + fcol + wm * 64 * 2, boff = 2 * VARR_A + frow * PB + fcol + wn * 32 * JW * 2;
   auto compute = [&](const char* st) __attribute__((always_inline)) {      // tail stages
     bf16x8 ah[2], al[2];
 #pragma unroll
@@ -513,9 +533,9 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
       if (!TWO) al[i] = trv<VPA>(st + VARR_A + aoff + i * 64);
     }
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const bf16x8 bh = trv<XPB>(st + boff + j * 64);
-      const bf16x8 bl = trv<XPB>(st + XARR_B + boff + j * 64);
+    for (int j = 0; j < JW; ++j) {
+      const bf16x8 bh = trv<PB>(st + boff + j * 64);
+      const bf16x8 bl = trv<PB>(st + ARRB + boff + j * 64);
       if (!TWO) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
@@ -538,13 +558,15 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
 #define SA12(i) XSUM(i); split2n(ra[i][0], ra[i][1], sh0, sl0); split2n(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) *reinterpret_cast<u32x2*>(nxt + soffA + (i) * 8 * VPA) = u32x2{sh0, sh1};                          \
                if constexpr (!TWO) *reinterpret_cast<u32x2*>(nxt + VARR_A + soffA + (i) * 8 * VPA) = u32x2{sl0, sl1}; \
-               ra[i] = bload4(asrd, avo + (unsigned)((i) * 8 * lda * 4), soa)
+               ra[i] = bload4(asrd, avo + (unsigned)((i) * 8 * lda * 4), soa);                                     \
+               if constexpr (XR > 0) rx[i] = bload1(xsrd, xvo + (unsigned)((i) * 8 * ldb * 4), sob)
 #define SB12(i) split2n(rb[i][0], rb[i][1], sh0, sl0); split2n(rb[i][2], rb[i][3], sh1, sl1)
 #define SB3(i) *reinterpret_cast<u32x2*>(nxt + soffB[i]) = u32x2{sh0, sh1};                                       \
-               *reinterpret_cast<u32x2*>(nxt + XARR_B + soffB[i]) = u32x2{sl0, sl1};                              \
+               *reinterpret_cast<u32x2*>(nxt + ARRB + soffB[i]) = u32x2{sl0, sl1};                                \
                rb[i] = bload4(bsrd, bvo[i] | phase_oob(i), sob)
-#define FBH(dst, j) dst = trv<XPB>(cur + boff + (j) * 64)
-#define FBL(j) bl = trv<XPB>(cur + XARR_B + boff + (j) * 64)
+#define FBH(dst, j) dst = trv<PB>(cur + boff + (j) * 64)
+#define FBL(j) bl = trv<PB>(cur + ARRB + boff + (j) * 64)
+#define NOP_ (void)0
 #define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                \
     MM1(al[0], bh_, 0, j); X0; SLOT;                          \
     MM1(al[1], bh_, 1, j); X1; SLOT;                          \
@@ -559,12 +581,20 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
     FBL(0);
     ah[1] = trv<VPA>(cur + aoff + 64);
     SLOT;
-    JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), (void)0, FBL(1), SA12(1));
-    JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), (void)0, SB12(0), FBL(2), SB3(0));
-    JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), (void)0, FBL(3), SB12(2));
-    JBLOCK(3, bhB, FBH(bhA, 4), SB3(2), (void)0, (void)0, FBL(4), (void)0);
-    JBLOCK(4, bhA, (void)0, (void)0, (void)0, (void)0, (void)0, (void)0);
+    if constexpr (JW == 5) {
+      JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
+      JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
+      JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), NOP_, FBL(3), SB12(2));
+      JBLOCK(3, bhB, FBH(bhA, 4), SB3(2), NOP_, NOP_, FBL(4), NOP_);
+      JBLOCK(4, bhA, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);
+    } else {
+      JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
+      JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
+      JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), NOP_, FBL(3), NOP_);
+      JBLOCK(3, bhB, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);
+    }
 #undef JBLOCK
+#undef NOP_
 #undef FBL
 #undef FBH
 #undef SB3
@@ -600,40 +630,45 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w320_kernel(
   }
 #undef XSUM
   float* Cz = C + (int64_t)zsplit * c_split_stride;
-  if constexpr (ONES) {
+  if constexpr (XN_ > 0) {
     if (nt == tmap.NT - 1) {                  // workgroup-uniform
-      float* xs = reinterpret_cast<float*>(lds);
-      *reinterpret_cast<f32x4*>(xs + wave * 256 + (tid & 63) * 4) = f32x4{xacc[0], xacc[1], xacc[2], xacc[3]};
+      float* xs = reinterpret_cast<float*>(lds);            // [extra column][row group = wave][256 columns of A]
+#pragma unroll
+      for (int e = 0; e < XN_; ++e)
+        *reinterpret_cast<f32x4*>(xs + (e * 8 + wave) * 256 + (tid & 63) * 4) = f32x4{xacc[e][0], xacc[e][1], xacc[e][2], xacc[e][3]};
       __syncthreads();
       if (tid < 256 && m0 + tid < M) {
-        float v = xs[tid];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) v += xs[w * 256 + tid];
-        float* dst = Cz + (m0 + tid) * ldc + N;
-        *dst = accumulate ? *dst + v : v;
+        for (int e = 0; e < XN_; ++e) {
+          float v = xs[e * 8 * 256 + tid];
+#pragma unroll
+          for (int w = 1; w < 8; ++w) v += xs[(e * 8 + w) * 256 + tid];
+          float* dst = Cz + (m0 + tid) * ldc + N + e;
+          *dst = accumulate ? *dst + v : v;
+        }
       }
       __syncthreads();
     }
   }
-  const int64_t nend = n0 + (wn + 1) * 160;
+  const int64_t nend = n0 + (wn + 1) * 32 * JW;
   const int64_t nlim = nend < N ? nend : N;
   for (int round = 0; round < 2; ++round) {          // four scratches of 17 KB at a time
     if (round) __syncthreads();
     if (wn == round) {
       float* stg = reinterpret_cast<float*>(lds) + wm * 64 * EPITCH;
 #pragma unroll
-      for (int jh = 0; jh < 3; ++jh) {
+      for (int jh = 0; jh < (JW + 1) / 2; ++jh) {
         f32x16 a2[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           a2[i][0] = acc[i][2 * jh];
-          if (jh < 2) a2[i][1] = acc[i][2 * jh + 1];
+          if (2 * jh + 1 < JW) a2[i][1] = acc[i][2 * jh + 1];
           else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) a2[i][1][e] = 0.f;
           }
         }
-        gemm_epilogue_rows(a2, stg, Cz, M, nlim, m0 + (int64_t)wm * 64, n0 + wn * 160 + jh * 64, lane, nullptr, 0, accumulate, ldc,
+        gemm_epilogue_rows(a2, stg, Cz, M, nlim, m0 + (int64_t)wm * 64, n0 + wn * 32 * JW + jh * 64, lane, nullptr, 0, accumulate, ldc,
                            splitk == 1);
       }
     }
@@ -654,7 +689,7 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   // masks by out-of-range loads: whole four-column pieces only (the time-shifted kernel exists in this form alone)
   const bool oob = (g->M & 3) == 0 && (g->N & 3) == 0 && !g->b_ones_col;
   if (shift && !oob) return TSSEP_E_UNSUPPORTED;
-  const bool wide = gemm_detail::tn_w160_wide(g);
+  const int wide = gemm_detail::tn_w160_wide(g);
   // 32-bit buffer offsets inside a split
   const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
@@ -663,15 +698,28 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   // an even number of 160-column tiles: pairs of them in one 512-thread workgroup (256 x 320)
   const int64_t nt160 = (g->N + VN - 1) / VN;
   if (TNW160_WIDE && wide) {
-    const bool ones = g->b_ones_col != 0;
-    const TileMap tmw = make_tile_map(m256 / VM, ((g->N - (ones ? 1 : 0)) + XN - 1) / XN, splitk);
+    // 0 = no; 5 -> 256 x 320 workgroups (XC = 0 / 1), 4 -> 256 x 256 (XC = 0 / 1 / 10 / 11)
+    const int xo = g->b_ones_col ? 1 : 0;
+    const int xr = wide == 4 ? (int)((g->N - xo) % 256) : 0;
+    const int xc = 10 * xr + xo;
+    const int wn_ = wide == 5 ? 320 : 256;
+    const TileMap tmw = make_tile_map(m256 / VM, (g->N - xr - xo + wn_ - 1) / wn_, splitk);
     const dim3 gridw((unsigned)tile_map_blocks(tmw));
-#define W_LAUNCH(SH, TW, ON) hipLaunchKernelGGL((gemm_bf16x3_tn_w320_kernel<SH, TW, ON>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
+#define W_LAUNCH(SH, TW, XC_, JW_) hipLaunchKernelGGL((gemm_bf16x3_tn_w8_kernel<SH, TW, XC_, JW_>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift, shift ? (int)g->kperiod : 1, g->accumulate, sm.ldc, \
       splitk, g->c_split_stride, tmw)
-    if (shift) { if (two) W_LAUNCH(true, true, false); else W_LAUNCH(true, false, false); }
-    else if (ones) { if (two) W_LAUNCH(false, true, true); else W_LAUNCH(false, false, true); }
-    else { if (two) W_LAUNCH(false, true, false); else W_LAUNCH(false, false, false); }
+#define W_TWO(SH, XC_, JW_) do { if (two) W_LAUNCH(SH, true, XC_, JW_); else W_LAUNCH(SH, false, XC_, JW_); } while (0)
+    if (wide == 5) {
+      if (shift) W_TWO(true, 0, 5);
+      else if (xc == 1) W_TWO(false, 1, 5);
+      else W_TWO(false, 0, 5);
+    } else {
+      if (xc == 11) W_TWO(false, 11, 4);
+      else if (xc == 10) W_TWO(false, 10, 4);
+      else if (xc == 1) W_TWO(false, 1, 4);
+      else W_TWO(false, 0, 4);
+    }
+#undef W_TWO
 #undef W_LAUNCH
     return tssep_launch_status();
   }

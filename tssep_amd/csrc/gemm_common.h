@@ -512,13 +512,19 @@ int tssep_gemm_bf16x3_tn_big_launch(const tssep_gemm_args* g, const gemm_detail:
 int tssep_gemm_bf16x3_tn_p320_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
 // (gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_h160.hip)
 namespace gemm_detail {
-// tn_w160 runs its 256 x 320 workgroups (512 threads, ONE per CU; masks by out-of-range loads) where the MFMA columns come
-// in pairs of 160-column tiles: M, N multiples of 4 and no ones column, or N = 320 q + 1 with the ones column (unshifted).
-// The launcher and the split rule (gemm.hip) both ask here.
-inline bool tn_w160_wide(const tssep_gemm_args* g) {
-  if (g->M & 3) return false;
-  if (g->b_ones_col) return g->kperiod <= 0 && g->N > 1 && (g->N - 1) % 320 == 0;
-  return (g->N & 3) == 0 && (((g->N + 159) / 160) & 1) == 0;
+// tn_w160 runs eight-wave workgroups (512 threads, ONE per CU; masks by out-of-range loads) where the shape allows:
+// 5 -> 256 x 320 tiles: M, N multiples of 4 and an even number of 160-column tiles without the ones column, or
+//      N = 320 q + 1 with it (unshifted);
+// 4 -> 256 x 256 tiles (unshifted): N = 256 q + XR + XO, q >= 2, XR <= 1 more real column and the ones column (XO) on the
+//      VALU -- dW_ih of birnn0: 513 + 1;
+// 0 -> the 256 x 160 workgroups.  The launcher, the dispatcher and the split rule (gemm.hip) all ask here.
+inline int tn_w160_wide(const tssep_gemm_args* g) {
+  if (g->M & 3) return 0;
+  const int64_t xo = g->b_ones_col ? 1 : 0;
+  if (g->kperiod <= 0 && (g->N - xo) >= 320 && (g->N - xo) % 320 == 0) return 5;
+  if (!xo && (g->N & 3) == 0 && (((g->N + 159) / 160) & 1) == 0) return 5;
+  if (g->kperiod <= 0 && g->N - xo >= 512 && (g->N - xo) % 256 <= 1) return 4;
+  return 0;
 }
 }  // namespace gemm_detail
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
