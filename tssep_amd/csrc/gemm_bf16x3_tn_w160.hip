@@ -1,15 +1,21 @@
-// Weight-gradient GEMM with a 256 (m) x 160 (n) output tile: C[M,N] (split-K partials) = A^T B, both operands
-// k-major (A = d(gates) [K rows][M], B = h or X [K rows][N]), for the column counts the 128-wide tiles fit badly --
-// the time-shifted dW_hh GEMMs of every BLSTM layer (tssep/train/rnnp.py:88-96, backward: M = 4 H = 1200 gate columns
-// of one direction, N = H = 300 hidden units, rows = time steps paired with their neighbour t -/+ 1).  N = 300 pads to
-// 3 x 128 = 384 (78 %) but to 2 x 160 = 320 (94 %); with M = 1200 -> 5 x 256 the tile utilisation goes from 73 % to 88 %.
-//  * FOUR waves stacked along m, wave tile 64 x 160 = 2 x 5 MFMA tiles (160 accumulators; 14 fragment reads per 30
-//    MFMAs, the 128 x 64 wave tile of the 256 x 128 kernel has 12 per 24), two workgroups per CU;
-//  * staging, transpose reads, masks, time shift (phase of each staged B row inside its sequence) and the two-stage
-//    pipeline are those of gemm_bf16x3_tn_tall_kernel (gemm_bf16x3.hip); a k row of B is 160 columns = 40 threads, so
-//    the 16 rows of a stage are 640 four-column pieces: three per thread for the first 128 threads, two for the rest;
-//    the B planes keep the 320-byte pitch (160 x 2 B, = 64 B mod 256 B: conflict-free transpose reads without padding);
-//  * same k order and MFMA sequence per output element as the other tn kernels -> bit-identical results.
+// Weight-gradient GEMMs on 64 x 160 / 64 x 128 wave tiles: C[M,N] (split-K partials) = A^T B, both operands k-major
+// (A = d(gates) [K rows][M], B = h or X [K rows][N]) -- the time-shifted dW_hh GEMMs of every BLSTM layer and, since round
+// 5, the dW_ih GEMMs (tssep/train/rnnp.py:88-96, backward: M = 4 H = 1200 gate columns of one direction against N = H = 300
+// hidden units, rows = time steps paired with their neighbour t -/+ 1; M = 8 H = 2400 against the layer's input width).
+// TWO kernels under one dispatcher id (tn_w160):
+//  (1) gemm_bf16x3_tn_w160_kernel (round 3): 256 (m) x 160 (n) tile, FOUR waves stacked along m, two workgroups per CU.
+//      N = 300 pads to 3 x 128 = 384 (78 %) but to 2 x 160 = 320 (94 %).  Staging, transpose reads, time shift (phase of
+//      each staged B row inside its sequence) and the two-stage pipeline are those of gemm_bf16x3_tn_tall_kernel
+//      (gemm_bf16x3.hip); the B planes keep the 320-byte pitch (= 64 B mod 256 B: conflict-free transpose reads).  Round 5:
+//      masks by out-of-range loads (OOB) and a slot-by-slot stage body.  Still takes what (2) cannot: an odd number of
+//      160-column tiles, M or N not multiples of 4, a ones column on N != 320 q + 1.
+//  (2) gemm_bf16x3_tn_w8_kernel (round 5): EIGHT waves as 4 (m) x 2 (n), one workgroup per CU, workgroup tile 256 x 320
+//      (JW = 5) or 256 x 256 (JW = 4): the same wave tile, but the staged d(gates) rows are shared by twice the columns --
+//      dW_hh 2.05 -> 1.70 ms per launch, dW_ih of birnn0 / 1 / 2 6.3 -> 5.5, 3.8 -> 3.2, 3.6 -> 3.1 ms (they ran on the
+//      512 x 128 and 192 x 320 tiles).  See the comment in front of it.
+//  Same k order and MFMA sequence per output element as the other tn kernels -> bit-identical results for equal split
+//  counts.  -DTNW160_PROBE=1..5: timing probes (wrong results) behind profiles/r5_gemm_probes.jsonl; -DTNW160_SLOTTED=0 /
+//  -DTNW160_WIDE=0: the previous stage body / no eight-wave kernel, for A/B builds.
 #include <cstdlib>
 #include <type_traits>
 #include "gemm_common.h"
