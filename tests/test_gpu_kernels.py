@@ -866,6 +866,59 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
         h.GEMM_PRECISION = old
 
 
+@pytest.mark.parametrize("R,M,N,S,ones", [(4096, 2400, 320, 8, True), (4104, 1200, 640, 3, True), (3000, 2400, 640, 1, False),
+                                          (4096, 2400, 513, 8, True), (4096, 1280, 512, 2, True), (4008, 1200, 768, 3, False),
+                                          (2000, 1200, 769, 1, True), (16 * 6, 2400, 513, 1, True)])
+def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
+    """The eight-wave weight-gradient workgroups of round 5 (csrc/gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_w8_kernel: 256 x
+    320 tiles for N = 320 q, 256 x 256 tiles for N = 256 q (+ one more real column), + the ones column; masks by
+    out-of-range loads, VALU extra columns reduced through LDS in a fixed order) bit for bit against the 128 x 128 tn kernel
+    on the MFMA columns for the same split count, against fp64 on every column, the same bits on a second run, and through
+    the opt-in two-product arithmetic: K tails (rows beyond K out of range), ragged last row tiles, several column tiles,
+    splits shorter than the pipeline.  (Split boundaries: this kernel cuts K in tiles of 16 rows, the 128 x 128 kernel in
+    tiles of 32 -- the shapes here put both on the same rows; where they differ the partial sums differ and only their
+    sum agrees.)"""
+    torch.manual_seed(17)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    try:
+        Nc = N + 1 if ones else N
+        dY = torch.randn(R, h.round_up(M, 4), device="cuda")
+        X = torch.full((R, h.round_up(Nc, 4)), 3.0, device="cuda")
+        X[:, :N] = torch.randn(R, N, device="cuda")
+        outs = {}
+        for kern in ("tn_w160", "tn"):
+            log = h.GEMM_LOG = []
+            with h.prefer_gemm_kernels(kern):
+                part, S_ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R, with_colsum=ones, splitk=S)
+            h.GEMM_LOG = None
+            assert [k for k, *_ in log] == [kern], log
+            outs[kern] = part.clone()
+        ldp = h.round_up(Nc, 4) if ones else N
+        a, b = outs["tn_w160"].view(S, M, ldp), outs["tn"].view(S, M, ldp)
+        nm = N // 320 * 320 if N % 320 == 0 else N // 256 * 256          # columns of the MFMA tiles
+        assert torch.equal(a[:, :, :nm], b[:, :, :nm]), int((a[:, :, :nm] != b[:, :, :nm]).sum())
+        got = a.double().sum(0)
+        ref = dY[:, :M].double().t() @ X[:, :N].double()
+        close(got[:, :N].float(), ref.float(), rtol=2e-4, atol=3e-3, name="eight-wave wgrad")
+        if ones:
+            close(got[:, N].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name="eight-wave wgrad column sums")
+        with h.prefer_gemm_kernels("tn_w160"):
+            again = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R, with_colsum=ones, splitk=S)[0]
+        assert torch.equal(again.view(S, M, ldp)[:, :, :Nc], a[:, :, :Nc])      # the same bits every run
+        h.WGRAD_PRODUCTS = 2
+        two = {}
+        for kern in ("tn_w160", "tn"):
+            with h.prefer_gemm_kernels(kern):
+                two[kern] = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R, with_colsum=ones, splitk=S)[0].clone()
+        assert torch.equal(two["tn_w160"].view(S, M, ldp)[:, :, :nm], two["tn"].view(S, M, ldp)[:, :, :nm])
+    finally:
+        h.WGRAD_PRODUCTS = 3
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("R,M,N,S", [(6072, 320, 600, 8), (1000, 320, 600, 1), (2580, 300, 530, 3), (3111, 318, 389, 2),
                                      (5000, 640, 257, 4), (40, 320, 600, 1), (2580, 320, 130, 3)])
 def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
