@@ -552,11 +552,23 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
       for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
     }
   };
-  // steady state: tile in `cur` computed, the registers' tile staged into `nxt`, tile ktl (full, inside the split) loaded
-  auto slotted = [&](const char* cur, char* nxt, int64_t ktl) __attribute__((always_inline)) {
+  // steady state: the tile in `cur` is computed, the registers' tile staged into `nxt`, tile ktl (full, inside the split)
+  // loaded.  The stage's ONE barrier stands in front of its LAST column block, not behind it: by then every LDS write to
+  // `nxt` and every read of `cur` has been issued, so behind the barrier the last six MFMAs cover the reads of the NEXT
+  // stage's first fragments (a_lo, the first b_hi, b_lo -- into the registers the last block has finished with; only the two
+  // a_hi reads remain at a stage's start).  With the barrier at the end every wave of the CU waited there for six transpose
+  // reads before its first MFMA.  PAR: which of the two b_hi registers holds a stage's first fragment (JW odd: they alternate).
+  bf16x8 al[2], bhA, bhB, bl;
+  auto first_frags = [&](const char* st) __attribute__((always_inline)) {      // in front of the first steady stage
+    if constexpr (!TWO) { al[0] = trv<VPA>(st + VARR_A + aoff); al[1] = trv<VPA>(st + VARR_A + aoff + 64); }
+    bhA = trv<PB>(st + boff);
+    bl = trv<PB>(st + ARRB + boff);
+  };
+  auto slotted = [&](auto par_tag, const char* cur, char* nxt, int64_t ktl) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
     advance_phase();
     const int soa = (int)((ktl - kt_begin) * BK * lda * 4), sob = (int)((ktl - kt_begin) * BK * ldb * 4);
-    bf16x8 ah[2], al[2], bhA, bhB, bl;
+    bf16x8 ah[2];
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
 #define SLOT __builtin_amdgcn_sched_barrier(0)
 #define MM(x, y, i, j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i][j], 0, 0, 0)
@@ -570,8 +582,16 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
 #define SB3(i) *reinterpret_cast<u32x2*>(nxt + soffB[i]) = u32x2{sh0, sh1};                                       \
                *reinterpret_cast<u32x2*>(nxt + ARRB + soffB[i]) = u32x2{sl0, sl1};                                \
                rb[i] = bload4(bsrd, bvo[i] | phase_oob(i), sob)
-#define FBH(dst, j) dst = trv<PB>(cur + boff + (j) * 64)
+    // X = the b_hi register of even column blocks, Y = of odd ones
+#define BX (PAR ? bhB : bhA)
+#define BY (PAR ? bhA : bhB)
+#define FBX(j) if constexpr (PAR) bhB = trv<PB>(cur + boff + (j) * 64); else bhA = trv<PB>(cur + boff + (j) * 64)
+#define FBY(j) if constexpr (PAR) bhA = trv<PB>(cur + boff + (j) * 64); else bhB = trv<PB>(cur + boff + (j) * 64)
 #define FBL(j) bl = trv<PB>(cur + ARRB + boff + (j) * 64)
+    // the next stage's first fragments (its b_hi goes where the next stage's PAR expects it: JW odd -> Y, JW even -> X)
+#define NAL(i) if constexpr (!TWO) al[i] = trv<VPA>(nxt + VARR_A + aoff + (i) * 64)
+#define NBH() if constexpr ((JW & 1) ? !PAR : PAR) bhB = trv<PB>(nxt + boff); else bhA = trv<PB>(nxt + boff)
+#define NBL() bl = trv<PB>(nxt + ARRB + boff)
 #define NOP_ (void)0
 #define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                \
     MM1(al[0], bh_, 0, j); X0; SLOT;                          \
@@ -580,29 +600,35 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     MM(ah[1], bl, 1, j); X3; SLOT;                            \
     MM(ah[0], bh_, 0, j); X4; SLOT;                           \
     MM(ah[1], bh_, 1, j); X5; SLOT
-    if constexpr (!TWO) al[0] = trv<VPA>(cur + VARR_A + aoff);
-    FBH(bhA, 0);
-    if constexpr (!TWO) al[1] = trv<VPA>(cur + VARR_A + aoff + 64);
+#define STAGE_BARRIER __syncthreads(); SLOT
     ah[0] = trv<VPA>(cur + aoff);
-    FBL(0);
     ah[1] = trv<VPA>(cur + aoff + 64);
     SLOT;
     if constexpr (JW == 5) {
-      JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
-      JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
-      JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), NOP_, FBL(3), SB12(2));
-      JBLOCK(3, bhB, FBH(bhA, 4), SB3(2), NOP_, NOP_, FBL(4), NOP_);
-      JBLOCK(4, bhA, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);
+      JBLOCK(0, BX, FBY(1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
+      JBLOCK(1, BY, FBX(2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
+      JBLOCK(2, BX, FBY(3), SB12(1), SB3(1), NOP_, FBL(3), SB12(2));
+      JBLOCK(3, BY, FBX(4), SB3(2), NOP_, NOP_, FBL(4), NOP_);
+      STAGE_BARRIER;
+      JBLOCK(4, BX, NBH(), NOP_, NAL(0), NAL(1), NBL(), NOP_);
     } else {
-      JBLOCK(0, bhA, FBH(bhB, 1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
-      JBLOCK(1, bhB, FBH(bhA, 2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
-      JBLOCK(2, bhA, FBH(bhB, 3), SB12(1), SB3(1), NOP_, FBL(3), NOP_);
-      JBLOCK(3, bhB, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);
+      JBLOCK(0, BX, FBY(1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
+      JBLOCK(1, BY, FBX(2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
+      JBLOCK(2, BX, FBY(3), SB12(1), SB3(1), NOP_, FBL(3), NOP_);
+      STAGE_BARRIER;
+      JBLOCK(3, BY, NBH(), NOP_, NAL(0), NAL(1), NBL(), NOP_);
     }
+#undef STAGE_BARRIER
 #undef JBLOCK
 #undef NOP_
+#undef NBL
+#undef NBH
+#undef NAL
 #undef FBL
-#undef FBH
+#undef FBY
+#undef FBX
+#undef BY
+#undef BX
 #undef SB3
 #undef SB12
 #undef SA3
@@ -610,8 +636,6 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
 #undef MM1
 #undef MM
 #undef SLOT
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (kt_begin < kt_end) {
@@ -621,10 +645,17 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     __syncthreads();
     int64_t kt = kt_begin;
     const int64_t lim = (kt_end < kt_full ? kt_end : kt_full) - 3;      // tiles kt + 2, kt + 3 full and inside the split
-    for (; kt < lim; kt += 2) {
-      slotted(lds0, lds1, kt + 2);
-      slotted(lds1, lds0, kt + 3);
+    if (kt < lim) {
+      first_frags(lds0);
+      using P0 = std::integral_constant<int, 0>;
+      using P1 = std::integral_constant<int, (JW & 1)>;
+      for (; kt < lim; kt += 2) {      // (ONE loop exit: the accumulators stay where they are)
+        slotted(P0{}, lds0, lds1, kt + 2);
+        slotted(P1{}, lds1, lds0, kt + 3);
+      }
     }
+    // tail: `lds0` holds tile kt, the registers tile kt + 1 (if inside the split); every wave is behind the last steady
+    // stage's barrier, i.e. done with its reads of the buffer the first tail stage writes
     for (int par = 0; kt < kt_end; ++kt, par ^= 1) {
       const char* cur = par ? lds1 : lds0;
       char* nxt = par ? lds0 : lds1;
