@@ -839,7 +839,8 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
             Nc = N if shift else N + 1
             ldp = outs["1"].numel() // (S * M)
             a, b = outs["1"].view(S, M, ldp)[:, :, :Nc], outs["0"].view(S, M, ldp)[:, :, :Nc]
-            assert torch.equal(a, b), f"shift {shift}: {(a != b).sum().item()} differ"
+            # (the ones column: the eight-wave workgroups sum it on the VALU, the other kernels through the MFMAs -- fp64 below)
+            assert torch.equal(a[:, :, :N], b[:, :, :N]), f"shift {shift}: {(a[:, :, :N] != b[:, :, :N]).sum().item()} differ"
             hs = torch.zeros(n, T, N, device="cuda", dtype=torch.float64)
             hv = hh[:, :N].double().view(n, T, N)
             if shift == -1:
@@ -868,7 +869,8 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
 
 @pytest.mark.parametrize("R,M,N,S,ones", [(4096, 2400, 320, 8, True), (4104, 1200, 640, 3, True), (3000, 2400, 640, 1, False),
                                           (4096, 2400, 513, 8, True), (4096, 1280, 512, 2, True), (4008, 1200, 768, 3, False),
-                                          (2000, 1200, 769, 1, True), (16 * 6, 2400, 513, 1, True)])
+                                          (2000, 1200, 769, 1, True), (16 * 6, 2400, 513, 1, True), (4096, 2400, 553, 8, True),
+                                          (3008, 1200, 556, 2, False)])
 def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
     """The eight-wave weight-gradient workgroups of round 5 (csrc/gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_w8_kernel: 256 x
     320 tiles for N = 320 q, 256 x 256 tiles for N = 256 q (+ one more real column), + the ones column; masks by
@@ -897,7 +899,8 @@ def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
             outs[kern] = part.clone()
         ldp = h.round_up(Nc, 4) if ones else N
         a, b = outs["tn_w160"].view(S, M, ldp), outs["tn"].view(S, M, ldp)
-        nm = N // 320 * 320 if N % 320 == 0 else N // 256 * 256          # columns of the MFMA tiles
+        # columns of the MFMA tiles: N = 320 q; N = 256 q (+ 1); else a ragged last 320-wide tile (+ 1 when N % 4 == 1)
+        nm = N if N % 320 == 0 else (N // 256 * 256 if N % 256 <= 1 else N - N % 4)
         assert torch.equal(a[:, :, :nm], b[:, :, :nm]), int((a[:, :, :nm] != b[:, :, :nm]).sum())
         got = a.double().sum(0)
         ref = dY[:, :M].double().t() @ X[:, :N].double()

@@ -57,8 +57,9 @@ def test_splitk_choice():
         # within 7 % of the best fill of whole rounds of 32 -- 10, 20 and 40 tiles -> 3 slabs (30 / 32, 60 / 64, 120 / 128)
         assert H.pick_splitk(2400, 321, 777216, ones_col=True) == 24 and H.pick_splitk(2400, 514, 777216, ones_col=True) == 24
         assert H.pick_splitk(2400, 1281, 194304, ones_col=True) == 24
-        # the 512 x 128 tile keeps what is left: N = 554 = 4 x 128 + 42 -> 5 column tiles, 25 tiles -> 1 slab (25 / 32)
-        assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 8
+        # the pre-net's N = 553 + 1: a ragged second 320-column tile (640 columns, as many as five 128-wide tiles), column 552
+        # and the ones column on the VALU: 20 tiles -> 3 slabs; N = 873 + 1 (960 against 896 columns) stays on the 512 x 128 tile
+        assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 24
         # dW_hh: both 160-column tiles in one 256 x 320 workgroup: 5 tiles -> 6 slabs per XCD (30 / 32)
         assert H.pick_splitk(1200, 300, 777216, shifted=True) == 48 and H.pick_splitk(1200, 300, 194304, shifted=True) == 48
         # the projection weight gradients (M = 320): the 320 x 128 tile, 5 column tiles, two workgroups per CU
@@ -107,7 +108,10 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     assert plan(4 * R, 320, 600, act=1) == "big_p320" and plan(4 * R, 320, 600, act=1, remap=True) == "big_p320"
     assert plan(4 * R, 600, 320) == "big_p320" and plan(4 * R, 1000, 320) == "big_p"  # dgrad proj dh: 640 columns computed for 600
     assert plan(4 * R, 780, 320) == "stream"                                         # ... 1024 for 780 is too many
-    assert plan(2400, 557, R, wgrad=True, ones=True) == "tn_big"
+    # round 5: the dW_ih GEMMs on the eight-wave workgroups of tn_w160 wherever 320-wide column tiles pad no more than 128-wide ones
+    assert plan(2400, 557, R, wgrad=True, ones=True) == "tn_w160" and plan(2400, 554, R, wgrad=True, ones=True) == "tn_w160"
+    assert plan(2400, 514, 4 * R, wgrad=True, ones=True) == "tn_w160" and plan(2400, 321, 4 * R, wgrad=True, ones=True) == "tn_w160"
+    assert plan(2400, 1281, R, wgrad=True, ones=True) == "tn_w160" and plan(2400, 874, R, wgrad=True, ones=True) == "tn_big"
     assert plan(1200, 300, 4 * R, wgrad=True, shifted=True) == "tn_w160"
     assert plan(320, 601, 4 * R, wgrad=True, ones=True) == "tn_h160"
     assert plan(513, 601, R, wgrad=True, ones=True) == "tn"

@@ -21,6 +21,8 @@ def timeit(fn, reps=6):
 
 
 SHAPES = [("dW_ih birnn0", 2400, 513, 3072 * T), ("dW_ih birnn1", 2400, 320, 3072 * T), ("dW_ih birnn2", 2400, 1280, 768 * T)]
+if "--prenet" in sys.argv:      # N = 553 + 1: ragged last 320-column tile, column 552 and the ones column on the VALU
+    SHAPES = [("dW_ih pre-net", 2400, 553, 768 * T), ("N 873", 2400, 873, 768 * T), ("N 552 no VALU column", 2400, 552, 768 * T)]
 if "--other" in sys.argv:       # shapes of other configurations the dispatch rule also sends to the eight-wave kernel
     SHAPES = [("N 768", 2400, 768, 768 * T), ("N 1024", 2400, 1024, 768 * T), ("N 1536", 2400, 1536, 768 * T), ("N 640", 2400, 640, 3072 * T),
               ("N 2560 (8 speakers)", 2400, 2560, 768 * T), ("M 1200 N 512", 1200, 512, 3072 * T), ("small K: dW_ih birnn0", 2400, 513, 32 * T)]

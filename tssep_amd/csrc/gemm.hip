@@ -440,8 +440,7 @@ static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid) {
       // rounds of 32 best, the smallest one among equals, >= 64 K tiles per split (tools/exp_wgrad_w320.py: dW_ih of birnn1,
       // 10 tiles: 3.14 ms at S = 24, 3.25 at 48, 3.75 at 16; birnn2, 40 tiles: 3.00 at 32, 3.09 at 24, 3.43 at 48; dW_hh,
       // 5 tiles: 48; tools/exp_wgrad_w320.py --sweep)
-      const int64_t nr = N - (g->b_ones_col ? 1 : 0);
-      const int64_t tiles = (rup(M, 256) / 256) * (wide == 5 ? cdiv(nr, 320) : nr / 256);      // (256-wide: the 513th column rides on the VALU)
+      const int64_t tiles = (rup(M, 256) / 256) * cdiv(tn_w160_wide_cols(g, wide), wide == 5 ? 320 : 256);      // (extra columns ride on the VALU)
       // (the smallest S within 7 % of the best fill: dW_ih of birnn0, 20 tiles, 5.54 ms at S = 24 (60 per XCD), 5.69-5.79 at 64
       // (160 = five full rounds) -- and a third of the partial sums to reduce)
       auto fill = [&](int S) { const int64_t wg = tiles * (S / 8); return (double)rup(wg, 32) / (double)wg; };

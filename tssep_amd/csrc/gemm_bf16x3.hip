@@ -1330,8 +1330,9 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         const int wide = tn_w160_wide(g);
         // (256 x 256 workgroups, round 5: dW_ih of birnn0, N = 513 + 1 -- two column tiles + two VALU columns, 20 % fewer staged
         // bytes per MFMA than the 512 x 128 tile)
-        const bool takes = (wide == 5 && nr % 320 == 0) || wide == 4;
-        const int64_t tilesw = (m256w / 256) * (wide == 4 ? nr / 256 : nr / 320);
+        const int64_t ncols = wide ? tn_w160_wide_cols(g, wide) : 0;
+        const bool takes = wide == 4 || (wide == 5 && (ncols + 319) / 320 * 320 <= (g->N + 127) / 128 * 128);
+        const int64_t tilesw = (m256w / 256) * ((ncols + (wide == 4 ? 255 : 319)) / (wide == 4 ? 256 : 320));
         if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && takes && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
                                                    tn_fills(tilesw))) {
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);

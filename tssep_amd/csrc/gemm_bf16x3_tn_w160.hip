@@ -458,8 +458,7 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
   }
   const srd_t asrd = make_srd(A + k_begin * lda);
   const srd_t bsrd = make_srd(B + (k_begin + (SHIFT ? kshift : 0)) * ldb);
-  const int64_t nfull = (int64_t)tmap.NT * G::WN;           // first extra column (XC)
-  const srd_t xsrd = make_srd(B + k_begin * ldb + (XR ? nfull : 0));
+  const srd_t xsrd = make_srd(B + k_begin * ldb + (XR ? N : 0));      // the one more real column: column N of B
   const unsigned avo = (unsigned)((krA * lda + m0 + cqA) * 4) | (m0 + cqA >= M ? VOOR : 0u);
   const unsigned xvo = (unsigned)(krA * ldb * 4);
   unsigned bvo[NPB];
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     return 0u;
   };
   f32x4 ra[2], rb[NPB];
-  float rx[2] = {0.f, 0.f};                   // XR: B[k row of A piece i][nfull]
+  float rx[2] = {0.f, 0.f};                   // XR: B[k row of A piece i][N]
   float xacc[XN_ > 0 ? XN_ : 1][4];            // sums over this thread's k rows, for its four A columns: [real column][ones column]
 #pragma unroll
   for (int e = 0; e < (XN_ > 0 ? XN_ : 1); ++e)
@@ -737,10 +736,11 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   if (TNW160_WIDE && wide) {
     // 0 = no; 5 -> 256 x 320 workgroups (XC = 0 / 1), 4 -> 256 x 256 (XC = 0 / 1 / 10 / 11)
     const int xo = g->b_ones_col ? 1 : 0;
-    const int xr = wide == 4 ? (int)((g->N - xo) % 256) : 0;
+    const int64_t ncols = gemm_detail::tn_w160_wide_cols(g, wide);
+    const int xr = (int)(g->N - xo - ncols);
     const int xc = 10 * xr + xo;
     const int wn_ = wide == 5 ? 320 : 256;
-    const TileMap tmw = make_tile_map(m256 / VM, (g->N - xr - xo + wn_ - 1) / wn_, splitk);
+    const TileMap tmw = make_tile_map(m256 / VM, (ncols + wn_ - 1) / wn_, splitk);
     const dim3 gridw((unsigned)tile_map_blocks(tmw));
 #define W_LAUNCH(SH, TW, XC_, JW_) hipLaunchKernelGGL((gemm_bf16x3_tn_w8_kernel<SH, TW, XC_, JW_>), gridw, dim3(XNT), 0, (hipStream_t)stream, \
       g->A, g->B, g->C, g->M, g->N, g->K, g->lda, g->ldb, (int)g->b_kshift, shift ? (int)g->kperiod : 1, g->accumulate, sm.ldc, \
@@ -748,6 +748,8 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
 #define W_TWO(SH, XC_, JW_) do { if (two) W_LAUNCH(SH, true, XC_, JW_); else W_LAUNCH(SH, false, XC_, JW_); } while (0)
     if (wide == 5) {
       if (shift) W_TWO(true, 0, 5);
+      else if (xc == 11) W_TWO(false, 11, 5);
+      else if (xc == 10) W_TWO(false, 10, 5);
       else if (xc == 1) W_TWO(false, 1, 5);
       else W_TWO(false, 0, 5);
     } else {

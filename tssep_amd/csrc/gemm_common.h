@@ -513,18 +513,25 @@ int tssep_gemm_bf16x3_tn_p320_launch(const tssep_gemm_args* g, const gemm_detail
 // (gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_h160.hip)
 namespace gemm_detail {
 // tn_w160 runs eight-wave workgroups (512 threads, ONE per CU; masks by out-of-range loads) where the shape allows:
-// 5 -> 256 x 320 tiles: M, N multiples of 4 and an even number of 160-column tiles without the ones column, or
-//      N = 320 q + 1 with it (unshifted);
+// 5 -> 256 x 320 tiles: M and the MFMA columns multiples of 4; an even number of 160-column tiles without the ones column
+//      (also time-shifted), or (unshifted) N = 320 q (+ the ones column), or a ragged last tile where 320-wide tiles pad no
+//      more than 128-wide ones, with one more real column (N % 4 == 1: the pre-net's 553) and the ones column on the VALU;
 // 4 -> 256 x 256 tiles (unshifted): N = 256 q + XR + XO, q >= 2, XR <= 1 more real column and the ones column (XO) on the
 //      VALU -- dW_ih of birnn0: 513 + 1;
 // 0 -> the 256 x 160 workgroups.  The launcher, the dispatcher and the split rule (gemm.hip) all ask here.
 inline int tn_w160_wide(const tssep_gemm_args* g) {
   if (g->M & 3) return 0;
-  const int64_t xo = g->b_ones_col ? 1 : 0;
-  if (g->kperiod <= 0 && (g->N - xo) >= 320 && (g->N - xo) % 320 == 0) return 5;
+  const int64_t xo = g->b_ones_col ? 1 : 0, nr = g->N - xo;
+  if (g->kperiod <= 0 && nr >= 320 && nr % 320 == 0) return 5;
   if (!xo && (g->N & 3) == 0 && (((g->N + 159) / 160) & 1) == 0) return 5;
-  if (g->kperiod <= 0 && g->N - xo >= 512 && (g->N - xo) % 256 <= 1) return 4;
+  if (g->kperiod <= 0 && nr >= 512 && nr % 256 <= 1) return 4;
+  if (g->kperiod <= 0 && nr > 320 && (nr & 3) <= 1 && (nr - (nr & 3) + 319) / 320 * 320 <= (nr + 127) / 128 * 128) return 5;
   return 0;
+}
+// columns of the MFMA tiles of such a request (the one more real column and the ones column come on top)
+inline int64_t tn_w160_wide_cols(const tssep_gemm_args* g, int wide) {
+  const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
+  return wide == 4 ? nr - nr % 256 : nr - (nr & 3);
 }
 }  // namespace gemm_detail
 int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail::StoreMap& sm, int splitk, int two, const gemm_detail::GemmCall& call);
