@@ -396,8 +396,9 @@ __global__ __launch_bounds__(VNT, 2) void gemm_bf16x3_tn_w160_kernel(
 // (M and the MFMA columns multiples of 4), every stage of the steady state written slot by slot like `slotted` above;
 // prologue and tail use a general loader (rows beyond K, time shift at the ends of the matrix: all out of range).  Same k
 // order and products per output element: bit-identical to the other tn kernels for equal split counts.
-// XC = 10 XR + XO (unshifted only, as in gemm_bf16x3_tn_big.hip): N = 64 JW q + XR + XO -- the MFMA tiles cover the first
-// columns; then XR <= 1 real columns of B and XO <= 1 virtual ones column (the bias gradient) are accumulated on the VALU
+// XC = 10 XR + XO (unshifted only, as in gemm_bf16x3_tn_big.hip): N = Nm + XR + XO -- the MFMA tiles cover the first Nm
+// columns (a multiple of 4; the last column tile may be ragged: pieces beyond Nm are out of range); then XR <= 1 real
+// columns of B and XO <= 1 virtual ones column (the bias gradient) are accumulated on the VALU
 // from the raw fp32 A pieces every thread stages anyway (exact fp32 chains in the order of the k rows, the eight row groups
 // of a workgroup reduced through LDS in a fixed order: deterministic; the workgroups of the last column tile write them).
 template <int JW> struct W8 {
