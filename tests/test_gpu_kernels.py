@@ -870,14 +870,16 @@ def test_gemm_wgrad_160_wide_tile_against_the_tn_kernels(n, T, M, N, S):
 @pytest.mark.parametrize("R,M,N,S,ones", [(4096, 2400, 320, 8, True), (4104, 1200, 640, 3, True), (3000, 2400, 640, 1, False),
                                           (4096, 2400, 513, 8, True), (4096, 1280, 512, 2, True), (4008, 1200, 768, 3, False),
                                           (2000, 1200, 769, 1, True), (16 * 6, 2400, 513, 1, True), (4096, 2400, 553, 8, True),
-                                          (3008, 1200, 556, 2, False)])
+                                          (3008, 1200, 556, 2, False), (4096, 320, 600, 8, True), (6080, 256, 1200, 5, False),
+                                          (16 * 6, 320, 600, 1, True), (4104, 320, 600, 3, True)])
 def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
     """The eight-wave weight-gradient workgroups of round 5 (csrc/gemm_bf16x3_tn_w160.hip, gemm_bf16x3_tn_w8_kernel: 256 x
     320 tiles for N = 320 q, 256 x 256 tiles for N = 256 q (+ one more real column), + the ones column; masks by
     out-of-range loads, VALU extra columns reduced through LDS in a fixed order) bit for bit against the 128 x 128 tn kernel
     on the MFMA columns for the same split count, against fp64 on every column, the same bits on a second run, and through
     the opt-in two-product arithmetic: K tails (rows beyond K out of range), ragged last row tiles, several column tiles,
-    splits shorter than the pipeline.  (Split boundaries: this kernel cuts K in tiles of 16 rows, the 128 x 128 kernel in
+    splits shorter than the pipeline; M <= 320: the swapped-operand launch (transposed store, the ones column as a row of ones).
+    (Split boundaries: this kernel cuts K in tiles of 16 rows, the 128 x 128 kernel in
     tiles of 32 -- the shapes here put both on the same rows; where they differ the partial sums differ and only their
     sum agrees.)"""
     torch.manual_seed(17)
@@ -901,6 +903,8 @@ def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
         a, b = outs["tn_w160"].view(S, M, ldp), outs["tn"].view(S, M, ldp)
         # columns of the MFMA tiles: N = 320 q; N = 256 q (+ 1); else a ragged last 320-wide tile (+ 1 when N % 4 == 1)
         nm = N if N % 320 == 0 else (N // 256 * 256 if N % 256 <= 1 else N - N % 4)
+        if M <= 320:      # swapped operands (the projection weight gradients): every column, the ones column too, on the MFMAs
+            nm = Nc
         assert torch.equal(a[:, :, :nm], b[:, :, :nm]), int((a[:, :, :nm] != b[:, :, :nm]).sum())
         got = a.double().sum(0)
         ref = dY[:, :M].double().t() @ X[:, :N].double()

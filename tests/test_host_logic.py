@@ -62,8 +62,9 @@ def test_splitk_choice():
         assert H.pick_splitk(2400, 554, 194304, ones_col=True) == 24
         # dW_hh: both 160-column tiles in one 256 x 320 workgroup: 5 tiles -> 6 slabs per XCD (30 / 32)
         assert H.pick_splitk(1200, 300, 777216, shifted=True) == 48 and H.pick_splitk(1200, 300, 194304, shifted=True) == 48
-        # the projection weight gradients (M = 320): the 320 x 128 tile, 5 column tiles, two workgroups per CU
-        assert H.pick_splitk(320, 601, 777216, ones_col=True) == 96 and H.pick_splitk(320, 601, 25600, ones_col=True) == 96
+        # the projection weight gradients (M = 320): round 5, with enough rows, the eight-wave workgroups on the SWAPPED problem
+        # (three 256 x 320 tiles -> 80 splits, 30 workgroups per XCD); short K: the 320 x 128 tile, 5 column tiles, two per CU
+        assert H.pick_splitk(320, 601, 777216, ones_col=True) == 80 and H.pick_splitk(320, 601, 25600, ones_col=True) == 96
         assert H.pick_splitk(640, 601, 777216, ones_col=True) == 32              # (M = 640 fits the 128-row tiles: 25 tiles)
         # one 128 x 128 tile with a long K never gets more splits than it has K-tile groups of 8
         assert H.pick_splitk(100, 100, 16 * 512) == 64 and H.pick_splitk(100, 100, 16 * 2048) <= 256
@@ -113,7 +114,7 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     assert plan(2400, 514, 4 * R, wgrad=True, ones=True) == "tn_w160" and plan(2400, 321, 4 * R, wgrad=True, ones=True) == "tn_w160"
     assert plan(2400, 1281, R, wgrad=True, ones=True) == "tn_w160" and plan(2400, 874, R, wgrad=True, ones=True) == "tn_big"
     assert plan(1200, 300, 4 * R, wgrad=True, shifted=True) == "tn_w160"
-    assert plan(320, 601, 4 * R, wgrad=True, ones=True) == "tn_h160"
+    assert plan(320, 601, 4 * R, wgrad=True, ones=True) == "tn_w160" and plan(320, 601, 100 * 253, wgrad=True, ones=True) == "tn_h160"
     assert plan(513, 601, R, wgrad=True, ones=True) == "tn"
     assert plan(100, 50, 30) == "pipe" and plan(100, 50, 30, prec=0) == "f32"
     # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the

@@ -436,6 +436,17 @@ static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid) {
   }
   if (kid == TSSEP_GEMM_TN_W160 && ktiles >= 64 * 8) {
     if (const int wide = tn_w160_wide(g)) {
+      if (wide == 7) {
+        // swapped operands: the tiles of the transposed problem (three for 320 x 600 + 1), up to 96 splits as on the 320 x 128
+        // tile before (0.92 ms at S = 80, 1.06 at 64, 1.16 at 48; 777 216 rows)
+        const int64_t tiles = cdiv(N, 256) * cdiv(M, 320);
+        auto fill = [&](int S) { const int64_t wg = tiles * (S / 8); return (double)rup(wg, 32) / (double)wg; };
+        double waste = 1e30;
+        for (int S = 8; S <= 96 && (int64_t)S * 64 <= ktiles; S += 8) waste = fill(S) < waste ? fill(S) : waste;
+        for (int S = 8; S <= 96 && (int64_t)S * 64 <= ktiles; S += 8)
+          if (fill(S) <= waste * 1.07) return S;
+        return 8;
+      }
       // 256 x 320 tiles, ONE workgroup per CU, the tiles of a K slab on one XCD (32 CUs): the multiple of 8 that fills whole
       // rounds of 32 best, the smallest one among equals, >= 64 K tiles per split (tools/exp_wgrad_w320.py: dW_ih of birnn1,
       // 10 tiles: 3.14 ms at S = 24, 3.25 at 48, 3.75 at 16; birnn2, 40 tiles: 3.00 at 32, 3.09 at 24, 3.43 at 48; dW_hh,

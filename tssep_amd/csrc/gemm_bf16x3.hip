@@ -1333,6 +1333,12 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
         const int64_t ncols = wide ? tn_w160_wide_cols(g, wide) : 0;
         const bool takes = wide == 4 || (wide == 5 && (ncols + 319) / 320 * 320 <= (g->N + 127) / 128 * 128);
         const int64_t tilesw = (m256w / 256) * ((ncols + (wide == 4 ? 255 : 319)) / (wide == 4 ? 256 : 320));
+        // (swapped operands, round 5: the projection weight gradients -- 320 x 600 + 1 -- 0.92 against 1.34 ms on the 320 x 128 tile)
+        // (from K = 81 920 rows: the three tiles of the swapped problem need ~80 splits of >= 64 K tiles each to fill the chip)
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && wide == 7 && !two && g->K >= 80 * 64 * 16)) {
+          const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
+          if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
+        }
         if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && takes && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
                                                    tn_fills(tilesw))) {
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);

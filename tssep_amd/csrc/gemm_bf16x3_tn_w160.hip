@@ -411,7 +411,17 @@ template <int JW> struct W8 {
 };
 constexpr int XNT = 512;
 
-template <bool SHIFT, bool TWO, int XC, int JW>
+// SW (round 5, the projection weight gradients: M = 320 outputs against N = 600 + 1 inputs, which no eight-wave tile fits
+// the way they are asked): the launcher SWAPS the operands -- the kernel's A is the caller's X (M' = 600 (+ 1) rows of the
+// transposed result in three 256-row tiles), its B the caller's dY (N' = 320: one 320-column tile) -- and the kernel
+// stores its accumulators TRANSPOSED, straight from the registers (a lane's four consecutive accumulator registers are
+// four consecutive columns of one row of the caller's C: 16-byte stores, no LDS transposition).  The ones column of the
+// caller (XO) is then ROW M' of the kernel's A: the A piece that holds it is set to {1, 0, 0, 0} by value when staged (rows
+// inside K only), the MFMAs do the rest -- the column sums of dY exactly as the other kernels' ones column computes them.
+// The three products of a k-step keep the CALLER's order per accumulator (a_hi b_lo first: the caller's dY_lo X_hi), so
+// the result is bit-identical to the unswapped kernels.  1.34 -> 0.92 ms per launch at 777 216 rows (tn_h160: 320 x 128
+// tiles, two four-wave workgroups per CU, matrix pipe busy 0.52).
+template <bool SHIFT, bool TWO, int XC, int JW, bool SW = false>
 __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int64_t M, int64_t Nfull,
     int64_t K, int64_t lda, int64_t ldb, int kshift, int kperiod, int accumulate, int64_t ldc, int splitk,
@@ -419,8 +429,9 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
   using G = W8<JW>;
   constexpr int XR = XC / 10, XO = XC % 10, XN_ = XR + XO;
   static_assert(!(SHIFT && XC), "extra columns exist for unshifted GEMMs only");
+  static_assert(!SW || (!SHIFT && !TWO && XR == 0), "swapped operands: unshifted, three products, ones row only");
   static_assert(4 * 64 * EPITCH * 4 <= 2 * G::STAGE, "four epilogue scratches at a time");
-  const int64_t N = Nfull - XN_;                    // columns of the MFMA tiles (all real)
+  const int64_t N = SW ? Nfull : Nfull - XN_;       // columns of the MFMA tiles (all real)
   constexpr int BK = VBK, NPB = G::NPB, PB = G::PB, ARRB = G::ARRB;
   __shared__ __attribute__((aligned(16))) char lds[2 * G::STAGE];
   char* const lds0 = lds;
@@ -490,14 +501,19 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
   for (int e = 0; e < (XN_ > 0 ? XN_ : 1); ++e)
 #pragma unroll
     for (int c = 0; c < 4; ++c) xacc[e][c] = 0.f;
-#define XSUM(i) { if constexpr (XR > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[0][c_] = fmaf(ra[i][c_], rx[i], xacc[0][c_]); } \
-                  if constexpr (XO > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[XR][c_] += ra[i][c_]; } }
+  // SW: this thread's A pieces hold row M of the kernel's A (the caller's ones column); rowok[i]: piece i's k row lies inside K
+  const bool ones_piece = SW && XO > 0 && m0 + cqA == M;
+  bool rowok[2] = {true, true};
+#define XSUM(i) { if constexpr (SW) { if constexpr (XO > 0) ra[i][0] = (ones_piece && rowok[i]) ? 1.f : ra[i][0]; }          \
+                  else { if constexpr (XR > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[0][c_] = fmaf(ra[i][c_], rx[i], xacc[0][c_]); } \
+                         if constexpr (XO > 0) { _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) xacc[XR][c_] += ra[i][c_]; } } }
   // general loader (prologue, tail): tile kt, rows beyond K out of range; `ph` is the phase of tile kt
   auto gload_any = [&](int64_t kt) __attribute__((always_inline)) {
     const int64_t rel = (kt - kt_begin) * BK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const unsigned tail = kt * BK + krA + 8 * i < K ? 0u : VOOR;
+      rowok[i] = tail == 0u;
       ra[i] = bload4(asrd, (avo + (unsigned)((rel + 8 * i) * lda * 4)) | tail, 0);
       if constexpr (XR > 0) rx[i] = bload1(xsrd, (xvo + (unsigned)((rel + 8 * i) * ldb * 4)) | tail, 0);
     }
@@ -542,12 +558,18 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
     for (int j = 0; j < JW; ++j) {
       const bf16x8 bh = trv<PB>(st + boff + j * 64);
       const bf16x8 bl = trv<PB>(st + ARRB + boff + j * 64);
+      if (SW) {      // (the caller's order: its a_lo b_hi is this kernel's a_hi b_lo)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+      }
       if (!TWO) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
       }
+      if (!SW) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
     }
@@ -593,13 +615,17 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
 #define NBH() if constexpr ((JW & 1) ? !PAR : PAR) bhB = trv<PB>(nxt + boff); else bhA = trv<PB>(nxt + boff)
 #define NBL() bl = trv<PB>(nxt + ARRB + boff)
 #define NOP_ (void)0
-#define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                \
-    MM1(al[0], bh_, 0, j); X0; SLOT;                          \
-    MM1(al[1], bh_, 1, j); X1; SLOT;                          \
-    MM(ah[0], bl, 0, j); X2; SLOT;                            \
-    MM(ah[1], bl, 1, j); X3; SLOT;                            \
-    MM(ah[0], bh_, 0, j); X4; SLOT;                           \
+    // (SW: a_hi b_lo in front of a_lo b_hi -- the caller's product order; b_lo is free two slots earlier, a_lo two later)
+#define JBLOCK(j, bh_, X0, X1, X2, X3, X4, X5)                                                      \
+    if constexpr (SW) { MM(ah[0], bl, 0, j); } else { MM1(al[0], bh_, 0, j); } X0; SLOT;            \
+    if constexpr (SW) { MM(ah[1], bl, 1, j); } else { MM1(al[1], bh_, 1, j); } X1; SLOT;            \
+    if constexpr (SW) { MM1(al[0], bh_, 0, j); } else { MM(ah[0], bl, 0, j); } X2; SLOT;            \
+    if constexpr (SW) { MM1(al[1], bh_, 1, j); } else { MM(ah[1], bl, 1, j); } X3; SLOT;            \
+    MM(ah[0], bh_, 0, j); X4; SLOT;                                                                 \
     MM(ah[1], bh_, 1, j); X5; SLOT
+#define LASTBLOCK(j, bh_)                                                                            \
+    if constexpr (SW) { JBLOCK(j, bh_, NBH(), NOP_, NBL(), NOP_, NAL(0), NAL(1)); }                  \
+    else { JBLOCK(j, bh_, NBH(), NOP_, NAL(0), NAL(1), NBL(), NOP_); }
 #define STAGE_BARRIER __syncthreads(); SLOT
     ah[0] = trv<VPA>(cur + aoff);
     ah[1] = trv<VPA>(cur + aoff + 64);
@@ -610,15 +636,16 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
       JBLOCK(2, BX, FBY(3), SB12(1), SB3(1), NOP_, FBL(3), SB12(2));
       JBLOCK(3, BY, FBX(4), SB3(2), NOP_, NOP_, FBL(4), NOP_);
       STAGE_BARRIER;
-      JBLOCK(4, BX, NBH(), NOP_, NAL(0), NAL(1), NBL(), NOP_);
+      LASTBLOCK(4, BX);
     } else {
       JBLOCK(0, BX, FBY(1), SA12(0), SA3(0), NOP_, FBL(1), SA12(1));
       JBLOCK(1, BY, FBX(2), SA3(1), NOP_, SB12(0), FBL(2), SB3(0));
       JBLOCK(2, BX, FBY(3), SB12(1), SB3(1), NOP_, FBL(3), NOP_);
       STAGE_BARRIER;
-      JBLOCK(3, BY, NBH(), NOP_, NAL(0), NAL(1), NBL(), NOP_);
+      LASTBLOCK(3, BY);
     }
 #undef STAGE_BARRIER
+#undef LASTBLOCK
 #undef JBLOCK
 #undef NOP_
 #undef NBL
@@ -667,7 +694,29 @@ __global__ __launch_bounds__(XNT, 1) void gemm_bf16x3_tn_w8_kernel(
   }
 #undef XSUM
   float* Cz = C + (int64_t)zsplit * c_split_stride;
-  if constexpr (XN_ > 0) {
+  if constexpr (SW) {
+    // transposed store: element (m, n) of the kernel's tile is C[n][m] of the caller; lane = column n of a 32 x 32 MFMA
+    // tile, registers 4 q .. 4 q + 3 = rows m, m + 1, m + 2, m + 3
+    const int64_t mstore = (M + (XO > 0 ? 1 : 0) + 3) & ~(int64_t)3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < JW; ++j) {
+        const int64_t n = n0 + wn * 32 * JW + j * 32 + (lane & 31);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t m = m0 + wm * 64 + i * 32 + 8 * q + 4 * (lane >> 5);
+          if (n < N && m < mstore) {
+            float* dst = Cz + n * ldc + m;
+            f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = v;
+          }
+        }
+      }
+    return;
+  }
+  if constexpr (XN_ > 0 && !SW) {
     if (nt == tmap.NT - 1) {                  // workgroup-uniform
       float* xs = reinterpret_cast<float*>(lds);            // [extra column][row group = wave][256 columns of A]
 #pragma unroll
@@ -722,11 +771,28 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
   const bool shift = g->kperiod > 0;
   const int64_t ks = g->b_kshift < 0 ? -g->b_kshift : g->b_kshift;
   const int64_t m256 = (g->M + VM - 1) / VM * VM;
+  const int wide = gemm_detail::tn_w160_wide(g);
+  if (wide == 7) {
+    // swapped operands (see the kernel): A' = X [K][N - ones], B' = dY [K][M], the result stored transposed
+    if (!TNW160_WIDE || two || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
+    const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
+    if (sm.ldc < ((g->N + 3) & ~(int64_t)3)) return TSSEP_E_UNSUPPORTED;
+    const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
+    const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;
+    if ((per + 4) * VBK * ldmax * 4 >= ((int64_t)1 << 31)) return TSSEP_E_UNSUPPORTED;
+    if (call.dry) return TSSEP_OK;
+    const TileMap tms = make_tile_map((g->N + 255) / 256, (g->M + 319) / 320, splitk);
+    const dim3 grids((unsigned)tile_map_blocks(tms));
+#define S_LAUNCH(XC_) hipLaunchKernelGGL((gemm_bf16x3_tn_w8_kernel<false, false, XC_, 5, true>), grids, dim3(XNT), 0, (hipStream_t)stream, \
+      g->B, g->A, g->C, nr, g->M, g->K, g->ldb, g->lda, 0, 1, g->accumulate, sm.ldc, splitk, g->c_split_stride, tms)
+    if (g->b_ones_col) S_LAUNCH(1); else S_LAUNCH(0);
+#undef S_LAUNCH
+    return tssep_launch_status();
+  }
   if (g->M < 1024 || (m256 - g->M) * 100 > 8 * g->M || (shift && ks > 16) || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
   // masks by out-of-range loads: whole four-column pieces only (the time-shifted kernel exists in this form alone)
   const bool oob = (g->M & 3) == 0 && (g->N & 3) == 0 && !g->b_ones_col;
   if (shift && !oob) return TSSEP_E_UNSUPPORTED;
-  const int wide = gemm_detail::tn_w160_wide(g);
   // 32-bit buffer offsets inside a split
   const int64_t ktiles = (g->K + VBK - 1) / VBK, per = (ktiles + splitk - 1) / splitk;
   const int64_t ldmax = g->lda > g->ldb ? g->lda : g->ldb;

@@ -518,10 +518,14 @@ namespace gemm_detail {
 //      more than 128-wide ones, with one more real column (N % 4 == 1: the pre-net's 553) and the ones column on the VALU;
 // 4 -> 256 x 256 tiles (unshifted): N = 256 q + XR + XO, q >= 2, XR <= 1 more real column and the ones column (XO) on the
 //      VALU -- dW_ih of birnn0: 513 + 1;
+// 7 -> 256 x 320 tiles with SWAPPED operands (unshifted): few output rows (192 < M <= 320: one 320-column tile of the
+//      swapped problem), many columns (N = 4 q >= 512, padding to 256-row tiles by at most 30 %) -- the projection weight
+//      gradients (320 x 600 + 1); the ones column becomes a row of ones on the MFMAs;
 // 0 -> the 256 x 160 workgroups.  The launcher, the dispatcher and the split rule (gemm.hip) all ask here.
 inline int tn_w160_wide(const tssep_gemm_args* g) {
   if (g->M & 3) return 0;
   const int64_t xo = g->b_ones_col ? 1 : 0, nr = g->N - xo;
+  if (g->kperiod <= 0 && g->M > 192 && g->M <= 320 && nr >= 512 && (nr & 3) == 0 && ((nr + xo + 255) / 256 * 256) * 10 <= nr * 13) return 7;
   if (g->kperiod <= 0 && nr >= 320 && nr % 320 == 0) return 5;
   if (!xo && (g->N & 3) == 0 && (((g->N + 159) / 160) & 1) == 0) return 5;
   if (g->kperiod <= 0 && nr >= 512 && nr % 256 <= 1) return 4;
@@ -531,6 +535,7 @@ inline int tn_w160_wide(const tssep_gemm_args* g) {
 // columns of the MFMA tiles of such a request (the one more real column and the ones column come on top)
 inline int64_t tn_w160_wide_cols(const tssep_gemm_args* g, int wide) {
   const int64_t nr = g->N - (g->b_ones_col ? 1 : 0);
+  if (wide == 7) return g->M;      // (of the swapped problem)
   return wide == 4 ? nr - nr % 256 : nr - (nr & 3);
 }
 }  // namespace gemm_detail
