@@ -217,7 +217,7 @@ int tssep_gemm_f32(const tssep_gemm_args* args, void* stream);
 #define TSSEP_GEMM_TN 9          /* weight gradient (both operands k-major), 128 x 128                         */
 #define TSSEP_GEMM_TN_TALL 10    /* weight gradient, 256 x 128                                                 */
 #define TSSEP_GEMM_TN_BIG 11     /* weight gradient, 512 x 128, four waves of 128 x 128                        */
-#define TSSEP_GEMM_TN_W160 12    /* weight gradient, 256 x 160                                                 */
+#define TSSEP_GEMM_TN_W160 12    /* weight gradient, 256 x 160; eight waves on 256 x 320 / 256 x 256 (also swapped)  */
 #define TSSEP_GEMM_TN_H160 13    /* weight gradient, 320 x 128                                                 */
 #define TSSEP_GEMM_BIG_P 14      /* row x row, 256 x 256 persistent: plain / bias / Tanh store hidden behind tiles */
 #define TSSEP_GEMM_BIG_P320 15   /* row x row, 192 x 320 persistent (N = 320 q): plain / bias / Tanh / its backward  */
