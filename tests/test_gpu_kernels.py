@@ -926,6 +926,58 @@ def test_gemm_wgrad_eight_wave_tiles_against_the_tn_kernel(R, M, N, S, ones):
         h.GEMM_PRECISION = old
 
 
+def test_gemm_wgrad_eight_wave_tiles_on_random_shapes():
+    """Forty seeded random weight-gradient requests in the ranges the eight-wave workgroups of tn_w160 take (M = 4 q in
+    1024 ... 2600 or 196 ... 320, N in 320 ... 1400 with and without the ones column, K = 32 S j rows so that every kernel
+    cuts the splits on the same rows, S in 1 ... 9): whatever the library picks and whatever tn_w160 does when named, bit for
+    bit against the 128 x 128 tn kernel on the columns both compute on the MFMAs, every column against fp64."""
+    import random
+    rng = random.Random(20261003)
+    torch.manual_seed(5)
+    h = H()
+    old = h.GEMM_PRECISION
+    h.GEMM_PRECISION = "bf16x3"
+    seen = set()
+    try:
+        for case in range(40):
+            small = case % 4 == 3
+            M = rng.randrange(196, 324, 4) if small else rng.randrange(1024, 2604, 4)
+            N = rng.choice([320, 640, 512, 513, 768, 553, 556, 600, 960, 1280, rng.randrange(324, 1400), rng.randrange(512, 1400, 4)])
+            ones = rng.random() < 0.6
+            S = rng.randrange(1, 10)
+            R = 32 * S * rng.randrange(1, 12)
+            Nc = N + 1 if ones else N
+            ldp = h.round_up(Nc, 4) if ones else N
+            if not ones and N % 4:
+                continue                      # (an unpadded partial row: no vector epilogue, not a shape of the step)
+            dY = torch.randn(R, h.round_up(M, 4), device="cuda")
+            X = torch.full((R, h.round_up(Nc, 4)), 3.0, device="cuda")
+            X[:, :N] = torch.randn(R, N, device="cuda")
+            outs = {}
+            for kern in ("auto", "tn_w160", "tn"):
+                log = h.GEMM_LOG = []
+                with h.prefer_gemm_kernels(*(() if kern == "auto" else (kern,))):
+                    part, _ = h.wgrad(dY, dY.shape[1], X, X.shape[1], M, N, R, with_colsum=ones, splitk=S)
+                h.GEMM_LOG = None
+                outs[kern] = (log[0][0], part.clone().view(S, M, ldp))
+            seen.add(outs["tn_w160"][0])
+            ref = dY[:, :M].double().t() @ X[:, :N].double()
+            for kern, (ran, part) in outs.items():
+                got = part.double().sum(0)
+                close(got[:, :N].float(), ref.float(), rtol=2e-4, atol=3e-3, name=f"case {case} {kern}->{ran} {M}x{Nc} K {R} S {S}")
+                if ones:
+                    close(got[:, N].float(), dY[:, :M].double().sum(0).float(), rtol=2e-4, atol=3e-3, name=f"case {case} {kern}->{ran} ones column")
+            # the MFMA columns common to every kernel of the family: all but the last (N % 4) real ones and the ones column
+            nm = N - N % 4 if N % 256 > 1 else N // 256 * 256
+            for kern in ("auto", "tn_w160"):
+                a, b = outs[kern][1][:, :, :nm], outs["tn"][1][:, :, :nm]
+                assert torch.equal(a, b), (case, kern, outs[kern][0], M, Nc, R, S, int((a != b).sum()))
+        assert "tn_w160" in seen
+    finally:
+        h.GEMM_LOG = None
+        h.GEMM_PRECISION = old
+
+
 @pytest.mark.parametrize("R,M,N,S", [(6072, 320, 600, 8), (1000, 320, 600, 1), (2580, 300, 530, 3), (3111, 318, 389, 2),
                                      (5000, 640, 257, 4), (40, 320, 600, 1), (2580, 320, 130, 3)])
 def test_gemm_wgrad_320_row_tile_against_the_tn_kernels(R, M, N, S):
