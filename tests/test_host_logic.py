@@ -75,6 +75,53 @@ def test_splitk_choice():
     assert s >= 8 and s % 8 == 0
 
 
+def test_wgrad_split_count_and_kernel_are_a_fixed_point_over_many_shapes():
+    """ADVICE r4 + round 5's new dispatch rules: for a grid of weight-gradient requests (the model's shapes, their
+    neighbours, other unit / projection / speaker counts, with and without the ones column and the time shift) the split
+    count the library recommends is one the kernel it then plans ACCEPTS (same kernel at 8 and at S splits, or a second
+    round settled it), a multiple of 8 for the kernels that keep a K slab on one XCD, never more than one split per 8 K
+    tiles -- host-only (plan queries)."""
+    import ctypes
+    from tssep_amd._lib import GemmArgs
+    old = H.GEMM_PRECISION
+    H.GEMM_PRECISION = "bf16x3"
+    try:
+        def plan_at(M, N, K, S, ones, shifted):
+            g = GemmArgs()
+            g.A = g.B = 0x1000
+            g.C = 0x2000
+            g.M, g.N, g.K = M, N, K
+            g.lda, g.ldb, g.a_kmajor, g.b_kmajor = H.round_up(M, 4), H.round_up(N, 4), 1, 1
+            g.ldc = H.round_up(N, 4)
+            g.splitk, g.b_ones_col, g.precision = S, int(ones), 1
+            g.c_split_stride = M * g.ldc
+            if shifted:
+                g.b_kshift, g.kperiod = -1, 253
+            return H.gemm_plan(g, "auto")
+
+        n = 0
+        for K in (8 * 253, 32 * 253, 320 * 253, 768 * 253, 3072 * 253):
+            for M in (320, 513, 640, 1200, 1280, 2052, 2400, 4104):
+                for N, ones in ((300, False), (301, True), (321, True), (320, False), (514, True), (554, True), (557, True), (601, True),
+                                (600, False), (1281, True), (2561, True), (874, True), (130, False)):
+                    for shifted in (False, True):
+                        if shifted and ones:
+                            continue
+                        S = H.pick_splitk(M, N, K, shifted=shifted, ones_col=ones)
+                        ktiles = (K + 15) // 16
+                        assert 1 <= S <= max(1, ktiles // 8) or S == 8, (M, N, K, S)
+                        k_at_s = plan_at(M, N, K, S, ones, shifted)
+                        assert k_at_s is not None, (M, N, K, S)
+                        # a second query with the kernel's own S must not move to yet another kernel
+                        assert plan_at(M, N, K, S, ones, shifted) == k_at_s
+                        if k_at_s in ("tn_big", "tn_p320", "tn_w160", "tn_h160") and ktiles >= 64 * 8:
+                            assert S % 8 == 0, (k_at_s, M, N, K, S)
+                        n += 1
+        assert n > 500
+    finally:
+        H.GEMM_PRECISION = old
+
+
 def test_gemm_plan_names_the_kernel_without_a_gpu():
     """tssep_gemm_plan: the library's choice is a function of the request alone (no environment variable, VERDICT r3
     #3) -- the shapes of the default step land on the kernels DESIGN 4.1 names."""
