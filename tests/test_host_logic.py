@@ -167,7 +167,8 @@ def test_gemm_plan_names_the_kernel_without_a_gpu():
     # round 4, from the shape sweep (profiles/r4_gemm_shape_sweep*.jsonl): the logit layer (N = 4 x 513, K = projs) on the
     # 160-wide tile, its weight gradient (M = 2052) and the 8-speaker one (4104) on the big weight-gradient tile, one /
     # two column tiles (projs = 256) on the big tile, never the eight-wave 256 x 256 tile below K = 448
-    assert plan(R, 2052, 320, remap=True) == "big_p" and plan(2052, 320, R, wgrad=True) == "tn_p320"
+    assert plan(R, 2052, 320, remap=True) == "big_p" and plan(2052, 320, R, wgrad=True) == "tn_w160"      # (round 5: 2304 rows of 256-row tiles)
+    assert plan(1800, 320, R, wgrad=True) == "tn_p320"                               # (13.8 % padding on 256-row tiles: the 192-row tile)
     assert plan(4104, 256, R // 2, wgrad=True) == "tn_big"
     assert plan(4 * R, 256, 1024, act=1) == "big_p" and plan(4 * R, 256, 256, act=1) == "big_p"
     assert plan(R // 2, 4104, 256, remap=True) == "tall2"

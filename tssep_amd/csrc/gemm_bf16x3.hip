@@ -1339,7 +1339,8 @@ int tssep_gemm_bf16x3_launch(const tssep_gemm_args* g, const gemm_detail::StoreM
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }
         }
-        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && takes && g->M >= 1024 && (m256w - g->M) * 100 <= 8 * g->M &&
+        // (M pads to 256-row tiles by at most 13 %: the logit layer's 2052 -> 2304, 0.69 against 0.83 ms on the 192 x 320 tile)
+        if (gemm_try(call, TSSEP_GEMM_TN_W160, sw.tn_w160 && !shift && takes && g->M >= 1024 && (m256w - g->M) * 100 <= 13 * g->M &&
                                                    tn_fills(tilesw))) {
           const int rc = tssep_gemm_bf16x3_tn_w160_launch(g, sm, splitk, two ? 1 : 0, call);
           if (rc != TSSEP_E_UNSUPPORTED) { call.chosen = TSSEP_GEMM_TN_W160; return rc; }

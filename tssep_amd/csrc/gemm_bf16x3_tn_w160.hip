@@ -789,7 +789,7 @@ int tssep_gemm_bf16x3_tn_w160_launch(const tssep_gemm_args* g, const gemm_detail
 #undef S_LAUNCH
     return tssep_launch_status();
   }
-  if (g->M < 1024 || (m256 - g->M) * 100 > 8 * g->M || (shift && ks > 16) || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
+  if (g->M < 1024 || (m256 - g->M) * 100 > 13 * g->M || (shift && ks > 16) || (sm.ldc & 3) != 0) return TSSEP_E_UNSUPPORTED;
   // masks by out-of-range loads: whole four-column pieces only (the time-shifted kernel exists in this form alone)
   const bool oob = (g->M & 3) == 0 && (g->N & 3) == 0 && !g->b_ones_col;
   if (shift && !oob) return TSSEP_E_UNSUPPORTED;
