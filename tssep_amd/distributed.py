@@ -26,6 +26,9 @@ def flat_offsets(params, align=FLAT_ALIGN):
     return offsets, off
 
 
+GUARD_SLOT = 64          # floats (256 bytes) behind the gradient: the failure flag that rides in the all-reduce
+
+
 class GradBucket:
     """Flat view over all parameter gradients: grads live inside ONE contiguous buffer, so the
     all-reduce needs no pack/unpack copies.
@@ -40,7 +43,13 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         offsets, n = flat_offsets(self.params)
         dev, dt = self.params[0].device, self.params[0].dtype
-        self.flats = [torch.zeros(n, device=dev, dtype=dt) for _ in range(replicas)]
+        # GUARD_SLOT floats behind buffer 0 travel with the all-reduce: element 0 is this rank's "my gradient is garbage"
+        # flag (a W-stationary recurrence launch gave up, err[0] of include/tssep_hip.h) as a float -- after the SUM it
+        # is non-zero on EVERY rank when any rank set it, which is what the guarded Adam launch tests (a
+        # rank-local flag let the peers apply a gradient that already contained the failed rank's garbage)
+        self._full = torch.zeros(n + GUARD_SLOT, device=dev, dtype=dt)
+        self.guard = self._full[n:]
+        self.flats = [self._full[:n]] + [torch.zeros(n, device=dev, dtype=dt) for _ in range(replicas - 1)]
         self.flat = self.flats[0]
         for p, off in zip(self.params, offsets):
             views = [f[off:off + p.numel()].view_as(p) for f in self.flats]
@@ -64,17 +73,27 @@ class GradBucket:
             from . import hip_ops
             hip_ops.join_side_stream(self.flat.device)
 
+    def set_guard(self, flag):
+        """`flag`: device int32 tensor whose element 0 is non-zero when this rank's gradient must not be applied; stored as
+        a float in the guard slot (one converting copy, no host sync; error codes are small positive integers, so a SUM
+        over ranks is non-zero exactly when some rank's flag was).  None clears the slot."""
+        if flag is None:
+            self.guard.zero_()
+        else:
+            self.guard[:1].copy_(flag[:1])
+
     def all_reduce(self, group=None, async_op=False):
+        """SUM over ranks of the gradient AND the guard slot behind it (one collective)."""
         self.sync()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+            if self._full.is_cuda and dist.get_backend(group) == "gloo":
                 # debugging / test configuration (several ranks on one GPU, where RCCL refuses to
                 # run): stage through the host.  Production is nccl = RCCL over xGMI, in place.
-                host = self.flat.cpu()
+                host = self._full.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-                self.flat.copy_(host)
+                self._full.copy_(host)
                 return None
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            return dist.all_reduce(self._full, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return None
 
     def global_norm(self):

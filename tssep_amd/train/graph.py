@@ -53,8 +53,11 @@ class GraphedStep:
         return tuple(dict.fromkeys(keys))
 
     def _signature(self, ex):
+        # (non-tensor entries that steer the computation are part of the signature: a batch with another reference
+        # channel must not replay the graph captured for the first one)
+        ref = ex.get("reference_channel")
         return tuple((k, tuple(ex[k].shape), ex[k].dtype) for k in self._tensor_keys(ex)) + \
-            (("training", self.model.training),)
+            (("training", self.model.training), ("reference_channel", ref if isinstance(ref, (int, type(None))) else repr(ref)))
 
     def _eager(self, ex, derived_tags=None):
         if self.zero_grad:
@@ -140,6 +143,7 @@ class GraphedStep:
             with torch.cuda.graph(g, stream=s):
                 st["out"], st["summary"] = run(st["derived_tags"])
             st["graph"] = g
+            st["per_example"] = self._per_example_scalars(st["summary"], st["rest"].get("dataset"))
         finally:
             me.permutation_source = prev
             if kept is not None:
@@ -147,6 +151,43 @@ class GraphedStep:
                 for f, k in zip(self.optimizer.bucket.flats, kept):
                     f.copy_(k)
         return st
+
+    def _per_example_scalars(self, summary, datasets):
+        """The captured summary keys its per-utterance loss scalars by the FIRST batch's dataset names (model.py:672-686).
+        -> the scalar / histogram tensors in batch order (None when the summary is not of that form), so that a replay can
+        hand out a summary named after the CURRENT batch's `dataset` entries."""
+        name = self.model.loss.name
+        if isinstance(datasets, str):
+            datasets = [datasets]
+        if not isinstance(datasets, (list, tuple)):
+            return None
+        queues = {k: list(v) for k, v in summary.get("scalars", {}).items()}
+        hqueues = {k: list(v) for k, v in summary.get("histograms", {}).items()}
+        items = []
+        for d in datasets:
+            q, hq = queues.get(f"{d}_{name}"), hqueues.get(f"hist_{d}_{name}")
+            if not q or not hq:
+                return None
+            items.append((q.pop(0), hq.pop(0)))
+        if any(queues.values()) or any(hqueues.values()):
+            return None                                   # something else was logged: keep the captured summary as it is
+        return items
+
+    def _summary_for(self, st, ex):
+        """The summary of a replay: the static loss buffers of the graph (overwritten by the next replay -- read or clone
+        them before the next call) under the names of THIS batch."""
+        items, datasets = st.get("per_example"), ex.get("dataset")
+        if isinstance(datasets, str):
+            datasets = [datasets]
+        if items is None or not isinstance(datasets, (list, tuple)) or len(datasets) != len(items):
+            return st["summary"]
+        name = self.model.loss.name
+        summary = type(st["summary"])()
+        summary["loss"] = st["summary"]["loss"]
+        for d, (sc, hist) in zip(datasets, items):
+            summary.setdefault("scalars", {}).setdefault(f"{d}_{name}", []).append(sc)
+            summary.setdefault("histograms", {}).setdefault(f"hist_{d}_{name}", []).append(hist)
+        return summary
 
     # ------------------------------------------------------------------------------- replay
     def __call__(self, ex):
@@ -175,7 +216,12 @@ class GraphedStep:
             ev = torch.cuda.Event()
             ev.record()
             st["perm_events"][slot] = ev
+        if not self.zero_grad:
+            # an EAGER micro-step of the same virtual minibatch may still be accumulating weight gradients into the bucket on
+            # the side stream; the captured wgrad nodes += into the same views, ordered only against the launch stream
+            # (ADVICE r5).  A stream wait, no host sync.
+            self.optimizer.bucket.sync()
         st["graph"].replay()
         self.replays += 1
         out = st["out"]
-        return (out.fresh() if hasattr(out, "fresh") else out), st["summary"]
+        return (out.fresh() if hasattr(out, "fresh") else out), self._summary_for(st, ex)

@@ -49,6 +49,14 @@ class Adam(Configurable):
     def step(self):
         """Clip to ``gradient_clipping`` (global L2 norm) and apply one Adam update.  Returns the
         pre-clip gradient norm as a device tensor (no host sync)."""
+        from .. import hip_ops
+        on_gpu = self.flat_param.is_cuda
+        # The guard of the update: this rank's err[0] (a W-stationary recurrence launch gave up on a peer: this step's
+        # gradient is garbage) is written into the bucket's guard slot and SUMMED over the ranks with the gradient, so
+        # that every rank skips the update when ANY rank's gradient was bad -- the replicas stay identical and nobody
+        # trains on the garbage that the all-reduce has already mixed into every peer's bucket (ADVICE r5).  The host
+        # raises at its next flag check (Trainer.agree_on_failure); `step_count` counts attempted updates.
+        self.bucket.set_guard(hip_ops._err_flag(self.flat_param.device) if on_gpu else None)
         if self.allreduce_events is not None and self.bucket.flat.is_cuda:
             self.bucket.sync()              # the side stream's weight gradients are not the collective's time
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -60,10 +68,8 @@ class Adam(Configurable):
             self.bucket.all_reduce()        # joins the side stream; SUM over ranks when distributed
         self.step_count += 1
         p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-        from .. import hip_ops
-        # (guarded: when a W-stationary recurrence launch of this step timed out on a peer -- err[0] of the C ABI -- the
-        # kernel skips the update on the device: garbage is never trained on, the host raises at its next flag check)
-        guard = hip_ops._err_flag(self.flat_param.device) if self.flat_param.is_cuda else None
+        # (the kernel tests the 32 bits of guard[0] against zero: 0.0f is the only value of the slot that applies the update)
+        guard = self.bucket.guard if on_gpu else None
         rc = _lib.lib().tssep_adam_step_guarded(
             p(self.flat_param), p(self.exp_avg), p(self.exp_avg_sq), p(self.bucket.flat),
             self.flat_param.numel(), self.step_count, float(self.gradient_clipping), float(self.lr),

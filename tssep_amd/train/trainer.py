@@ -160,6 +160,9 @@ class Trainer(Configurable):
         """Rank 0 validates and writes the checkpoint; EVERY rank calls this and leaves it together
         (``agree_on_failure`` is the barrier, and carries a failure of the chief to the others)."""
         error = None
+        # (all ranks agree FIRST that nobody's device flag is up: a checkpoint trigger without a summary trigger must not
+        # let the chief write parameters of a step some rank has flagged as garbage, ADVICE r5)
+        self.agree_on_failure()
         if do_it:
             try:
                 self.save_checkpoint(self.validate())
