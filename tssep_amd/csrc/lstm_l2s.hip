@@ -1,0 +1,310 @@
+// Sequence-parallel BLSTM recurrence on the bf16 matrix cores with W_hh STREAMED from the XCD's L2 every step
+// (round 6; VERDICT r5 "Next round" #1).  Replaces the T-sequential part of torch.nn.LSTM as the reference uses it
+// (tssep/train/rnnp.py:88-95,146-153: one bidirectional layer, batch_first, zero initial state) for launches with
+// enough sequences to fill the chip WITHOUT any exchange between workgroups:
+//
+//   * one workgroup (4 waves, one per SIMD) owns 32 sequences of ONE direction for the whole launch: no peers, no
+//     tags, no spin, no error flag, no co-residency contract -- other kernels (weight gradients, RCCL) may run beside it;
+//   * W_hh lives in HBM/L2 as packed split-bf16 MFMA A-fragments (hi | lo, 4 bytes per weight, 1.44 MB per direction
+//     at H = 300); every step every wave streams the fragments of ITS row tiles straight into registers (16 B per
+//     lane, 1 KB per wave and load, each byte used by exactly one wave: LDS would only add a copy).  The ring of
+//     KS fragment pairs is refilled right behind the MFMAs that consumed a slot and keeps running across tiles and
+//     time steps (the next step re-reads the same planes: they stay in the L2 -- blocks of one direction share an XCD);
+//   * h_{t-1} of the 32 sequences sits in LDS as bf16 hi / lo B-fragments (double-buffered, one barrier per step) and
+//     is held in registers for the whole step (KS x 2 x 4 VGPRs);
+//   * v_mfma_f32_32x32x16_bf16, D[32 gate rows x 32 sequences]: the tile's rows are ordered so that a lane ends up
+//     with the four gate pre-activations of four CONSECUTIVE units of one sequence: the cell update is lane-local and
+//     every access to gates / cell / h is one 16-byte access;
+//   * product = w_lo h_hi + w_hi h_lo + w_hi h_hi, fp32 accumulate on top of the input projection (x W_ih^T + b,
+//     computed beforehand by the GEMMs into `gates`): the arithmetic of the W-stationary kernels (lstm_onchip.hip).
+//
+// Tensor layouts: those of tssep_blstm_fwd / _bwd (lstm.hip): gates [N T][2 dirs][H][4 gates] (pre-activations in,
+// activations out / activations in, d(pre-activations) out), cell [N T][2][H], hout / dhout rows of ldo floats with
+// direction d at column d * dstride.
+//
+// Packed weights (tssep_lstm_pack_l2s), forward: [dir][tile RT][kstep KS][hi, lo][lane 64][8 bf16] with KS = ceil(H/16),
+// RT = 2 KS tiles of 8 units; fragment row i (= lane % 32) of tile `tile` is gate i % 4 of unit
+// tile * 8 + ((i / 4) % 2) * 4 + i / 8, fragment column 8 (lane / 32) + e is k = 16 kstep + 8 (lane / 32) + e.
+#include "common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SEQ = 32;      // sequences per workgroup = the N of the MFMA
+#ifndef L2S_PROBE
+#define L2S_PROBE 0        // timing probes, results wrong by construction: 1 no MFMAs, 2 no weight loads, 4 no pre-activation loads / stores
+#endif
+#ifndef L2S_RING
+#define L2S_RING 10       // weight-ring depth in fragment pairs (a divisor of 10 * KS)
+#endif
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = cvt_pk_bf16(a, b);
+  const float ha = __uint_as_float(hi << 16), hb = __uint_as_float(hi & 0xffff0000u);
+  lo = cvt_pk_bf16(a - ha, b - hb);
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// the gate non-linearities of the W-stationary kernels (v_exp_f32 / v_rcp_f32, relative error ~2^-22)
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * x));
+}
+
+__host__ __device__ inline int l2s_ks(int H) { return (H + 15) / 16; }
+
+// ------------------------------------------------------------------------------------------------ pack
+// one thread per packed bf16 PAIR (hi and lo of one weight are written by the same thread)
+__global__ void l2s_pack_fwd_kernel(const float* __restrict__ w_hh_f, const float* __restrict__ w_hh_r, int H, int KS,
+                                    unsigned short* __restrict__ out) {
+  const int RT = 2 * KS;
+  const int64_t total = (int64_t)2 * RT * KS * 64 * 8;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e;
+    const int el = (int)(r & 7); r >>= 3;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ks = (int)(r % KS); r /= KS;
+    const int tile = (int)(r % RT);
+    const int dir = (int)(r / RT);
+    const int i = lane & 31;
+    const int unit = tile * 8 + ((i >> 2) & 1) * 4 + (i >> 3), gate = i & 3;
+    const int k = ks * 16 + 8 * (lane >> 5) + el;
+    const float* w = dir ? w_hh_r : w_hh_f;
+    const float v = (unit < H && k < H) ? w[(int64_t)(gate * H + unit) * H + k] : 0.f;
+    unsigned hi, lo;
+    split2(v, 0.f, hi, lo);
+    const int64_t base = ((((int64_t)dir * RT + tile) * KS + ks) * 2) * 512 + lane * 8 + el;
+    out[base] = (unsigned short)(hi & 0xffffu);
+    out[base + 512] = (unsigned short)(lo & 0xffffu);
+  }
+}
+
+// --------------------------------------------------------------------------------------------- forward
+// Buffer addressing throughout: one resource per tensor (base = the workgroup's first sequence), ONE 32-bit lane offset
+// per tensor for the whole launch, everything that moves (time step, tile, kstep) in the scalar offset -- with plain
+// pointers the compiler hoists the ~400 loop-invariant 64-bit fragment addresses out of the time loop and spills.
+// Lanes without work (sequence >= N, units >= H) carry an out-of-range offset: loads return zeros, stores are dropped.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+constexpr unsigned VOOR = 0x80000000u;
+constexpr int AUX_NT = 2;
+__device__ __forceinline__ srd_t make_srd(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bload(srd_t r, unsigned voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+}
+__device__ __forceinline__ f32x4 bload_nt(srd_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, AUX_NT));
+}
+// (the scalar part of a store's address is added to the LANE offset, soffset stays the immediate 0: a > 64-bit buffer
+// store with a register soffset is not guarded against a VALU write of its data registers in the next issue slot --
+// tools/scan_store_hazard.py, round 4.  An out-of-range lane offset stays out of range: the sums stay below 2^32.)
+__device__ __forceinline__ void bstore_nt(f32x4 v, srd_t r, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(voff + (unsigned)soff), 0, AUX_NT);
+}
+
+template <int KS, int R>
+__global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict__ gates, float* __restrict__ cell,
+                                                               float* __restrict__ hout, int64_t ldo, int64_t dstride,
+                                                               const u32x4* __restrict__ wpk, int64_t N, int64_t T, int H) {
+  constexpr int RT = 2 * KS, NTW = (RT + 3) / 4, NF = NTW * KS;     // NF fragment pairs per wave and step
+  static_assert(NTW % 2 == 0, "the two-deep pre-activation ring needs an even tile count per wave");
+  static_assert(NF % R == 0, "the weight ring must close over one time step");
+  extern __shared__ __attribute__((aligned(16))) u32x4 hfr[];      // [2 buffers][KS + 1 (spare)][hi, lo][64 lanes]
+  constexpr int HB = (KS + 1) * 128;                               // u32x4 per buffer
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = lane & 31, hl = lane >> 5;
+  // blocks of one direction share an XCD (workgroup b runs on XCD b % 8): ONE direction's planes per L2
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int dir = xcd & 1;
+  const int64_t grp = (int64_t)slot * 4 + (xcd >> 1);
+  if (grp * SEQ >= N) return;
+  const int64_t n0 = grp * SEQ;
+  const unsigned nmask = (n0 + s < N) ? 0u : VOOR;
+  const int G4 = H * 4;                    // floats per (row, direction)
+
+  for (int i = tid; i < 2 * HB; i += 256) hfr[i] = u32x4{0u, 0u, 0u, 0u};
+
+  const srd_t rw = make_srd(wpk + (int64_t)dir * RT * KS * 128);
+  const srd_t rg = make_srd(gates + n0 * T * 2 * G4);
+  const srd_t rc = make_srd(cell + n0 * T * 2 * H);
+  const srd_t rh = make_srd(hout + n0 * T * ldo);
+  const unsigned vw = (unsigned)lane * 16u;
+  const unsigned vg = (unsigned)((((int64_t)s * T * 2 + dir) * G4 + hl * 16) * 4) | nmask;
+  const unsigned vc = (unsigned)((((int64_t)s * T * 2 + dir) * H + hl * 4) * 4) | nmask;
+  const unsigned vh = (unsigned)(((int64_t)s * T * ldo + dir * dstride + hl * 4) * 4) | nmask;
+  const int sg_t = 2 * G4 * 4, sc_t = 2 * H * 4, sh_t = (int)ldo * 4;      // bytes per time step
+
+  // byte offset of the fragments of this wave's i-th tile (waves whose last tile does not exist run it on the last
+  // real tile's weights with every store out of range and the h fragment in a spare LDS slot: straight-line code, and
+  // the barrier waits for the waves with NTW real tiles anyway)
+  auto tile_off = [&](int i_) { const int t_ = wave + 4 * i_; return (t_ < RT ? t_ : RT - 1) * KS * 2048; };
+
+  // weight ring: R fragment pairs, refilled R fragments ahead right behind the MFMAs that read a slot; it runs across
+  // tiles and across time steps (NF % R == 0: slot f % R of step t + 1 is slot f % R of step t)
+  u32x4 wh[R], wl[R];
+#pragma unroll
+  for (int f = 0; f < R; ++f) {
+    const int o = tile_off(f / KS) + (f % KS) * 2048;
+    wh[f] = bload(rw, vw, o);
+    wl[f] = bload(rw, vw, o + 1024);
+  }
+  float c[NTW][4];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[i][q] = 0.f;
+
+  // pre-activation ring, two tiles deep, running across time steps
+  f32x4 gx[2][4] = {};
+  auto gx_load = [&](int slot_, int i_, int t_) {
+    const int tile_ = wave + 4 * i_;
+    const unsigned v_ = vg | ((tile_ * 8 + hl * 4 < H) ? 0u : VOOR);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (!(L2S_PROBE & 4)) gx[slot_][q] = bload_nt(rg, v_, t_ * sg_t + tile_ * 128 + q * 16);
+  };
+  {
+    const int t0 = dir ? (int)T - 1 : 0;
+    gx_load(0, 0, t0);
+    gx_load(1, 1, t0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+#pragma clang loop unroll(disable)
+  for (int step = 0; step < (int)T; ++step) {
+    const int t = dir ? (int)T - 1 - step : step;
+    const int tn = step + 1 < (int)T ? (dir ? t - 1 : t + 1) : t;      // (the last step prefetches its own row again)
+    // (per-tile fragment offsets the compiler cannot see through: it would otherwise hoist the ~400 loop-invariant
+    // offsets out of the time loop into SGPRs it then spills to VGPR lanes)
+    int tb[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      tb[i] = tile_off(i);
+      asm volatile("" : "+s"(tb[i]));
+    }
+    bf16x8 bh[KS], bl[KS];
+    {
+      const u32x4* hb = hfr + cur * HB + lane;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bh[ks] = as_bf16x8(hb[ks * 128]);
+        bl[ks] = as_bf16x8(hb[ks * 128 + 64]);
+      }
+    }
+    u32x4* hnext = hfr + (cur ^ 1) * HB;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int tile = wave + 4 * i;
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        constexpr int dummy = 0; (void)dummy;
+        const int f = i * KS + ks, sl = f % R;
+        if (L2S_PROBE & 1) {
+          acc[ks & 15] += __uint_as_float(wl[sl][0] ^ wh[sl][1]) + (float)bh[ks][0] + (float)bl[ks][1];
+        } else {
+          acc = MFMA_BF16(as_bf16x8(wl[sl]), bh[ks], acc);
+          acc = MFMA_BF16(as_bf16x8(wh[sl]), bl[ks], acc);
+          acc = MFMA_BF16(as_bf16x8(wh[sl]), bh[ks], acc);
+        }
+        const int fn = (f + R) % NF;
+        const int o = tb[fn / KS] + (fn % KS) * 2048;
+        if (!(L2S_PROBE & 2)) {
+          wh[sl] = bload(rw, vw, o);
+          wl[sl] = bload(rw, vw, o + 1024);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 cv, hv;
+      const unsigned umask = (tile * 8 + hl * 4 < H) ? 0u : VOOR;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // (the pre-activations are ADDED behind the MFMA chain: a load that fed the chain's accumulator was waited for
+        // -- and with it, in order, the whole weight ring -- as soon as it was issued)
+        const f32x4 gq = gx[i & 1][q];
+        const float ig = fast_sigmoid(acc[4 * q + 0] + gq[0]), fg = fast_sigmoid(acc[4 * q + 1] + gq[1]);
+        const float gg = fast_tanh(acc[4 * q + 2] + gq[2]), og = fast_sigmoid(acc[4 * q + 3] + gq[3]);
+        const float cn = fg * c[i][q] + ig * gg;
+        c[i][q] = cn;
+        cv[q] = cn;
+        hv[q] = og * fast_tanh(cn);
+        if (!(L2S_PROBE & 4)) bstore_nt(f32x4{ig, fg, gg, og}, rg, vg | umask, t * sg_t + tile * 128 + q * 16);
+      }
+      if (!(L2S_PROBE & 4) || step == (int)T - 1) {
+        bstore_nt(cv, rc, vc | umask, t * sc_t + tile * 32);
+        bstore_nt(hv, rh, vh | umask, t * sh_t + tile * 32);
+      }
+      // the ring slot just consumed: two tiles ahead (this step's, or the first two of the next step)
+      if (i + 2 < NTW) gx_load(i & 1, i + 2, t); else gx_load(i & 1, i + 2 - NTW, tn);
+      // h as B-fragment halves: k = unit, kstep tile / 2, fragment lane s + 32 (tile % 2), elements hl * 4 + q
+      unsigned h01, l01, h23, l23;
+      split2(hv[0], hv[1], h01, l01);
+      split2(hv[2], hv[3], h23, l23);
+      u32x2* dst = reinterpret_cast<u32x2*>(hnext + (tile >> 1) * 128 + s + 32 * (tile & 1)) + hl;
+      dst[0] = u32x2{h01, h23};
+      dst[64 * 2] = u32x2{l01, l23};
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int tssep_lstm_l2s_supported(int H) { return (H > 0 && (H & 3) == 0 && (l2s_ks(H) == 19 || l2s_ks(H) == 20)) ? 1 : 0; }
+
+extern "C" int64_t tssep_lstm_l2s_pack_floats(int H, int which) {
+  if (!tssep_lstm_l2s_supported(H) || which < 0 || which > 1) return 0;
+  const int64_t KS = l2s_ks(H);
+  return (int64_t)2 * (2 * KS) * KS * 2 * 64 * 4;      // u32x4 per lane = 4 floats
+}
+
+extern "C" int tssep_lstm_pack_l2s(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream) {
+  if (!w_hh_f || !w_hh_r || !wf) return TSSEP_E_NULL;
+  if (!tssep_lstm_l2s_supported(H)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(wf)) return TSSEP_E_ALIGN;
+  const int KS = l2s_ks(H);
+  hipLaunchKernelGGL(l2s_pack_fwd_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, w_hh_f, w_hh_r, H, KS,
+                     reinterpret_cast<unsigned short*>(wf));
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_blstm_l2s_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride, const float* wf,
+                                   int64_t N, int64_t T, int H, void* stream) {
+  if (!gates || !cell || !hout || !wf) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  if (!tssep_lstm_l2s_supported(H) || (ldo & 3) || (dstride & 3)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(cell) || !aligned16(hout) || !aligned16(wf)) return TSSEP_E_ALIGN;
+  const int KS = l2s_ks(H);
+  const int64_t groups = (N + SEQ - 1) / SEQ;
+  const unsigned grid = (unsigned)(8 * ((groups + 3) / 4));
+  const size_t lds = (size_t)2 * (KS + 1) * 2 * 64 * 16;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_done[2] = {false, false};
+  if (KS == 19) {
+    if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&blstm_l2s_fwd_kernel<19, (L2S_RING == 10 ? 10 : 19)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    hipLaunchKernelGGL((blstm_l2s_fwd_kernel<19, (L2S_RING == 10 ? 10 : 19)>), dim3(grid), dim3(256), lds, s, gates, cell, hout, ldo, dstride,
+                       reinterpret_cast<const u32x4*>(wf), N, T, H);
+  } else {
+    if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&blstm_l2s_fwd_kernel<20, (L2S_RING == 10 ? 10 : 20)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    hipLaunchKernelGGL((blstm_l2s_fwd_kernel<20, (L2S_RING == 10 ? 10 : 20)>), dim3(grid), dim3(256), lds, s, gates, cell, hout, ldo, dstride,
+                       reinterpret_cast<const u32x4*>(wf), N, T, H);
+  }
+  return tssep_launch_status();
+}
