@@ -306,19 +306,6 @@ int tssep_blstm_cluster_bwd(float* gates, const float* cell, const float* dhout,
                             int64_t dstride, const float* whh_cb, void* xbuf, int* err,
                             int64_t N, int64_t T, int H, int max_wgs, int ms, void* stream);
 
-/* Sequence-parallel recurrence with W_hh streamed from the XCD's L2 (lstm_l2s.hip, ABI 4): one workgroup owns 32
- * sequences of one direction for the whole launch and re-reads the packed split-bf16 planes of W_hh (4 bytes per
- * weight) every step; the arithmetic of the on-chip kernels below (w_lo h_hi + w_hi h_lo + w_hi h_hi, fp32
- * accumulate, hardware exp / reciprocal in the cell).  NO exchange between workgroups: no xbuf, no err, NO concurrency
- * contract -- any other kernel may run beside it.  Meant for launches that fill the chip (N >= ~2048 sequences);
- * 288 < H <= 320, H % 4 == 0, ldo % 4 == dstride % 4 == 0 (else TSSEP_E_UNSUPPORTED).  Same tensor layouts as
- * tssep_blstm_fwd/bwd.  Replaces the T loop of torch.nn.LSTM inside tssep/train/rnnp.py:146-153. */
-int tssep_lstm_l2s_supported(int H);
-int64_t tssep_lstm_l2s_pack_floats(int H, int which /* 0: forward, 1: backward */);
-int tssep_lstm_pack_l2s(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream);
-int tssep_blstm_l2s_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride, const float* wf,
-                        int64_t N, int64_t T, int H, void* stream);
-
 /* On-chip-weights recurrence on the bf16 matrix cores (lstm_onchip.hip): a cluster of
  * ceil(H/64) workgroups keeps W_hh on chip as split bf16 (hi+lo) and evaluates the recurrent
  * product as hi*hi + hi*lo + lo*hi with fp32 accumulation (fp32-class accuracy), 32 sequences per

@@ -1,12 +1,40 @@
-"""GPU box: the L2-streamed sequence-parallel recurrence (lstm_l2s.hip) against the streaming fp32 kernel (parity) and
-the W-stationary interleaved kernels (time), per launch, H = 300, T = 253.   python tools/bench_l2s.py [N ...]"""
+"""GPU box: the L2-streamed sequence-parallel recurrence (lstm_l2s.hip, EXPERIMENT build: `make -C tssep_amd/csrc exp`, not in
+the product or its ABI -- profiles/r6_l2s_probe.jsonl) against the streaming fp32 kernel (parity) and the W-stationary
+interleaved kernels (time), per launch, H = 300, T = 253.
+
+    TSSEP_HIP_LIB=$PWD/tssep_amd/libtssep_hip_exp.so python tools/bench_l2s.py [N ...]"""
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-from tssep_amd import hip_ops as h  # noqa: E402
+import ctypes  # noqa: E402
+from tssep_amd import _lib, hip_ops as h  # noqa: E402
+
+_L = _lib.lib()
+if not hasattr(_L, "tssep_blstm_l2s_fwd"):
+    sys.exit("this library has no tssep_blstm_l2s_fwd: build `make -C tssep_amd/csrc exp` and set TSSEP_HIP_LIB")
+_vp, _i64, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+_L.tssep_lstm_l2s_pack_floats.restype, _L.tssep_lstm_l2s_pack_floats.argtypes = _i64, [_i, _i]
+_L.tssep_lstm_pack_l2s.restype, _L.tssep_lstm_pack_l2s.argtypes = _i, [_vp, _vp, _i, _vp, _vp]
+_L.tssep_blstm_l2s_fwd.restype, _L.tssep_blstm_l2s_fwd.argtypes = _i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _vp]
+
+
+def _pack_l2s(w_hh_f, w_hh_r, H):
+    buf = torch.empty(int(_L.tssep_lstm_l2s_pack_floats(H, 0)), device=w_hh_f.device, dtype=torch.float32)
+    a, b = w_hh_f.detach().float().contiguous(), w_hh_r.detach().float().contiguous()
+    h.check(_L.tssep_lstm_pack_l2s(a.data_ptr(), b.data_ptr(), H, buf.data_ptr(), h._stream()), "lstm_pack_l2s")
+    return buf
+
+
+def _l2s_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H):
+    h.check(_L.tssep_blstm_l2s_fwd(gates.data_ptr(), cell.data_ptr(), hout.data_ptr(), ldo, dstride, wf.data_ptr(), N, T, H,
+                                   h._stream()), "blstm_l2s_fwd")
+
+
+h.lstm_pack_l2s = lambda a, b, H, which=0: _pack_l2s(a, b, H)
+h.blstm_l2s_fwd = _l2s_fwd
 
 T, Hh, I = int(os.environ.get("L2S_T", 253)), int(os.environ.get("L2S_H", 300)), 320
 torch.manual_seed(0)

@@ -97,6 +97,9 @@ __global__ void l2s_pack_fwd_kernel(const float* __restrict__ w_hh_f, const floa
 // Lanes without work (sequence >= N, units >= H) carry an out-of-range offset: loads return zeros, stores are dropped.
 typedef __amdgpu_buffer_rsrc_t srd_t;
 constexpr unsigned VOOR = 0x80000000u;
+#ifndef L2S_STORE_AUX
+#define L2S_STORE_AUX 2
+#endif
 constexpr int AUX_NT = 2;
 __device__ __forceinline__ srd_t make_srd(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
@@ -111,18 +114,41 @@ __device__ __forceinline__ f32x4 bload_nt(srd_t r, unsigned voff, int soff) {
 // store with a register soffset is not guarded against a VALU write of its data registers in the next issue slot --
 // tools/scan_store_hazard.py, round 4.  An out-of-range lane offset stays out of range: the sums stay below 2^32.)
 __device__ __forceinline__ void bstore_nt(f32x4 v, srd_t r, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(voff + (unsigned)soff), 0, AUX_NT);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(voff + (unsigned)soff), 0, L2S_STORE_AUX);
 }
 
+// LDS-DMA copy of 64 x 16 bytes: lane l's 16 bytes at `base + voff` land at LDS address `lds + 16 l`.  Inline assembly:
+// the compiler must not know that LDS is written (with the builtin it waits `vmcnt(0)` in front of every LDS read that
+// follows, i.e. for the copy just requested two tiles ahead AND, in order, for the whole weight ring); the consumer waits
+// explicitly.  The LDS reads of the slot's previous content have returned (lgkmcnt(0)) before the copy is issued.
+__device__ __forceinline__ void dma16(const void* base, unsigned voff, unsigned lds) {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) const void*)p);
+}
+
+// Forward.  Wave w owns the NTW CONSECUTIVE row tiles w NTW ... (8 units each); per tile and step:
+//   1. the tile's pre-activations (32 sequences x 128 B) leave its LDS slot (filled two tiles earlier by four LDS-DMA
+//      instructions, each 8 sequences x 128 contiguous bytes) for 16 registers; the slot is refilled for two tiles ahead;
+//   2. KS x 3 MFMAs against the weight ring (refilled R fragment pairs ahead, straight from the L2);
+//   3. lane-local cell update; activations, c, h go to a staging image in LDS (swizzled: conflict-free both ways) and
+//      the bf16 hi / lo of h into the next step's B fragments;
+//   4. the staging image leaves as six coalesced 1-KB stores (128-byte runs per sequence).
+// A lane of the MFMA layout touches 16 bytes of 32 different sequences (2.4 MB apart): issued as global accesses these
+// run at 0.85 TB/s (probe, round 6: 82 us per step, the weights + MFMAs alone 14.8).
 template <int KS, int R>
 __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict__ gates, float* __restrict__ cell,
                                                                float* __restrict__ hout, int64_t ldo, int64_t dstride,
                                                                const u32x4* __restrict__ wpk, int64_t N, int64_t T, int H) {
   constexpr int RT = 2 * KS, NTW = (RT + 3) / 4, NF = NTW * KS;     // NF fragment pairs per wave and step
-  static_assert(NTW % 2 == 0, "the two-deep pre-activation ring needs an even tile count per wave");
+  static_assert(NTW % 2 == 0, "the two pre-activation slots alternate by tile parity across steps");
   static_assert(NF % R == 0, "the weight ring must close over one time step");
-  extern __shared__ __attribute__((aligned(16))) u32x4 hfr[];      // [2 buffers][KS + 1 (spare)][hi, lo][64 lanes]
-  constexpr int HB = (KS + 1) * 128;                               // u32x4 per buffer
+  static_assert(NTW * 4 - RT <= 2, "one spare B-fragment slot takes the tiles that do not exist");
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  constexpr int HB = (KS + 1) * 128;                               // u32x4 per h buffer: [KS + 1 (spare)][hi, lo][64 lanes]
+  constexpr int GI = 2 * HB, GO = GI + 4 * 2 * 256;                // gin[wave][slot 2][256], gout[wave][256 + 64 + 64]
+  u32x4* hfr = smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s = lane & 31, hl = lane >> 5;
@@ -132,29 +158,67 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
   const int64_t grp = (int64_t)slot * 4 + (xcd >> 1);
   if (grp * SEQ >= N) return;
   const int64_t n0 = grp * SEQ;
-  const unsigned nmask = (n0 + s < N) ? 0u : VOOR;
   const int G4 = H * 4;                    // floats per (row, direction)
 
   for (int i = tid; i < 2 * HB; i += 256) hfr[i] = u32x4{0u, 0u, 0u, 0u};
 
   const srd_t rw = make_srd(wpk + (int64_t)dir * RT * KS * 128);
-  const srd_t rg = make_srd(gates + n0 * T * 2 * G4);
+  const char* gb = reinterpret_cast<const char*>(gates + n0 * T * 2 * G4);
+  const srd_t rg = make_srd(gb);
   const srd_t rc = make_srd(cell + n0 * T * 2 * H);
   const srd_t rh = make_srd(hout + n0 * T * ldo);
   const unsigned vw = (unsigned)lane * 16u;
-  const unsigned vg = (unsigned)((((int64_t)s * T * 2 + dir) * G4 + hl * 16) * 4) | nmask;
-  const unsigned vc = (unsigned)((((int64_t)s * T * 2 + dir) * H + hl * 4) * 4) | nmask;
-  const unsigned vh = (unsigned)(((int64_t)s * T * ldo + dir * dstride + hl * 4) * 4) | nmask;
   const int sg_t = 2 * G4 * 4, sc_t = 2 * H * 4, sh_t = (int)ldo * 4;      // bytes per time step
 
-  // byte offset of the fragments of this wave's i-th tile (waves whose last tile does not exist run it on the last
-  // real tile's weights with every store out of range and the h fragment in a spare LDS slot: straight-line code, and
-  // the barrier waits for the waves with NTW real tiles anyway)
-  auto tile_off = [&](int i_) { const int t_ = wave + 4 * i_; return (t_ < RT ? t_ : RT - 1) * KS * 2048; };
+  // ---- io lanes (lane-linear images): gates instruction j covers sequences 8 j ... 8 j + 7, 128 bytes each; a
+  // sequence's eight 16-byte pieces (one unit's four gates each) are rotated by seq / 2 inside its row of the image
+  unsigned gl[4];                           // byte offset of this lane's piece from (first sequence, t = 0, tile 0) | VOOR: no such sequence
+  int gpiece[2];                            // its unit within the tile (instructions 0, 2 / 1, 3)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int seq = j * 8 + (lane >> 3), piece = ((lane & 7) - (seq >> 1)) & 7;
+    gl[j] = (unsigned)((((int64_t)seq * T * 2 + dir) * G4) * 4 + piece * 16) | ((n0 + seq < N) ? 0u : VOOR);
+    gpiece[j & 1] = piece;
+  }
+  const unsigned gsafe = (unsigned)(dir * G4 * 4);                           // a piece that always exists (first sequence, unit 0)
+  const int cseq = lane >> 1, cpiece = ((lane & 1) - (cseq >> 3)) & 1;       // c / h image: 32 bytes per sequence, rotated by seq / 8
+  const unsigned cmask = (n0 + cseq < N) ? 0u : VOOR;
+  const unsigned cl = (unsigned)((((int64_t)cseq * T * 2 + dir) * H) * 4 + cpiece * 16) | cmask;
+  const unsigned hlo = (unsigned)(((int64_t)cseq * T * ldo + dir * dstride) * 4 + cpiece * 16) | cmask;
+  // ---- MFMA lanes: sequence s, units hl * 4 + q of the tile
+  int swz[4];                               // u32x4 index of piece hl * 4 + q in a gates image
+#pragma unroll
+  for (int q = 0; q < 4; ++q) swz[q] = s * 8 + ((hl * 4 + q + (s >> 1)) & 7);
+  const int cswz = s * 2 + ((hl + (s >> 3)) & 1);
+  u32x4* gin = smem + GI + wave * 512;
+  u32x4* gout = smem + GO + wave * 384;
+  const unsigned gin_lds = lds_addr(gin), gin_lane = gin_lds;  (void)gin_lane;
+
+  auto tile_of = [&](int i_) { return wave * NTW + i_; };
+  // byte offset of the weight fragments of the i-th tile (tiles that do not exist run on the last real tile's weights
+  // with every store out of range and h = 0 in the spare fragment slot: straight-line code, and the barrier waits for
+  // the waves with NTW real tiles anyway)
+  auto tile_off = [&](int i_) { const int t_ = tile_of(i_); return (t_ < RT ? t_ : RT - 1) * KS * 2048; };
+  // four LDS-DMA instructions: tile i_ of time step t_ into slot i_ & 1
+  auto gx_dma = [&](int i_, int t_) {
+    if (L2S_PROBE & (4 | 16)) return;
+    const int tile_ = tile_of(i_);
+    const char* base = gb + (int64_t)t_ * sg_t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = !(gl[j] & VOOR) && tile_ * 8 + gpiece[j & 1] < H;
+      dma16(base, ok ? gl[j] + (unsigned)(tile_ * 128) : gsafe, gin_lds + (unsigned)(((i_ & 1) * 256 + j * 64) * 16));
+    }
+  };
 
   // weight ring: R fragment pairs, refilled R fragments ahead right behind the MFMAs that read a slot; it runs across
   // tiles and across time steps (NF % R == 0: slot f % R of step t + 1 is slot f % R of step t)
   u32x4 wh[R], wl[R];
+  {
+    const int t0 = dir ? (int)T - 1 : 0;
+    gx_dma(0, t0);
+    gx_dma(1, t0);
+  }
 #pragma unroll
   for (int f = 0; f < R; ++f) {
     const int o = tile_off(f / KS) + (f % KS) * 2048;
@@ -166,20 +230,7 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) c[i][q] = 0.f;
-
-  // pre-activation ring, two tiles deep, running across time steps
-  f32x4 gx[2][4] = {};
-  auto gx_load = [&](int slot_, int i_, int t_) {
-    const int tile_ = wave + 4 * i_;
-    const unsigned v_ = vg | ((tile_ * 8 + hl * 4 < H) ? 0u : VOOR);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) if (!(L2S_PROBE & 4)) gx[slot_][q] = bload_nt(rg, v_, t_ * sg_t + tile_ * 128 + q * 16);
-  };
-  {
-    const int t0 = dir ? (int)T - 1 : 0;
-    gx_load(0, 0, t0);
-    gx_load(1, 1, t0);
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
@@ -207,13 +258,20 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
     u32x4* hnext = hfr + (cur ^ 1) * HB;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      const int tile = wave + 4 * i;
+      const int tile = tile_of(i);
+      // 1. this tile's pre-activations: requested two tiles (>= 64 vector-memory instructions) ago
+      f32x4 gq[4];
+      asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gq[q] = (L2S_PROBE & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, gin[(i & 1) * 256 + swz[q]]);
+      if (i + 2 < NTW) gx_dma(i + 2, t); else gx_dma(i + 2 - NTW, tn);
+      __builtin_amdgcn_sched_barrier(0);
+      // 2.
       f32x16 acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        constexpr int dummy = 0; (void)dummy;
         const int f = i * KS + ks, sl = f % R;
         if (L2S_PROBE & 1) {
           acc[ks & 15] += __uint_as_float(wl[sl][0] ^ wh[sl][1]) + (float)bh[ks][0] + (float)bl[ks][1];
@@ -230,27 +288,21 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      // 3.
       f32x4 cv, hv;
-      const unsigned umask = (tile * 8 + hl * 4 < H) ? 0u : VOOR;
+      const bool uok = tile * 8 + hl * 4 < H;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        // (the pre-activations are ADDED behind the MFMA chain: a load that fed the chain's accumulator was waited for
-        // -- and with it, in order, the whole weight ring -- as soon as it was issued)
-        const f32x4 gq = gx[i & 1][q];
-        const float ig = fast_sigmoid(acc[4 * q + 0] + gq[0]), fg = fast_sigmoid(acc[4 * q + 1] + gq[1]);
-        const float gg = fast_tanh(acc[4 * q + 2] + gq[2]), og = fast_sigmoid(acc[4 * q + 3] + gq[3]);
+        const float ig = fast_sigmoid(acc[4 * q + 0] + gq[q][0]), fg = fast_sigmoid(acc[4 * q + 1] + gq[q][1]);
+        const float gg = fast_tanh(acc[4 * q + 2] + gq[q][2]), og = fast_sigmoid(acc[4 * q + 3] + gq[q][3]);
         const float cn = fg * c[i][q] + ig * gg;
         c[i][q] = cn;
         cv[q] = cn;
-        hv[q] = og * fast_tanh(cn);
-        if (!(L2S_PROBE & 4)) bstore_nt(f32x4{ig, fg, gg, og}, rg, vg | umask, t * sg_t + tile * 128 + q * 16);
+        hv[q] = uok ? og * fast_tanh(cn) : 0.f;      // (units >= H ran on whatever the copy found: h stays 0, finite)
+        gout[swz[q]] = __builtin_bit_cast(u32x4, f32x4{ig, fg, gg, og});
       }
-      if (!(L2S_PROBE & 4) || step == (int)T - 1) {
-        bstore_nt(cv, rc, vc | umask, t * sc_t + tile * 32);
-        bstore_nt(hv, rh, vh | umask, t * sh_t + tile * 32);
-      }
-      // the ring slot just consumed: two tiles ahead (this step's, or the first two of the next step)
-      if (i + 2 < NTW) gx_load(i & 1, i + 2, t); else gx_load(i & 1, i + 2 - NTW, tn);
+      gout[256 + cswz] = __builtin_bit_cast(u32x4, cv);
+      gout[320 + cswz] = __builtin_bit_cast(u32x4, hv);
       // h as B-fragment halves: k = unit, kstep tile / 2, fragment lane s + 32 (tile % 2), elements hl * 4 + q
       unsigned h01, l01, h23, l23;
       split2(hv[0], hv[1], h01, l01);
@@ -258,6 +310,18 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
       u32x2* dst = reinterpret_cast<u32x2*>(hnext + (tile >> 1) * 128 + s + 32 * (tile & 1)) + hl;
       dst[0] = u32x2{h01, h23};
       dst[64 * 2] = u32x2{l01, l23};
+      // 4. (lane offsets only: see bstore_nt)
+      if (!(L2S_PROBE & (4 | 8))) {
+        const unsigned so = (unsigned)(t * sg_t + tile * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned v = (tile * 8 + gpiece[j & 1] < H) ? gl[j] + so : VOOR;      // (gl | VOOR stays out of range)
+          bstore_nt(__builtin_bit_cast(f32x4, gout[j * 64 + lane]), rg, v, 0);
+        }
+        const bool cok = tile * 8 + cpiece * 4 < H;
+        bstore_nt(__builtin_bit_cast(f32x4, gout[256 + lane]), rc, cok ? cl + (unsigned)(t * sc_t + tile * 32) : VOOR, 0);
+        bstore_nt(__builtin_bit_cast(f32x4, gout[320 + lane]), rh, cok ? hlo + (unsigned)(t * sh_t + tile * 32) : VOOR, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -294,7 +358,7 @@ extern "C" int tssep_blstm_l2s_fwd(float* gates, float* cell, float* hout, int64
   const int KS = l2s_ks(H);
   const int64_t groups = (N + SEQ - 1) / SEQ;
   const unsigned grid = (unsigned)(8 * ((groups + 3) / 4));
-  const size_t lds = (size_t)2 * (KS + 1) * 2 * 64 * 16;
+  const size_t lds = (size_t)(2 * (KS + 1) * 128 + 4 * 2 * 256 + 4 * 384) * 16;
   hipStream_t s = (hipStream_t)stream;
   static bool attr_done[2] = {false, false};
   if (KS == 19) {

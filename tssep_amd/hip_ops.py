@@ -807,27 +807,6 @@ def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, l
               "blstm_onchip16_fwd")
 
 
-# L2-streamed sequence-parallel recurrence (lstm_l2s.hip, round 6): no exchange, no error flag, no co-residency contract
-def lstm_l2s_supported(H):
-    return bool(_lib.lib().tssep_lstm_l2s_supported(int(H)))
-
-
-def lstm_pack_l2s(w_hh_f, w_hh_r, H, which=0):
-    L = _lib.lib()
-    buf = torch.empty(int(L.tssep_lstm_l2s_pack_floats(H, which)), device=w_hh_f.device, dtype=torch.float32)
-    a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
-    fn = L.tssep_lstm_pack_l2s if which == 0 else L.tssep_lstm_pack_l2s_bwd
-    check(fn(_p(a), _p(b), H, _p(buf), _stream()), "lstm_pack_l2s")
-    return buf
-
-
-def blstm_l2s_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H):
-    _log_recurrence("l2s_bf16x3", "fwd", N, T, H, 0)
-    with _timed("blstm_l2s_fwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 40):
-        check(_lib.lib().tssep_blstm_l2s_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf), N, T, H, _stream()),
-              "blstm_l2s_fwd")
-
-
 def onchip16_bwd_groups(N, H, device):
     """group count of the interleaved backward (0: use the 32-sequence kernel; policy runtime.onchip16_bwd)"""
     if not ONCHIP16_BWD or not (256 < H <= 320):
