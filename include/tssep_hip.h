@@ -350,20 +350,6 @@ int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs);
 int tssep_blstm_onchip16_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
                              const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
                              int max_wgs, int layout, int groups, void* stream);
-/* The same kernels with `waves` waves per workgroup (round 5).  8 = the entry points above: five workgroups of 64 units per
- * cluster, one per CU.  4: ten workgroups of 32 units per cluster, TWO per CU from different clusters -- the two waves of a
- * SIMD then belong to independent phase chains of different sequence groups and the hardware overlaps one chain's matrix
- * section with the other's exchange / cell update / HBM traffic; same tensors, semantics, err / concurrency contract; own
- * weight pack (the k axis of a workgroup starts at its own 32-unit slice) and exchange layout; groups = 1 (2 on request).
- * max_wgs = the device's CU count, as above (the four-wave kernel launches up to two workgroups per CU). */
-int64_t tssep_lstm_onchip16w_pack_floats(int H, int waves);
-int tssep_lstm_pack_onchip16w(const float* w_hh_f, const float* w_hh_r, int H, int waves, float* wf, void* stream);
-int64_t tssep_lstm_onchip16w_xbuf_bytes(int64_t N, int H, int waves);
-int tssep_blstm_onchip16w_groups(int64_t N, int H, int max_wgs, int waves);
-int tssep_blstm_onchip16w_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
-                              const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
-                              int max_wgs, int layout, int groups, int waves, void* stream);
-
 /* Interleaved backward: the same rotation for the reduce-scatter of dh (exchange waves / io waves as in the forward, a
  * ring of four LDS slots {gate activations, c_(t-1), dh} filled by asynchronous copies two phases ahead).  Own weight
  * pack (W_hh^T as 16 x 16 x 32 MFMA fragments) and exchange layout; H = 257 .. 320 (five workgroups per cluster),

@@ -19,7 +19,7 @@ def test_build_and_symbols():
     exported = set(re.findall(r" T (tssep_\w+)", out))
     assert exported == set(protos), (exported ^ set(protos))
     L = _lib.lib()
-    assert L.tssep_abi_version() == 3
+    assert L.tssep_abi_version() == 4
     assert L.tssep_arch() == b"gfx950"
 
 

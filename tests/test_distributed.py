@@ -132,6 +132,36 @@ def test_dataset_shard_stage():
     assert [len(b_) for b_ in ds.shard(1, 2).batch(2)] == [2, 2, 1]
 
 
+def _guard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 3)
+    bucket = GradBucket(lin.parameters())
+    out = []
+    for bad_rank in (1, None):
+        bucket.zero()
+        lin(torch.ones(4, 6) * (rank + 1)).sum().backward()
+        flag = torch.tensor([5 if rank == bad_rank else 0, 7, 0, 0], dtype=torch.int32)      # err[0]; err[1] (the epoch) never counts
+        bucket.set_guard(flag)
+        bucket.all_reduce()
+        out.append((float(bucket.guard[0]), float(bucket.guard[1:].abs().sum()), float(bucket.flat.abs().sum())))
+    q.put((rank, out, int(bucket._full.numel() - bucket.flat.numel())))
+    dist.destroy_process_group()
+
+
+def test_failure_flag_rides_in_the_gradient_allreduce_world2():
+    """the guard slot behind the flat gradient carries every rank's "my gradient is garbage" flag through the
+    SAME all-reduce(SUM): non-zero on both ranks when one rank set it, zero when none did; the gradient itself
+    is untouched by the slot."""
+    res = _spawn(_guard_worker, 2)
+    for rank, (bad, good), slot in res:
+        assert slot == 64
+        assert bad[0] == 5.0 and bad[1] == 0.0, (rank, bad)
+        assert good[0] == 0.0 and good[1] == 0.0, (rank, good)
+        assert bad[2] == good[2] > 0
+
+
 def test_gradient_sum_allreduce_world2():
     res = _spawn(_worker, 2)
     torch.manual_seed(0)

@@ -4,7 +4,7 @@
 #include <stdint.h>
 #include "../../include/tssep_hip.h"
 
-#define TSSEP_ABI_VERSION 3      // 3: + tssep_stft_plan (general FFT plans), tssep_*onchip16w* (waves per workgroup)
+#define TSSEP_ABI_VERSION 4      // 3: + tssep_stft_plan (general FFT plans), tssep_*onchip16w*; 4: - tssep_*onchip16w* (experiment build only)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

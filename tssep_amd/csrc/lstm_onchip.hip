@@ -2179,14 +2179,23 @@ extern "C" int tssep_blstm_onchip_bwd(float* gates, const float* cell, const flo
 
 // ---- interleaved forward (blstm_onchip16_fwd_kernel): own weight pack, own exchange layout (16-sequence items)
 // `waves` = waves per workgroup: 8 (five workgroups of 64 units per cluster, one per CU) or 4 (ten of 32 units, two per CU)
+// (ABI 4: the four-wave variant -- built, parity-green, 1.4-1.8x slower at every size, profiles/r5_onchip16_w4_rejected.jsonl
+// -- exists in the EXPERIMENT build only (-DTSSEP_GEMM_EXP, `make exp`); the product exports the eight-wave entry
+// points and instantiates no four-wave kernel)
+#ifdef TSSEP_GEMM_EXP
+#define W16_API extern "C"
 static inline bool waves_ok(int waves) { return waves == 8 || waves == 4; }
+#else
+#define W16_API static
+static inline bool waves_ok(int waves) { return waves == 8; }
+#endif
 static inline int g_of(int H, int waves) { return (H + 8 * waves - 1) / (8 * waves); }
-extern "C" int64_t tssep_lstm_onchip16w_pack_floats(int H, int waves) {
+W16_API int64_t tssep_lstm_onchip16w_pack_floats(int H, int waves) {
   if (!waves_ok(waves)) return 0;
   return (int64_t)2 * g_of(H, waves) * waves * 2 * KS2 * 2 * 64 * 4;
 }
 extern "C" int64_t tssep_lstm_onchip16_pack_floats(int H) { return tssep_lstm_onchip16w_pack_floats(H, 8); }
-extern "C" int tssep_lstm_pack_onchip16w(const float* w_hh_f, const float* w_hh_r, int H, int waves, float* wf, void* stream) {
+W16_API int tssep_lstm_pack_onchip16w(const float* w_hh_f, const float* w_hh_r, int H, int waves, float* wf, void* stream) {
   if (!w_hh_f || !w_hh_r || !wf) return TSSEP_E_NULL;
   if (H <= 0 || H > KP2 || !waves_ok(waves)) return TSSEP_E_UNSUPPORTED;
   if (!aligned16(wf)) return TSSEP_E_ALIGN;
@@ -2201,7 +2210,7 @@ extern "C" int tssep_lstm_pack_onchip16w(const float* w_hh_f, const float* w_hh_
 extern "C" int tssep_lstm_pack_onchip16(const float* w_hh_f, const float* w_hh_r, int H, float* wf, void* stream) {
   return tssep_lstm_pack_onchip16w(w_hh_f, w_hh_r, H, 8, wf, stream);
 }
-extern "C" int64_t tssep_lstm_onchip16w_xbuf_bytes(int64_t N, int H, int waves) {
+W16_API int64_t tssep_lstm_onchip16w_xbuf_bytes(int64_t N, int H, int waves) {
   if (!waves_ok(waves)) return 0;
   return HDR_BYTES + 2 * ((N + SQ - 1) / SQ) * 2 * g_of(H, waves) * SQ * (8 * waves) * 4;
 }
@@ -2210,7 +2219,7 @@ extern "C" int64_t tssep_lstm_onchip16_xbuf_bytes(int64_t N, int H) { return tss
 // 2 where that divides the number of 16-sequence groups and still gives every cluster a bundle, else 1 (four groups
 // -- `groups` = 4 -- stay available: slower than two since the two-group kernel requests its operands early).
 // Four-wave workgroups: ONE group per workgroup -- the second chain of a CU is its second workgroup.
-extern "C" int tssep_blstm_onchip16w_groups(int64_t N, int H, int max_wgs, int waves) {
+W16_API int tssep_blstm_onchip16w_groups(int64_t N, int H, int max_wgs, int waves) {
   if (!waves_ok(waves)) return 0;
   const int G = g_of(H, waves), slots = max_wgs * (8 / waves);
   if (N <= 0 || H <= 0 || H > KP2 || (H & 3) || G > 40 / waves || slots < 8 * G) return 0;
@@ -2222,7 +2231,7 @@ extern "C" int tssep_blstm_onchip16w_groups(int64_t N, int H, int max_wgs, int w
   return 1;
 }
 extern "C" int tssep_blstm_onchip16_groups(int64_t N, int H, int max_wgs) { return tssep_blstm_onchip16w_groups(N, H, max_wgs, 8); }
-extern "C" int tssep_blstm_onchip16w_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
+W16_API int tssep_blstm_onchip16w_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride,
                                          const float* wf, void* xbuf, int* err, int64_t N, int64_t T, int H,
                                          int max_wgs, int layout, int groups, int waves, void* stream) {
   if (!gates || !cell || !hout || !wf || !xbuf || !err) return TSSEP_E_NULL;
@@ -2245,8 +2254,10 @@ extern "C" int tssep_blstm_onchip16w_fwd(float* gates, float* cell, float* hout,
 #define L16(NGA_, NW_) if (nt) L16B(NGA_, true, NW_); else L16B(NGA_, false, NW_)
 #define L16B(NGA_, NT_, NW_) hipLaunchKernelGGL((blstm_onchip16_fwd_kernel<NGA_, NT_, NW_>), dim3(grid), dim3(64 * NW_), 0, s, gates, cell, hout, \
                     ldo, dstride, (const u32x4*)wf, (unsigned*)base, (float*)(base + HDR_BYTES), err, N, T, H, G, nc, klayout)
-  if (waves == 4) { if (nga == 2) { L16(2, 4); } else { L16(1, 4); } }
-  else if (nga == 4) { L16(4, 8); } else if (nga == 2) { L16(2, 8); } else { L16(1, 8); }
+#ifdef TSSEP_GEMM_EXP
+  if (waves == 4) { if (nga == 2) { L16(2, 4); } else { L16(1, 4); } } else
+#endif
+  if (nga == 4) { L16(4, 8); } else if (nga == 2) { L16(2, 8); } else { L16(1, 8); }
 #undef L16
 #undef L16B
   return tssep_launch_status();

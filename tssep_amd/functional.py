@@ -85,8 +85,7 @@ class _RNNP(torch.autograd.Function):
         if "cluster" in (kf, kb):
             cf, cb = H.derived("pack_cluster", [w_hh, w_hh_r], lambda: H.lstm_pack_cluster(w_hh, w_hh_r, Hh))
         # the 32-sequence W-stationary kernels' packed weights only where one of the two directions of time runs on them
-        fw = H.ONCHIP16_FWD_WAVES      # (8: five workgroups of 64 units per cluster; 4: ten of 32, two per CU -- runtime policy)
-        g16 = H.onchip16_groups(N, Hh, dev, fw) if kf == "onchip" and (2 * Hp) % 4 == 0 and Hp % 4 == 0 else 0
+        g16 = H.onchip16_groups(N, Hh, dev) if kf == "onchip" and (2 * Hp) % 4 == 0 and Hp % 4 == 0 else 0
         g16b = H.onchip16_bwd_groups(N, Hh, dev) if kb == "onchip" and Hp % 4 == 0 else 0
         if (kf == "onchip" and not g16) or (kb == "onchip" and not g16b):
             wf3, wb3 = H.derived("pack_onchip", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip(w_hh, w_hh_r, Hh))
@@ -94,8 +93,8 @@ class _RNNP(torch.autograd.Function):
             H.blstm_cluster_fwd(gates, cell, hout, 2 * Hp, Hp, cf, N, T, Hh)
         elif kf == "onchip":
             if g16:      # interleaved 16-sequence groups (round 3)
-                wf16 = H.derived(f"pack_onchip16_w{fw}", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip16(w_hh, w_hh_r, Hh, fw))
-                H.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16, N, T, Hh, g16, waves=fw)
+                wf16 = H.derived("pack_onchip16", [w_hh, w_hh_r], lambda: H.lstm_pack_onchip16(w_hh, w_hh_r, Hh))
+                H.blstm_onchip16_fwd(gates, cell, hout, 2 * Hp, Hp, wf16, N, T, Hh, g16)
             else:
                 H.blstm_onchip_fwd(gates, cell, hout, 2 * Hp, Hp, wf3, N, T, Hh)
         else:

@@ -772,14 +772,30 @@ ONCHIP16_BWD_GROUPS = 2  # at most: a backward phase is paced by its three barri
 
 
 KEEP_XBUF = None         # a list: the exchange buffers of the interleaved forward launches are appended (trace builds, tools)
-ONCHIP16_FWD_WAVES = 8   # waves per workgroup of the interleaved forward: 8 (five workgroups per cluster, one per CU) | 4 (ten, two per CU)
+
+
+def _w16(name, restype, argtypes):
+    """Entry point of the four-wave variant of the interleaved forward: EXPERIMENT build only since ABI 4 (rejected in
+    round 5: 1.4-1.8x slower at every size) -- `make -C tssep_amd/csrc exp`, TSSEP_HIP_LIB=.../libtssep_hip_exp.so."""
+    L = _lib.lib()
+    if not hasattr(L, name):
+        raise RuntimeError(f"{name}: the four-wave workgroups exist in the experiment build only (make exp, TSSEP_HIP_LIB)")
+    fn = getattr(L, name)
+    fn.restype, fn.argtypes = restype, argtypes
+    return fn
+
+
+_VP, _I64, _I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 
 
 def onchip16_groups(N, H, device, waves=8):
     if not ONCHIP16:
         return 0
     forced = ONCHIP16_GROUPS
-    g = int(_lib.lib().tssep_blstm_onchip16w_groups(N, H, n_cus(device), waves))
+    if waves == 8:
+        g = int(_lib.lib().tssep_blstm_onchip16_groups(N, H, n_cus(device)))
+    else:
+        g = int(_w16("tssep_blstm_onchip16w_groups", _I, [_I64, _I, _I, _I])(N, H, n_cus(device), waves))
     if g and forced in (1, 2, 4) and ((N + 15) // 16) % forced == 0 and not (waves == 4 and forced == 4):
         return forced
     return g if N >= ONCHIP16_MIN_N else 0
@@ -787,24 +803,36 @@ def onchip16_groups(N, H, device, waves=8):
 
 def lstm_pack_onchip16(w_hh_f, w_hh_r, H, waves=8):
     L = _lib.lib()
-    buf = torch.empty(int(L.tssep_lstm_onchip16w_pack_floats(H, waves)), device=w_hh_f.device, dtype=torch.float32)
     a, b = _f32(w_hh_f.detach()).contiguous(), _f32(w_hh_r.detach()).contiguous()
-    check(L.tssep_lstm_pack_onchip16w(_p(a), _p(b), H, waves, _p(buf), _stream()), "lstm_pack_onchip16")
+    if waves == 8:
+        buf = torch.empty(int(L.tssep_lstm_onchip16_pack_floats(H)), device=w_hh_f.device, dtype=torch.float32)
+        check(L.tssep_lstm_pack_onchip16(_p(a), _p(b), H, _p(buf), _stream()), "lstm_pack_onchip16")
+        return buf
+    buf = torch.empty(int(_w16("tssep_lstm_onchip16w_pack_floats", _I64, [_I, _I])(H, waves)), device=w_hh_f.device, dtype=torch.float32)
+    check(_w16("tssep_lstm_pack_onchip16w", _I, [_VP, _VP, _I, _I, _VP, _VP])(_p(a), _p(b), H, waves, _p(buf), _stream()),
+          "lstm_pack_onchip16")
     return buf
 
 
 def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, layout=0, waves=8):
-    """wf16: the pack made for the SAME `waves` (lstm_pack_onchip16)."""
+    """wf16: the pack made for the SAME `waves` (lstm_pack_onchip16); waves = 4: experiment build only (`_w16`)."""
     _log_recurrence("onchip16_bf16x3" + ("_w4" if waves == 4 else ""), "fwd", N, T, H, groups)
     L = _lib.lib()
     cus = n_cus(gates.device)
-    xbuf = torch.empty(int(L.tssep_lstm_onchip16w_xbuf_bytes(N, H, waves)) // 8 + 2, device=gates.device, dtype=torch.int64)
+    nbytes = int(L.tssep_lstm_onchip16_xbuf_bytes(N, H)) if waves == 8 else \
+        int(_w16("tssep_lstm_onchip16w_xbuf_bytes", _I64, [_I64, _I, _I])(N, H, waves))
+    xbuf = torch.empty(nbytes // 8 + 2, device=gates.device, dtype=torch.int64)
     if KEEP_XBUF is not None:
         KEEP_XBUF.append(xbuf)
     with _timed("blstm_onchip_fwd", 2 * 2 * N * T * 4 * H * H, N * T * 2 * H * 40):      # gates in / activations out 16 + 16, c 4, h 4 B per cell
-        check(L.tssep_blstm_onchip16w_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf),
-                                          _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, waves, _stream()),
-              "blstm_onchip16_fwd")
+        if waves == 8:
+            rc = L.tssep_blstm_onchip16_fwd(_p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf),
+                                            _p(_err_flag(gates.device)), N, T, H, cus, layout, groups, _stream())
+        else:
+            rc = _w16("tssep_blstm_onchip16w_fwd", _I, [_VP, _VP, _VP, _I64, _I64, _VP, _VP, _VP, _I64, _I64, _I, _I, _I, _I, _I, _VP])(
+                _p(gates), _p(cell), _p(hout), ldo, dstride, _p(wf16), _p(xbuf), _p(_err_flag(gates.device)), N, T, H, cus,
+                layout, groups, waves, _stream())
+        check(rc, "blstm_onchip16_fwd")
 
 
 def onchip16_bwd_groups(N, H, device):

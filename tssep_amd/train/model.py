@@ -349,7 +349,11 @@ class Model(Configurable, torch.nn.Module):
             else:
                 out.time_estimate = self.fe.istft(out.stft_estimate, num_samples=n)
         loss_value = self.loss.from_ex_out(ex, out, self, summary)
-        summary.add_to_loss(loss_value.sum())                            # model.py:669
+        # (`loss_weight`, checker-only, not a key of the reference: per-utterance weights of the batch sum -- with 0 / 1
+        # weights the backward of a FULL batch, on the kernels a full batch selects, yields the gradient of a slice of it,
+        # which is what bench.py compares with the CPU oracle's backward over that slice)
+        w = ex.get("loss_weight")
+        summary.add_to_loss(loss_value.sum() if w is None else (loss_value * w.to(loss_value)).sum())      # model.py:669
         with torch.no_grad():
             name = self.loss.name
             if loss_value.ndim == 0:                                      # model.py:672-679

@@ -32,7 +32,6 @@ _POLICY = {
     "onchip16": ("ONCHIP16", True, lambda v: isinstance(v, bool)),
     "onchip16_groups": ("ONCHIP16_GROUPS", 0, lambda v: v in (0, 1, 2, 4)),
     "onchip16_min_n": ("ONCHIP16_MIN_N", 1, lambda v: isinstance(v, int) and v >= 1),
-    "onchip16_fwd_waves": ("ONCHIP16_FWD_WAVES", 8, lambda v: v in (4, 8)),
     "onchip16_bwd": ("ONCHIP16_BWD", True, lambda v: isinstance(v, bool)),
     "onchip16_bwd_groups": ("ONCHIP16_BWD_GROUPS", 2, lambda v: v in (1, 2, 4)),
     # step scheduling
