@@ -32,6 +32,9 @@ using namespace gemm_detail;
 #ifndef BIGP_PROBE_NOB
 #define BIGP_PROBE_NOB 0
 #endif
+#ifndef BIGP_PROBE_NOA      // round 6, the twin for the ACTIVATION operand: 1 = neither loaded, split nor written; 2 = eight 1-KB LDS-DMA copies
+#define BIGP_PROBE_NOA 0   // per wave and stage in its place (timing probes, results wrong; profiles/r6_gemm_noa_probe.jsonl)
+#endif
 constexpr int GM = 256, GN = 256, GBK = 32, GNT = 256;
 constexpr int GROWB = 64;                                   // bytes per LDS row: 32 bf16
 constexpr int GARR = GM * GROWB;                            // 16 384 B per plane
@@ -235,11 +238,22 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
 #define SPLIT(a_, b_, h_, l_) if constexpr (ONE) h_ = bf16_pair(a_, b_); else split2n(a_, b_, h_, l_)
+#if BIGP_PROBE_NOA == 2
+#define SA1(i) (void)0
+#define SA2(i) (void)0
+#define SA3(i) { const int la_ = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(nxt + ((tid >> 6) * 8 + (i)) * 1024)); \
+                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((unsigned)(tid * 16 + (i) * 4096)), "s"(A), "s"(la_) : "memory"); }
+#elif BIGP_PROBE_NOA
+#define SA1(i) (void)0
+#define SA2(i) (void)0
+#define SA3(i) (void)0
+#else
 #define SA1(i) if constexpr (XCOL) XDOT(i); SPLIT(ra[i][0], ra[i][1], sh0, sl0)
 #define SA2(i) SPLIT(ra[i][2], ra[i][3], sh1, sl1)
 #define SA3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
                if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                ra[i] = load_a(i, tmask, so)
+#endif
 #if BIGP_PROBE_NOB == 2 // timing probe (wrong results): operand B as eight 1-KB LDS-DMA copies per wave and stage from somewhere valid
 #define SB1(i) (void)0
 #define SB2(i) (void)0

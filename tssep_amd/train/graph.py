@@ -195,6 +195,12 @@ class GraphedStep:
         call overwrites (lazily computed fields -- mask, stft_estimate -- are evaluated from them on
         access).  Gradients are in the optimizer's flat bucket afterwards (call ``optimizer.step()``)."""
         ex = self._host_side_targets(ex)
+        if not self.zero_grad:
+            # an EAGER micro-step of the same virtual minibatch may still be accumulating weight gradients into the bucket on
+            # the side stream; the captured wgrad nodes += into the same views, ordered only against the launch stream, and
+            # a CAPTURE saves and restores the half-filled bucket around its warm-up passes (ADVICE r5; the test of the
+            # mixed routing lost the eager step's weight gradients in exactly that copy).  A stream wait, no host sync.
+            self.optimizer.bucket.sync()
         sig = self._signature(ex)
         st = self._graphs.get(sig)
         if st is None:
@@ -216,11 +222,6 @@ class GraphedStep:
             ev = torch.cuda.Event()
             ev.record()
             st["perm_events"][slot] = ev
-        if not self.zero_grad:
-            # an EAGER micro-step of the same virtual minibatch may still be accumulating weight gradients into the bucket on
-            # the side stream; the captured wgrad nodes += into the same views, ordered only against the launch stream
-            # (ADVICE r5).  A stream wait, no host sync.
-            self.optimizer.bucket.sync()
         st["graph"].replay()
         self.replays += 1
         out = st["out"]
