@@ -433,6 +433,9 @@ def main():
     opt.set_parameters(model.parameters())               # flat params + the flat gradient bucket
     if world > 1:                                        # identical replicas, as Trainer.train does
         D.broadcast_(opt.flat_param, src=0)
+    bucketed = world > 1 and H.BUCKETED_ALLREDUCE        # --runtime bucketed_allreduce=true: per-layer segments (default off)
+    if bucketed:
+        opt.bucket.set_segments(D.layer_groups(model.named_parameters()))
     obs, aux, tgt = synth_batch(B, K, N_s, seed=rank)    # each rank its own shard
     ex0 = dict(observation=torch.as_tensor(obs).to(dev), auxInput=torch.as_tensor(aux).to(dev),
                speaker_reverberation_early_ch0=torch.as_tensor(tgt).to(dev),
@@ -456,10 +459,12 @@ def main():
             out, _ = gstep(dict(ex0))
         else:
             opt.zero_grad()
+            if bucketed:
+                opt.bucket.arm()     # every step is the last micro-step of its minibatch: layers reduce as they complete
             ex = dict(ex0)
             out = model(ex)
             model.review(ex, out)["loss"].backward()
-        opt.step()                   # joins the side stream, all-reduces, clips, updates
+        opt.step()                   # joins the side stream, all-reduces (what is left of it), clips, updates
         return out
 
     def barrier():
@@ -759,6 +764,12 @@ def main():
                           process_group_world_size=dist.get_world_size(), bytes=int(opt.bucket.flat.numel()) * 4,
                           allreduce_ms=round(float(ar_ms[0]), 4), allreduce_ms_max=round(float(ar_ms[1]), 4),
                           launches=len(ar), replicas_agree=bool(D.replicas_agree(opt.flat_param)),
+                          parameter_checksum=float(opt.flat_param.double().abs().sum()),
+                          bucketed=dict(enabled=bool(bucketed), segments=len(opt.bucket.segments),
+                                        reduced_during_backward_in_order=getattr(opt.bucket, "last_reduction_order", None),
+                                        note="segments all-reduced on a communication stream as their layer's backward "
+                                             "completes (reverse layer order); every W-stationary recurrence launch waits for "
+                                             "the reductions queued so far; graph replays reduce after the replay"),
                           overlap="none: issued after the last weight gradient (the clip needs the norm of the SUMMED gradient)")
         if not collective["replicas_agree"]:
             raise SystemExit(f"bench.py: rank {rank}: the parameter replicas diverged -- a lost or doubled all-reduce")

@@ -162,6 +162,57 @@ def test_failure_flag_rides_in_the_gradient_allreduce_world2():
         assert bad[2] == good[2] > 0
 
 
+def _segments_worker(rank, world, port, q):
+    from tssep_amd.distributed import layer_groups
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def build():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential()
+        m.add_module("a", torch.nn.Linear(7, 5))
+        m.add_module("b", torch.nn.Linear(5, 9))
+        m.add_module("c", torch.nn.Linear(9, 3))
+        return m
+
+    x = torch.randn(16, 7, generator=torch.Generator().manual_seed(10 + rank))
+    res = {}
+    for mode in ("flat", "all_layers", "some_layers", "unarmed"):
+        m = build()
+        b = GradBucket(m.parameters())
+        if mode != "flat":
+            b.set_segments(layer_groups(m.named_parameters()))
+            assert len(b.segments) == 3 and b.segments[0][0] == 0
+        b.zero()
+        if mode in ("all_layers", "some_layers"):
+            b.arm()
+        m(x).pow(2).sum().backward()
+        b.set_guard(torch.tensor([rank], dtype=torch.int32))      # rank 1 "failed": the slot must still arrive
+        # the layers report in reverse order, as a backward does; "some": the first layer never reports (unfused path)
+        for name in ("c", "b", "a")[:3 if mode != "some_layers" else 2]:
+            b.notify(list(getattr(m, name).parameters()))
+        order = list(b._reduced)
+        b.all_reduce()
+        res[mode] = (b._full.clone().numpy(), order, list(getattr(b, "last_reduction_order", []) or []))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_the_flat_one_world2():
+    """per-layer segments reduced as their layer reports (reverse layer order) + the rest at the end give
+    the flat all-reduce's buffer BIT FOR BIT -- gradient, alignment gaps and the guard slot -- whether all layers report,
+    only some do, or the bucket was never armed (then nothing is reduced early)."""
+    res = _spawn(_segments_worker, 2)
+    for rank, r in res:
+        flat = r["flat"][0]
+        assert float(np.abs(flat).sum()) > 0 and flat[-64] == 1.0          # guard slot: 0 + 1
+        for mode in ("all_layers", "some_layers", "unarmed"):
+            assert np.array_equal(r[mode][0], flat), (rank, mode)
+        assert r["all_layers"][1] == [2, 1, 0] and r["some_layers"][1] == [2, 1] and r["unarmed"][1] == []
+        assert r["flat"][1] == []
+    assert np.array_equal(res[0][1]["flat"][0], res[1][1]["flat"][0])
+
+
 def test_gradient_sum_allreduce_world2():
     res = _spawn(_worker, 2)
     torch.manual_seed(0)

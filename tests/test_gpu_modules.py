@@ -1382,8 +1382,12 @@ def test_bench_default_flags_print_one_json_line():
     assert d["two_product_wgrad"] is not None and d["two_product_wgrad"]["value"] > 0
 
 
-@pytest.mark.parametrize("workload,batch,graph", [("cfg3", 4, "off"), ("cfg4", 8, "on")])
-def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
+_TWO_RANK_CHECKSUMS = {}
+
+
+@pytest.mark.parametrize("workload,batch,graph,bucketed", [("cfg3", 4, "off", False), ("cfg4", 8, "on", False),
+                                                           ("cfg3", 4, "off", True), ("cfg4", 8, "on", True)])
+def test_bench_two_ranks_on_one_gpu(workload, batch, graph, bucketed):
     """The N > 1 path of bench.py exactly as the driver launches it (`python -m torch.distributed.run ... bench.py
     --gpus 2`): rank-0 broadcast of the parameters, per-rank shards, barrier + max-over-ranks timing, the flat
     gradient all-reduce inside the optimizer step, ONE JSON line from rank 0 with n_gpus = 2 and the doubled global
@@ -1391,7 +1395,11 @@ def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
     recurrences are the streaming ones (two processes must not run W-stationary launches concurrently).
     cfg4 + graph on: the per-GPU shard of configs[3] as the replayed hipGraph with the all-reduce +
     optimizer outside it -- the replicas must still agree after the timed steps, i.e. the all-reduce sees the complete
-    gradient of replay i and replay i + 1 starts from the updated weights."""
+    gradient of replay i and replay i + 1 starts from the updated weights.
+    bucketed (round 6, `--runtime bucketed_allreduce=true`): the five layers' segments are all-reduced as their backward
+    completes, last layer first, the rest (alignment tail, guard slot) in the optimizer step; a graph replay reduces
+    after the replay.  Two ranks: a + b = b + a, so the parameters after the run are those of the flat all-reduce BIT FOR
+    BIT (`parameter_checksum` of the un-bucketed case of the same workload, which runs first)."""
     import json
     import socket
     import subprocess
@@ -1401,7 +1409,8 @@ def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload, "--batch", str(batch),
-                        "--recurrence", "stream", "--no-cpu-baseline", "--no-exact-f32", "--graph", graph],
+                        "--recurrence", "stream", "--no-cpu-baseline", "--no-exact-f32", "--graph", graph,
+                        *(["--runtime", "bucketed_allreduce=true"] if bucketed else [])],
                        capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1417,6 +1426,15 @@ def test_bench_two_ranks_on_one_gpu(workload, batch, graph):
     # what the first 8-GPU run should explain by itself: per-rank step times, bus bandwidth, the library behind "nccl"
     assert len(c["ms_per_step_by_rank"]) == 2 and all(v > 0 for v in c["ms_per_step_by_rank"])
     assert c["allreduce_busbw_gbps"] > 0 and "collective_library" in c and "environment" in c
+    assert c["bucketed"]["enabled"] is bucketed
+    if bucketed:
+        assert c["bucketed"]["segments"] == 5
+        # (the last step of either run is an eager one: every layer reported, last layer first)
+        assert c["bucketed"]["reduced_during_backward_in_order"] == [4, 3, 2, 1, 0], c["bucketed"]
+        if (workload, graph) in _TWO_RANK_CHECKSUMS:
+            assert c["parameter_checksum"] == _TWO_RANK_CHECKSUMS[(workload, graph)]
+    else:
+        _TWO_RANK_CHECKSUMS[(workload, graph)] = c["parameter_checksum"]
 
 
 def test_headline_batch_gemm_requests_on_every_covering_kernel():

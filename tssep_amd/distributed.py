@@ -6,6 +6,8 @@ loss is SUMMED over the batch (tssep/train/model.py:669), so gradients of the sh
 not averaged, to equal a single-process run over the concatenated batch.  Utterances are
 independent in forward and backward, so the data path needs no other collective.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -24,6 +26,22 @@ def flat_offsets(params, align=FLAT_ALIGN):
         offsets.append(off)
         off += -(-p.numel() // align) * align
     return offsets, off
+
+
+def layer_groups(named_parameters):
+    """-> lists of parameters, one per layer in forward (= registration) order, for GradBucket.set_segments: the two
+    modules of an RNNP layer (`<layer>.net.0` nn.LSTM + `<layer>.net.1` projection, tssep/train/rnnp.py:88-96) are one
+    group -- its backward completes all ten tensors together --, every other module is its own."""
+    groups, last = [], None
+    for name, p in named_parameters:
+        if not p.requires_grad:
+            continue
+        key = name.split(".net.")[0] if ".net." in name else name.rsplit(".", 1)[0]
+        if key != last:
+            groups.append([])
+            last = key
+        groups[-1].append(p)
+    return groups
 
 
 GUARD_SLOT = 64          # floats (256 bytes) behind the gradient: the failure flag that rides in the all-reduce
@@ -58,6 +76,97 @@ class GradBucket:
             # on a side stream): see tssep_amd.functional._grad_sink
             p._tssep_grad_sinks = views
             p._tssep_grad_sink = views[0]
+            p._tssep_bucket = weakref.ref(self)
+        self._offsets, self._n = offsets, n
+        self.segments = []          # [(start, end)] element ranges of `_full`, one per layer, in forward order (set_segments)
+        self._seg_of = {}           # id(parameter) -> segment index
+        self._seg_params = []       # per segment: ids of its parameters
+        self._armed = False         # only the LAST micro-step of a virtual minibatch may reduce early (arm)
+        self._reported = []         # per segment: ids reported complete in this backward
+        self._reduced = []          # segment indices already all-reduced (in launch order)
+        self._works = []
+        self.comm_stream = None
+
+    # ---- per-layer segments, reduced as soon as a layer's gradients are complete (round 6) -------------
+    # Policy `runtime.bucketed_allreduce` (default OFF: no multi-GPU box has run this yet).  The backward of a layer
+    # reports its parameters (`notify`, from tssep_amd.functional where the weight gradients are accumulated straight
+    # into the bucket); when every parameter of a segment has reported, the bucket is armed and more than one rank takes
+    # part, the segment is all-reduced at once on a COMMUNICATION stream that waits for the compute stream and its
+    # weight-gradient side stream -- layers are reported in reverse order, so the reductions queue in reverse layer order
+    # while the backward of the layers in front is still running.  `all_reduce()` then reduces what is left (layers that
+    # never reported: unfused paths, graph replays; the guard slot) and joins the communication stream.
+    # What an RCCL kernel may run beside: the GEMMs and the fused tail of the backward -- NOT a W-stationary recurrence
+    # (include/tssep_hip.h, concurrency contract: its clusters need all their workgroups resident): every W-stationary
+    # launch first waits for the communication stream (hip_ops.fence_comm), so a reduction overlaps the dz / dh GEMMs
+    # between two recurrences and no more.
+    def set_segments(self, groups):
+        """groups: lists of parameters, one per layer, in forward order; each group must be contiguous in the flat layout."""
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self.segments, self._seg_of, self._seg_params = [], {}, []
+        for g in groups:
+            ids = sorted(index[id(p)] for p in g if id(p) in index)
+            if not ids:
+                continue
+            assert ids == list(range(ids[0], ids[-1] + 1)), "a segment's parameters must be neighbours in the flat buffer"
+            start = self._offsets[ids[0]]
+            end = self._offsets[ids[-1] + 1] if ids[-1] + 1 < len(self.params) else self._n
+            k = len(self.segments)
+            self.segments.append((start, end))
+            self._seg_params.append({id(self.params[i]) for i in ids})
+            for i in ids:
+                self._seg_of[id(self.params[i])] = k
+        self._reset_step()
+
+    def _reset_step(self):
+        self._reported = [set() for _ in self.segments]
+        self._reduced, self._works, self._armed = [], [], False
+
+    def arm(self):
+        """The backward that follows is the LAST of its virtual minibatch: complete segments may be reduced at once."""
+        self._armed = bool(self.segments) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def notify(self, params):
+        """The gradients of `params` are complete for this backward (queued on the current stream / its side stream)."""
+        if not self._armed:
+            return
+        if self.flat.is_cuda and torch.cuda.is_current_stream_capturing():
+            return                                   # (a captured step reduces after the replay, in all_reduce)
+        for p in params:
+            k = self._seg_of.get(id(p))
+            if k is None or k in self._reduced:
+                continue
+            self._reported[k].add(id(p))
+            if self._reported[k] == self._seg_params[k]:
+                self._launch(k)
+
+    def _reduce_range(self, start, end, group=None):
+        buf = self._full[start:end]
+        if buf.is_cuda and dist.get_backend(group) == "gloo":       # test configuration: staged through the host
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf.copy_(host)
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=buf.is_cuda)
+
+    def _launch(self, k):
+        start, end = self.segments[k]
+        if self.flat.is_cuda:
+            from . import hip_ops
+            dev = self.flat.device
+            cur = torch.cuda.current_stream(dev)
+            comm = self.comm_stream = self.comm_stream or torch.cuda.Stream(device=dev)
+            comm.wait_stream(cur)
+            side = hip_ops._SIDE.get((str(cur.device), cur.cuda_stream))
+            if side is not None:
+                comm.wait_stream(side)
+            with torch.cuda.stream(comm):
+                w = self._reduce_range(start, end)
+            hip_ops.COMM_PENDING[str(dev)] = comm      # the next W-stationary launch waits for it (fence_comm)
+        else:
+            w = self._reduce_range(start, end)
+        self._reduced.append(k)
+        if w is not None:
+            self._works.append(w)
 
     def reduce_replicas(self):
         for f in self.flats[1:]:
@@ -66,6 +175,8 @@ class GradBucket:
     def zero(self):
         for f in self.flats:
             f.zero_()
+        if self.segments:
+            self._reset_step()
 
     def sync(self):
         """Wait for gradient work queued on the side stream (no-op on CPU / when unused)."""
@@ -83,17 +194,33 @@ class GradBucket:
             self.guard[:1].copy_(flag[:1])
 
     def all_reduce(self, group=None, async_op=False):
-        """SUM over ranks of the gradient AND the guard slot behind it (one collective)."""
+        """SUM over ranks of the gradient AND the guard slot behind it: one collective -- or, with segments reduced early
+        (`arm` / `notify`), one collective per remaining contiguous range, last layers first, then a join."""
         self.sync()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            if self._full.is_cuda and dist.get_backend(group) == "gloo":
-                # debugging / test configuration (several ranks on one GPU, where RCCL refuses to
-                # run): stage through the host.  Production is nccl = RCCL over xGMI, in place.
-                host = self._full.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-                self._full.copy_(host)
-                return None
-            return dist.all_reduce(self._full, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return None
+        if not self._reduced:
+            w = self._reduce_range(0, self._full.numel(), group)
+            return w if async_op else (w.wait() if w is not None else None)
+        done = sorted(self.segments[k] for k in self._reduced)
+        rest, pos = [], 0
+        for a, b in done + [(self._full.numel(), self._full.numel())]:
+            if a > pos:
+                rest.append((pos, a))
+            pos = max(pos, b)
+        for a, b in reversed(rest):
+            w = self._reduce_range(a, b, group)
+            if w is not None:
+                self._works.append(w)
+        for w in self._works:
+            w.wait()                                 # (nccl: the CURRENT stream waits for the collective; no host sync)
+        if self.comm_stream is not None and self.flat.is_cuda:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+            from . import hip_ops
+            hip_ops.COMM_PENDING.pop(str(self.flat.device), None)
+        self.last_reduction_order = list(self._reduced)
+        self._reduced, self._works, self._armed = [], [], False
+        self._reported = [set() for _ in self.segments]
         return None
 
     def global_norm(self):

@@ -252,6 +252,7 @@ class _RNNP(torch.autograd.Function):
                 t_.record_stream(side)
             with torch.cuda.stream(side):
                 lstm_grads = lstm_wgrads()
+            _notify_grads(params)                    # (10 tensors: both directions' LSTM weights + the projection)
         else:
             lstm_grads = lstm_wgrads()
         dx = None
@@ -283,6 +284,15 @@ class _RNNP(torch.autograd.Function):
                 if tuple(ctx.x_shape) != tuple(dx.shape):
                     dx = dx.reshape(ctx.x_shape)
         return (dx, *lstm_grads, d_w_proj, d_b_proj, None, None, None, None, None, None, None)
+
+
+def _notify_grads(params):
+    """The gradients of `params` are queued completely (directly into the flat bucket): a bucket with per-layer
+    segments may all-reduce the layer now (distributed.GradBucket.notify; a no-op unless armed)."""
+    b = getattr(params[0], "_tssep_bucket", None)
+    b = b() if b is not None else None
+    if b is not None and b._armed:
+        b.notify(params)
 
 
 def _grad_sink(p):
@@ -425,6 +435,7 @@ class _Head(torch.autograd.Function):
                     H.reduce_splits(part, S, Nout * P, sw, accumulate=True)
                     H.colsum(dv, ld_d, R, Nout, out=sb, accumulate=True)
             dw = db = None
+            _notify_grads(ctx.params)
         else:
             part, S = H.wgrad(dv, ld_d, xv, ld_x, Nout, P, R)
             dw = torch.empty(Nout, P, device=dev, dtype=torch.float32)

@@ -718,6 +718,7 @@ def lstm_pack_cluster(w_hh_f, w_hh_r, H):
 
 def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H, ms=2):
     _log_recurrence("cluster_f32", "fwd", N, T, H, 0)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 0, cus, ms)) // 8 + 1,
@@ -730,6 +731,7 @@ def blstm_cluster_fwd(gates, cell, hout, ldo, dstride, whh_cf, N, T, H, ms=2):
 
 def blstm_cluster_bwd(gates, cell, dhout, ldo, dstride, whh_cb, N, T, H, ms=2):
     _log_recurrence("cluster_f32", "bwd", N, T, H, 0)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_cluster_xbuf_bytes(N, H, 1, cus, ms)) // 8 + 1,
@@ -753,6 +755,7 @@ def lstm_pack_onchip(w_hh_f, w_hh_r, H):
 
 def blstm_onchip_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H, layout=0):
     _log_recurrence("onchip32_bf16x3", "fwd", N, T, H, 0)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 0)) // 8 + 2, device=gates.device,
@@ -817,6 +820,7 @@ def lstm_pack_onchip16(w_hh_f, w_hh_r, H, waves=8):
 def blstm_onchip16_fwd(gates, cell, hout, ldo, dstride, wf16, N, T, H, groups, layout=0, waves=8):
     """wf16: the pack made for the SAME `waves` (lstm_pack_onchip16); waves = 4: experiment build only (`_w16`)."""
     _log_recurrence("onchip16_bf16x3" + ("_w4" if waves == 4 else ""), "fwd", N, T, H, groups)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     nbytes = int(L.tssep_lstm_onchip16_xbuf_bytes(N, H)) if waves == 8 else \
@@ -854,6 +858,7 @@ def lstm_pack_onchip16_bwd(w_hh_f, w_hh_r, H):
 
 def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, layout=0):
     _log_recurrence("onchip16_bf16x3", "bwd", N, T, H, groups)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip16_bwd_xbuf_bytes(N, H)) // 8 + 2, device=gates.device, dtype=torch.int64)
@@ -867,6 +872,7 @@ def blstm_onchip16_bwd(gates, cell, dhout, ldo, dstride, wb16, N, T, H, groups, 
 
 def blstm_onchip_bwd(gates, cell, dhout, ldo, dstride, wb, N, T, H, layout=0):
     _log_recurrence("onchip32_bf16x3", "bwd", N, T, H, 0)
+    fence_comm(gates.device)
     L = _lib.lib()
     cus = n_cus(gates.device)
     xbuf = torch.empty(int(L.tssep_lstm_onchip_xbuf_bytes(N, H, 1)) // 8 + 2, device=gates.device,
@@ -895,6 +901,18 @@ SIDE_STREAM_MAX_SEQS = 512   # layers with more sequences (x 253 frames) stay on
 ACTIVE_SINK = 0          # which gradient bucket the running micro-batch accumulates into
 GRAPH_STEP = "auto"      # Trainer: hipGraph replay of forward + loss + backward ("auto": batches of <= GRAPH_MAX_UTTERANCES utterances)
 GRAPH_MAX_UTTERANCES = 32
+
+
+BUCKETED_ALLREDUCE = False     # per-layer gradient segments reduced during the backward (distributed.GradBucket; default off)
+COMM_PENDING = {}              # str(device) -> the communication stream with gradient reductions in flight
+
+
+def fence_comm(device):
+    """In front of every W-stationary recurrence launch: an RCCL kernel must not run beside it (include/tssep_hip.h:
+    the clusters need all their workgroups resident) -- the compute stream waits for the reductions queued so far."""
+    st = COMM_PENDING.pop(str(torch.device(device) if not isinstance(device, torch.device) else device), None)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
 
 
 def side_stream(device, rows=0):

@@ -38,6 +38,9 @@ _POLICY = {
     "overlap_wgrad": ("OVERLAP_WGRAD", True, lambda v: isinstance(v, bool)),
     "side_stream": ("SIDE_STREAM", True, lambda v: isinstance(v, bool)),
     "side_stream_max_seqs": ("SIDE_STREAM_MAX_SEQS", 512, lambda v: isinstance(v, int) and v >= 0),
+    # data parallel: per-layer gradient segments all-reduced during the backward instead of one collective behind it
+    # (distributed.GradBucket.notify; off until a scaling curve exists)
+    "bucketed_allreduce": ("BUCKETED_ALLREDUCE", False, lambda v: isinstance(v, bool)),
     "fold_tanh": ("FOLD_TANH", True, lambda v: isinstance(v, bool)),
     "fold_tail": ("FOLD_TAIL", 1, lambda v: v in (0, 1, 2, 3)),
     "prepare_derived": ("PREPARE_DERIVED", True, lambda v: isinstance(v, bool)),

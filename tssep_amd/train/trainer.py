@@ -201,6 +201,9 @@ class Trainer(Configurable):
         from .. import hip_ops as _H
         gstep = None
         on_gpu = next(self.model.parameters()).is_cuda
+        bucketed = world > 1 and _H.BUCKETED_ALLREDUCE
+        if bucketed:      # per-layer segments, reduced during the last micro-step's backward (runtime.bucketed_allreduce)
+            self.optimizer.bucket.set_segments(_dist.layer_groups(self.model.named_parameters()))
         if _H.GRAPH_STEP != "off" and on_gpu and hasattr(getattr(self.model, "mask_estimator", None), "permutation_source"):
             from .graph import GraphedStep
             gstep = GraphedStep(self.model, self.optimizer, zero_grad=False, max_graphs=8)
@@ -240,6 +243,8 @@ class Trainer(Configurable):
                 while True:
                     ex = next(batches, None)
                     boundary = (self.iteration + 1) % self.virtual_minibatch_size == 0
+                    if bucketed and boundary and ex is not None:
+                        self.optimizer.bucket.arm()
                     if agree_per_step:
                         if not _dist.same_on_all_ranks(0 if ex is None else 1) or ex is None:
                             break
