@@ -233,6 +233,10 @@ const char* tssep_gemm_kernel_name(int32_t kernel);
  * `args` (a_kmajor = b_kmajor = 1; splitk, c_split_stride and C are ignored): follows the kernel the library
  * picks for it. */
 int tssep_gemm_wgrad_splits(const tssep_gemm_args* args);
+/* The split count the split rule OF kernel `kernel_id` (TSSEP_GEMM_*) gives this request: tssep_gemm_wgrad_splits returns
+ * an S for which tssep_gemm_plan(.., splitk = S) names a kernel k with tssep_gemm_wgrad_split_rule(g, k) == S (a fixed
+ * point), or 8 when there is none (ABI 4). */
+int tssep_gemm_wgrad_split_rule(const tssep_gemm_args* g, int32_t kernel_id);
 
 /* column sums: out[n] (+)= sum_m A[m*lda+n]  (bias gradients) */
 int tssep_colsum_f32(const float* A, int64_t M, int64_t N, int64_t lda, float* out,

@@ -1025,6 +1025,7 @@ def test_trainer_mixes_eager_and_graph_micro_steps_in_one_virtual_minibatch():
                 _, summ = g(dict(ex))
                 assert set(summ["scalars"]) == {"a_LogMAE", "b_LogMAE"}      # (names of THIS batch)
             else:
+                ex = dict(ex)                                # (the forward caches Observation / Input in the example it is given)
                 m.review(ex, m(ex))["loss"].backward()
             if i % 2 == 1:                                   # virtual minibatch of two micro-steps: eager, then graph
                 opt.bucket.sync()

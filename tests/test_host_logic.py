@@ -97,9 +97,12 @@ def test_wgrad_split_count_and_kernel_are_a_fixed_point_over_many_shapes():
             g.c_split_stride = M * g.ldc
             if shifted:
                 g.b_kshift, g.kperiod = -1, 253
-            return H.gemm_plan(g, "auto")
+            name = H.gemm_plan(g, "auto")
+            # the split count the rule OF THAT kernel gives the request (tssep_gemm_wgrad_split_rule, ABI 4)
+            rule = int(H._lib.lib().tssep_gemm_wgrad_split_rule(ctypes.byref(g), H.GEMM_KERNELS[name])) if name else None
+            return name, rule
 
-        n = 0
+        n = fallbacks = 0
         for K in (8 * 253, 32 * 253, 320 * 253, 768 * 253, 3072 * 253):
             for M in (320, 513, 640, 1200, 1280, 2052, 2400, 4104):
                 for N, ones in ((300, False), (301, True), (321, True), (320, False), (514, True), (554, True), (557, True), (601, True),
@@ -110,14 +113,17 @@ def test_wgrad_split_count_and_kernel_are_a_fixed_point_over_many_shapes():
                         S = H.pick_splitk(M, N, K, shifted=shifted, ones_col=ones)
                         ktiles = (K + 15) // 16
                         assert 1 <= S <= max(1, ktiles // 8) or S == 8, (M, N, K, S)
-                        k_at_s = plan_at(M, N, K, S, ones, shifted)
+                        k_at_s, rule_s = plan_at(M, N, K, S, ones, shifted)
                         assert k_at_s is not None, (M, N, K, S)
-                        # a second query with the kernel's own S must not move to yet another kernel
-                        assert plan_at(M, N, K, S, ones, shifted) == k_at_s
+                        # the kernel planned AT S is the kernel whose rule produced S (the former check
+                        # compared two identical queries) -- or the library found no fixed point and fell back to 8
+                        if rule_s != S:
+                            assert S == 8, (k_at_s, M, N, K, S, rule_s)
+                            fallbacks += 1
                         if k_at_s in ("tn_big", "tn_p320", "tn_w160", "tn_h160") and ktiles >= 64 * 8:
                             assert S % 8 == 0, (k_at_s, M, N, K, S)
                         n += 1
-        assert n > 500
+        assert n > 500 and fallbacks <= n // 20, (n, fallbacks)
     finally:
         H.GEMM_PRECISION = old
 

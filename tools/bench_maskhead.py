@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tssep_amd import hip_ops as h
 
-K, T, F = 4, 253, 513
+K, T, F = int(os.environ.get("MH_K", 4)), int(os.environ.get("MH_T", 253)), 513
 
 
 def timeit(fn, reps=10):

@@ -392,13 +392,25 @@ extern "C" int tssep_gemm_wgrad_splits(const tssep_gemm_args* g) {
   // kernel than the one the rule was written for.  So: plan again with the S just chosen and, when the kernel
   // changed, apply THAT kernel's rule -- until the (kernel, S) pair is a fixed point (two rounds at most in practice).
   int S = wgrad_split_rule(g, kid);
-  for (int round = 0; round < 3; ++round) {
+  bool fixed = false;
+  for (int round = 0; round < 4 && !fixed; ++round) {
     int32_t kid2 = TSSEP_GEMM_AUTO;
-    if (planned(S, &kid2) != TSSEP_OK || kid2 == kid) break;
+    if (planned(S, &kid2) != TSSEP_OK) break;
+    if (kid2 == kid) { fixed = true; break; }
     kid = kid2;
     S = wgrad_split_rule(g, kid);
   }
-  return S;
+  // (no fixed point -- kernels whose rules keep handing the request to each other, or a refused plan: 8 splits, which
+  // every weight-gradient kernel takes)
+  return fixed ? S : 8;
+}
+
+// The split count the rule of kernel `kernel_id` gives this request (tests: the kernel planned AT the returned S of
+// tssep_gemm_wgrad_splits must be the kernel whose rule produced that S).
+extern "C" int tssep_gemm_wgrad_split_rule(const tssep_gemm_args* g, int32_t kernel_id) {
+  if (!g) return TSSEP_E_NULL;
+  if (g->M <= 0 || g->N <= 0 || g->K <= 0) return TSSEP_E_SHAPE;
+  return wgrad_split_rule(g, kernel_id);
 }
 
 static int wgrad_split_rule(const tssep_gemm_args* g, int32_t kid) {
