@@ -77,61 +77,12 @@ __global__ __launch_bounds__(256) void maskhead_fwd_kernel(
   }
 }
 
-// Forward, speakers innermost (round 6): a wave takes 256 consecutive (t, f) bins of ONE utterance, keeps their observation
-// bins in registers and walks the K speakers over them -- the observation is read once per bin instead of once per
-// speaker.  The flat walk above relies on the L2 for that re-use; with 30-s chunks an utterance's observation (7.7 MB)
-// no longer fits an XCD's 4-MB L2 and every speaker re-reads it from the memory side (BASELINE configs[4]: the
-// "HBM-bound mask-head stress", stand-alone forward 0.58 of 8 TB/s against 0.61-0.64 at 4 s).  Rows of 513 bins and odd
-// frame counts leave k TF + tf only 4-byte aligned: vector accesses at their natural element alignment (the HSA
-// default is unaligned access mode; gemm_common.h f32x4u).
-typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-typedef float f32x4c __attribute__((ext_vector_type(4), aligned(8)));
-#ifndef MH_KINNER_MIN_TF
-#define MH_KINNER_MIN_TF (3 << 17)      // bins per utterance from which the observation (8 B / bin) overflows an XCD's L2 share
-#endif
-__global__ __launch_bounds__(256) void maskhead_fwd_kinner_kernel(
-    const float* __restrict__ logit, const float2* __restrict__ obs, float* __restrict__ mask,
-    float2* __restrict__ est, int64_t B, int K, int64_t TF) {
-  const int lane = threadIdx.x & 63;
-  const int64_t chunks = (TF + 255) / 256, items = B * chunks;
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += nwaves) {
-    const int64_t b = it / chunks, c = it - b * chunks;
-    const int64_t tf0 = c * 256 + 2 * lane, tf1 = tf0 + 128;
-    const float2* ob = obs + b * TF;
-    f32x4c xa = {0.f, 0.f, 0.f, 0.f}, xb = {0.f, 0.f, 0.f, 0.f};
-    const int na = tf0 + 2 <= TF ? 2 : (tf0 < TF ? 1 : 0), nb = tf1 + 2 <= TF ? 2 : (tf1 < TF ? 1 : 0);
-    if (na == 2) xa = *reinterpret_cast<const f32x4c*>(ob + tf0);
-    else if (na == 1) { const float2 v = ob[tf0]; xa[0] = v.x; xa[1] = v.y; }
-    if (nb == 2) xb = *reinterpret_cast<const f32x4c*>(ob + tf1);
-    else if (nb == 1) { const float2 v = ob[tf1]; xb[0] = v.x; xb[1] = v.y; }
-    int64_t e0 = b * K * TF + tf0;
-    for (int k = 0; k < K; ++k, e0 += TF) {
-      const int64_t e1 = e0 + 128;
-      f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
-      if (na == 2) la = __builtin_nontemporal_load(reinterpret_cast<const f32x2u*>(logit + e0));
-      else if (na == 1) la[0] = logit[e0];
-      if (nb == 2) lb = __builtin_nontemporal_load(reinterpret_cast<const f32x2u*>(logit + e1));
-      else if (nb == 1) lb[0] = logit[e1];
-      const float a0 = sigmoidf_mask(la[0]), a1 = sigmoidf_mask(la[1]), b0 = sigmoidf_mask(lb[0]), b1 = sigmoidf_mask(lb[1]);
-      if (na == 2) {
-        __builtin_nontemporal_store(f32x2u{a0, a1}, reinterpret_cast<f32x2u*>(mask + e0));
-        __builtin_nontemporal_store(f32x4c{xa[0] * a0, xa[1] * a0, xa[2] * a1, xa[3] * a1}, reinterpret_cast<f32x4c*>(est + e0));
-      } else if (na == 1) {
-        mask[e0] = a0;
-        est[e0] = make_float2(xa[0] * a0, xa[1] * a0);
-      }
-      if (nb == 2) {
-        __builtin_nontemporal_store(f32x2u{b0, b1}, reinterpret_cast<f32x2u*>(mask + e1));
-        __builtin_nontemporal_store(f32x4c{xb[0] * b0, xb[1] * b0, xb[2] * b1, xb[3] * b1}, reinterpret_cast<f32x4c*>(est + e1));
-      } else if (nb == 1) {
-        mask[e1] = b0;
-        est[e1] = make_float2(xb[0] * b0, xb[1] * b0);
-      }
-    }
-  }
-}
-
+// (Round 6, BASELINE configs[4] -- 8 speakers, 30-s chunks, stand-alone forward 0.58-0.59 of 8 TB/s against 0.61 at 4 s: a
+// variant with the speakers INNERMOST -- a wave keeps the observation bins of 256 (t, f) positions in registers and walks
+// the K speakers over them, so that the 7.7-MB observation of an utterance, which no longer fits an XCD's L2, is read once
+// per bin -- measured SLOWER, 4.55-4.60 against 4.69 TB/s in three alternating pairs: the re-reads are served on the die
+// (Infinity Cache); the forward is bound by its 12 written bytes per element, where a torch copy of the same bytes reaches
+// 4.35-4.88 TB/s on these boxes.  profiles/r6_maskhead_kinner_rejected.jsonl)
 // Backward: FOUR 128-element halves per wave and iteration with every load of the iteration issued before the first use
 // (8 streaming loads + 8 L2-served observation bins per lane in flight), non-temporal on all four streams: 4.71 -> 4.95 TB/s
 // at batch 768 (0.59 -> 0.62 of 8 TB/s; a torch copy of the same bytes 4.6-5.1), alternating builds on one box, round 5
@@ -239,12 +190,6 @@ extern "C" int tssep_maskhead_fwd(const float* logit, const float* obs, float* m
   if (!aligned16(logit) || !aligned16(mask) || !aligned16(est) || (((uintptr_t)obs) & 7u))
     return TSSEP_E_ALIGN;
   const int64_t TF = T * F, KTF = K * TF, total = B * KTF;
-  if (K > 1 && K < (1 << 20) && TF >= MH_KINNER_MIN_TF) {
-    // long chunks: the speakers innermost, the observation bins in registers (the flat walk's re-use through the L2 is gone)
-    hipLaunchKernelGGL(maskhead_fwd_kinner_kernel, dim3(stream_grid((B * ((TF + 255) / 256) * 64 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, logit, (const float2*)obs, mask, (float2*)est, B, (int)K, TF);
-    return tssep_launch_status();
-  }
   hipLaunchKernelGGL(maskhead_fwd_kernel, dim3(stream_grid((total + 3) / 4)), dim3(256), 0,
                      (hipStream_t)stream, logit, (const float2*)obs, mask, (float2*)est, total, KTF,
                      TF);
