@@ -261,9 +261,22 @@ static bool make_plan(int size, GenPlan* pl) {
 }  // namespace
 
 // ---- host side (called from stft.hip's entry points for plans other than 1024 / 256) -------------------------------
+static size_t generic_lds_bytes(const GenPlan& pl);
+// The kernels keep two LDS lines of size / 2 complex values per wave (72 bytes per value and workgroup of four waves: 144 KB
+// at size 4096): a plan is advertised only where that fits the device's LDS (160 KB on gfx950; without a device
+// -- build / CPU tests -- the gfx950 figure).
+static size_t device_lds_limit() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+    return (size_t)v;
+  (void)hipGetLastError();
+  return (size_t)160 * 1024;
+}
 int tssep_generic_plan_supported(int size, int shift) {
   GenPlan pl;
-  return make_plan(size, &pl) && shift >= 1 && shift <= size && shift <= 64 * GEN_MAX_ACC;
+  return make_plan(size, &pl) && shift >= 1 && shift <= size && shift <= 64 * GEN_MAX_ACC &&
+         generic_lds_bytes(pl) <= device_lds_limit();
 }
 
 int tssep_generic_twiddles(int size, float* host_out) {

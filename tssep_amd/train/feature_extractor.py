@@ -77,8 +77,20 @@ class STFT(Configurable):
         plan = int(_lib.lib().tssep_stft_plan(int(self.size), int(self.shift)))
         if not plan:
             raise RuntimeError(f"unsupported FFT plan size={self.size}, shift={self.shift}: libtssep_hip.so builds even sizes "
-                               "with size / 2 = 2^a 3^b 5^c <= 2048 and shift <= min(size, 512) (TSSEP_E_UNSUPPORTED)")
+                               "with size / 2 = 2^a 3^b 5^c <= 2048 and shift <= min(size, 512) whose two LDS lines per "
+                               "wave fit the device (TSSEP_E_UNSUPPORTED)")
         return plan
+
+    FEATURE_MAX_BINS = 1032      # MAXF of csrc/feat.hip: the feature kernels keep one LDS line of F bins per wave
+
+    def _check_feature_bins(self):
+        """The feature kernels (tssep_feat_fwd) take at most FEATURE_MAX_BINS frequency bins (size <= 2062): say so up
+        front instead of TSSEP_E_SHAPE out of the kernel launch after the STFT plan was accepted."""
+        F = self.size // 2 + 1
+        if F > self.FEATURE_MAX_BINS:
+            raise RuntimeError(f"{type(self).__name__}: size={self.size} gives {F} frequency bins; the feature kernels of "
+                               f"libtssep_hip.so take at most {self.FEATURE_MAX_BINS} (size <= {2 * (self.FEATURE_MAX_BINS - 1)}); "
+                               "the STFT / iSTFT themselves support this plan")
 
     def frames(self, num_samples):
         lead, tail = self._fade()
@@ -164,6 +176,7 @@ class Log1pMaxNormAbsSTFT(STFT):
         if statistics_axis not in H.STAT_AXES:
             raise ValueError(f"statistics_axis = {statistics_axis!r}: 'tf', 't' or 'f' (feature_extractor.py:239-242)")
         self.statistics_axis = statistics_axis
+        self._check_feature_bins()
 
     def stft_to_feature(self, stft_signals):
         X = stft_signals
@@ -221,6 +234,7 @@ class TorchMFCC(STFT, torch.nn.Module):
         if X.dim() == 2:        # un-batched example: the dB floor is per utterance (torchaudio 2-D case)
             return self.stft_to_feature(X[None])[0]
         assert X.dim() == 3, X.shape
+        self._check_feature_bins()
         out, _ = H.feat_fwd(X, self.fb, self.dct_mat, self.n_mfcc, self._db_arg)
         return out[..., :self.n_mfcc]
 
