@@ -559,7 +559,7 @@ def main():
                                 traffic=traffic_src if traffic.get(name) is not None else None,
                                 mfma_pipe_busy_frac_pmc=mfma_src if (mfma_busy is not None and name.startswith("gemm_")) else None,
                                 note="NOT measured in this run: counters need their own rocprofv3 --pmc passes; these "
-                                     "are the committed results of the same command line (tools/collect_profiles.sh)"),
+                                     "are the committed results of the same command line (tools/collect_r<round>.sh)"),
                             timing="HIP events around every launch of this kernel, recorded INSIDE the timed "
                                    "region (their cost is part of ms_per_step)" if gstep is None else
                                    "HIP events in an eager pass after the graph-replayed timed region",

@@ -19,6 +19,14 @@ _vp, _i64, _i = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 _L.tssep_lstm_l2s_pack_floats.restype, _L.tssep_lstm_l2s_pack_floats.argtypes = _i64, [_i, _i]
 _L.tssep_lstm_pack_l2s.restype, _L.tssep_lstm_pack_l2s.argtypes = _i, [_vp, _vp, _i, _vp, _vp]
 _L.tssep_blstm_l2s_fwd.restype, _L.tssep_blstm_l2s_fwd.argtypes = _i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _vp]
+HAS8 = hasattr(_L, "tssep_blstm_l2s8_fwd")
+if HAS8:
+    _L.tssep_blstm_l2s8_fwd.restype, _L.tssep_blstm_l2s8_fwd.argtypes = _i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _vp]
+
+
+def _l2s8_fwd(gates, cell, hout, ldo, dstride, wf, N, T, H):
+    h.check(_L.tssep_blstm_l2s8_fwd(gates.data_ptr(), cell.data_ptr(), hout.data_ptr(), ldo, dstride, wf.data_ptr(), N, T, H,
+                                    h._stream()), "blstm_l2s8_fwd")
 
 
 def _pack_l2s(w_hh_f, w_hh_r, H):
@@ -77,15 +85,25 @@ for N in [int(a) for a in sys.argv[1:]] or [40, 3072]:
         out[name] = (g, c, ho)
     for k, nm in enumerate(("gates", "cell", "h")):
         res["fwd_rel_" + nm] = rel(out["l2s"][k], out["stream"][k])
+    if HAS8:      # the eight-wave K-split variant (v3)
+        g, c, ho = g0.clone(), torch.zeros(N, T, 2, Hh, device="cuda"), torch.zeros(N, T, 2 * Hp, device="cuda")
+        _l2s8_fwd(g, c, ho, 2 * Hp, Hp, wl2s, N, T, Hh)
+        torch.cuda.synchronize()
+        for k, (nm, t_) in enumerate(zip(("gates", "cell", "h"), (g, c, ho))):
+            res["fwd8_rel_" + nm] = rel(t_, out["stream"][k])
     g, c, ho = g0.clone(), torch.zeros(N, T, 2, Hh, device="cuda"), torch.zeros(N, T, 2 * Hp, device="cuda")
     for rep in range(2):      # interleaved A/B
         res.setdefault("l2s_fwd_ms", []).append(round(timeit(lambda: h.blstm_l2s_fwd(g, c, ho, 2 * Hp, Hp, wl2s, N, T, Hh)), 3))
+        if HAS8:
+            res.setdefault("l2s8_fwd_ms", []).append(round(timeit(lambda: _l2s8_fwd(g, c, ho, 2 * Hp, Hp, wl2s, N, T, Hh)), 3))
         g16 = h.onchip16_groups(N, Hh, g.device)
         if g16:
             res.setdefault("onchip16_fwd_ms", []).append(round(timeit(
                 lambda: h.blstm_onchip16_fwd(g, c, ho, 2 * Hp, Hp, w16, N, T, Hh, g16)), 3))
             h.check_cluster_errors()
     res["l2s_fwd_us_per_step"] = round(min(res["l2s_fwd_ms"]) * 1e3 / T, 2)
+    if HAS8:
+        res["l2s8_fwd_us_per_step"] = round(min(res["l2s8_fwd_ms"]) * 1e3 / T, 2)
     if HAS_BWD:
         dh = torch.randn(N, T, 2 * Hp, device="cuda") * 0.1
         ga, ca, _ = out["stream"]

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copies what tools/collect_r5.sh wrote under gpurun_out/final/ into profiles/ (tracked), names r<round>_*.
+# Copies what tools/collect_r6.sh wrote under gpurun_out/final/ into profiles/ (tracked), names r<round>_*.
 # usage: bash tools/install_profiles.sh [round] [batch] [gemm]      then re-run `python bench.py` on the GPU box
 # for the default line with the PMC fields filled (profiles/r<round>_bench_default.json).
 set -e
-R=${1:-5}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
+R=${1:-6}; B=${2:-768}; G=${3:-bf16x3}; F=gpurun_out/final; P=profiles/r${R}
 python tools/pmc_traffic.py $F/pmc_fetch/f_counter_collection.csv $F/pmc_write/w_counter_collection.csv $B $G cfg3 > ${P}_traffic_pmc.json
 python tools/pmc_mfma.py $F/pmc_sq/q_counter_collection.csv $B $G cfg3 > ${P}_mfma_pmc.json
 for f in recurrence_microbench.jsonl recurrence_stress.json gemm_microbench_bf16x3.jsonl gemm_microbench_bf16x3_wide0.jsonl \

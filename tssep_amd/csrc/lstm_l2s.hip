@@ -25,6 +25,7 @@
 // Packed weights (tssep_lstm_pack_l2s), forward: [dir][tile RT][kstep KS][hi, lo][lane 64][8 bf16] with KS = ceil(H/16),
 // RT = 2 KS tiles of 8 units; fragment row i (= lane % 32) of tile `tile` is gate i % 4 of unit
 // tile * 8 + ((i / 4) % 2) * 4 + i / 8, fragment column 8 (lane / 32) + e is k = 16 kstep + 8 (lane / 32) + e.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -329,6 +330,209 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------- forward, eight waves (v3)
+// The same recurrence with TWO waves per SIMD (<= 256 registers each), so that a wave stalled behind an HBM-latency
+// access in its in-order vector-memory queue leaves the SIMD's matrix pipe to its partner: the pair of waves (w, w + 4)
+// owns the NTW tiles of v2's wave w and splits K -- wave w the k-steps [0, KA), wave w + 4 the rest -- with h fragments
+// and weight ring for its half only.  Per tile the wave that does NOT finalise hands its 32 x 32 partial sums over through
+// LDS (4 KB, lane-linear, then a counter word; the finaliser polls it), the other adds, runs the cell update and the
+// tile's io exactly as in v2; the finaliser alternates with the tile parity (its pre-activation slot is refilled for ITS
+// next tile, two tiles ahead).  h is single-buffered (two barriers per step) to make room for the hand-over buffers.
+template <int KS, int R>
+__global__ __launch_bounds__(512, 1) void blstm_l2s8_fwd_kernel(float* __restrict__ gates, float* __restrict__ cell,
+                                                                float* __restrict__ hout, int64_t ldo, int64_t dstride,
+                                                                const u32x4* __restrict__ wpk, int64_t N, int64_t T, int H) {
+  constexpr int RT = 2 * KS, NTW = (RT + 3) / 4, KA = (KS + 1) / 2, KB = KS - KA;
+  static_assert(NTW % 2 == 0, "the finaliser alternates with the tile parity");
+  static_assert((NTW * KA) % R == 0 && (NTW * KB) % R == 0, "the weight ring must close over one time step in both halves");
+  static_assert(NTW * 4 - RT <= 2, "one spare B-fragment slot takes the tiles that do not exist");
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  constexpr int HB = (KS + 1) * 128;                               // h: [KS + 1 (spare)][hi, lo][64 lanes], ONE buffer
+  constexpr int GI = HB, GO = GI + 8 * 256, PB = GO + 8 * 384, FL = PB + 8 * 256;      // gin[wave][256], gout[wave][384], pbuf[wave][256], flags
+  u32x4* hfr = smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pr = wave & 3, kh = wave >> 2;                          // SIMD pair, K half = finaliser parity
+  const int s = lane & 31, hl = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int dir = xcd & 1;
+  const int64_t grp = (int64_t)slot * 4 + (xcd >> 1);
+  if (grp * SEQ >= N) return;
+  const int64_t n0 = grp * SEQ;
+  const int G4 = H * 4;
+
+  for (int i = tid; i < HB; i += 512) hfr[i] = u32x4{0u, 0u, 0u, 0u};
+  volatile unsigned* flags = reinterpret_cast<volatile unsigned*>(smem + FL);      // [wave]: hand-overs published BY that wave
+  if (tid < 8) flags[tid] = 0u;
+
+  const srd_t rw = make_srd(wpk + (int64_t)dir * RT * KS * 128);
+  const char* gb = reinterpret_cast<const char*>(gates + n0 * T * 2 * G4);
+  const srd_t rg = make_srd(gb);
+  const srd_t rc = make_srd(cell + n0 * T * 2 * H);
+  const srd_t rh = make_srd(hout + n0 * T * ldo);
+  const unsigned vw = (unsigned)lane * 16u;
+  const int sg_t = 2 * G4 * 4, sc_t = 2 * H * 4, sh_t = (int)ldo * 4;
+
+  unsigned gl[4];
+  int gpiece[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int seq = j * 8 + (lane >> 3), piece = ((lane & 7) - (seq >> 1)) & 7;
+    gl[j] = (unsigned)((((int64_t)seq * T * 2 + dir) * G4) * 4 + piece * 16) | ((n0 + seq < N) ? 0u : VOOR);
+    gpiece[j & 1] = piece;
+  }
+  const unsigned gsafe = (unsigned)(dir * G4 * 4);
+  const int cseq = lane >> 1, cpiece = ((lane & 1) - (cseq >> 3)) & 1;
+  const unsigned cmask = (n0 + cseq < N) ? 0u : VOOR;
+  const unsigned cl = (unsigned)((((int64_t)cseq * T * 2 + dir) * H) * 4 + cpiece * 16) | cmask;
+  const unsigned hlo = (unsigned)(((int64_t)cseq * T * ldo + dir * dstride) * 4 + cpiece * 16) | cmask;
+  int swz[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) swz[q] = s * 8 + ((hl * 4 + q + (s >> 1)) & 7);
+  const int cswz = s * 2 + ((hl + (s >> 3)) & 1);
+  u32x4* gin = smem + GI + wave * 256;
+  u32x4* gout = smem + GO + wave * 384;
+  u32x4* pmine = smem + PB + wave * 256;                  // what I hand over
+  const u32x4* ptheirs = smem + PB + (wave ^ 4) * 256;    // what my partner hands over
+  const unsigned gin_lds = lds_addr(gin);
+
+  auto tile_of = [&](int i_) { return pr * NTW + i_; };
+  auto tile_off = [&](int i_) { const int t_ = tile_of(i_); return (t_ < RT ? t_ : RT - 1) * KS * 2048; };
+  auto gx_dma = [&](int i_, int t_) {       // tile i_ (one I finalise) of time step t_ into my slot
+    if (L2S_PROBE & (4 | 16)) return;
+    const int tile_ = tile_of(i_);
+    const char* base = gb + (int64_t)t_ * sg_t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = !(gl[j] & VOOR) && tile_ * 8 + gpiece[j & 1] < H;
+      dma16(base, ok ? gl[j] + (unsigned)(tile_ * 128) : gsafe, gin_lds + (unsigned)(j * 64 * 16));
+    }
+  };
+
+  // this wave's K half: k-steps [k0, k0 + KH)
+  const int k0 = kh ? KA : 0;
+  u32x4 wh[R], wl[R];
+  float c[NTW / 2][4];
+#pragma unroll
+  for (int i = 0; i < NTW / 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[i][q] = 0.f;
+  gx_dma(kh, dir ? (int)T - 1 : 0);           // my first tile: i = kh
+
+  auto run = [&](auto kh_tag) __attribute__((always_inline)) {
+    constexpr int KHC = decltype(kh_tag)::value ? KB : KA;     // k-steps of this half
+    constexpr int PAR = decltype(kh_tag)::value;               // tiles with i % 2 == PAR are finalised here
+    constexpr int NF = NTW * KHC;
+#pragma unroll
+    for (int f = 0; f < R; ++f) {
+      const int o = tile_off(f / KHC) + (k0 + f % KHC) * 2048;
+      wh[f] = bload(rw, vw, o);
+      wl[f] = bload(rw, vw, o + 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned cnt = 0;                          // hand-overs so far (mine published / theirs consumed: both advance per tile)
+#pragma clang loop unroll(disable)
+    for (int step = 0; step < (int)T; ++step) {
+      const int t = dir ? (int)T - 1 - step : step;
+      const int tn = step + 1 < (int)T ? (dir ? t - 1 : t + 1) : t;
+      int tb[NTW];
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        tb[i] = tile_off(i) + k0 * 2048;
+        asm volatile("" : "+s"(tb[i]));
+      }
+      bf16x8 bh[KHC], bl[KHC];
+      {
+        const u32x4* hb = hfr + k0 * 128 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KHC; ++ks) {
+          bh[ks] = as_bf16x8(hb[ks * 128]);
+          bl[ks] = as_bf16x8(hb[ks * 128 + 64]);
+        }
+      }
+      __syncthreads();                         // every wave holds its fragments of h_{t-1}: h_t may be written
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int tile = tile_of(i);
+        constexpr int dummy = 0; (void)dummy;
+        const bool fin = (i & 1) == PAR;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KHC; ++ks) {
+          const int f = i * KHC + ks, sl = f % R;
+          acc = MFMA_BF16(as_bf16x8(wl[sl]), bh[ks], acc);
+          acc = MFMA_BF16(as_bf16x8(wh[sl]), bl[ks], acc);
+          acc = MFMA_BF16(as_bf16x8(wh[sl]), bh[ks], acc);
+          const int fn = (f + R) % NF;
+          const int o = tb[fn / KHC] + (fn % KHC) * 2048;
+          if (!(L2S_PROBE & 2)) {
+            wh[sl] = bload(rw, vw, o);
+            wl[sl] = bload(rw, vw, o + 1024);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ++cnt;
+        if (!fin) {
+          // hand my partial sums over: four lane-linear 16-byte writes, then the counter (LDS operations of a wave complete in order)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            pmine[q * 64 + lane] = __builtin_bit_cast(u32x4, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) flags[wave] = cnt;
+        } else {
+          // my pre-activations of this tile (copied in two tiles -- more than 30 vector-memory instructions -- ago; read
+          // behind the K loop: sixteen registers the loop does not have), then the slot is refilled for my next tile
+          f32x4 gq[4];
+          asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gq[q] = (L2S_PROBE & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, gin[swz[q]]);
+          if (i + 2 < NTW) gx_dma(i + 2, t); else gx_dma(i + 2 - NTW, tn);
+          while (flags[wave ^ 4] < cnt) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+          f32x4 cv, hv;
+          const bool uok = tile * 8 + hl * 4 < H;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 pq = __builtin_bit_cast(f32x4, ptheirs[q * 64 + lane]);
+            const float ig = fast_sigmoid(acc[4 * q + 0] + pq[0] + gq[q][0]), fg = fast_sigmoid(acc[4 * q + 1] + pq[1] + gq[q][1]);
+            const float gg = fast_tanh(acc[4 * q + 2] + pq[2] + gq[q][2]), og = fast_sigmoid(acc[4 * q + 3] + pq[3] + gq[q][3]);
+            const float cn = fg * c[i / 2][q] + ig * gg;
+            c[i / 2][q] = cn;
+            cv[q] = cn;
+            hv[q] = uok ? og * fast_tanh(cn) : 0.f;
+            gout[swz[q]] = __builtin_bit_cast(u32x4, f32x4{ig, fg, gg, og});
+          }
+          gout[256 + cswz] = __builtin_bit_cast(u32x4, cv);
+          gout[320 + cswz] = __builtin_bit_cast(u32x4, hv);
+          unsigned h01, l01, h23, l23;
+          split2(hv[0], hv[1], h01, l01);
+          split2(hv[2], hv[3], h23, l23);
+          u32x2* dst = reinterpret_cast<u32x2*>(hfr + (tile >> 1) * 128 + s + 32 * (tile & 1)) + hl;
+          dst[0] = u32x2{h01, h23};
+          dst[64 * 2] = u32x2{l01, l23};
+          if (!(L2S_PROBE & (4 | 8))) {
+            const unsigned so = (unsigned)(t * sg_t + tile * 128);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned v = (tile * 8 + gpiece[j & 1] < H) ? gl[j] + so : VOOR;
+              bstore_nt(__builtin_bit_cast(f32x4, gout[j * 64 + lane]), rg, v, 0);
+            }
+            const bool cok = tile * 8 + cpiece * 4 < H;
+            bstore_nt(__builtin_bit_cast(f32x4, gout[256 + lane]), rc, cok ? cl + (unsigned)(t * sc_t + tile * 32) : VOOR, 0);
+            bstore_nt(__builtin_bit_cast(f32x4, gout[320 + lane]), rh, cok ? hlo + (unsigned)(t * sh_t + tile * 32) : VOOR, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();                         // h_t complete
+    }
+  };
+  if (kh) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+}
+
 }  // namespace
 
 extern "C" int tssep_lstm_l2s_supported(int H) { return (H > 0 && (H & 3) == 0 && (l2s_ks(H) == 19 || l2s_ks(H) == 20)) ? 1 : 0; }
@@ -370,5 +574,22 @@ extern "C" int tssep_blstm_l2s_fwd(float* gates, float* cell, float* hout, int64
     hipLaunchKernelGGL((blstm_l2s_fwd_kernel<20, (L2S_RING == 10 ? 10 : 20)>), dim3(grid), dim3(256), lds, s, gates, cell, hout, ldo, dstride,
                        reinterpret_cast<const u32x4*>(wf), N, T, H);
   }
+  return tssep_launch_status();
+}
+
+extern "C" int tssep_blstm_l2s8_fwd(float* gates, float* cell, float* hout, int64_t ldo, int64_t dstride, const float* wf,
+                                    int64_t N, int64_t T, int H, void* stream) {
+  if (!gates || !cell || !hout || !wf) return TSSEP_E_NULL;
+  if (N <= 0 || T <= 0 || dstride < H || ldo < dstride + H) return TSSEP_E_SHAPE;
+  if (l2s_ks(H) != 19 || (H & 3) || (ldo & 3) || (dstride & 3)) return TSSEP_E_UNSUPPORTED;
+  if (!aligned16(gates) || !aligned16(cell) || !aligned16(hout) || !aligned16(wf)) return TSSEP_E_ALIGN;
+  constexpr int KS = 19;
+  const int64_t groups = (N + SEQ - 1) / SEQ;
+  const unsigned grid = (unsigned)(8 * ((groups + 3) / 4));
+  const size_t lds = (size_t)((KS + 1) * 128 + 8 * 256 + 8 * 384 + 8 * 256 + 1) * 16;
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&blstm_l2s8_fwd_kernel<19, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  hipLaunchKernelGGL((blstm_l2s8_fwd_kernel<19, 5>), dim3(grid), dim3(512), lds, (hipStream_t)stream, gates, cell, hout, ldo, dstride,
+                     reinterpret_cast<const u32x4*>(wf), N, T, H);
   return tssep_launch_status();
 }
