@@ -213,6 +213,27 @@ def test_bucketed_allreduce_equals_the_flat_one_world2():
     assert np.array_equal(res[0][1]["flat"][0], res[1][1]["flat"][0])
 
 
+def test_layer_groups_of_the_mask_estimator_are_its_five_layers():
+    """`distributed.layer_groups` on the real TS-SEP mask estimator (net.py:809-986): pre-net, birnn0 / 1 / 2 (nn.LSTM +
+    projection = ten tensors each, the unit one RNNP layer's backward completes together) and the logit layer; the groups are
+    contiguous in the flat layout, cover every parameter once, and an un-armed bucket never reduces early."""
+    from tssep_amd.distributed import layer_groups
+    from tssep_amd.train import net
+    m = net.MaskEstimator_v2(idim=553, odim=513, units=12, projs=16, combination="mul", aux_net_output_size=513, ts_vad=4,
+                             output_resolution="tf")
+    groups = layer_groups(m.named_parameters())
+    assert [len(g) for g in groups] == [10, 10, 10, 10, 2]
+    assert sum(len(g) for g in groups) == len(list(m.parameters()))
+    b = GradBucket(m.parameters())
+    b.set_segments(groups)
+    assert len(b.segments) == 5 and b.segments[0][0] == 0 and b.segments[-1][1] == b.flat.numel()
+    assert all(a[1] == c[0] for a, c in zip(b.segments, b.segments[1:]))
+    b.notify(groups[-1])                       # not armed (no process group, not the last micro-step): nothing happens
+    assert b._reduced == [] and b._armed is False
+    b.arm()
+    assert b._armed is False                   # a single process never arms
+
+
 def test_gradient_sum_allreduce_world2():
     res = _spawn(_worker, 2)
     torch.manual_seed(0)
