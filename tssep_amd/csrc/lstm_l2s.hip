@@ -38,6 +38,9 @@ constexpr int SEQ = 32;      // sequences per workgroup = the N of the MFMA
 #ifndef L2S_PROBE
 #define L2S_PROBE 0        // timing probes, results wrong by construction: 1 no MFMAs, 2 no weight loads, 4 no pre-activation loads / stores
 #endif
+#ifndef L2S_GXMODE
+#define L2S_GXMODE 0       // v2: 0 = pre-activations by LDS-DMA (asm, two tiles ahead); 1 = by ordinary coalesced loads into 16 registers per
+#endif                     // tile in flight (two tiles ahead), written to the LDS image when the tile starts (probe: profiles/r6_l2s_probe.jsonl)
 #ifndef L2S_RING
 #define L2S_RING 10       // weight-ring depth in fragment pairs (a divisor of 10 * KS)
 #endif
@@ -212,13 +215,20 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
     }
   };
 
+  f32x4 gxr[2][4];
+  auto gx_regs = [&](int slot_, int i_, int t_) {       // L2S_GXMODE 1: four coalesced 1-KB loads into registers
+    const int tile_ = tile_of(i_);
+    const unsigned so = (unsigned)(t_ * sg_t + tile_ * 128);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      gxr[slot_][j] = bload_nt(rg, (tile_ * 8 + gpiece[j & 1] < H) ? gl[j] + so : VOOR, 0);
+  };
   // weight ring: R fragment pairs, refilled R fragments ahead right behind the MFMAs that read a slot; it runs across
   // tiles and across time steps (NF % R == 0: slot f % R of step t + 1 is slot f % R of step t)
   u32x4 wh[R], wl[R];
   {
     const int t0 = dir ? (int)T - 1 : 0;
-    gx_dma(0, t0);
-    gx_dma(1, t0);
+    if (L2S_GXMODE == 1) { gx_regs(0, 0, t0); gx_regs(1, 1, t0); } else { gx_dma(0, t0); gx_dma(1, t0); }
   }
 #pragma unroll
   for (int f = 0; f < R; ++f) {
@@ -262,10 +272,20 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
       const int tile = tile_of(i);
       // 1. this tile's pre-activations: requested two tiles (>= 64 vector-memory instructions) ago
       f32x4 gq[4];
-      asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+      if (L2S_GXMODE == 1) {
+        // the tile's pre-activations arrived in registers (coalesced 1-KB loads, two tiles ago): into the lane-linear image,
+        // back in the MFMA layout; the registers are reloaded for two tiles ahead
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gq[q] = (L2S_PROBE & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, gin[(i & 1) * 256 + swz[q]]);
-      if (i + 2 < NTW) gx_dma(i + 2, t); else gx_dma(i + 2 - NTW, tn);
+        for (int j = 0; j < 4; ++j) gin[(i & 1) * 256 + j * 64 + lane] = __builtin_bit_cast(u32x4, gxr[i & 1][j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gq[q] = __builtin_bit_cast(f32x4, gin[(i & 1) * 256 + swz[q]]);
+        if (i + 2 < NTW) gx_regs(i & 1, i + 2, t); else gx_regs(i & 1, i + 2 - NTW, tn);
+      } else {
+        asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gq[q] = (L2S_PROBE & 4) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, gin[(i & 1) * 256 + swz[q]]);
+        if (i + 2 < NTW) gx_dma(i + 2, t); else gx_dma(i + 2 - NTW, tn);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // 2.
       f32x16 acc;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
           const unsigned v = (tile * 8 + gpiece[j & 1] < H) ? gl[j] + so : VOOR;      // (gl | VOOR stays out of range)
           bstore_nt(__builtin_bit_cast(f32x4, gout[j * 64 + lane]), rg, v, 0);
         }
-        const bool cok = tile * 8 + cpiece * 4 < H;
+        const bool cok = tile * 8 + cpiece * 4 < H && !(L2S_PROBE & 32);      // (32: no c / h stores -- the partial sectors)
         bstore_nt(__builtin_bit_cast(f32x4, gout[256 + lane]), rc, cok ? cl + (unsigned)(t * sc_t + tile * 32) : VOOR, 0);
         bstore_nt(__builtin_bit_cast(f32x4, gout[320 + lane]), rh, cok ? hlo + (unsigned)(t * sh_t + tile * 32) : VOOR, 0);
       }
