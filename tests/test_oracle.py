@@ -266,3 +266,38 @@ def test_mfcc_restatement_against_independent_paths():
     ref2 = scipy.fft.dct(np.maximum(db[2], db[2].max() - 80.0), type=2, norm="ortho", axis=-1)
     np.testing.assert_allclose(got2, ref2, rtol=2e-4, atol=2e-3)
     assert np.abs(got2[:, 1:]).max() > 1.0
+
+
+def test_torch_mfcc_against_an_independent_third_party_implementation():
+    """SURVEY 8a2 / VERDICT r5 "missing" #2: torchaudio 2.0.2 (what `TorchMFCC` wraps, feature_extractor_torchaudio.py:57-106)
+    is not in the image and the reference holds no MFCC value, so the oracle's MFCC stays "parity unpinned" by the rules.
+    What CAN be checked without it (round 6): the whole chain against code nobody here wrote -- the mel filterbank and the
+    dB conversion of `transformers.audio_utils` (HuggingFace's numpy port of torchaudio's `melscale_fbanks` /
+    librosa's `power_to_db`, installed in this image) and scipy's DCT-II: |STFT|^2 -> mel (HTK and Slaney scales, with
+    and without Slaney area normalisation, the reference's f_max = sample_rate - 400 quirk) -> 10 log10 with the 80-dB
+    floor below the maximum of the WHOLE 3-D batch (torchaudio's batching rule) -> orthonormal DCT, on the FFT sizes
+    the configurations use (1024 shipped, 400 TorchMFCC's default, 512)."""
+    import warnings
+    import pytest
+    import scipy.fft
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import features as ofeat
+    rng = np.random.RandomState(5)
+    for size in (1024, 400, 512):
+        F = size // 2 + 1
+        X = torch.as_tensor((rng.randn(3, 37, F) + 1j * rng.randn(3, 37, F)).astype(np.complex64)) * \
+            torch.as_tensor(10.0 ** rng.uniform(-4, 1, size=(3, 37, 1)).astype(np.float32))       # 100 dB of level spread: the floor bites
+        for scale, norm in (("htk", None), ("slaney", None), ("slaney", "slaney"), ("htk", "slaney")):
+            fb, dct = ofeat.mfcc_tables(size, mel_scale=scale, mel_norm=norm)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")               # (f_max above Nyquist leaves empty filters: the reference's quirk)
+                ref_fb = au.mel_filter_bank(F, 40, 40.0, 16000.0 - 400.0, 16000, norm=norm, mel_scale=scale)
+            assert float(np.abs(fb.numpy() - ref_fb).max()) < 5e-6, (size, scale, norm)
+            power = np.abs(X.numpy().astype(np.complex128)) ** 2                                  # [B, T, F]
+            mel = np.einsum("btf,fm->bmt", power, ref_fb.astype(np.float64))                      # [B, n_mels, T]
+            db = au.power_to_db(mel, reference=1.0, min_value=1e-10, db_range=80.0)               # max over the whole array
+            ref = scipy.fft.dct(db, type=2, norm="ortho", axis=1).transpose(0, 2, 1)              # [B, T, n_mfcc]
+            got = ofeat.torch_mfcc(X, fb, dct).numpy()
+            assert got.shape == ref.shape == (3, 37, 40)
+            assert float(np.abs(got - ref).max()) < 1e-3, (size, scale, norm)      # (fp32 against fp64: 2e-4 at values up to 270)
+            assert float(db.min()) == pytest.approx(float(db.max()) - 80.0, abs=1e-9)             # the floor was active
