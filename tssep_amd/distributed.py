@@ -84,7 +84,6 @@ class GradBucket:
         self._armed = False         # only the LAST micro-step of a virtual minibatch may reduce early (arm)
         self._reported = []         # per segment: ids reported complete in this backward
         self._reduced = []          # segment indices already all-reduced (in launch order)
-        self._works = []
         self.comm_stream = None
 
     # ---- per-layer segments, reduced as soon as a layer's gradients are complete (round 6) -------------
@@ -119,7 +118,7 @@ class GradBucket:
 
     def _reset_step(self):
         self._reported = [set() for _ in self.segments]
-        self._reduced, self._works, self._armed = [], [], False
+        self._reduced, self._armed = [], False
 
     def arm(self):
         """The backward that follows is the LAST of its virtual minibatch: complete segments may be reduced at once."""
@@ -140,13 +139,17 @@ class GradBucket:
                 self._launch(k)
 
     def _reduce_range(self, start, end, group=None):
+        """SUM over ranks of `_full[start:end]`, enqueued behind the CURRENT stream; the current stream waits for it
+        (a synchronous collective: with nccl = RCCL the kernel runs on the library's own stream, which first waits for
+        the current stream, and the current stream then waits for that kernel -- so "the current stream" is a handle a
+        later `wait_stream` can order against; an async work object would leave the kernel on a stream nobody here sees)."""
         buf = self._full[start:end]
         if buf.is_cuda and dist.get_backend(group) == "gloo":       # test configuration: staged through the host
             host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             buf.copy_(host)
-            return None
-        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=buf.is_cuda)
+            return
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
 
     def _launch(self, k):
         start, end = self.segments[k]
@@ -160,13 +163,11 @@ class GradBucket:
             if side is not None:
                 comm.wait_stream(side)
             with torch.cuda.stream(comm):
-                w = self._reduce_range(start, end)
+                self._reduce_range(start, end)         # the COMMUNICATION stream waits for the collective, not the compute stream
             hip_ops.COMM_PENDING[str(dev)] = comm      # the next W-stationary launch waits for it (fence_comm)
         else:
-            w = self._reduce_range(start, end)
+            self._reduce_range(start, end)
         self._reduced.append(k)
-        if w is not None:
-            self._works.append(w)
 
     def reduce_replicas(self):
         for f in self.flats[1:]:
@@ -193,15 +194,15 @@ class GradBucket:
         else:
             self.guard[:1].copy_(flag[:1])
 
-    def all_reduce(self, group=None, async_op=False):
+    def all_reduce(self, group=None):
         """SUM over ranks of the gradient AND the guard slot behind it: one collective -- or, with segments reduced early
         (`arm` / `notify`), one collective per remaining contiguous range, last layers first, then a join."""
         self.sync()
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
             return None
         if not self._reduced:
-            w = self._reduce_range(0, self._full.numel(), group)
-            return w if async_op else (w.wait() if w is not None else None)
+            self._reduce_range(0, self._full.numel(), group)
+            return None
         done = sorted(self.segments[k] for k in self._reduced)
         rest, pos = [], 0
         for a, b in done + [(self._full.numel(), self._full.numel())]:
@@ -209,17 +210,13 @@ class GradBucket:
                 rest.append((pos, a))
             pos = max(pos, b)
         for a, b in reversed(rest):
-            w = self._reduce_range(a, b, group)
-            if w is not None:
-                self._works.append(w)
-        for w in self._works:
-            w.wait()                                 # (nccl: the CURRENT stream waits for the collective; no host sync)
+            self._reduce_range(a, b, group)
         if self.comm_stream is not None and self.flat.is_cuda:
-            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.comm_stream)      # the early segments
             from . import hip_ops
             hip_ops.COMM_PENDING.pop(str(self.flat.device), None)
         self.last_reduction_order = list(self._reduced)
-        self._reduced, self._works, self._armed = [], [], False
+        self._reduced, self._armed = [], False
         self._reported = [set() for _ in self.segments]
         return None
 
