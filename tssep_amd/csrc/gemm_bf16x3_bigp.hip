@@ -238,7 +238,20 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
     // a staged piece in three slots: split the first pair, split the second pair, write both planes + reload
     unsigned sh0 = 0, sl0 = 0, sh1 = 0, sl1 = 0;
 #define SPLIT(a_, b_, h_, l_) if constexpr (ONE) h_ = bf16_pair(a_, b_); else split2n(a_, b_, h_, l_)
-#if BIGP_PROBE_NOA == 2
+#if BIGP_PROBE_NOB == 3   // round 6: what pre-split weights by LDS-DMA would deliver WITH the waits a correct kernel needs: the eight copies of
+// a wave in the EARLY slots of the stage (they must land before the barrier that ends it), the activation operand's split /
+// write / reload in the late ones (same distance to its use), and `vmcnt(8)` -- everything but the eight activation loads
+// issued behind the copies -- in front of the barrier.  Timing probe, results wrong (the copies read somewhere valid).
+#define SA1(i) (void)0
+#define SA2(i) (void)0
+#define SA3(i) { const int la_ = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(nxt + 2 * GARR + ((tid >> 6) * 8 + (i)) * 1024)); \
+                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"((unsigned)(tid * 16 + (i) * 4096)), "s"(B), "s"(la_) : "memory"); }
+#define SB1(i) if constexpr (XCOL) XDOT(i); SPLIT(ra[i][0], ra[i][1], sh0, sl0)
+#define SB2(i) SPLIT(ra[i][2], ra[i][3], sh1, sl1)
+#define SB3(i) { *reinterpret_cast<u32x2*>(nxt + soff + i * 32 * GROWB) = u32x2{sh0, sh1};        \
+               if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
+               ra[i] = load_a(i, tmask, so)
+#elif BIGP_PROBE_NOA == 2
 #define SA1(i) (void)0
 #define SA2(i) (void)0
 #define SA3(i) { const int la_ = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(nxt + ((tid >> 6) * 8 + (i)) * 1024)); \
@@ -254,7 +267,9 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
                if constexpr (!ONE) *reinterpret_cast<u32x2*>(nxt + GARR + soff + i * 32 * GROWB) = u32x2{sl0, sl1}; } \
                ra[i] = load_a(i, tmask, so)
 #endif
-#if BIGP_PROBE_NOB == 2 // timing probe (wrong results): operand B as eight 1-KB LDS-DMA copies per wave and stage from somewhere valid
+#if BIGP_PROBE_NOB == 3
+// (defined together with the activation operand, above)
+#elif BIGP_PROBE_NOB == 2 // timing probe (wrong results): operand B as eight 1-KB LDS-DMA copies per wave and stage from somewhere valid
 #define SB1(i) (void)0
 #define SB2(i) (void)0
 #define SB3(i) { const int la_ = __builtin_amdgcn_readfirstlane((int)(uintptr_t)(__attribute__((address_space(3))) void*)(nxt + 2 * GARR + ((tid >> 6) * 8 + (i)) * 1024)); \
@@ -505,6 +520,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
       // stores stage 1 (registers), loads stage 2
       body(std::true_type{}, lds + par * GSTAGE, nxt, ktl);
       if (ktail && KT == 2) fix_tail(nxt);
+      if (BIGP_PROBE_NOB == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       par ^= 1;
@@ -518,6 +534,7 @@ __global__ __launch_bounds__(GNT, 1) void gemm_bf16x3_bigp_kernel(
       }
       body(std::false_type{}, lds + par * GSTAGE, nxt, ktl);
       if (ktail && kt + 1 == KT - 1) fix_tail(nxt);
+      if (BIGP_PROBE_NOB == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       par ^= 1;
