@@ -1,3 +1,8 @@
+// EXPERIMENT BUILD ONLY (`make exp`; not in libtssep_hip.so, not in the ABI).  Measured in round 6 and NOT built into the
+// product: profiles/r6_l2s_probe.jsonl, DESIGN.md 4.2 -- forward kernels v2 (four waves) and v3 (eight waves, K split
+// between the two waves of a SIMD), both parity-green against the exact-fp32 kernel; compute core 14.6-15.2 us per step,
+// with the activation stream 37-40 (W-stationary production kernel: 21.4).
+//
 // Sequence-parallel BLSTM recurrence on the bf16 matrix cores with W_hh STREAMED from the XCD's L2 every step
 // (round 6; VERDICT r5 "Next round" #1).  Replaces the T-sequential part of torch.nn.LSTM as the reference uses it
 // (tssep/train/rnnp.py:88-95,146-153: one bidirectional layer, batch_first, zero initial state) for launches with
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 1) void blstm_l2s_fwd_kernel(float* __restrict
   const int cswz = s * 2 + ((hl + (s >> 3)) & 1);
   u32x4* gin = smem + GI + wave * 512;
   u32x4* gout = smem + GO + wave * 384;
-  const unsigned gin_lds = lds_addr(gin), gin_lane = gin_lds;  (void)gin_lane;
+  const unsigned gin_lds = lds_addr(gin);
 
   auto tile_of = [&](int i_) { return wave * NTW + i_; };
   // byte offset of the weight fragments of the i-th tile (tiles that do not exist run on the last real tile's weights
@@ -475,7 +480,6 @@ __global__ __launch_bounds__(512, 1) void blstm_l2s8_fwd_kernel(float* __restric
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
         const int tile = tile_of(i);
-        constexpr int dummy = 0; (void)dummy;
         const bool fin = (i & 1) == PAR;
         f32x16 acc;
 #pragma unroll
